@@ -1,0 +1,202 @@
+/*
+ * birdnet_hip.h -- C ABI of libbirdnet_hip.so, the MI355X-native (gfx950 / HIP)
+ * replacement for the ONNX Runtime session behind the reference's
+ * Classifier::predict / predict_batch / BatchInferenceContext path.
+ *
+ * The reference (tphakala/rust-birdnet-onnx, crate birdnet-onnx 2.0.0-rc.5) has
+ * no FFI of its own; its seam is the safe `ort` crate API.  Every entry point
+ * below names the `ort` call site (file:line under the reference tree) it
+ * stands in for.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Threading: a bn_model is immutable after load and may be shared between
+ * threads; a bn_ctx owns one HIP stream plus its buffers and must be used by
+ * one thread at a time (same contract as BatchInferenceContext,
+ * src/batch_context.rs:56-60).
+ *
+ * Errors: every call returns a bn_status; the message of the last failure on
+ * the calling thread is available from bn_last_error().
+ */
+#ifndef BIRDNET_HIP_H
+#define BIRDNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BN_ABI_VERSION 1
+#define BN_MAX_OUTPUTS 8
+#define BN_MAX_RANK 6
+#define BN_NAME_LEN 64
+
+typedef struct bn_model bn_model; /* stands in for ort::session::Session (src/classifier.rs:340-350,435) */
+typedef struct bn_ctx bn_ctx;     /* stands in for ort IoBinding + buffers (src/batch_context.rs:70-85) */
+
+typedef enum bn_status {
+    BN_OK = 0,
+    BN_ERR_INVALID_ARG = 1,       /* NULL handle, B > max_batch, bad index ... */
+    BN_ERR_BAD_SIZE = 2,          /* reserved: size checks live in the host shim (classifier.rs:612-618,688-696) */
+    BN_ERR_TIMEOUT = 3,           /* -> Error::Timeout   (classifier.rs:568-573) */
+    BN_ERR_CANCELLED = 4,         /* -> Error::Cancelled (classifier.rs:568-573) */
+    BN_ERR_BACKEND = 5,           /* HIP runtime failure -> Error::Inference(String) */
+    BN_ERR_MODEL_LOAD = 6,        /* unreadable / malformed .onnx -> Error::ModelLoad */
+    BN_ERR_UNSUPPORTED_MODEL = 7, /* graph uses an operator/shape outside the native subset */
+    BN_ERR_MODEL_DETECTION = 8,   /* -> Error::ModelDetection{reason} (detection.rs:15-145) */
+    BN_ERR_NO_DEVICE = 9          /* no usable gfx950 device: the path never falls back to CPU */
+} bn_status;
+
+/* ModelType (src/types.rs:3-11) */
+typedef enum bn_model_type {
+    BN_MODEL_BIRDNET_V24 = 0,
+    BN_MODEL_BIRDNET_V30 = 1,
+    BN_MODEL_PERCH_V2 = 2
+} bn_model_type;
+
+/* Tensor metadata: what session.inputs()/outputs() + dtype().tensor_shape()
+ * return (src/classifier.rs:387-420).  A dynamic dimension is reported as -1. */
+typedef struct bn_io_info {
+    int32_t input_rank;
+    int64_t input_shape[BN_MAX_RANK];
+    char input_name[BN_NAME_LEN];
+    int32_t n_outputs;
+    int32_t output_rank[BN_MAX_OUTPUTS];
+    int64_t output_shape[BN_MAX_OUTPUTS][BN_MAX_RANK];
+    char output_name[BN_MAX_OUTPUTS][BN_NAME_LEN];
+} bn_io_info;
+
+/* ModelConfig (src/types.rs:72-85) + which graph outputs carry logits /
+ * embeddings (src/classifier.rs:917-934: v2.4 -> 0; v3.0 -> 1,0; Perch -> 3,0). */
+typedef struct bn_model_config {
+    int32_t model_type; /* bn_model_type */
+    uint32_t sample_rate;
+    float segment_duration;
+    uint64_t sample_count;
+    uint64_t num_species;
+    int32_t has_embedding;
+    uint64_t embedding_dim;
+    int32_t logits_output;    /* graph output index of the logits */
+    int32_t embedding_output; /* graph output index of the embeddings, -1 if none */
+} bn_model_config;
+
+/* Work the loaded graph costs per segment, from the engine's own graph walk
+ * (denominators for roofline reporting). */
+typedef struct bn_model_cost {
+    double macs_mfma;          /* multiply-accumulates issued on matrix cores (1x1 conv / conv1d / FC) */
+    double macs_valu;          /* multiply-accumulates on the vector ALU (depthwise, stem conv) */
+    double weight_bytes;       /* resident parameter bytes after folding/pruning */
+    double activation_bytes;   /* bytes of intermediates written to HBM per segment by the current plan */
+    int32_t n_launches;        /* kernel launches per batch in the current plan */
+} bn_model_cost;
+
+/* ---- version / device ------------------------------------------------- */
+int32_t bn_abi_version(void);
+/* Number of visible HIP devices whose arch is gfx950 (0 => every load fails with BN_ERR_NO_DEVICE). */
+int32_t bn_device_count(void);
+
+/* ---- model load: Session::builder()...commit_from_file(path)  (classifier.rs:340-350) ---- */
+/* model_type_override: -1 for auto-detection, else a bn_model_type (ClassifierBuilder::model_type). */
+bn_status bn_model_load(const char *onnx_path, int32_t device, int32_t model_type_override,
+                        bn_model **out);
+bn_status bn_model_load_buffer(const void *onnx_bytes, size_t len, int32_t device,
+                               int32_t model_type_override, bn_model **out);
+void bn_model_free(bn_model *m);
+/* session.inputs()/outputs() metadata (classifier.rs:387-420) */
+bn_status bn_model_io_info(const bn_model *m, bn_io_info *out);
+/* detect_model_type() result for the loaded graph (detection.rs:15-145) */
+bn_status bn_model_get_config(const bn_model *m, bn_model_config *out);
+bn_status bn_model_get_cost(const bn_model *m, bn_model_cost *out);
+
+/* The same detection rules exposed on raw shapes, for shims that keep
+ * detection on their side (detection.rs:15-80; override < 0 means None).
+ * out_shapes is the concatenation of all output shapes, out_ranks their ranks. */
+bn_status bn_detect_model_type(const int64_t *in_shape, size_t in_rank, const int64_t *out_shapes,
+                               const size_t *out_ranks, size_t n_out, int32_t model_type_override,
+                               bn_model_config *out);
+
+/* ---- context: session.create_binding() + vec![0f32; max*S]  (batch_context.rs:102-133) ---- */
+#define BN_CTX_DEFAULT 0u
+#define BN_CTX_ALL_OUTPUTS 1u /* also compute graph outputs the reference discards (Perch 1,2) */
+#define BN_CTX_NO_GRAPH 2u    /* launch kernels eagerly instead of replaying a captured hipGraph */
+bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **out);
+void bn_ctx_destroy(bn_ctx *c);
+size_t bn_ctx_max_batch(const bn_ctx *c);
+/* Bytes of device memory held by the context (activations arena + I/O buffers). */
+size_t bn_ctx_device_bytes(const bn_ctx *c);
+
+/*
+ * The hot call: session.run_with_options / run_binding_with_options
+ * (classifier.rs:637-639, 721-723, 851-853) together with the host staging of
+ * prepare_input (batch_context.rs:188-226) and the output copies of
+ * extract_outputs / extract_tensor_data (batch_context.rs:289-338,
+ * classifier.rs:1062-1077).
+ *
+ *   segs        batch_size pointers to sample_count host floats each
+ *   logits_out  host [batch_size * num_species]
+ *   emb_out     host [batch_size * embedding_dim], or NULL
+ *   cancel      optional flag polled while the batch runs (CancellationToken,
+ *               inference_options.rs:24-47); non-zero => BN_ERR_CANCELLED
+ *   timeout_ns  0 = none; exceeded => BN_ERR_TIMEOUT (RunOptions::terminate,
+ *               classifier.rs:527-554).  Granularity is one launch group.
+ * batch_size == 0 returns BN_OK and touches nothing (classifier.rs:681-683).
+ */
+bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch_size, float *logits_out,
+                   float *emb_out, const volatile int32_t *cancel, uint64_t timeout_ns);
+
+/* Same computation with the batch already resident in HBM as one contiguous
+ * [batch_size, sample_count] f32 array; outputs stay on the device.
+ * Asynchronous on the context's stream unless `sync` is non-zero. */
+bn_status bn_infer_device(bn_ctx *c, const float *d_pcm, size_t batch_size, int32_t sync);
+/* Device pointer and row length of graph output `index` after the last run
+ * (row-major [batch, row_elems] f32). */
+bn_status bn_ctx_output_device(const bn_ctx *c, int32_t index, const float **d_ptr,
+                               size_t *row_elems);
+/* Copy graph output `index` of the last run to host: [batch_size * row_elems]. */
+bn_status bn_ctx_read_output(bn_ctx *c, int32_t index, size_t batch_size, float *host_out);
+/* Block until the context's stream is idle (IoBinding::synchronize_outputs, batch_context.rs:276-281). */
+bn_status bn_ctx_synchronize(bn_ctx *c);
+/* The context's hipStream_t, for callers that order their own device work after it. */
+void *bn_ctx_stream(const bn_ctx *c);
+/* Mean device time per launch group of the last timed run is not kept here;
+ * use bn_ctx_time_kernels to measure: runs the plan once for batch_size with a
+ * HIP event pair around every launch on the context's stream and writes up to
+ * cap (name, microseconds) pairs.  Returns the number of launches. */
+size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch_size, char (*names)[BN_NAME_LEN], float *usec,
+                           double *macs, double *bytes, size_t cap);
+
+/*
+ * top_k_predictions (postprocess.rs:40-87) on the device-resident logits of
+ * the last run: per row the K = min(top_k, num_species) entries the
+ * reference's BinaryHeap keeps, sigmoid (postprocess.rs:91-93), the
+ * `confidence >= min_confidence` filter and the stable descending sort.
+ * Outputs are host arrays with row stride k_stride >= K:
+ *   idx_out[b*k_stride + j], conf_out[b*k_stride + j] for j < count_out[b].
+ * has_min == 0 <=> min_confidence == None.
+ */
+bn_status bn_topk(bn_ctx *c, size_t batch_size, size_t top_k, int32_t has_min, float min_conf,
+                  size_t k_stride, uint32_t *idx_out, float *conf_out, uint32_t *count_out);
+/* The same kernel on caller-provided device logits [rows, n] (any device buffer). */
+bn_status bn_topk_device(int32_t device, const float *d_logits, size_t rows, size_t n, size_t top_k,
+                         int32_t has_min, float min_conf, size_t k_stride, uint32_t *idx_out,
+                         float *conf_out, uint32_t *count_out);
+/* Host logits in, host results out (uploads, runs the kernel, downloads). */
+bn_status bn_topk_host(int32_t device, const float *logits, size_t rows, size_t n, size_t top_k,
+                       int32_t has_min, float min_conf, size_t k_stride, uint32_t *idx_out,
+                       float *conf_out, uint32_t *count_out);
+
+/* Diagnostic, needs no device: parse the file, build the launch plan (all graph
+ * outputs when all_outputs != 0, else logits + embeddings only) and write a
+ * text description (one line per launch, then totals) into buf.  Returns the
+ * number of bytes the full text needs (excluding the NUL); *status receives the
+ * outcome of the parse / detection / planning steps. */
+size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int32_t all_outputs,
+                        char *buf, size_t cap, bn_status *status);
+
+/* Message of the last failing call on this thread; returns its length. */
+size_t bn_last_error(char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIRDNET_HIP_H */

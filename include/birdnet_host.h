@@ -1,0 +1,291 @@
+/*
+ * birdnet_host.h -- host-side mirror of the reference's public inference API
+ * in C++17, layered on the C ABI of birdnet_hip.h.
+ *
+ * The reference's host language is Rust and no Rust toolchain exists in the
+ * build image, so the code a Rust maintainer would keep on their side of the
+ * FFI (Classifier, ClassifierBuilder, BatchInferenceContext, InferenceOptions,
+ * CancellationToken, Error, Prediction, PredictionResult) is written here in
+ * C++ with the same names, argument meaning and error behaviour:
+ *
+ *   birdnet::Classifier              src/classifier.rs:436-867
+ *   birdnet::ClassifierBuilder       src/classifier.rs:46-383
+ *   birdnet::BatchInferenceContext   src/batch_context.rs:70-165
+ *   birdnet::InferenceOptions        src/inference_options.rs:73-114
+ *   birdnet::CancellationToken       src/inference_options.rs:24-47
+ *   birdnet::Error                   src/error.rs:6-128 (variants on this path)
+ *   birdnet::ModelConfig / Prediction / PredictionResult   src/types.rs:72-109
+ *
+ * The second half of this header is a flat C ABI over those classes (bnh_*),
+ * used by the ctypes test/bench harness so that the parity tests exercise the
+ * compiled host code rather than a Python re-implementation.
+ */
+#ifndef BIRDNET_HOST_H
+#define BIRDNET_HOST_H
+
+#include "birdnet_hip.h"
+
+#ifdef __cplusplus
+#include <atomic>
+#include <chrono>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace birdnet {
+
+enum class ModelType { BirdNetV24 = 0, BirdNetV30 = 1, PerchV2 = 2 };
+uint32_t sample_rate(ModelType t);
+float segment_duration(ModelType t);
+size_t sample_count(ModelType t);
+bool has_embeddings(ModelType t);
+
+/* ExecutionProviderInfo (src/types.rs:124-185): only the two values this build can report. */
+enum class ExecutionProviderInfo { Cpu, Rocm };
+const char *as_str(ExecutionProviderInfo p);
+const char *category(ExecutionProviderInfo p);
+
+struct ModelConfig {
+    ModelType model_type;
+    uint32_t sample_rate;
+    float segment_duration;
+    size_t sample_count;
+    size_t num_species;
+    std::optional<size_t> embedding_dim;
+};
+
+struct Prediction {
+    std::string species;
+    float confidence;
+    size_t index;
+};
+
+struct PredictionResult {
+    ModelType model_type;
+    std::vector<Prediction> predictions;
+    std::optional<std::vector<float>> embeddings;
+    std::vector<float> raw_scores;
+};
+
+/* Error (src/error.rs): `kind` selects the variant, what() is the Display text. */
+class Error : public std::runtime_error {
+   public:
+    enum Kind {
+        InputSize,       /* expected, got */
+        BatchInputSize,  /* index, expected, got */
+        ModelDetection,
+        LabelCount,      /* expected, got */
+        ModelPathRequired,
+        LabelsRequired,
+        ModelLoad,
+        LabelLoad,
+        LabelParse,
+        Inference,
+        Timeout,         /* duration_ns */
+        Cancelled,
+    };
+    Error(Kind k, const std::string &msg, size_t index = 0, size_t expected = 0, size_t got = 0, uint64_t duration_ns = 0)
+        : std::runtime_error(msg), kind(k), index(index), expected(expected), got(got), duration_ns(duration_ns) {}
+    Kind kind;
+    size_t index, expected, got;
+    uint64_t duration_ns;
+};
+
+class CancellationToken {
+   public:
+    CancellationToken() : flag_(std::make_shared<std::atomic<int32_t>>(0)) {}
+    /* A token that observes a caller-owned flag (FFI callers hand over a plain int32). */
+    static CancellationToken alias(volatile int32_t *external) {
+        CancellationToken t;
+        t.flag_ = std::shared_ptr<std::atomic<int32_t>>(reinterpret_cast<std::atomic<int32_t> *>(const_cast<int32_t *>(external)),
+                                                        [](std::atomic<int32_t> *) {});
+        return t;
+    }
+    void cancel() const { flag_->store(1, std::memory_order_seq_cst); }
+    bool is_cancelled() const { return flag_->load(std::memory_order_seq_cst) != 0; }
+    const volatile int32_t *raw() const { return reinterpret_cast<const volatile int32_t *>(flag_.get()); }
+
+   private:
+    std::shared_ptr<std::atomic<int32_t>> flag_;
+};
+
+struct InferenceOptions {
+    std::optional<std::chrono::nanoseconds> timeout;
+    std::optional<CancellationToken> cancellation_token;
+    static InferenceOptions with_timeout_of(std::chrono::nanoseconds d) {
+        InferenceOptions o;
+        o.timeout = d;
+        return o;
+    }
+    InferenceOptions &with_timeout(std::chrono::nanoseconds d) {
+        timeout = d;
+        return *this;
+    }
+    InferenceOptions &with_cancellation_token(CancellationToken t) {
+        cancellation_token = std::move(t);
+        return *this;
+    }
+    bool needs_monitor() const { return timeout.has_value() || cancellation_token.has_value(); }
+};
+
+class Classifier;
+
+/* BatchInferenceContext (src/batch_context.rs:70-165): not thread-safe, one per thread. */
+class BatchInferenceContext {
+   public:
+    ~BatchInferenceContext();
+    BatchInferenceContext(const BatchInferenceContext &) = delete;
+    BatchInferenceContext &operator=(const BatchInferenceContext &) = delete;
+    size_t max_batch_size() const { return max_batch_size_; }
+    size_t sample_count() const { return sample_count_; }
+    size_t input_buffer_capacity() const { return max_batch_size_ * sample_count_; }
+    size_t input_buffer_bytes() const { return input_buffer_capacity() * sizeof(float); }
+    ModelType model_type() const { return model_type_; }
+
+   private:
+    friend class Classifier;
+    BatchInferenceContext() = default;
+    bn_ctx *ctx_ = nullptr;
+    size_t max_batch_size_ = 0, sample_count_ = 0;
+    ModelType model_type_ = ModelType::BirdNetV24;
+};
+
+struct ClassifierInner;
+
+class Classifier {
+   public:
+    const ModelConfig &config() const;
+    const std::vector<std::string> &labels() const;
+    ExecutionProviderInfo requested_provider() const;
+    /* src/classifier.rs:610-643 */
+    PredictionResult predict(const float *segment, size_t len, const InferenceOptions &options = {}) const;
+    /* src/classifier.rs:676-727; segments[i] has lens[i] samples */
+    std::vector<PredictionResult> predict_batch(const float *const *segments, const size_t *lens, size_t n,
+                                                const InferenceOptions &options = {}) const;
+    /* src/classifier.rs:777-792 (PerchV2 => Error::Inference, batch_context.rs:107-114) */
+    std::unique_ptr<BatchInferenceContext> create_batch_context(size_t max_batch_size) const;
+    /* src/classifier.rs:826-867 */
+    std::vector<PredictionResult> predict_batch_with_context(BatchInferenceContext &ctx, const float *const *segments, const size_t *lens,
+                                                             size_t n, const InferenceOptions &options = {}) const;
+
+   private:
+    friend class ClassifierBuilder;
+    std::shared_ptr<ClassifierInner> inner_;
+};
+
+class ClassifierBuilder {
+   public:
+    ClassifierBuilder &model_path(std::string p) { model_path_ = std::move(p); return *this; }
+    ClassifierBuilder &labels_path(std::string p) { labels_path_ = std::move(p); labels_.reset(); return *this; }
+    ClassifierBuilder &labels(std::vector<std::string> l) { labels_ = std::move(l); labels_path_.reset(); return *this; }
+    ClassifierBuilder &model_type(ModelType t) { model_type_ = t; return *this; }
+    ClassifierBuilder &top_k(size_t k) { top_k_ = k; return *this; }
+    ClassifierBuilder &min_confidence(float c) { min_confidence_ = c; return *this; }
+    /* with_rocm() (src/classifier.rs:287-292) selects the native MI355X path; device = HIP ordinal. */
+    ClassifierBuilder &with_rocm(int device = 0) { device_ = device; provider_ = ExecutionProviderInfo::Rocm; return *this; }
+    Classifier build();  /* src/classifier.rs:334-383 */
+
+   private:
+    std::optional<std::string> model_path_, labels_path_;
+    std::optional<std::vector<std::string>> labels_;
+    std::optional<ModelType> model_type_;
+    size_t top_k_ = 10;                    /* classifier.rs:72 */
+    std::optional<float> min_confidence_;  /* classifier.rs:73 */
+    int device_ = 0;
+    ExecutionProviderInfo provider_ = ExecutionProviderInfo::Cpu; /* classifier.rs:71 */
+};
+
+/* labels.rs:22-81: text (one per line, trimmed, blanks dropped) for v2.4, CSV first column for v3.0/Perch. */
+std::vector<std::string> load_labels_from_file(const std::string &path, ModelType t);
+std::vector<std::string> parse_text_labels(const std::string &content);
+std::vector<std::string> parse_csv_labels(const std::string &content);
+
+/* chunk_audio (src/bin/birdnet-analyze.rs:707-743): start sample + start time of every chunk. */
+struct Chunk {
+    size_t start;
+    float start_time;
+};
+std::vector<Chunk> chunk_plan(size_t n_samples, size_t segment_samples, float overlap_secs, uint32_t sample_rate);
+
+}  // namespace birdnet
+
+extern "C" {
+#endif /* __cplusplus */
+
+/* ---------------- flat C ABI over the C++ mirror (test / bench harness) ---------------- */
+typedef struct bnh_classifier bnh_classifier;
+typedef struct bnh_context bnh_context;
+typedef struct bnh_results bnh_results; /* Vec<PredictionResult> */
+
+/* Error kinds, same order as birdnet::Error::Kind; 0 = success. */
+enum {
+    BNH_OK = 0,
+    BNH_ERR_INPUT_SIZE = 1,
+    BNH_ERR_BATCH_INPUT_SIZE = 2,
+    BNH_ERR_MODEL_DETECTION = 3,
+    BNH_ERR_LABEL_COUNT = 4,
+    BNH_ERR_MODEL_PATH_REQUIRED = 5,
+    BNH_ERR_LABELS_REQUIRED = 6,
+    BNH_ERR_MODEL_LOAD = 7,
+    BNH_ERR_LABEL_LOAD = 8,
+    BNH_ERR_LABEL_PARSE = 9,
+    BNH_ERR_INFERENCE = 10,
+    BNH_ERR_TIMEOUT = 11,
+    BNH_ERR_CANCELLED = 12,
+    BNH_ERR_OTHER = 13
+};
+typedef struct bnh_error {
+    int32_t kind;
+    uint64_t index, expected, got, duration_ns;
+    char message[512];
+} bnh_error;
+
+/* Builder in one call.  labels: NULL => labels_path is used (either may be NULL => LabelsRequired).
+ * model_type < 0 => auto; top_k: value of .top_k(); has_min/min_conf: .min_confidence(). */
+int32_t bnh_classifier_build(const char *model_path, const char *labels_path, const char *const *labels, size_t n_labels,
+                             int32_t model_type, int64_t top_k, int32_t has_min, float min_conf, int32_t device,
+                             bnh_classifier **out, bnh_error *err);
+void bnh_classifier_free(bnh_classifier *c);
+void bnh_classifier_config(const bnh_classifier *c, bn_model_config *out);
+const char *bnh_classifier_provider(const bnh_classifier *c);
+size_t bnh_classifier_label_count(const bnh_classifier *c);
+const char *bnh_classifier_label(const bnh_classifier *c, size_t i);
+
+/* timeout_ns < 0 => None; cancel NULL => None (else a flag the caller may set from another thread). */
+int32_t bnh_predict(const bnh_classifier *c, const float *segment, size_t len, int64_t timeout_ns, const volatile int32_t *cancel,
+                    bnh_results **out, bnh_error *err);
+int32_t bnh_predict_batch(const bnh_classifier *c, const float *const *segments, const size_t *lens, size_t n, int64_t timeout_ns,
+                          const volatile int32_t *cancel, bnh_results **out, bnh_error *err);
+int32_t bnh_create_batch_context(const bnh_classifier *c, size_t max_batch, bnh_context **out, bnh_error *err);
+void bnh_context_free(bnh_context *ctx);
+size_t bnh_context_max_batch_size(const bnh_context *ctx);
+size_t bnh_context_sample_count(const bnh_context *ctx);
+size_t bnh_context_input_buffer_capacity(const bnh_context *ctx);
+size_t bnh_context_input_buffer_bytes(const bnh_context *ctx);
+int32_t bnh_context_model_type(const bnh_context *ctx);
+int32_t bnh_predict_batch_with_context(const bnh_classifier *c, bnh_context *ctx, const float *const *segments, const size_t *lens, size_t n,
+                                       int64_t timeout_ns, const volatile int32_t *cancel, bnh_results **out, bnh_error *err);
+
+size_t bnh_results_len(const bnh_results *r);
+int32_t bnh_result_model_type(const bnh_results *r, size_t i);
+size_t bnh_result_n_predictions(const bnh_results *r, size_t i);
+const char *bnh_result_species(const bnh_results *r, size_t i, size_t j);
+float bnh_result_confidence(const bnh_results *r, size_t i, size_t j);
+size_t bnh_result_index(const bnh_results *r, size_t i, size_t j);
+size_t bnh_result_raw_scores(const bnh_results *r, size_t i, const float **data);
+/* returns 0 and leaves *data NULL when embeddings is None */
+size_t bnh_result_embeddings(const bnh_results *r, size_t i, const float **data);
+void bnh_results_free(bnh_results *r);
+
+/* labels.rs parsers and chunk_audio, for host-logic tests */
+size_t bnh_parse_labels(const char *content, int32_t csv, char *out, size_t cap); /* '\n'-joined; returns needed bytes */
+size_t bnh_chunk_plan(size_t n_samples, size_t segment_samples, float overlap_secs, uint32_t sample_rate, uint64_t *starts,
+                      float *start_times, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIRDNET_HOST_H */

@@ -1,0 +1,401 @@
+"""CPU oracle for the network arithmetic -- TEST INFRASTRUCTURE ONLY.
+
+The reference (tphakala/rust-birdnet-onnx) contains no model arithmetic: the
+front end, the CNN and the head all live inside an external .onnx file that
+ONNX Runtime 1.22 executes (crate ``ort`` 2.0.0-rc.11, Cargo.lock:654-669;
+call sites src/classifier.rs:637-639, 721-723, 851-853).  Neither ONNX Runtime
+nor any model file exists offline, so this oracle restates the *published ONNX
+operator specification* (onnx.ai operator docs, default-domain opset 13-17) for
+the operators the model files use, evaluated with plain torch CPU tensor ops
+in NCHW exactly as the graph is written -- no fusion, no layout change, no
+shared code with the product (it even has its own protobuf reader).
+
+PARITY UNPINNED: there is no golden vector, known-answer test or runnable
+reference for the network's numeric output; what this oracle
+pins is "the HIP path computes the function the .onnx file denotes", to the
+fp32 tolerance stated in tests/test_gpu_parity.py.  ``dtype=torch.float64``
+evaluates the same graph in double precision to bound the oracle's own
+rounding error.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------ protobuf wire reader
+def _varint(buf: memoryview, pos: int):
+    v = 0
+    shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        v |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return v, pos
+        shift += 7
+
+
+def _fields(buf: memoryview):
+    pos, end = 0, len(buf)
+    while pos < end:
+        key, pos = _varint(buf, pos)
+        f, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 1:
+            v = bytes(buf[pos:pos + 8])
+            pos += 8
+        elif wt == 2:
+            n, pos = _varint(buf, pos)
+            v = buf[pos:pos + n]
+            pos += n
+        elif wt == 5:
+            v = bytes(buf[pos:pos + 4])
+            pos += 4
+        else:
+            raise ValueError(f"wire type {wt}")
+        yield f, wt, v
+
+
+def _signed(v: int) -> int:
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+_NP = {1: np.float32, 6: np.int32, 7: np.int64, 9: np.bool_, 11: np.float64}
+
+
+def _tensor(buf: memoryview):
+    dims, dt, raw, name = [], 0, None, ""
+    fl, i64, i32 = [], [], []
+    for f, wt, v in _fields(buf):
+        if f == 1:
+            if wt == 2:
+                p = 0
+                while p < len(v):
+                    d, p = _varint(v, p)
+                    dims.append(_signed(d))
+            else:
+                dims.append(_signed(v))
+        elif f == 2:
+            dt = v
+        elif f == 4:
+            fl.extend(struct.unpack(f"<{len(v) // 4}f", bytes(v)) if wt == 2 else struct.unpack("<f", v))
+        elif f == 5:
+            if wt == 2:
+                p = 0
+                while p < len(v):
+                    d, p = _varint(v, p)
+                    i32.append(_signed(d))
+            else:
+                i32.append(_signed(v))
+        elif f == 7:
+            if wt == 2:
+                p = 0
+                while p < len(v):
+                    d, p = _varint(v, p)
+                    i64.append(_signed(d))
+            else:
+                i64.append(_signed(v))
+        elif f == 8:
+            name = bytes(v).decode()
+        elif f == 9:
+            raw = bytes(v)
+    npdt = _NP[dt]
+    if raw is not None:
+        arr = np.frombuffer(raw, dtype=npdt).reshape(dims)
+    elif dt == 1:
+        arr = np.asarray(fl, dtype=np.float32).reshape(dims)
+    elif dt == 7:
+        arr = np.asarray(i64, dtype=np.int64).reshape(dims)
+    else:
+        arr = np.asarray(i32, dtype=npdt).reshape(dims)
+    return name, arr.copy()
+
+
+@dataclass
+class Node:
+    op: str
+    name: str
+    inputs: list
+    outputs: list
+    attrs: dict = field(default_factory=dict)
+
+
+def _attr(buf: memoryview):
+    name, val, ints, floats = "", None, [], []
+    for f, wt, v in _fields(buf):
+        if f == 1:
+            name = bytes(v).decode()
+        elif f == 2:
+            val = struct.unpack("<f", v)[0]
+        elif f == 3:
+            val = _signed(v)
+        elif f == 4:
+            val = bytes(v).decode()
+        elif f == 5:
+            val = _tensor(v)[1]
+        elif f == 7:
+            floats.extend(struct.unpack(f"<{len(v) // 4}f", bytes(v)) if wt == 2 else struct.unpack("<f", v))
+        elif f == 8:
+            if wt == 2:
+                p = 0
+                while p < len(v):
+                    d, p = _varint(v, p)
+                    ints.append(_signed(d))
+            else:
+                ints.append(_signed(v))
+    if val is None:
+        val = ints if ints else floats
+    return name, val
+
+
+def _node(buf: memoryview) -> Node:
+    n = Node("", "", [], [])
+    for f, wt, v in _fields(buf):
+        if f == 1:
+            n.inputs.append(bytes(v).decode())
+        elif f == 2:
+            n.outputs.append(bytes(v).decode())
+        elif f == 3:
+            n.name = bytes(v).decode()
+        elif f == 4:
+            n.op = bytes(v).decode()
+        elif f == 5:
+            k, val = _attr(v)
+            n.attrs[k] = val
+    return n
+
+
+def _value_info_name(buf: memoryview) -> str:
+    for f, wt, v in _fields(buf):
+        if f == 1:
+            return bytes(v).decode()
+    return ""
+
+
+@dataclass
+class Graph:
+    nodes: list
+    inits: dict
+    inputs: list
+    outputs: list
+
+
+def load_graph(data: bytes) -> Graph:
+    mv = memoryview(data)
+    g = None
+    for f, wt, v in _fields(mv):
+        if f == 7:
+            g = v
+    if g is None:
+        raise ValueError("no graph in model")
+    nodes, inits, inputs, outputs = [], {}, [], []
+    for f, wt, v in _fields(g):
+        if f == 1:
+            nodes.append(_node(v))
+        elif f == 5:
+            name, arr = _tensor(v)
+            inits[name] = arr
+        elif f == 11:
+            inputs.append(_value_info_name(v))
+        elif f == 12:
+            outputs.append(_value_info_name(v))
+    inputs = [i for i in inputs if i not in inits]
+    return Graph(nodes, inits, inputs, outputs)
+
+
+# ------------------------------------------------------------------ operator semantics (ONNX spec)
+def _t(a, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dtype) if t.is_floating_point() else t
+
+
+def _axes(node, env, idx, default=None):
+    if "axes" in node.attrs:
+        return [int(a) for a in node.attrs["axes"]]
+    if len(node.inputs) > idx and node.inputs[idx]:
+        return [int(a) for a in env[node.inputs[idx]].reshape(-1).tolist()]
+    return default
+
+
+def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dict:
+    """Evaluate the graph on input x (numpy [B, ...]); returns {output_name: numpy array}."""
+    env = {k: _t(v, dtype) for k, v in g.inits.items()}
+    env[g.inputs[0]] = _t(np.asarray(x), dtype)
+    want = list(outputs) if outputs is not None else list(g.outputs)
+    # dead code elimination so that only what is asked for is computed
+    producer = {o: n for n in g.nodes for o in n.outputs}
+    live, stack = set(), list(want)
+    while stack:
+        t = stack.pop()
+        n = producer.get(t)
+        if n is None or id(n) in live:
+            continue
+        live.add(id(n))
+        stack.extend(i for i in n.inputs if i)
+    with torch.no_grad():
+        for n in g.nodes:
+            if id(n) not in live:
+                continue
+            i = [env[k] if k else None for k in n.inputs]
+            a = n.attrs
+            op = n.op
+            if op == "Conv":
+                xx, w = i[0], i[1]
+                b = i[2] if len(i) > 2 else None
+                sp = xx.dim() - 2
+                strides = [int(s) for s in a.get("strides", [1] * sp)]
+                dil = [int(s) for s in a.get("dilations", [1] * sp)]
+                pads = [int(p) for p in a.get("pads", [0] * (2 * sp))]
+                groups = int(a.get("group", 1))
+                if a.get("auto_pad", "NOTSET") != "NOTSET":
+                    raise NotImplementedError("auto_pad")
+                # explicit zero padding (begin/end may differ), then an unpadded convolution
+                padl = []
+                for d in reversed(range(sp)):
+                    padl += [pads[d], pads[d + sp]]
+                if any(padl):
+                    xx = F.pad(xx, padl)
+                r = (F.conv1d if sp == 1 else F.conv2d)(xx, w, b, stride=strides, dilation=dil, groups=groups)
+            elif op == "BatchNormalization":
+                xx, sc, bi, mu, var = i[:5]
+                shape = [1, -1] + [1] * (xx.dim() - 2)
+                r = (xx - mu.reshape(shape)) / torch.sqrt(var.reshape(shape) + float(a.get("epsilon", 1e-5))) * sc.reshape(shape) + bi.reshape(shape)
+            elif op == "Relu":
+                r = torch.relu(i[0])
+            elif op == "Sigmoid":
+                r = torch.sigmoid(i[0])
+            elif op == "Tanh":
+                r = torch.tanh(i[0])
+            elif op == "Clip":
+                lo = i[1] if len(i) > 1 and i[1] is not None else a.get("min")
+                hi = i[2] if len(i) > 2 and i[2] is not None else a.get("max")
+                r = i[0]
+                if lo is not None:
+                    r = torch.maximum(r, torch.as_tensor(lo, dtype=r.dtype))
+                if hi is not None:
+                    r = torch.minimum(r, torch.as_tensor(hi, dtype=r.dtype))
+            elif op == "HardSigmoid":
+                r = torch.clamp(float(a.get("alpha", 0.2)) * i[0] + float(a.get("beta", 0.5)), 0.0, 1.0)
+            elif op == "HardSwish":
+                r = i[0] * torch.clamp(i[0] / 6.0 + 0.5, 0.0, 1.0)
+            elif op == "LeakyRelu":
+                r = torch.where(i[0] >= 0, i[0], float(a.get("alpha", 0.01)) * i[0])
+            elif op in ("Add", "Sub", "Mul", "Div", "Pow", "Max", "Min"):
+                fn = {"Add": torch.add, "Sub": torch.sub, "Mul": torch.mul, "Div": torch.div, "Pow": torch.pow,
+                      "Max": torch.maximum, "Min": torch.minimum}[op]
+                r = fn(i[0], i[1])
+            elif op in ("Exp", "Log", "Sqrt", "Abs", "Neg", "Floor", "Ceil", "Erf", "Reciprocal"):
+                r = {"Exp": torch.exp, "Log": torch.log, "Sqrt": torch.sqrt, "Abs": torch.abs, "Neg": torch.neg,
+                     "Floor": torch.floor, "Ceil": torch.ceil, "Erf": torch.erf, "Reciprocal": torch.reciprocal}[op](i[0])
+            elif op == "Softplus":
+                r = F.softplus(i[0])
+            elif op in ("Identity", "Dropout"):
+                r = i[0]
+            elif op == "Cast":
+                to = int(a["to"])
+                r = i[0].to(dtype) if to in (1, 10, 11) else i[0].to(torch.int64)
+            elif op == "Transpose":
+                perm = a.get("perm") or list(reversed(range(i[0].dim())))
+                r = i[0].permute(*[int(p) for p in perm])
+            elif op == "Reshape":
+                shape = [int(s) for s in i[1].tolist()]
+                shape = [i[0].shape[k] if s == 0 and not a.get("allowzero", 0) else s for k, s in enumerate(shape)]
+                r = i[0].reshape(shape)
+            elif op == "Flatten":
+                ax = int(a.get("axis", 1))
+                r = i[0].reshape(int(np.prod(i[0].shape[:ax])) if ax else 1, -1)
+            elif op == "Squeeze":
+                ax = _axes(n, env, 1)
+                r = i[0]
+                if ax is None:
+                    r = r.squeeze()
+                else:
+                    for d in sorted([d % i[0].dim() for d in ax], reverse=True):
+                        r = r.squeeze(d)
+            elif op == "Unsqueeze":
+                ax = _axes(n, env, 1)
+                rank = i[0].dim() + len(ax)
+                r = i[0]
+                for d in sorted(d % rank for d in ax):
+                    r = r.unsqueeze(d)
+            elif op == "Concat":
+                r = torch.cat(i, dim=int(a["axis"]))
+            elif op == "Slice":
+                if "starts" in a:
+                    starts, ends, axes = a["starts"], a["ends"], a.get("axes")
+                    steps = None
+                else:
+                    starts, ends = i[1].tolist(), i[2].tolist()
+                    axes = i[3].tolist() if len(i) > 3 and i[3] is not None else None
+                    steps = i[4].tolist() if len(i) > 4 and i[4] is not None else None
+                axes = axes if axes is not None else list(range(len(starts)))
+                steps = steps if steps is not None else [1] * len(starts)
+                arr = i[0].numpy()
+                idx = [slice(None)] * arr.ndim
+                for s, e, ax, st in zip(starts, ends, axes, steps):
+                    d = arr.shape[ax]
+                    s, e, st = int(s), int(e), int(st)
+                    if st > 0:
+                        s = min(max(s + d if s < 0 else s, 0), d)
+                        e = min(max(e + d if e < 0 else e, 0), d)
+                        idx[ax] = slice(s, e, st)
+                    else:
+                        s = min(max(s + d if s < 0 else s, 0), d - 1)
+                        e = -1 if e < -d - 1 else (e + d if e < 0 else e)
+                        e = min(max(e, -1), d - 1)
+                        idx[ax] = slice(s, None if e < 0 else e, st)
+                r = torch.from_numpy(np.ascontiguousarray(arr[tuple(idx)]))
+            elif op in ("ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "ReduceProd", "ReduceL2", "ReduceSumSquare"):
+                ax = _axes(n, env, 1)
+                keep = bool(a.get("keepdims", 1))
+                xx = i[0]
+                if op == "ReduceMean":
+                    r = xx.mean(dim=ax, keepdim=keep)
+                elif op == "ReduceSum":
+                    r = xx.sum(dim=ax, keepdim=keep)
+                elif op == "ReduceMax":
+                    r = xx.amax(dim=ax, keepdim=keep)
+                elif op == "ReduceMin":
+                    r = xx.amin(dim=ax, keepdim=keep)
+                elif op == "ReduceProd":
+                    r = xx
+                    for d in sorted([d % xx.dim() for d in ax], reverse=True):
+                        r = r.prod(dim=d, keepdim=keep)
+                elif op == "ReduceL2":
+                    r = (xx * xx).sum(dim=ax, keepdim=keep).sqrt()
+                else:
+                    r = (xx * xx).sum(dim=ax, keepdim=keep)
+            elif op == "GlobalAveragePool":
+                r = i[0].mean(dim=list(range(2, i[0].dim())), keepdim=True)
+            elif op == "GlobalMaxPool":
+                r = i[0].amax(dim=list(range(2, i[0].dim())), keepdim=True)
+            elif op == "MatMul":
+                r = torch.matmul(i[0], i[1])
+            elif op == "Gemm":
+                A = i[0].t() if a.get("transA", 0) else i[0]
+                Bm = i[1].t() if a.get("transB", 0) else i[1]
+                r = float(a.get("alpha", 1.0)) * (A @ Bm)
+                if len(i) > 2 and i[2] is not None:
+                    r = r + float(a.get("beta", 1.0)) * i[2]
+            elif op == "Constant":
+                r = _t(a["value"], dtype)
+            elif op == "Shape":
+                r = torch.tensor(list(i[0].shape), dtype=torch.int64)
+            elif op == "Gather":
+                r = torch.index_select(i[0], int(a.get("axis", 0)), i[1].reshape(-1).to(torch.int64))
+                if i[1].dim() == 0:
+                    r = r.squeeze(int(a.get("axis", 0)))
+            else:
+                raise NotImplementedError(f"oracle: operator {op}")
+            env[n.outputs[0]] = r
+    return {k: env[k].numpy() for k in want}
+
+
+def run_model(onnx_bytes: bytes, x: np.ndarray, dtype=torch.float32, outputs=None) -> dict:
+    return run_graph(load_graph(onnx_bytes), x, dtype, outputs)

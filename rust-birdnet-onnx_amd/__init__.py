@@ -1,0 +1,613 @@
+"""rust-birdnet-onnx_amd -- MI355X-native (gfx950 / HIP) BirdNET / Perch inference path.
+
+Python here is a ctypes harness over the C ABI of ``libbirdnet_hip.so``
+(``include/birdnet_hip.h`` = engine level, ``include/birdnet_host.h`` = the
+compiled C++ mirror of the reference's ``Classifier`` API).  Nothing in this
+package computes: if the shared library is missing the import fails loudly,
+and if no gfx950 device is visible every load fails with ``NoDevice`` -- there
+is no CPU fallback.
+
+Names mirror the reference (tphakala/rust-birdnet-onnx ``src/lib.rs:93-108``):
+``Classifier``, ``ClassifierBuilder``, ``BatchInferenceContext``,
+``InferenceOptions``, ``CancellationToken``, ``ModelType``, ``ModelConfig``,
+``Prediction``, ``PredictionResult``, ``Error``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbirdnet_hip.so")
+
+BN_MAX_OUTPUTS, BN_MAX_RANK, BN_NAME_LEN = 8, 6, 64
+BN_CTX_DEFAULT, BN_CTX_ALL_OUTPUTS, BN_CTX_NO_GRAPH = 0, 1, 2
+
+# every symbol include/birdnet_hip.h and include/birdnet_host.h declare
+ENGINE_SYMBOLS = [
+    "bn_abi_version", "bn_device_count", "bn_model_load", "bn_model_load_buffer", "bn_model_free",
+    "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create",
+    "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_device",
+    "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
+    "bn_topk", "bn_topk_device", "bn_topk_host", "bn_plan_describe", "bn_last_error",
+]
+HOST_SYMBOLS = [
+    "bnh_classifier_build", "bnh_classifier_free", "bnh_classifier_config", "bnh_classifier_provider",
+    "bnh_classifier_label_count", "bnh_classifier_label", "bnh_predict", "bnh_predict_batch",
+    "bnh_create_batch_context", "bnh_context_free", "bnh_context_max_batch_size", "bnh_context_sample_count",
+    "bnh_context_input_buffer_capacity", "bnh_context_input_buffer_bytes", "bnh_context_model_type",
+    "bnh_predict_batch_with_context", "bnh_results_len", "bnh_result_model_type", "bnh_result_n_predictions",
+    "bnh_result_species", "bnh_result_confidence", "bnh_result_index", "bnh_result_raw_scores",
+    "bnh_result_embeddings", "bnh_results_free", "bnh_parse_labels", "bnh_chunk_plan",
+]
+
+
+class BnIoInfo(C.Structure):
+    _fields_ = [("input_rank", C.c_int32), ("input_shape", C.c_int64 * BN_MAX_RANK),
+                ("input_name", C.c_char * BN_NAME_LEN), ("n_outputs", C.c_int32),
+                ("output_rank", C.c_int32 * BN_MAX_OUTPUTS),
+                ("output_shape", (C.c_int64 * BN_MAX_RANK) * BN_MAX_OUTPUTS),
+                ("output_name", (C.c_char * BN_NAME_LEN) * BN_MAX_OUTPUTS)]
+
+
+class BnModelConfig(C.Structure):
+    _fields_ = [("model_type", C.c_int32), ("sample_rate", C.c_uint32), ("segment_duration", C.c_float),
+                ("sample_count", C.c_uint64), ("num_species", C.c_uint64), ("has_embedding", C.c_int32),
+                ("embedding_dim", C.c_uint64), ("logits_output", C.c_int32), ("embedding_output", C.c_int32)]
+
+
+class BnModelCost(C.Structure):
+    _fields_ = [("macs_mfma", C.c_double), ("macs_valu", C.c_double), ("weight_bytes", C.c_double),
+                ("activation_bytes", C.c_double), ("n_launches", C.c_int32)]
+
+
+class BnhError(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("index", C.c_uint64), ("expected", C.c_uint64), ("got", C.c_uint64),
+                ("duration_ns", C.c_uint64), ("message", C.c_char * 512)]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or `make`. "
+            "This package has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    f32p, u32p, i64p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int64)
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int32
+    sig = {
+        "bn_abi_version": (i32, []),
+        "bn_device_count": (i32, []),
+        "bn_model_load": (i32, [C.c_char_p, i32, i32, C.POINTER(vp)]),
+        "bn_model_load_buffer": (i32, [vp, sz, i32, i32, C.POINTER(vp)]),
+        "bn_model_free": (None, [vp]),
+        "bn_model_io_info": (i32, [vp, C.POINTER(BnIoInfo)]),
+        "bn_model_get_config": (i32, [vp, C.POINTER(BnModelConfig)]),
+        "bn_model_get_cost": (i32, [vp, C.POINTER(BnModelCost)]),
+        "bn_detect_model_type": (i32, [i64p, sz, i64p, C.POINTER(sz), sz, i32, C.POINTER(BnModelConfig)]),
+        "bn_ctx_create": (i32, [vp, sz, C.c_uint32, C.POINTER(vp)]),
+        "bn_ctx_destroy": (None, [vp]),
+        "bn_ctx_max_batch": (sz, [vp]),
+        "bn_ctx_device_bytes": (sz, [vp]),
+        "bn_infer": (i32, [vp, C.POINTER(f32p), sz, f32p, f32p, C.POINTER(C.c_int32), C.c_uint64]),
+        "bn_infer_device": (i32, [vp, vp, sz, i32]),
+        "bn_ctx_output_device": (i32, [vp, i32, C.POINTER(vp), C.POINTER(sz)]),
+        "bn_ctx_read_output": (i32, [vp, i32, sz, f32p]),
+        "bn_ctx_synchronize": (i32, [vp]),
+        "bn_ctx_stream": (vp, [vp]),
+        "bn_ctx_time_kernels": (sz, [vp, sz, vp, f32p, C.POINTER(C.c_double), C.POINTER(C.c_double), sz]),
+        "bn_topk": (i32, [vp, sz, sz, i32, C.c_float, sz, u32p, f32p, u32p]),
+        "bn_topk_device": (i32, [i32, vp, sz, sz, sz, i32, C.c_float, sz, u32p, f32p, u32p]),
+        "bn_topk_host": (i32, [i32, f32p, sz, sz, sz, i32, C.c_float, sz, u32p, f32p, u32p]),
+        "bn_plan_describe": (sz, [C.c_char_p, i32, i32, C.c_char_p, sz, C.POINTER(i32)]),
+        "bn_last_error": (sz, [C.c_char_p, sz]),
+        # host mirror
+        "bnh_classifier_build": (i32, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), sz, i32, C.c_int64, i32,
+                                       C.c_float, i32, C.POINTER(vp), C.POINTER(BnhError)]),
+        "bnh_classifier_free": (None, [vp]),
+        "bnh_classifier_config": (None, [vp, C.POINTER(BnModelConfig)]),
+        "bnh_classifier_provider": (C.c_char_p, [vp]),
+        "bnh_classifier_label_count": (sz, [vp]),
+        "bnh_classifier_label": (C.c_char_p, [vp, sz]),
+        "bnh_predict": (i32, [vp, f32p, sz, C.c_int64, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(BnhError)]),
+        "bnh_predict_batch": (i32, [vp, C.POINTER(f32p), C.POINTER(sz), sz, C.c_int64, C.POINTER(C.c_int32),
+                                    C.POINTER(vp), C.POINTER(BnhError)]),
+        "bnh_create_batch_context": (i32, [vp, sz, C.POINTER(vp), C.POINTER(BnhError)]),
+        "bnh_context_free": (None, [vp]),
+        "bnh_context_max_batch_size": (sz, [vp]),
+        "bnh_context_sample_count": (sz, [vp]),
+        "bnh_context_input_buffer_capacity": (sz, [vp]),
+        "bnh_context_input_buffer_bytes": (sz, [vp]),
+        "bnh_context_model_type": (i32, [vp]),
+        "bnh_predict_batch_with_context": (i32, [vp, vp, C.POINTER(f32p), C.POINTER(sz), sz, C.c_int64,
+                                                 C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(BnhError)]),
+        "bnh_results_len": (sz, [vp]),
+        "bnh_result_model_type": (i32, [vp, sz]),
+        "bnh_result_n_predictions": (sz, [vp, sz]),
+        "bnh_result_species": (C.c_char_p, [vp, sz, sz]),
+        "bnh_result_confidence": (C.c_float, [vp, sz, sz]),
+        "bnh_result_index": (sz, [vp, sz, sz]),
+        "bnh_result_raw_scores": (sz, [vp, sz, C.POINTER(f32p)]),
+        "bnh_result_embeddings": (sz, [vp, sz, C.POINTER(f32p)]),
+        "bnh_results_free": (None, [vp]),
+        "bnh_parse_labels": (sz, [C.c_char_p, i32, C.c_char_p, sz]),
+        "bnh_chunk_plan": (sz, [sz, sz, C.c_float, C.c_uint32, C.POINTER(C.c_uint64), f32p, sz]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError => the library does not export what the headers declare
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(2048)
+    lib.bn_last_error(buf, 2048)
+    return buf.value.decode("utf-8", "replace")
+
+
+# ------------------------------------------------------------------ boundary types
+class ModelType(enum.IntEnum):
+    BirdNetV24 = 0
+    BirdNetV30 = 1
+    PerchV2 = 2
+
+    def sample_rate(self) -> int:
+        return 48000 if self is ModelType.BirdNetV24 else 32000
+
+    def segment_duration(self) -> float:
+        return 3.0 if self is ModelType.BirdNetV24 else 5.0
+
+    def sample_count(self) -> int:
+        return 144000 if self is ModelType.BirdNetV24 else 160000
+
+    def has_embeddings(self) -> bool:
+        return self is not ModelType.BirdNetV24
+
+
+@dataclass
+class ModelConfig:
+    model_type: ModelType
+    sample_rate: int
+    segment_duration: float
+    sample_count: int
+    num_species: int
+    embedding_dim: Optional[int]
+
+    @staticmethod
+    def _from(c: BnModelConfig) -> "ModelConfig":
+        return ModelConfig(ModelType(c.model_type), c.sample_rate, c.segment_duration, c.sample_count,
+                           c.num_species, c.embedding_dim if c.has_embedding else None)
+
+
+@dataclass
+class Prediction:
+    species: str
+    confidence: np.float32
+    index: int
+
+
+@dataclass
+class PredictionResult:
+    model_type: ModelType
+    predictions: list
+    embeddings: Optional[np.ndarray]
+    raw_scores: np.ndarray
+
+
+class ErrorKind(enum.IntEnum):
+    InputSize = 1
+    BatchInputSize = 2
+    ModelDetection = 3
+    LabelCount = 4
+    ModelPathRequired = 5
+    LabelsRequired = 6
+    ModelLoad = 7
+    LabelLoad = 8
+    LabelParse = 9
+    Inference = 10
+    Timeout = 11
+    Cancelled = 12
+    Other = 13
+
+
+class Error(Exception):
+    """reference src/error.rs: ``kind`` is the variant, ``str()`` the Display text."""
+
+    def __init__(self, e: BnhError):
+        super().__init__(e.message.decode("utf-8", "replace"))
+        self.kind = ErrorKind(e.kind)
+        self.index, self.expected, self.got, self.duration_ns = e.index, e.expected, e.got, e.duration_ns
+
+
+class EngineError(RuntimeError):
+    def __init__(self, status: int):
+        super().__init__(f"bn_status {status}: {last_error()}")
+        self.status = status
+
+
+class CancellationToken:
+    """reference src/inference_options.rs:24-47 (an int32 flag shared with the C ABI)."""
+
+    def __init__(self):
+        self._flag = C.c_int32(0)
+
+    def cancel(self):
+        self._flag.value = 1
+
+    def is_cancelled(self) -> bool:
+        return self._flag.value != 0
+
+
+class InferenceOptions:
+    """reference src/inference_options.rs:73-114; timeout in seconds (float) or None."""
+
+    def __init__(self, timeout: Optional[float] = None, cancellation_token: Optional[CancellationToken] = None):
+        self.timeout = timeout
+        self.cancellation_token = cancellation_token
+
+    @staticmethod
+    def with_timeout_of(seconds: float) -> "InferenceOptions":
+        return InferenceOptions(timeout=seconds)
+
+    def with_timeout(self, seconds: float) -> "InferenceOptions":
+        self.timeout = seconds
+        return self
+
+    def with_cancellation_token(self, token: CancellationToken) -> "InferenceOptions":
+        self.cancellation_token = token
+        return self
+
+    def needs_monitor(self) -> bool:
+        return self.timeout is not None or self.cancellation_token is not None
+
+    def _raw(self):
+        t = -1 if self.timeout is None else int(round(self.timeout * 1e9))
+        c = None if self.cancellation_token is None else C.byref(self.cancellation_token._flag)
+        return C.c_int64(t), c
+
+
+def _segments_arg(segments: Sequence[np.ndarray]):
+    arrs = [np.ascontiguousarray(s, dtype=np.float32) for s in segments]
+    n = len(arrs)
+    f32p = C.POINTER(C.c_float)
+    ptrs = (f32p * max(n, 1))(*[a.ctypes.data_as(f32p) for a in arrs])
+    lens = (C.c_size_t * max(n, 1))(*[a.shape[0] for a in arrs])
+    return arrs, ptrs, lens, n
+
+
+def _collect(res: C.c_void_p) -> list:
+    out = []
+    try:
+        for i in range(lib.bnh_results_len(res)):
+            preds = [Prediction(lib.bnh_result_species(res, i, j).decode("utf-8"),
+                                np.float32(lib.bnh_result_confidence(res, i, j)), lib.bnh_result_index(res, i, j))
+                     for j in range(lib.bnh_result_n_predictions(res, i))]
+            p = C.POINTER(C.c_float)()
+            n = lib.bnh_result_raw_scores(res, i, C.byref(p))
+            raw = np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+            n = lib.bnh_result_embeddings(res, i, C.byref(p))
+            emb = np.ctypeslib.as_array(p, shape=(n,)).copy() if n else None
+            out.append(PredictionResult(ModelType(lib.bnh_result_model_type(res, i)), preds, emb, raw))
+    finally:
+        lib.bnh_results_free(res)
+    return out
+
+
+class BatchInferenceContext:
+    """reference src/batch_context.rs:70-165."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.bnh_context_free(self._h)
+            self._h = None
+
+    def max_batch_size(self) -> int:
+        return lib.bnh_context_max_batch_size(self._h)
+
+    def sample_count(self) -> int:
+        return lib.bnh_context_sample_count(self._h)
+
+    def input_buffer_capacity(self) -> int:
+        return lib.bnh_context_input_buffer_capacity(self._h)
+
+    def input_buffer_bytes(self) -> int:
+        return lib.bnh_context_input_buffer_bytes(self._h)
+
+    def model_type(self) -> ModelType:
+        return ModelType(lib.bnh_context_model_type(self._h))
+
+
+class Classifier:
+    """reference src/classifier.rs:436-867, backed by the compiled C++ mirror."""
+
+    def __init__(self, handle):
+        self._h = handle
+        cfg = BnModelConfig()
+        lib.bnh_classifier_config(handle, C.byref(cfg))
+        self._config = ModelConfig._from(cfg)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.bnh_classifier_free(self._h)
+            self._h = None
+
+    @staticmethod
+    def builder() -> "ClassifierBuilder":
+        return ClassifierBuilder()
+
+    def config(self) -> ModelConfig:
+        return self._config
+
+    def labels(self) -> list:
+        return [lib.bnh_classifier_label(self._h, i).decode("utf-8") for i in range(lib.bnh_classifier_label_count(self._h))]
+
+    def requested_provider(self) -> str:
+        return lib.bnh_classifier_provider(self._h).decode()
+
+    def predict(self, segment, options: Optional[InferenceOptions] = None) -> PredictionResult:
+        options = options or InferenceOptions()
+        a = np.ascontiguousarray(segment, dtype=np.float32)
+        t, c = options._raw()
+        res, err = C.c_void_p(), BnhError()
+        if lib.bnh_predict(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.shape[0], t, c, C.byref(res), C.byref(err)):
+            raise Error(err)
+        return _collect(res)[0]
+
+    def predict_batch(self, segments, options: Optional[InferenceOptions] = None) -> list:
+        options = options or InferenceOptions()
+        arrs, ptrs, lens, n = _segments_arg(segments)
+        t, c = options._raw()
+        res, err = C.c_void_p(), BnhError()
+        if lib.bnh_predict_batch(self._h, ptrs, lens, n, t, c, C.byref(res), C.byref(err)):
+            raise Error(err)
+        return _collect(res)
+
+    def create_batch_context(self, max_batch_size: int) -> BatchInferenceContext:
+        h, err = C.c_void_p(), BnhError()
+        if lib.bnh_create_batch_context(self._h, max_batch_size, C.byref(h), C.byref(err)):
+            raise Error(err)
+        return BatchInferenceContext(h)
+
+    def predict_batch_with_context(self, context: BatchInferenceContext, segments,
+                                   options: Optional[InferenceOptions] = None) -> list:
+        options = options or InferenceOptions()
+        arrs, ptrs, lens, n = _segments_arg(segments)
+        t, c = options._raw()
+        res, err = C.c_void_p(), BnhError()
+        if lib.bnh_predict_batch_with_context(self._h, context._h, ptrs, lens, n, t, c, C.byref(res), C.byref(err)):
+            raise Error(err)
+        return _collect(res)
+
+
+class ClassifierBuilder:
+    """reference src/classifier.rs:46-383."""
+
+    def __init__(self):
+        self._model_path = None
+        self._labels_path = None
+        self._labels = None
+        self._model_type = -1
+        self._top_k = 10
+        self._min_conf = None
+        self._device = 0
+
+    def model_path(self, p: str):
+        self._model_path = p
+        return self
+
+    def labels_path(self, p: str):
+        self._labels_path, self._labels = p, None
+        return self
+
+    def labels(self, l: Sequence[str]):
+        self._labels, self._labels_path = list(l), None
+        return self
+
+    def model_type(self, t: ModelType):
+        self._model_type = int(t)
+        return self
+
+    def top_k(self, k: int):
+        self._top_k = k
+        return self
+
+    def min_confidence(self, c: float):
+        self._min_conf = c
+        return self
+
+    def with_rocm(self, device: int = 0):
+        self._device = device
+        return self
+
+    def build(self) -> Classifier:
+        h, err = C.c_void_p(), BnhError()
+        labs = None
+        n = 0
+        if self._labels is not None:
+            n = len(self._labels)
+            labs = (C.c_char_p * max(n, 1))(*[s.encode("utf-8") for s in self._labels])
+        top_k = self._top_k if self._top_k < 2 ** 63 else -1
+        rc = lib.bnh_classifier_build(None if self._model_path is None else self._model_path.encode(),
+                                      None if self._labels_path is None else self._labels_path.encode(), labs, n,
+                                      self._model_type, top_k, 0 if self._min_conf is None else 1,
+                                      C.c_float(self._min_conf or 0.0), self._device, C.byref(h), C.byref(err))
+        if rc:
+            raise Error(err)
+        return Classifier(h)
+
+
+# ------------------------------------------------------------------ engine-level wrappers (bench / tests)
+class Model:
+    """bn_model: what the Rust shim would hold in place of ort::Session."""
+
+    def __init__(self, path: str, device: int = 0, model_type: int = -1):
+        h = C.c_void_p()
+        st = lib.bn_model_load(path.encode(), device, model_type, C.byref(h))
+        if st:
+            raise EngineError(st)
+        self._h = h
+        cfg = BnModelConfig()
+        lib.bn_model_get_config(h, C.byref(cfg))
+        self.config = cfg
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.bn_model_free(self._h)
+            self._h = None
+
+    def io_info(self) -> BnIoInfo:
+        io = BnIoInfo()
+        lib.bn_model_io_info(self._h, C.byref(io))
+        return io
+
+    def cost(self) -> BnModelCost:
+        c = BnModelCost()
+        lib.bn_model_get_cost(self._h, C.byref(c))
+        return c
+
+
+class Context:
+    """bn_ctx: buffers + stream for one in-flight batch."""
+
+    def __init__(self, model: Model, max_batch: int, flags: int = BN_CTX_DEFAULT):
+        h = C.c_void_p()
+        st = lib.bn_ctx_create(model._h, max_batch, flags, C.byref(h))
+        if st:
+            raise EngineError(st)
+        self._h, self.model, self.max_batch = h, model, max_batch
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.bn_ctx_destroy(self._h)
+            self._h = None
+
+    def infer(self, segments: np.ndarray, want_embeddings: bool = True, timeout_ns: int = 0, cancel=None):
+        x = np.ascontiguousarray(segments, dtype=np.float32)
+        b = x.shape[0]
+        cfg = self.model.config
+        f32p = C.POINTER(C.c_float)
+        ptrs = (f32p * max(b, 1))(*[x[i].ctypes.data_as(f32p) for i in range(b)])
+        logits = np.empty((b, cfg.num_species), dtype=np.float32)
+        emb = np.empty((b, cfg.embedding_dim), dtype=np.float32) if (cfg.has_embedding and want_embeddings) else None
+        st = lib.bn_infer(self._h, ptrs, b, logits.ctypes.data_as(f32p),
+                          None if emb is None else emb.ctypes.data_as(f32p), cancel, timeout_ns)
+        if st:
+            raise EngineError(st)
+        return logits, emb
+
+    def infer_device(self, d_ptr: int, batch: int, sync: bool = False):
+        st = lib.bn_infer_device(self._h, C.c_void_p(d_ptr), batch, 1 if sync else 0)
+        if st:
+            raise EngineError(st)
+
+    def synchronize(self):
+        st = lib.bn_ctx_synchronize(self._h)
+        if st:
+            raise EngineError(st)
+
+    def output_device(self, index: int):
+        p, n = C.c_void_p(), C.c_size_t()
+        st = lib.bn_ctx_output_device(self._h, index, C.byref(p), C.byref(n))
+        if st:
+            raise EngineError(st)
+        return p.value, n.value
+
+    def read_output(self, index: int, batch: int) -> np.ndarray:
+        _, n = self.output_device(index)
+        out = np.empty((batch, n), dtype=np.float32)
+        st = lib.bn_ctx_read_output(self._h, index, batch, out.ctypes.data_as(C.POINTER(C.c_float)))
+        if st:
+            raise EngineError(st)
+        return out
+
+    def topk(self, batch: int, top_k: int, min_confidence: Optional[float] = None):
+        n = self.model.config.num_species
+        k = max(min(top_k, n), 1)
+        idx = np.zeros((batch, k), dtype=np.uint32)
+        conf = np.zeros((batch, k), dtype=np.float32)
+        cnt = np.zeros(batch, dtype=np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        st = lib.bn_topk(self._h, batch, top_k, 0 if min_confidence is None else 1,
+                         C.c_float(min_confidence or 0.0), k, idx.ctypes.data_as(u32p),
+                         conf.ctypes.data_as(C.POINTER(C.c_float)), cnt.ctypes.data_as(u32p))
+        if st:
+            raise EngineError(st)
+        return idx, conf, cnt
+
+    def time_kernels(self, batch: int):
+        cap = 1024
+        names = C.create_string_buffer(cap * BN_NAME_LEN)
+        usec = (C.c_float * cap)()
+        macs = (C.c_double * cap)()
+        byts = (C.c_double * cap)()
+        n = lib.bn_ctx_time_kernels(self._h, batch, C.cast(names, C.c_void_p), usec, macs, byts, cap)
+        out = []
+        for i in range(min(n, cap)):
+            nm = names.raw[i * BN_NAME_LEN:(i + 1) * BN_NAME_LEN].split(b"\0", 1)[0].decode()
+            out.append((nm, float(usec[i]), float(macs[i]), float(byts[i])))
+        return out
+
+    def stream(self) -> int:
+        return lib.bn_ctx_stream(self._h) or 0
+
+
+def topk_host(logits: np.ndarray, top_k: int, min_confidence: Optional[float] = None, device: int = 0):
+    """top_k_predictions (reference src/postprocess.rs:40-87) on the GPU for host logits [rows, n]."""
+    a = np.ascontiguousarray(logits, dtype=np.float32)
+    if a.ndim == 1:
+        a = a[None, :]
+    rows, n = a.shape
+    k = max(min(top_k, n), 1)
+    idx = np.zeros((rows, k), dtype=np.uint32)
+    conf = np.zeros((rows, k), dtype=np.float32)
+    cnt = np.zeros(rows, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    st = lib.bn_topk_host(device, a.ctypes.data_as(C.POINTER(C.c_float)), rows, n, min(top_k, 2 ** 63 - 1),
+                          0 if min_confidence is None else 1, C.c_float(min_confidence or 0.0), k,
+                          idx.ctypes.data_as(u32p), conf.ctypes.data_as(C.POINTER(C.c_float)), cnt.ctypes.data_as(u32p))
+    if st:
+        raise EngineError(st)
+    return idx, conf, cnt
+
+
+def plan_describe(path: str, model_type: int = -1, all_outputs: bool = False) -> str:
+    st = C.c_int32()
+    n = lib.bn_plan_describe(path.encode(), model_type, 1 if all_outputs else 0, None, 0, C.byref(st))
+    if st.value:
+        raise EngineError(st.value)
+    buf = C.create_string_buffer(n + 1)
+    lib.bn_plan_describe(path.encode(), model_type, 1 if all_outputs else 0, buf, n + 1, C.byref(st))
+    return buf.value.decode()
+
+
+def parse_labels(content: str, csv: bool) -> list:
+    n = lib.bnh_parse_labels(content.encode("utf-8"), 1 if csv else 0, None, 0)
+    buf = C.create_string_buffer(max(n, 1))
+    lib.bnh_parse_labels(content.encode("utf-8"), 1 if csv else 0, buf, max(n, 1))
+    s = buf.value.decode("utf-8")
+    return s.split("\n") if s else []
+
+
+def chunk_plan(n_samples: int, segment_samples: int, overlap_secs: float, sample_rate: int):
+    n = lib.bnh_chunk_plan(n_samples, segment_samples, C.c_float(overlap_secs), sample_rate, None, None, 0)
+    starts = np.zeros(max(n, 1), dtype=np.uint64)
+    times = np.zeros(max(n, 1), dtype=np.float32)
+    lib.bnh_chunk_plan(n_samples, segment_samples, C.c_float(overlap_secs), sample_rate,
+                       starts.ctypes.data_as(C.POINTER(C.c_uint64)), times.ctypes.data_as(C.POINTER(C.c_float)), n)
+    return starts[:n], times[:n]
+
+
+def device_count() -> int:
+    return lib.bn_device_count()

@@ -1,0 +1,679 @@
+// C ABI of libbirdnet_hip.so (include/birdnet_hip.h).
+#include "../../include/birdnet_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "detect.h"
+#include "engine.h"
+#include "kernels.h"
+
+using namespace bn;
+
+namespace {
+
+thread_local std::string g_err;
+
+bn_status fail(bn_status st, const std::string &msg) {
+    g_err = msg;
+    return st;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(BN_ERR_BACKEND, std::string(#expr) + " failed: " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct PlanDev {
+    std::unique_ptr<Plan> plan;
+    float *d_consts = nullptr;
+    ~PlanDev() {
+        if (d_consts) (void)hipFree(d_consts);
+    }
+};
+
+bool device_is_gfx950(int dev) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+}  // namespace
+
+struct bn_model {
+    int device = 0;
+    OnnxModel onnx;  // kept for the lazily built all-outputs plan
+    bn_model_config cfg{};
+    IoMeta io;
+    std::unique_ptr<PlanDev> main_plan;  // computes logits (+ embeddings) only
+    std::unique_ptr<PlanDev> full_plan;  // every graph output
+    std::mutex mu;
+};
+
+struct bn_ctx {
+    bn_model *model = nullptr;
+    PlanDev *pd = nullptr;
+    size_t max_batch = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    float *d_arena = nullptr;
+    float *d_input = nullptr;
+    float *h_input = nullptr;  // pinned
+    float *h_out = nullptr;    // pinned staging for logits + embeddings
+    size_t h_out_elems = 0;
+    size_t device_bytes = 0;
+    bool in_flight = false;  // a cancelled/timed-out run may still be executing
+    size_t last_batch = 0;
+    // top-K scratch
+    uint32_t *d_tk_idx = nullptr, *d_tk_cnt = nullptr;
+    float *d_tk_conf = nullptr;
+    size_t tk_cap = 0;  // elements of idx/conf
+    struct GraphKey {
+        size_t batch;
+        const float *in;
+        bool operator<(const GraphKey &o) const { return batch != o.batch ? batch < o.batch : in < o.in; }
+    };
+    std::map<GraphKey, hipGraphExec_t> graphs;
+};
+
+namespace {
+
+float *resolve(const bn_ctx *c, const Ref &r, const float *d_in) {
+    const Plan &p = *c->pd->plan;
+    switch (r.space) {
+        case Space::INPUT: return const_cast<float *>(d_in) + r.offset;
+        case Space::ARENA: return c->d_arena + p.storages[r.id].arena_off * (int64_t)c->max_batch + r.offset;
+        case Space::CONSTS: return c->pd->d_consts + p.const_off[r.id] + r.offset;
+        default: return nullptr;
+    }
+}
+
+void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t batch) {
+    float *out = resolve(c, op.out, d_in);
+    const float *a = resolve(c, op.a, d_in);
+    switch (op.kind) {
+        case OpKind::ELT: launch_eltwise(c->stream, op.elt, out, a, resolve(c, op.b, d_in), batch); break;
+        case OpKind::REDUCE: launch_reduce(c->stream, op.red, out, a, batch); break;
+        case OpKind::GEMM:
+            launch_gemm(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in),
+                        resolve(c, op.scale, d_in), batch);
+            break;
+        case OpKind::CONV:
+            launch_conv(c->stream, op.conv, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in), batch);
+            break;
+        case OpKind::DWCONV: launch_dwconv(c->stream, op.dw, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), batch); break;
+    }
+}
+
+// Enqueue the whole plan for `batch` segments on the context's stream.
+bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatile int32_t *cancel) {
+    const Plan &p = *c->pd->plan;
+    const bool use_graph = !(c->flags & BN_CTX_NO_GRAPH);
+    if (use_graph) {
+        bn_ctx::GraphKey key{batch, d_in};
+        auto it = c->graphs.find(key);
+        if (it == c->graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            for (auto &op : p.ops) launch_op(c, op, d_in, (int64_t)batch);
+            hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+            hipGraphExec_t ge = nullptr;
+            e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            if (c->graphs.size() >= 16) {  // bounded cache
+                for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+                c->graphs.clear();
+            }
+            it = c->graphs.emplace(key, ge).first;
+        }
+        HIP_TRY(hipGraphLaunch(it->second, c->stream));
+    } else {
+        for (auto &op : p.ops) {
+            if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
+            launch_op(c, op, d_in, (int64_t)batch);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return BN_OK;
+}
+
+bn_status drain_if_needed(bn_ctx *c) {
+    if (c->in_flight) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->in_flight = false;
+    }
+    return BN_OK;
+}
+
+// Wait for the stream while honouring cancel / deadline (classifier.rs:527-554 polls every
+// 10 ms; here the stream is polled, so a finished batch is never reported as timed out).
+bn_status wait_stream(bn_ctx *c, const volatile int32_t *cancel, uint64_t timeout_ns) {
+    if (!cancel && timeout_ns == 0) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return BN_OK;
+    }
+    const auto start = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (true) {
+        hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return BN_OK;
+        if (q != hipErrorNotReady) return fail(BN_ERR_BACKEND, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+        if (cancel && *cancel) {
+            c->in_flight = true;
+            return fail(BN_ERR_CANCELLED, "inference was cancelled");
+        }
+        if (timeout_ns) {
+            const uint64_t el = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - start).count();
+            if (el >= timeout_ns) {
+                c->in_flight = true;
+                return fail(BN_ERR_TIMEOUT, "inference timed out after " + std::to_string(timeout_ns) + " ns");
+            }
+        }
+        if (++spins > 200) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else std::this_thread::yield();
+    }
+}
+
+bn_status make_plan(bn_model *m, const std::vector<int> &wanted, std::unique_ptr<PlanDev> &out) {
+    auto pd = std::make_unique<PlanDev>();
+    try {
+        pd->plan = build_plan(m->onnx, wanted);
+    } catch (const UnsupportedModel &e) {
+        return fail(BN_ERR_UNSUPPORTED_MODEL, e.what());
+    } catch (const std::exception &e) {
+        return fail(BN_ERR_MODEL_LOAD, e.what());
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    const Plan &p = *pd->plan;
+    HIP_TRY(hipMalloc(&pd->d_consts, (size_t)p.consts_elems * sizeof(float)));
+    for (size_t k = 0; k < p.consts.size(); k++)
+        if (!p.consts[k].empty())
+            HIP_TRY(hipMemcpy(pd->d_consts + p.const_off[k], p.consts[k].data(), p.consts[k].size() * sizeof(float), hipMemcpyHostToDevice));
+    out = std::move(pd);
+    return BN_OK;
+}
+
+bn_status finish_load(std::unique_ptr<bn_model> m, int32_t device, int32_t model_type_override, bn_model **out) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(BN_ERR_NO_DEVICE, "no HIP device is visible; this path has no CPU fallback");
+    if (device < 0 || device >= n) return fail(BN_ERR_NO_DEVICE, "device index " + std::to_string(device) + " out of range (" + std::to_string(n) + " visible)");
+    if (!device_is_gfx950(device) && !getenv("BN_ALLOW_ANY_ARCH")) return fail(BN_ERR_NO_DEVICE, "device " + std::to_string(device) + " is not gfx950 (MI355X)");
+    m->device = device;
+    m->io = read_io_meta(m->onnx);
+    if (m->onnx.inputs.size() != 1) return fail(BN_ERR_MODEL_DETECTION, "model has " + std::to_string(m->onnx.inputs.size()) + " inputs, expected 1");
+    // Output shapes missing from the file: infer them by planning every output once.
+    bool missing = false;
+    for (auto &s : m->io.output_shapes) missing |= s.empty();
+    if (missing) {
+        std::vector<int> all;
+        for (size_t k = 0; k < m->onnx.outputs.size(); k++) all.push_back((int)k);
+        try {
+            auto p = build_plan(m->onnx, all);
+            for (size_t k = 0; k < p->outputs.size(); k++)
+                if (m->io.output_shapes[k].empty()) {
+                    m->io.output_shapes[k].push_back(-1);
+                    for (auto d : p->outputs[k].dims) m->io.output_shapes[k].push_back(d);
+                }
+        } catch (const UnsupportedModel &e) {
+            return fail(BN_ERR_UNSUPPORTED_MODEL, e.what());
+        } catch (const std::exception &e) {
+            return fail(BN_ERR_MODEL_LOAD, e.what());
+        }
+    }
+    std::string reason;
+    if (!detect_model_type(m->io.input_shape, m->io.output_shapes, model_type_override, m->cfg, reason)) return fail(BN_ERR_MODEL_DETECTION, reason);
+    std::vector<int> wanted{m->cfg.logits_output};
+    if (m->cfg.embedding_output >= 0) wanted.push_back(m->cfg.embedding_output);
+    bn_status st = make_plan(m.get(), wanted, m->main_plan);
+    if (st != BN_OK) return st;
+    if ((uint64_t)m->main_plan->plan->sample_count != m->cfg.sample_count) return fail(BN_ERR_MODEL_DETECTION, "input element count disagrees with the detected sample count");
+    *out = m.release();
+    return BN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t bn_abi_version(void) { return BN_ABI_VERSION; }
+
+int32_t bn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; d++) ok += device_is_gfx950(d) ? 1 : 0;
+    return ok;
+}
+
+bn_status bn_model_load(const char *onnx_path, int32_t device, int32_t model_type_override, bn_model **out) {
+    if (!onnx_path || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    auto m = std::make_unique<bn_model>();
+    try {
+        m->onnx = parse_onnx_file(onnx_path);
+    } catch (const std::exception &e) {
+        return fail(BN_ERR_MODEL_LOAD, e.what());
+    }
+    return finish_load(std::move(m), device, model_type_override, out);
+}
+
+bn_status bn_model_load_buffer(const void *bytes, size_t len, int32_t device, int32_t model_type_override, bn_model **out) {
+    if (!bytes || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    auto m = std::make_unique<bn_model>();
+    try {
+        m->onnx = parse_onnx(static_cast<const uint8_t *>(bytes), len);
+    } catch (const std::exception &e) {
+        return fail(BN_ERR_MODEL_LOAD, e.what());
+    }
+    return finish_load(std::move(m), device, model_type_override, out);
+}
+
+void bn_model_free(bn_model *m) { delete m; }
+
+bn_status bn_model_io_info(const bn_model *m, bn_io_info *out) {
+    if (!m || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    memset(out, 0, sizeof(*out));
+    out->input_rank = (int32_t)std::min<size_t>(m->io.input_shape.size(), BN_MAX_RANK);
+    for (int k = 0; k < out->input_rank; k++) out->input_shape[k] = m->io.input_shape[k];
+    snprintf(out->input_name, BN_NAME_LEN, "%s", m->io.input_name.c_str());
+    out->n_outputs = (int32_t)std::min<size_t>(m->io.output_names.size(), BN_MAX_OUTPUTS);
+    for (int o = 0; o < out->n_outputs; o++) {
+        out->output_rank[o] = (int32_t)std::min<size_t>(m->io.output_shapes[o].size(), BN_MAX_RANK);
+        for (int k = 0; k < out->output_rank[o]; k++) out->output_shape[o][k] = m->io.output_shapes[o][k] <= 0 && k == 0 ? -1 : m->io.output_shapes[o][k];
+        snprintf(out->output_name[o], BN_NAME_LEN, "%s", m->io.output_names[o].c_str());
+    }
+    return BN_OK;
+}
+
+bn_status bn_model_get_config(const bn_model *m, bn_model_config *out) {
+    if (!m || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    *out = m->cfg;
+    return BN_OK;
+}
+
+bn_status bn_model_get_cost(const bn_model *m, bn_model_cost *out) {
+    if (!m || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    const Plan &p = *m->main_plan->plan;
+    out->macs_mfma = p.macs_mfma;
+    out->macs_valu = p.macs_valu;
+    out->weight_bytes = p.weight_bytes;
+    out->activation_bytes = p.act_bytes;
+    out->n_launches = (int32_t)p.ops.size();
+    return BN_OK;
+}
+
+bn_status bn_detect_model_type(const int64_t *in_shape, size_t in_rank, const int64_t *out_shapes, const size_t *out_ranks, size_t n_out,
+                               int32_t model_type_override, bn_model_config *out) {
+    if (!in_shape || !out || (n_out && (!out_shapes || !out_ranks))) return fail(BN_ERR_INVALID_ARG, "null argument");
+    std::vector<int64_t> in(in_shape, in_shape + in_rank);
+    std::vector<std::vector<int64_t>> outs;
+    size_t off = 0;
+    for (size_t k = 0; k < n_out; k++) {
+        outs.emplace_back(out_shapes + off, out_shapes + off + out_ranks[k]);
+        off += out_ranks[k];
+    }
+    std::string reason;
+    if (!detect_model_type(in, outs, model_type_override, *out, reason)) return fail(BN_ERR_MODEL_DETECTION, reason);
+    return BN_OK;
+}
+
+bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **out) {
+    if (!m || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (max_batch == 0 || max_batch > 65535) return fail(BN_ERR_INVALID_ARG, "max_batch must be in 1..65535");
+    PlanDev *pd = m->main_plan.get();
+    if (flags & BN_CTX_ALL_OUTPUTS) {
+        std::lock_guard<std::mutex> lk(m->mu);
+        if (!m->full_plan) {
+            std::vector<int> all;
+            for (size_t k = 0; k < m->onnx.outputs.size(); k++) all.push_back((int)k);
+            bn_status st = make_plan(m, all, m->full_plan);
+            if (st != BN_OK) return st;
+        }
+        pd = m->full_plan.get();
+    }
+    if (getenv("BN_NO_GRAPH")) flags |= BN_CTX_NO_GRAPH;
+    auto c = std::make_unique<bn_ctx>();
+    c->model = m;
+    c->pd = pd;
+    c->max_batch = max_batch;
+    c->flags = flags;
+    const Plan &p = *pd->plan;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t arena_b = (size_t)p.arena_elems * max_batch * sizeof(float);
+    const size_t in_b = (size_t)p.sample_count * max_batch * sizeof(float);
+    HIP_TRY(hipMalloc(&c->d_arena, arena_b));
+    HIP_TRY(hipMalloc(&c->d_input, in_b));
+    HIP_TRY(hipHostMalloc(&c->h_input, in_b, hipHostMallocDefault));
+    c->h_out_elems = (size_t)(m->cfg.num_species + m->cfg.embedding_dim) * max_batch;
+    HIP_TRY(hipHostMalloc(&c->h_out, c->h_out_elems * sizeof(float), hipHostMallocDefault));
+    c->device_bytes = arena_b + in_b;
+    *out = c.release();
+    return BN_OK;
+}
+
+void bn_ctx_destroy(bn_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->model->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->d_input) (void)hipFree(c->d_input);
+    if (c->h_input) (void)hipHostFree(c->h_input);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->d_tk_idx) (void)hipFree(c->d_tk_idx);
+    if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
+    if (c->d_tk_cnt) (void)hipFree(c->d_tk_cnt);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+size_t bn_ctx_max_batch(const bn_ctx *c) { return c ? c->max_batch : 0; }
+size_t bn_ctx_device_bytes(const bn_ctx *c) { return c ? c->device_bytes : 0; }
+void *bn_ctx_stream(const bn_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+bn_status bn_ctx_synchronize(bn_ctx *c) {
+    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->in_flight = false;
+    return BN_OK;
+}
+
+bn_status bn_infer_device(bn_ctx *c, const float *d_pcm, size_t batch, int32_t sync) {
+    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
+    if (batch == 0) return BN_OK;
+    if (!d_pcm) return fail(BN_ERR_INVALID_ARG, "null input");
+    if (batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(batch) + " exceeds context max " + std::to_string(c->max_batch));
+    HIP_TRY(hipSetDevice(c->model->device));
+    bn_status st = drain_if_needed(c);
+    if (st != BN_OK) return st;
+    st = enqueue_plan(c, d_pcm, batch, nullptr);
+    if (st != BN_OK) return st;
+    c->last_batch = batch;
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    return BN_OK;
+}
+
+bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch, float *logits_out, float *emb_out, const volatile int32_t *cancel,
+                   uint64_t timeout_ns) {
+    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
+    if (batch == 0) return BN_OK;
+    if (!segs || !logits_out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    if (batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(batch) + " exceeds context max " + std::to_string(c->max_batch));
+    const Plan &p = *c->pd->plan;
+    const bn_model_config &cfg = c->model->cfg;
+    HIP_TRY(hipSetDevice(c->model->device));
+    bn_status st = drain_if_needed(c);
+    if (st != BN_OK) return st;
+    if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
+    const size_t S = (size_t)p.sample_count;
+    for (size_t b = 0; b < batch; b++) {
+        if (!segs[b]) return fail(BN_ERR_INVALID_ARG, "segment " + std::to_string(b) + " is null");
+        memcpy(c->h_input + b * S, segs[b], S * sizeof(float));
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_input, c->h_input, batch * S * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    st = enqueue_plan(c, c->d_input, batch, cancel);
+    if (st != BN_OK) {
+        c->in_flight = true;
+        return st;
+    }
+    c->last_batch = batch;
+    const OutputInfo &lo = p.outputs[cfg.logits_output];
+    const size_t N = (size_t)lo.row_elems;
+    float *h_logits = c->h_out;
+    float *h_emb = c->h_out + N * c->max_batch;
+    HIP_TRY(hipMemcpyAsync(h_logits, resolve(c, lo.ref, c->d_input), batch * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    size_t E = 0;
+    if (emb_out && cfg.embedding_output >= 0) {
+        const OutputInfo &eo = p.outputs[cfg.embedding_output];
+        E = (size_t)eo.row_elems;
+        HIP_TRY(hipMemcpyAsync(h_emb, resolve(c, eo.ref, c->d_input), batch * E * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    st = wait_stream(c, cancel, timeout_ns);
+    if (st != BN_OK) return st;
+    memcpy(logits_out, h_logits, batch * N * sizeof(float));
+    if (E) memcpy(emb_out, h_emb, batch * E * sizeof(float));
+    return BN_OK;
+}
+
+bn_status bn_ctx_output_device(const bn_ctx *c, int32_t index, const float **d_ptr, size_t *row_elems) {
+    if (!c || !d_ptr || !row_elems) return fail(BN_ERR_INVALID_ARG, "null argument");
+    const Plan &p = *c->pd->plan;
+    if (index < 0 || index >= (int)p.outputs.size()) return fail(BN_ERR_INVALID_ARG, "output index out of range");
+    if (!p.outputs[index].computed) return fail(BN_ERR_INVALID_ARG, "output " + std::to_string(index) + " is not computed by this context (create it with BN_CTX_ALL_OUTPUTS)");
+    *d_ptr = resolve(c, p.outputs[index].ref, c->d_input);
+    *row_elems = (size_t)p.outputs[index].row_elems;
+    return BN_OK;
+}
+
+bn_status bn_ctx_read_output(bn_ctx *c, int32_t index, size_t batch, float *host_out) {
+    const float *d = nullptr;
+    size_t row = 0;
+    bn_status st = bn_ctx_output_device(c, index, &d, &row);
+    if (st != BN_OK) return st;
+    if (!host_out || batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "bad host buffer / batch");
+    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->in_flight = false;
+    HIP_TRY(hipMemcpy(host_out, d, batch * row * sizeof(float), hipMemcpyDeviceToHost));
+    return BN_OK;
+}
+
+size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch, char (*names)[BN_NAME_LEN], float *usec, double *macs, double *bytes, size_t cap) {
+    if (!c || batch == 0 || batch > c->max_batch) return 0;
+    const Plan &p = *c->pd->plan;
+    if (hipSetDevice(c->model->device) != hipSuccess) return 0;
+    (void)hipStreamSynchronize(c->stream);
+    std::vector<hipEvent_t> ev(p.ops.size() + 1);
+    for (auto &e : ev) (void)hipEventCreate(&e);
+    // warm (instruction caches, clocks) then measure
+    for (auto &op : p.ops) launch_op(c, op, c->d_input, (int64_t)batch);
+    (void)hipEventRecord(ev[0], c->stream);
+    for (size_t k = 0; k < p.ops.size(); k++) {
+        launch_op(c, p.ops[k], c->d_input, (int64_t)batch);
+        (void)hipEventRecord(ev[k + 1], c->stream);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    for (size_t k = 0; k < p.ops.size() && k < cap; k++) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
+        if (usec) usec[k] = ms * 1000.0f;
+        if (names) snprintf(names[k], BN_NAME_LEN, "%s", p.ops[k].name.c_str());
+        if (macs) macs[k] = p.ops[k].macs * (double)batch;
+        if (bytes) bytes[k] = p.ops[k].bytes * (double)batch + p.ops[k].weight_bytes;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return p.ops.size();
+}
+
+static bn_status topk_run(int device, hipStream_t stream, const float *d_logits, size_t rows, size_t n, size_t top_k, int32_t has_min,
+                          float min_conf, size_t k_stride, uint32_t *d_idx, float *d_conf, uint32_t *d_cnt, uint32_t *idx_out,
+                          float *conf_out, uint32_t *count_out) {
+    (void)device;
+    const size_t k = std::min(top_k, n);
+    if (k_stride < k) return fail(BN_ERR_INVALID_ARG, "k_stride smaller than min(top_k, n)");
+    if (topk_lds_bytes((int64_t)n, (int64_t)k) == 0) return fail(BN_ERR_INVALID_ARG, "top_k too large for the on-chip heap (k <= 9000)");
+    launch_topk(stream, d_logits, (int64_t)rows, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, d_idx, d_conf, d_cnt);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> h_idx(rows * k), h_cnt(rows);
+    std::vector<float> h_conf(rows * k);
+    HIP_TRY(hipMemcpyAsync(h_cnt.data(), d_cnt, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_idx.data(), d_idx, rows * k * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_conf.data(), d_conf, rows * k * sizeof(float), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (size_t r = 0; r < rows; r++) {
+        count_out[r] = h_cnt[r];
+        for (size_t j = 0; j < h_cnt[r]; j++) {
+            idx_out[r * k_stride + j] = h_idx[r * k + j];
+            conf_out[r * k_stride + j] = h_conf[r * k + j];
+        }
+    }
+    return BN_OK;
+}
+
+bn_status bn_topk(bn_ctx *c, size_t batch, size_t top_k, int32_t has_min, float min_conf, size_t k_stride, uint32_t *idx_out, float *conf_out,
+                  uint32_t *count_out) {
+    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
+    if (batch == 0) return BN_OK;
+    if (!count_out || batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "bad arguments");
+    const Plan &p = *c->pd->plan;
+    const OutputInfo &lo = p.outputs[c->model->cfg.logits_output];
+    const size_t n = (size_t)lo.row_elems;
+    const size_t k = std::min(top_k, n);
+    if (k == 0) {
+        for (size_t r = 0; r < batch; r++) count_out[r] = 0;
+        return BN_OK;
+    }
+    if (!idx_out || !conf_out) return fail(BN_ERR_INVALID_ARG, "null output");
+    HIP_TRY(hipSetDevice(c->model->device));
+    const size_t need = c->max_batch * k;
+    if (need > c->tk_cap) {
+        if (c->d_tk_idx) (void)hipFree(c->d_tk_idx);
+        if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
+        c->d_tk_idx = nullptr;
+        c->d_tk_conf = nullptr;
+        HIP_TRY(hipMalloc(&c->d_tk_idx, need * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_tk_conf, need * sizeof(float)));
+        c->tk_cap = need;
+    }
+    if (!c->d_tk_cnt) HIP_TRY(hipMalloc(&c->d_tk_cnt, c->max_batch * sizeof(uint32_t)));
+    return topk_run(c->model->device, c->stream, resolve(c, lo.ref, c->d_input), batch, n, top_k, has_min, min_conf, k_stride, c->d_tk_idx,
+                    c->d_tk_conf, c->d_tk_cnt, idx_out, conf_out, count_out);
+}
+
+bn_status bn_topk_device(int32_t device, const float *d_logits, size_t rows, size_t n, size_t top_k, int32_t has_min, float min_conf,
+                         size_t k_stride, uint32_t *idx_out, float *conf_out, uint32_t *count_out) {
+    if (rows == 0) return BN_OK;
+    if (!count_out) return fail(BN_ERR_INVALID_ARG, "null output");
+    const size_t k = std::min(top_k, n);
+    if (k == 0) {
+        for (size_t r = 0; r < rows; r++) count_out[r] = 0;
+        return BN_OK;
+    }
+    if (!d_logits || !idx_out || !conf_out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BN_ERR_NO_DEVICE, "no HIP device is visible; this path has no CPU fallback");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *d_idx = nullptr, *d_cnt = nullptr;
+    float *d_conf = nullptr;
+    HIP_TRY(hipMalloc(&d_idx, rows * k * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&d_conf, rows * k * sizeof(float)));
+    HIP_TRY(hipMalloc(&d_cnt, rows * sizeof(uint32_t)));
+    bn_status st = topk_run(device, nullptr, d_logits, rows, n, top_k, has_min, min_conf, k_stride, d_idx, d_conf, d_cnt, idx_out, conf_out, count_out);
+    (void)hipFree(d_idx);
+    (void)hipFree(d_conf);
+    (void)hipFree(d_cnt);
+    return st;
+}
+
+bn_status bn_topk_host(int32_t device, const float *logits, size_t rows, size_t n, size_t top_k, int32_t has_min, float min_conf,
+                       size_t k_stride, uint32_t *idx_out, float *conf_out, uint32_t *count_out) {
+    if (rows == 0) return BN_OK;
+    if (!count_out) return fail(BN_ERR_INVALID_ARG, "null output");
+    if (n == 0 || top_k == 0) {
+        for (size_t r = 0; r < rows; r++) count_out[r] = 0;
+        return BN_OK;
+    }
+    if (!logits) return fail(BN_ERR_INVALID_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BN_ERR_NO_DEVICE, "no HIP device is visible; this path has no CPU fallback");
+    HIP_TRY(hipSetDevice(device));
+    float *d = nullptr;
+    HIP_TRY(hipMalloc(&d, rows * n * sizeof(float)));
+    hipError_t e = hipMemcpy(d, logits, rows * n * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(BN_ERR_BACKEND, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    }
+    bn_status st = bn_topk_device(device, d, rows, n, top_k, has_min, min_conf, k_stride, idx_out, conf_out, count_out);
+    (void)hipFree(d);
+    return st;
+}
+
+size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int32_t all_outputs, char *buf, size_t cap, bn_status *status) {
+    bn_status dummy;
+    if (!status) status = &dummy;
+    *status = BN_OK;
+    std::string text;
+    try {
+        if (!onnx_path) throw std::runtime_error("null path");
+        OnnxModel om = parse_onnx_file(onnx_path);
+        IoMeta io = read_io_meta(om);
+        std::vector<int> wanted;
+        bn_model_config cfg{};
+        std::string reason;
+        if (all_outputs) {
+            for (size_t k = 0; k < om.outputs.size(); k++) wanted.push_back((int)k);
+        } else {
+            if (!detect_model_type(io.input_shape, io.output_shapes, model_type_override, cfg, reason)) {
+                *status = fail(BN_ERR_MODEL_DETECTION, reason);
+                return 0;
+            }
+            wanted.push_back(cfg.logits_output);
+            if (cfg.embedding_output >= 0) wanted.push_back(cfg.embedding_output);
+        }
+        auto p = build_plan(om, wanted);
+        static const char *kinds[] = {"ELT", "REDUCE", "GEMM", "CONV", "DWCONV"};
+        char line[512];
+        for (size_t k = 0; k < p->ops.size(); k++) {
+            const PlanOp &op = p->ops[k];
+            std::string extra;
+            if (op.kind == OpKind::GEMM) {
+                snprintf(line, sizeof(line), " rows=%lld K=%d N=%d lda=%lld act=%d bias=%d res=%d", (long long)op.gemm.rows, op.gemm.K, op.gemm.N, (long long)op.gemm.lda, op.gemm.act, op.gemm.has_bias, op.gemm.has_res);
+                extra = line;
+            } else if (op.kind == OpKind::DWCONV) {
+                snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%d act=%d", op.dw.H, op.dw.W, op.dw.C, op.dw.OH, op.dw.OW, op.dw.kh, op.dw.kw, op.dw.sh, op.dw.act);
+                extra = line;
+            } else if (op.kind == OpKind::CONV) {
+                snprintf(line, sizeof(line), " %dx%dx%d->%dx%dx%d k=%dx%d s=%d g=%d act=%d", op.conv.H, op.conv.W, op.conv.Cin, op.conv.OH, op.conv.OW, op.conv.Cout, op.conv.kh, op.conv.kw, op.conv.sh, op.conv.groups, op.conv.act);
+                extra = line;
+            } else if (op.kind == OpKind::ELT) {
+                snprintf(line, sizeof(line), " n=%lld nd=%d bin=%d act=%d flat=%d", (long long)op.elt.per_sample, op.elt.nd, op.elt.bin, op.elt.act, op.elt.flat);
+                extra = line;
+            } else {
+                snprintf(line, sizeof(line), " kept=%lld red=%lld op=%d inner_kept=%d", (long long)op.red.kept, (long long)op.red.red, op.red.op, op.red.inner_kept);
+                extra = line;
+            }
+            snprintf(line, sizeof(line), "%3zu %-6s %-40s macs=%.3g bytes=%.3g", k, kinds[(int)op.kind], op.name.c_str(), op.macs, op.bytes);
+            text += line + extra + "\n";
+        }
+        snprintf(line, sizeof(line), "TOTAL launches=%zu macs_mfma=%.6g macs_valu=%.6g act_bytes=%.6g weight_bytes=%.6g arena_bytes_per_sample=%lld consts_bytes=%lld\n",
+                 p->ops.size(), p->macs_mfma, p->macs_valu, p->act_bytes, p->weight_bytes, (long long)p->arena_elems * 4, (long long)p->consts_elems * 4);
+        text += line;
+        for (size_t k = 0; k < p->outputs.size(); k++) {
+            snprintf(line, sizeof(line), "OUTPUT %zu %s computed=%d row_elems=%lld\n", k, p->outputs[k].name.c_str(), (int)p->outputs[k].computed, (long long)p->outputs[k].row_elems);
+            text += line;
+        }
+    } catch (const UnsupportedModel &e) {
+        *status = fail(BN_ERR_UNSUPPORTED_MODEL, e.what());
+        return 0;
+    } catch (const std::exception &e) {
+        *status = fail(BN_ERR_MODEL_LOAD, e.what());
+        return 0;
+    }
+    if (buf && cap) snprintf(buf, cap, "%s", text.c_str());
+    return text.size();
+}
+
+size_t bn_last_error(char *buf, size_t cap) {
+    if (buf && cap) snprintf(buf, cap, "%s", g_err.c_str());
+    return g_err.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,1429 @@
+// ONNX graph -> launch plan.  See engine.h.
+//
+// Conventions
+//  * Every activation has the batch as its outermost dimension; `dims` /
+//    `strides` below describe ONE sample (batch stripped).  Ops that would mix
+//    the batch with other dimensions are refused.
+//  * Activations are strided views over per-sample storages, so Transpose,
+//    Reshape, Squeeze, Unsqueeze, Slice (incl. negative steps) and Identity
+//    cost nothing.  Convolutions produce channels-last (NHWC / NWC) storage,
+//    which is what the MFMA GEMM and the depthwise kernel want; an ONNX NCHW
+//    tensor is simply the view dims=[C,H,W], strides=[1,W*C,C] over it.
+//  * Conv+BatchNorm+activation(+residual Add) and MatMul/Gemm+bias+activation
+//    chains are folded into one launch at import time.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <numeric>
+#include <set>
+
+namespace bn {
+namespace {
+
+constexpr int64_t BATCH_SENTINEL = -1000000007;  // "the batch size" inside folded shape tensors
+
+using Dims = std::vector<int64_t>;
+
+int64_t prod(const Dims &d) {
+    int64_t n = 1;
+    for (auto v : d) n *= v;
+    return n;
+}
+Dims row_major(const Dims &d) {
+    Dims s(d.size());
+    int64_t acc = 1;
+    for (int i = (int)d.size() - 1; i >= 0; i--) {
+        s[i] = acc;
+        acc *= d[i];
+    }
+    return s;
+}
+std::string dims_str(const Dims &d) {
+    std::string s = "[";
+    for (size_t i = 0; i < d.size(); i++) s += (i ? "," : "") + std::to_string(d[i]);
+    return s + "]";
+}
+
+struct Val {
+    bool is_const = false;
+    bool is_int = false;
+    Dims dims;     // const: full dims; activation: per-sample dims
+    Dims strides;  // activation only (elements)
+    Space space = Space::NONE;
+    int32_t storage = -1;
+    int64_t offset = 0;
+    std::vector<float> f;
+    std::vector<int64_t> i;
+    int64_t numel() const { return prod(dims); }
+    bool contiguous() const { return !is_const && strides_equal(row_major(dims)); }
+    bool strides_equal(const Dims &s) const {
+        for (size_t k = 0; k < dims.size(); k++)
+            if (dims[k] != 1 && strides[k] != s[k]) return false;
+        return true;
+    }
+};
+
+[[noreturn]] void unsupported(const OnnxNode &n, const std::string &why) {
+    throw UnsupportedModel("node '" + n.name + "' (" + n.op_type + "): " + why);
+}
+
+struct ActSpec {
+    int32_t act = ACT_NONE;
+    float p0 = 0, p1 = 0;
+};
+
+class Builder {
+   public:
+    Builder(const OnnxModel &m, Plan &p) : m_(m), plan_(p) {}
+
+    void run(const std::vector<int> &wanted) {
+        plan_.io = read_io_meta(m_);
+        if (m_.inputs.size() != 1)
+            throw UnsupportedModel("expected exactly one graph input, found " + std::to_string(m_.inputs.size()));
+        nodes_ = m_.nodes;  // mutable copy (pruning edits attributes / initializers)
+        for (auto &t : m_.initializers) {
+            Val v;
+            v.is_const = true;
+            v.dims = t.dims;
+            if (t.is_float()) v.f = t.f;
+            else { v.is_int = true; v.i = t.i; }
+            vals_[t.name] = std::move(v);
+        }
+        // graph input
+        const auto &in = m_.inputs[0];
+        if (!in.has_shape || in.shape.size() < 2)
+            throw UnsupportedModel("graph input must have a [batch, samples] or [batch, 1, samples] shape");
+        {
+            Val v;
+            v.dims.assign(in.shape.begin() + 1, in.shape.end());
+            for (auto d : v.dims)
+                if (d <= 0) throw UnsupportedModel("graph input has a dynamic non-batch dimension");
+            v.strides = row_major(v.dims);
+            v.space = Space::INPUT;
+            vals_[in.name] = v;
+            plan_.sample_count = v.numel();
+        }
+        // liveness from wanted outputs
+        std::set<std::string> want;
+        for (int w : wanted) {
+            if (w < 0 || w >= (int)m_.outputs.size()) throw UnsupportedModel("wanted output index out of range");
+            want.insert(m_.outputs[w].name);
+        }
+        for (auto &o : m_.outputs) graph_outputs_.insert(o.name);
+        live_.assign(nodes_.size(), false);
+        {
+            std::map<std::string, int> producer;
+            for (size_t k = 0; k < nodes_.size(); k++)
+                for (auto &o : nodes_[k].outputs) producer[o] = (int)k;
+            std::vector<std::string> stack(want.begin(), want.end());
+            while (!stack.empty()) {
+                std::string t = stack.back();
+                stack.pop_back();
+                auto it = producer.find(t);
+                if (it == producer.end() || live_[it->second]) continue;
+                live_[it->second] = true;
+                for (auto &i : nodes_[it->second].inputs)
+                    if (!i.empty()) stack.push_back(i);
+            }
+        }
+        for (size_t k = 0; k < nodes_.size(); k++)
+            if (live_[k])
+                for (auto &i : nodes_[k].inputs)
+                    if (!i.empty()) consumers_[i].push_back((int)k);
+        wanted_names_ = want;
+        absorbed_.assign(nodes_.size(), false);
+
+        prune_zero_rows();
+
+        for (size_t k = 0; k < nodes_.size(); k++) {
+            if (!live_[k] || absorbed_[k]) continue;
+            cur_ = (int)k;
+            lower(nodes_[k]);
+        }
+        // outputs
+        plan_.outputs.resize(m_.outputs.size());
+        for (size_t k = 0; k < m_.outputs.size(); k++) {
+            auto &oi = plan_.outputs[k];
+            oi.name = m_.outputs[k].name;
+            if (!want.count(oi.name)) continue;
+            auto it = vals_.find(oi.name);
+            if (it == vals_.end()) throw UnsupportedModel("graph output '" + oi.name + "' was never produced");
+            Val v = it->second;
+            if (v.is_const) v = upload_as_activation(v);
+            if (v.space == Space::INPUT || !v.contiguous()) v = materialize(v, row_major(v.dims), "output:" + oi.name);
+            oi.dims = v.dims;
+            oi.row_elems = v.numel();
+            oi.ref = Ref{v.space, v.storage, v.offset};
+            oi.computed = true;
+            plan_.storages[v.storage].pinned = true;
+        }
+        plan_memory();
+        for (auto &op : plan_.ops) {
+            (op.mfma ? plan_.macs_mfma : plan_.macs_valu) += op.macs;
+            plan_.act_bytes += op.bytes;
+            plan_.weight_bytes += op.weight_bytes;
+        }
+    }
+
+   private:
+    const OnnxModel &m_;
+    Plan &plan_;
+    std::vector<OnnxNode> nodes_;
+    std::map<std::string, Val> vals_;
+    std::map<std::string, std::vector<int>> consumers_;
+    std::set<std::string> graph_outputs_, wanted_names_;
+    std::vector<bool> live_, absorbed_;
+    int cur_ = 0;
+
+    // ------------------------------------------------------------------ utils
+    const Val &get(const OnnxNode &n, size_t idx) {
+        if (idx >= n.inputs.size() || n.inputs[idx].empty()) unsupported(n, "missing input " + std::to_string(idx));
+        auto it = vals_.find(n.inputs[idx]);
+        if (it == vals_.end()) unsupported(n, "input '" + n.inputs[idx] + "' is not defined (graph not topologically sorted?)");
+        return it->second;
+    }
+    bool has_input(const OnnxNode &n, size_t idx) const { return idx < n.inputs.size() && !n.inputs[idx].empty(); }
+    const Val *opt(const OnnxNode &n, size_t idx) {
+        if (!has_input(n, idx)) return nullptr;
+        return &get(n, idx);
+    }
+    // Sole live consumer of tensor `t` (and t is not itself a wanted graph output), else -1.
+    int sole_consumer(const std::string &t) {
+        if (wanted_names_.count(t)) return -1;
+        auto it = consumers_.find(t);
+        if (it == consumers_.end()) return -1;
+        int found = -1, cnt = 0;
+        for (int k : it->second)
+            if (!absorbed_[k]) { found = k; cnt++; }
+        return cnt == 1 ? found : -1;
+    }
+    std::vector<int> live_consumers(const std::string &t) {
+        std::vector<int> r;
+        auto it = consumers_.find(t);
+        if (it != consumers_.end())
+            for (int k : it->second)
+                if (!absorbed_[k]) r.push_back(k);
+        return r;
+    }
+    bool const_scalar(const Val &v, float &out) {
+        if (!v.is_const || v.numel() != 1) return false;
+        out = v.is_int ? (float)v.i[0] : v.f[0];
+        return true;
+    }
+    std::vector<int64_t> const_ints(const OnnxNode &n, const Val &v) {
+        if (!v.is_const) unsupported(n, "expected a constant integer tensor");
+        if (v.is_int) return v.i;
+        std::vector<int64_t> r(v.f.size());
+        for (size_t k = 0; k < r.size(); k++) r[k] = (int64_t)v.f[k];
+        return r;
+    }
+
+    int32_t new_storage(int64_t elems) {
+        Storage s;
+        s.elems = elems;
+        plan_.storages.push_back(s);
+        return (int32_t)plan_.storages.size() - 1;
+    }
+    Val new_act(const Dims &dims, const Dims &strides) {
+        Val v;
+        v.dims = dims;
+        v.strides = strides;
+        v.space = Space::ARENA;
+        // storage extent: max offset + 1
+        int64_t ext = 1;
+        for (size_t k = 0; k < dims.size(); k++) ext += (dims[k] - 1) * std::abs(strides[k]);
+        v.storage = new_storage(ext);
+        return v;
+    }
+    int32_t add_const(const std::vector<float> &data) {
+        plan_.consts.push_back(data);
+        return (int32_t)plan_.consts.size() - 1;
+    }
+    Ref ref_of(const Val &v) const { return Ref{v.space, v.storage, v.offset}; }
+    void touch(const Ref &r, int op_index) {
+        if (r.space != Space::ARENA) return;
+        auto &s = plan_.storages[r.id];
+        if (s.first < 0) s.first = op_index;
+        s.last = std::max(s.last, op_index);
+    }
+    void push_op(PlanOp &&op) {
+        int idx = (int)plan_.ops.size();
+        touch(op.out, idx);
+        touch(op.a, idx);
+        touch(op.b, idx);
+        touch(op.res, idx);
+        touch(op.scale, idx);
+        plan_.ops.push_back(std::move(op));
+    }
+
+    // Physical order of logical dims (outermost first) for an activation.
+    static std::vector<int> phys_order(const Val &v) {
+        std::vector<int> ord(v.dims.size());
+        std::iota(ord.begin(), ord.end(), 0);
+        // size-1 dims carry no layout information: treat them as outermost
+        auto key = [&](int a) { return v.dims[a] == 1 ? INT64_MAX : std::abs(v.strides[a]); };
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key(a) > key(b); });
+        return ord;
+    }
+    // Contiguous strides for `dims` laid out in the given physical order.
+    static Dims strides_for_order(const Dims &dims, const std::vector<int> &ord) {
+        Dims s(dims.size(), 0);
+        int64_t acc = 1;
+        for (int k = (int)ord.size() - 1; k >= 0; k--) {
+            s[ord[k]] = acc;
+            acc *= dims[ord[k]];
+        }
+        return s;
+    }
+
+    // Broadcast strides of `v` against out dims (right aligned); const operands are row-major.
+    Dims bcast_strides(const OnnxNode *n, const Dims &vdims, const Dims &vstrides, const Dims &out) {
+        Dims s(out.size(), 0);
+        int off = (int)out.size() - (int)vdims.size();
+        if (off < 0) {
+            if (n) unsupported(*n, "operand rank exceeds result rank");
+            throw UnsupportedModel("broadcast rank mismatch");
+        }
+        for (size_t k = 0; k < vdims.size(); k++) {
+            if (vdims[k] == out[k + off]) s[k + off] = vdims[k] == 1 ? 0 : vstrides[k];
+            else if (vdims[k] == 1) s[k + off] = 0;
+            else {
+                if (n) unsupported(*n, "shapes " + dims_str(vdims) + " and " + dims_str(out) + " do not broadcast");
+                throw UnsupportedModel("broadcast mismatch");
+            }
+        }
+        return s;
+    }
+
+    // Emit an elementwise op.  sb/b may be empty for unary ops.
+    void emit_elt(const std::string &name, const Val &out, const Ref &a, const Dims &sa, int64_t a_bs,
+                  const Ref &b, const Dims &sb, int64_t b_bs, int bin, ActSpec act) {
+        // iterate in out's physical order
+        std::vector<int> ord = phys_order(out);
+        struct L { int64_t n, so, sa, sb; };
+        std::vector<L> loops;
+        for (int d : ord) {
+            if (out.dims[d] == 1) continue;
+            L l{out.dims[d], out.strides[d], sa[d], sb.empty() ? 0 : sb[d]};
+            if (!loops.empty()) {
+                L &p = loops.back();
+                if (p.so == l.so * l.n && p.sa == l.sa * l.n && p.sb == l.sb * l.n) {
+                    p.n *= l.n; p.so = l.so; p.sa = l.sa; p.sb = l.sb;
+                    continue;
+                }
+            }
+            loops.push_back(l);
+        }
+        if (loops.empty()) loops.push_back(L{1, 1, 0, 0});
+        if ((int)loops.size() > ELT_MAX_DIMS) throw UnsupportedModel("elementwise op '" + name + "' needs more than 5 loop dims");
+        PlanOp op;
+        op.kind = OpKind::ELT;
+        op.name = name;
+        op.out = ref_of(out);
+        op.a = a;
+        op.b = b;
+        EltDesc &d = op.elt;
+        d.nd = (int)loops.size();
+        d.per_sample = 1;
+        for (int k = 0; k < d.nd; k++) {
+            d.size[k] = loops[k].n; d.so[k] = loops[k].so; d.sa[k] = loops[k].sa; d.sb[k] = loops[k].sb;
+            d.per_sample *= loops[k].n;
+        }
+        int64_t out_ext = plan_.storages[out.storage].elems;
+        d.bo = out_ext; d.ba = a_bs; d.bb = b_bs;
+        d.bin = bin; d.act = act.act; d.p0 = act.p0; d.p1 = act.p1;
+        d.flat = (d.nd == 1 && d.so[0] == 1 && d.sa[0] == 1 && (bin == BIN_NONE || d.sb[0] == 1)) ? 1 : 0;
+        op.bytes = 4.0 * (double)d.per_sample * (bin == BIN_NONE ? 2 : 3);
+        push_op(std::move(op));
+    }
+    int64_t batch_stride(const Val &v) const {
+        if (v.space == Space::INPUT) return plan_.sample_count;
+        if (v.space == Space::ARENA) return plan_.storages[v.storage].elems;
+        return 0;
+    }
+
+    // Copy `v` into fresh storage with the requested strides.
+    Val materialize(const Val &v, const Dims &strides, const std::string &why) {
+        Val out = new_act(v.dims, strides);
+        emit_elt("copy(" + why + ")", out, ref_of(v), v.strides, batch_stride(v), Ref{}, {}, 0, BIN_NONE, ActSpec{});
+        return out;
+    }
+    Val upload_as_activation(const Val &c) {
+        // a constant graph output / concat input: broadcast over the batch via stride 0
+        std::vector<float> data = c.is_int ? std::vector<float>(c.i.begin(), c.i.end()) : c.f;
+        Dims d = c.dims;
+        if (!d.empty() && d[0] == 1) d.erase(d.begin());
+        Val out = new_act(d, row_major(d));
+        Ref src{Space::CONSTS, add_const(data), 0};
+        emit_elt("copy(const)", out, src, row_major(d), 0, Ref{}, {}, 0, BIN_NONE, ActSpec{});
+        return out;
+    }
+    void define(const std::string &name, Val v) { vals_[name] = std::move(v); }
+
+    // --------------------------------------------------------- constant folding
+    static bool all_const(const std::vector<const Val *> &vs) {
+        for (auto v : vs)
+            if (v && !v->is_const) return false;
+        return true;
+    }
+    Val make_const_f(const Dims &d, std::vector<float> f) {
+        Val v; v.is_const = true; v.dims = d; v.f = std::move(f); return v;
+    }
+    Val make_const_i(const Dims &d, std::vector<int64_t> i) {
+        Val v; v.is_const = true; v.is_int = true; v.dims = d; v.i = std::move(i); return v;
+    }
+    static Dims bcast_dims(const Dims &a, const Dims &b) {
+        size_t r = std::max(a.size(), b.size());
+        Dims o(r);
+        for (size_t k = 0; k < r; k++) {
+            int64_t da = k + a.size() >= r ? a[k + a.size() - r] : 1;
+            int64_t db = k + b.size() >= r ? b[k + b.size() - r] : 1;
+            if (da != db && da != 1 && db != 1) throw UnsupportedModel("constant broadcast mismatch");
+            o[k] = std::max(da, db);
+        }
+        return o;
+    }
+    template <class T, class F>
+    static std::vector<T> bcast_apply(const Dims &ad, const std::vector<T> &a, const Dims &bd, const std::vector<T> &b,
+                                      const Dims &od, F fn) {
+        int64_t n = prod(od);
+        std::vector<T> o((size_t)n);
+        Dims as = row_major(ad), bs = row_major(bd), os = row_major(od);
+        for (int64_t lin = 0; lin < n; lin++) {
+            int64_t ia = 0, ib = 0, rem = lin;
+            for (size_t k = 0; k < od.size(); k++) {
+                int64_t idx = rem / os[k];
+                rem %= os[k];
+                int ka = (int)k - (int)(od.size() - ad.size()), kb = (int)k - (int)(od.size() - bd.size());
+                if (ka >= 0 && ad[ka] != 1) ia += idx * as[ka];
+                if (kb >= 0 && bd[kb] != 1) ib += idx * bs[kb];
+            }
+            o[lin] = fn(a[ia], b[ib]);
+        }
+        return o;
+    }
+    bool fold_binary(const OnnxNode &n, const Val &a, const Val &b) {
+        const std::string &t = n.op_type;
+        Dims od = bcast_dims(a.dims, b.dims);
+        if (a.is_int && b.is_int) {
+            std::function<int64_t(int64_t, int64_t)> fn;
+            if (t == "Add") fn = [](int64_t x, int64_t y) { return x + y; };
+            else if (t == "Sub") fn = [](int64_t x, int64_t y) { return x - y; };
+            else if (t == "Mul") fn = [](int64_t x, int64_t y) { return (x == BATCH_SENTINEL || y == BATCH_SENTINEL) ? (x == 1 ? y : (y == 1 ? x : BATCH_SENTINEL)) : x * y; };
+            else if (t == "Div") fn = [](int64_t x, int64_t y) { return y ? x / y : 0; };
+            else if (t == "Max") fn = [](int64_t x, int64_t y) { return std::max(x, y); };
+            else if (t == "Min") fn = [](int64_t x, int64_t y) { return std::min(x, y); };
+            else return false;
+            define(n.outputs[0], make_const_i(od, bcast_apply<int64_t>(a.dims, a.i, b.dims, b.i, od, fn)));
+            return true;
+        }
+        std::vector<float> af = a.is_int ? std::vector<float>(a.i.begin(), a.i.end()) : a.f;
+        std::vector<float> bf = b.is_int ? std::vector<float>(b.i.begin(), b.i.end()) : b.f;
+        std::function<float(float, float)> fn;
+        if (t == "Add") fn = [](float x, float y) { return x + y; };
+        else if (t == "Sub") fn = [](float x, float y) { return x - y; };
+        else if (t == "Mul") fn = [](float x, float y) { return x * y; };
+        else if (t == "Div") fn = [](float x, float y) { return x / y; };
+        else if (t == "Pow") fn = [](float x, float y) { return std::pow(x, y); };
+        else if (t == "Max") fn = [](float x, float y) { return std::max(x, y); };
+        else if (t == "Min") fn = [](float x, float y) { return std::min(x, y); };
+        else return false;
+        define(n.outputs[0], make_const_f(od, bcast_apply<float>(a.dims, af, b.dims, bf, od, fn)));
+        return true;
+    }
+    bool fold_unary(const OnnxNode &n, const Val &a) {
+        const std::string &t = n.op_type;
+        std::function<float(float)> fn;
+        if (t == "Sqrt") fn = [](float x) { return std::sqrt(x); };
+        else if (t == "Exp") fn = [](float x) { return std::exp(x); };
+        else if (t == "Log") fn = [](float x) { return std::log(x); };
+        else if (t == "Neg") fn = [](float x) { return -x; };
+        else if (t == "Abs") fn = [](float x) { return std::fabs(x); };
+        else if (t == "Reciprocal") fn = [](float x) { return 1.0f / x; };
+        else if (t == "Floor") fn = [](float x) { return std::floor(x); };
+        else if (t == "Ceil") fn = [](float x) { return std::ceil(x); };
+        else if (t == "Sigmoid") fn = [](float x) { return 1.0f / (1.0f + std::exp(-x)); };
+        else if (t == "Relu") fn = [](float x) { return x > 0 ? x : 0.0f; };
+        else if (t == "Tanh") fn = [](float x) { return std::tanh(x); };
+        else return false;
+        if (a.is_int) {
+            if (t == "Neg") { std::vector<int64_t> o = a.i; for (auto &x : o) x = -x; define(n.outputs[0], make_const_i(a.dims, o)); return true; }
+            if (t == "Abs") { std::vector<int64_t> o = a.i; for (auto &x : o) x = std::llabs(x); define(n.outputs[0], make_const_i(a.dims, o)); return true; }
+        }
+        std::vector<float> af = a.is_int ? std::vector<float>(a.i.begin(), a.i.end()) : a.f;
+        for (auto &x : af) x = fn(x);
+        define(n.outputs[0], make_const_f(a.dims, af));
+        return true;
+    }
+    // generic strided gather of a constant: out[idx] = src[offset + sum idx*stride]
+    Val const_view(const Val &c, const Dims &dims, const Dims &strides, int64_t offset) {
+        Val o; o.is_const = true; o.is_int = c.is_int; o.dims = dims;
+        int64_t n = prod(dims);
+        Dims os = row_major(dims);
+        if (c.is_int) o.i.resize(n); else o.f.resize(n);
+        for (int64_t lin = 0; lin < n; lin++) {
+            int64_t src = offset, rem = lin;
+            for (size_t k = 0; k < dims.size(); k++) { src += (rem / os[k]) * strides[k]; rem %= os[k]; }
+            if (c.is_int) o.i[lin] = c.i[src]; else o.f[lin] = c.f[src];
+        }
+        return o;
+    }
+
+    // ------------------------------------------------------------- pruning
+    // Conv(out channels c) -> [Transpose] -> MatMul(const W[c, :]): output channels whose W row is
+    // all zero never influence the result, drop them (mel filterbanks cover a fraction of the bins).
+    void prune_zero_rows() {
+        for (size_t k = 0; k < nodes_.size(); k++) {
+            if (!live_[k] || nodes_[k].op_type != "Conv") continue;
+            OnnxNode &conv = nodes_[k];
+            int c1 = sole_consumer(conv.outputs[0]);
+            if (c1 < 0) continue;
+            int mm = -1;
+            if (nodes_[c1].op_type == "Transpose") {
+                auto perm = nodes_[c1].attr_ints("perm");
+                if (perm != std::vector<int64_t>{0, 2, 1}) continue;
+                mm = sole_consumer(nodes_[c1].outputs[0]);
+            } else continue;
+            if (mm < 0 || nodes_[mm].op_type != "MatMul") continue;
+            auto wi = vals_.find(nodes_[mm].inputs[1]);
+            auto cw = vals_.find(conv.inputs[1]);
+            if (wi == vals_.end() || cw == vals_.end() || !wi->second.is_const || !cw->second.is_const) continue;
+            Val &W = wi->second;
+            Val &CW = cw->second;
+            if (W.dims.size() != 2 || CW.dims.empty() || W.dims[0] != CW.dims[0] || W.is_int) continue;
+            // weights must not be shared with other nodes
+            if (live_consumers(nodes_[mm].inputs[1]).size() != 1 || live_consumers(conv.inputs[1]).size() != 1) continue;
+            int64_t C = W.dims[0], N = W.dims[1];
+            std::vector<int64_t> keep;
+            for (int64_t c = 0; c < C; c++) {
+                bool nz = false;
+                for (int64_t j = 0; j < N && !nz; j++) nz = W.f[c * N + j] != 0.0f;
+                if (nz) keep.push_back(c);
+            }
+            if ((int64_t)keep.size() == C || keep.empty()) continue;
+            int64_t per = CW.numel() / C;
+            std::vector<float> nw(keep.size() * per), nW(keep.size() * N);
+            for (size_t r = 0; r < keep.size(); r++) {
+                std::copy(CW.f.begin() + keep[r] * per, CW.f.begin() + (keep[r] + 1) * per, nw.begin() + r * per);
+                std::copy(W.f.begin() + keep[r] * N, W.f.begin() + (keep[r] + 1) * N, nW.begin() + r * N);
+            }
+            CW.f = nw; CW.dims[0] = (int64_t)keep.size();
+            W.f = nW; W.dims[0] = (int64_t)keep.size();
+            if (conv.inputs.size() > 2 && !conv.inputs[2].empty()) {
+                auto bi = vals_.find(conv.inputs[2]);
+                if (bi != vals_.end() && bi->second.is_const && live_consumers(conv.inputs[2]).size() == 1) {
+                    std::vector<float> nb(keep.size());
+                    for (size_t r = 0; r < keep.size(); r++) nb[r] = bi->second.f[keep[r]];
+                    bi->second.f = nb; bi->second.dims[0] = (int64_t)keep.size();
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------- lowering
+    void lower(const OnnxNode &n) {
+        const std::string &t = n.op_type;
+        // constant folding first
+        std::vector<const Val *> ins;
+        for (size_t k = 0; k < n.inputs.size(); k++) ins.push_back(n.inputs[k].empty() ? nullptr : &get(n, k));
+        if (t == "Constant") { lower_constant(n); return; }
+        if (t == "Shape") { lower_shape(n); return; }
+        bool allc = !ins.empty() && all_const(ins);
+        if (allc && try_fold(n, ins)) return;
+
+        if (t == "Identity" || t == "Dropout" || (t == "Cast" && !get(n, 0).is_const)) { define(n.outputs[0], get(n, 0)); return; }
+        if (t == "Transpose") return lower_transpose(n);
+        if (t == "Reshape" || t == "Flatten" || t == "Squeeze" || t == "Unsqueeze") return lower_reshape_like(n);
+        if (t == "Slice") return lower_slice(n);
+        if (t == "Concat") return lower_concat(n);
+        if (t == "Conv") return lower_conv(n);
+        if (t == "MatMul" || t == "Gemm") return lower_matmul(n);
+        if (t == "BatchNormalization") return lower_batchnorm(n);
+        if (t == "Add" || t == "Sub" || t == "Mul" || t == "Div" || t == "Pow" || t == "Max" || t == "Min") return lower_binary(n);
+        if (t == "GlobalAveragePool" || t == "GlobalMaxPool" || t.rfind("Reduce", 0) == 0) return lower_reduce(n);
+        ActSpec a;
+        if (unary_spec(n, a)) return lower_unary(n, a);
+        unsupported(n, "operator is outside the native subset");
+    }
+
+    void lower_constant(const OnnxNode &n) {
+        auto it = n.attrs.find("value");
+        if (it != n.attrs.end()) {
+            const OnnxTensor &t = it->second.t;
+            define(n.outputs[0], t.is_float() ? make_const_f(t.dims, t.f) : make_const_i(t.dims, t.i));
+        } else if (n.has("value_float")) define(n.outputs[0], make_const_f({}, {n.attr_f("value_float", 0)}));
+        else if (n.has("value_int")) define(n.outputs[0], make_const_i({}, {n.attr_i("value_int", 0)}));
+        else if (n.has("value_ints")) { auto v = n.attr_ints("value_ints"); define(n.outputs[0], make_const_i({(int64_t)v.size()}, v)); }
+        else if (n.has("value_floats")) { auto v = n.attrs.at("value_floats").floats; define(n.outputs[0], make_const_f({(int64_t)v.size()}, v)); }
+        else unsupported(n, "Constant without a supported value attribute");
+    }
+    void lower_shape(const OnnxNode &n) {
+        const Val &v = get(n, 0);
+        std::vector<int64_t> s;
+        if (v.is_const) s = v.dims;
+        else { s.push_back(BATCH_SENTINEL); s.insert(s.end(), v.dims.begin(), v.dims.end()); }
+        define(n.outputs[0], make_const_i({(int64_t)s.size()}, s));
+    }
+
+    bool try_fold(const OnnxNode &n, const std::vector<const Val *> &ins) {
+        const std::string &t = n.op_type;
+        const Val &a = *ins[0];
+        if (ins.size() >= 2 && ins[1] && (t == "Add" || t == "Sub" || t == "Mul" || t == "Div" || t == "Pow" || t == "Max" || t == "Min"))
+            return fold_binary(n, a, *ins[1]);
+        if (t == "Identity") { define(n.outputs[0], a); return true; }
+        if (t == "Cast") {
+            int64_t to = n.attr_i("to", 1);
+            Val o = a;
+            if (to == 1 || to == 11 || to == 10) { if (a.is_int) { o.is_int = false; o.f.assign(a.i.begin(), a.i.end()); o.i.clear(); } }
+            else { if (!a.is_int) { o.is_int = true; o.i.resize(a.f.size()); for (size_t k = 0; k < a.f.size(); k++) o.i[k] = (int64_t)a.f[k]; o.f.clear(); } }
+            define(n.outputs[0], o);
+            return true;
+        }
+        if (t == "Unsqueeze" || t == "Squeeze" || t == "Reshape" || t == "Flatten") {
+            Dims nd = reshape_target(n, a.dims, /*is_const=*/true);
+            Val o = a; o.dims = nd;
+            define(n.outputs[0], o);
+            return true;
+        }
+        if (t == "Transpose") {
+            auto perm = n.attr_ints("perm");
+            size_t r = a.dims.size();
+            if (perm.empty()) for (size_t k = 0; k < r; k++) perm.push_back((int64_t)(r - 1 - k));
+            Dims rs = row_major(a.dims), nd(r), ns(r);
+            for (size_t k = 0; k < r; k++) { nd[k] = a.dims[perm[k]]; ns[k] = rs[perm[k]]; }
+            define(n.outputs[0], const_view(a, nd, ns, 0));
+            return true;
+        }
+        if (t == "Concat") {
+            int64_t axis = n.attr_i("axis", 0);
+            size_t r = a.dims.size();
+            if (axis < 0) axis += (int64_t)r;
+            Dims od = a.dims;
+            od[axis] = 0;
+            for (auto v : ins) od[axis] += v->dims[axis];
+            int64_t outer = 1, inner = 1;
+            for (int64_t k = 0; k < axis; k++) outer *= od[k];
+            for (size_t k = axis + 1; k < r; k++) inner *= od[k];
+            Val o; o.is_const = true; o.is_int = a.is_int; o.dims = od;
+            for (int64_t ou = 0; ou < outer; ou++)
+                for (auto v : ins) {
+                    int64_t chunk = v->dims[axis] * inner;
+                    for (int64_t e = 0; e < chunk; e++) {
+                        if (o.is_int) o.i.push_back(v->is_int ? v->i[ou * chunk + e] : (int64_t)v->f[ou * chunk + e]);
+                        else o.f.push_back(v->is_int ? (float)v->i[ou * chunk + e] : v->f[ou * chunk + e]);
+                    }
+                }
+            define(n.outputs[0], o);
+            return true;
+        }
+        if (t == "Gather") {
+            int64_t axis = n.attr_i("axis", 0);
+            const Val &idx = *ins[1];
+            if (axis < 0) axis += (int64_t)a.dims.size();
+            if (axis != 0 || a.dims.size() != 1) return false;
+            auto ids = const_ints(n, idx);
+            Val o; o.is_const = true; o.is_int = a.is_int; o.dims = idx.dims;
+            for (auto id : ids) {
+                if (id < 0) id += a.dims[0];
+                if (a.is_int) o.i.push_back(a.i[id]); else o.f.push_back(a.f[id]);
+            }
+            define(n.outputs[0], o);
+            return true;
+        }
+        if (t == "Slice") {
+            Dims nd, ns; int64_t off;
+            slice_params(n, a.dims, row_major(a.dims), nd, ns, off, /*batched=*/false);
+            define(n.outputs[0], const_view(a, nd, ns, off));
+            return true;
+        }
+        if (t == "ConstantOfShape") {
+            auto shape = const_ints(n, a);
+            float fv = 0; bool isint = false; int64_t iv = 0;
+            auto it = n.attrs.find("value");
+            if (it != n.attrs.end()) { if (it->second.t.is_float()) fv = it->second.t.f[0]; else { isint = true; iv = it->second.t.i[0]; } }
+            for (auto d : shape) if (d < 0) return false;
+            if (isint) define(n.outputs[0], make_const_i(shape, std::vector<int64_t>(prod(shape), iv)));
+            else define(n.outputs[0], make_const_f(shape, std::vector<float>(prod(shape), fv)));
+            return true;
+        }
+        if (t == "Range") {
+            if (!a.is_int) return false;
+            int64_t s = a.i[0], e = ins[1]->i[0], d = ins[2]->i[0];
+            std::vector<int64_t> r;
+            for (int64_t x = s; d > 0 ? x < e : x > e; x += d) r.push_back(x);
+            define(n.outputs[0], make_const_i({(int64_t)r.size()}, r));
+            return true;
+        }
+        return fold_unary(n, a);
+    }
+
+    // Target dims for Reshape/Flatten/Squeeze/Unsqueeze.  For activations `dims`
+    // is per-sample and ONNX axes/shapes include the batch at position 0.
+    Dims reshape_target(const OnnxNode &n, const Dims &dims, bool is_const) {
+        const std::string &t = n.op_type;
+        Dims full = dims;
+        if (!is_const) full.insert(full.begin(), BATCH_SENTINEL);
+        Dims out;
+        auto axes_of = [&](size_t input_idx) {
+            std::vector<int64_t> ax = n.attr_ints("axes");
+            if (ax.empty() && has_input(n, input_idx)) ax = const_ints(n, get(n, input_idx));
+            return ax;
+        };
+        if (t == "Flatten") {
+            int64_t axis = n.attr_i("axis", 1);
+            int64_t r = (int64_t)full.size();
+            if (axis < 0) axis += r;
+            if (!is_const && axis != 1) unsupported(n, "Flatten must keep the batch as the leading dimension (axis=1)");
+            int64_t a = 1, b = 1;
+            for (int64_t k = 0; k < axis; k++) a *= full[k];
+            for (int64_t k = axis; k < r; k++) b *= full[k];
+            out = is_const ? Dims{a, b} : Dims{BATCH_SENTINEL, b};
+        } else if (t == "Squeeze") {
+            auto ax = axes_of(1);
+            int64_t r = (int64_t)full.size();
+            std::set<int64_t> drop;
+            if (ax.empty()) { for (int64_t k = 0; k < r; k++) if (full[k] == 1) drop.insert(k); }
+            else for (auto a : ax) drop.insert(a < 0 ? a + r : a);
+            for (int64_t k = 0; k < r; k++) {
+                if (drop.count(k)) { if (full[k] != 1) unsupported(n, "cannot squeeze a dimension of size " + std::to_string(full[k])); }
+                else out.push_back(full[k]);
+            }
+        } else if (t == "Unsqueeze") {
+            auto ax = axes_of(1);
+            int64_t r = (int64_t)full.size() + (int64_t)ax.size();
+            std::set<int64_t> ins;
+            for (auto a : ax) ins.insert(a < 0 ? a + r : a);
+            size_t src = 0;
+            for (int64_t k = 0; k < r; k++) {
+                if (ins.count(k)) out.push_back(1);
+                else out.push_back(full[src++]);
+            }
+        } else {  // Reshape
+            auto shape = const_ints(n, get(n, 1));
+            bool allowzero = n.attr_i("allowzero", 0) != 0;
+            int64_t known = 1, total = 1;
+            int infer = -1;
+            bool batch_in_total = false;
+            for (auto d : full) { if (d == BATCH_SENTINEL) batch_in_total = true; else total *= d; }
+            bool batch_in_out = false;
+            for (size_t k = 0; k < shape.size(); k++) {
+                int64_t d = shape[k];
+                if (d == 0 && !allowzero) d = k < full.size() ? full[k] : 0;
+                if (d == -1) { infer = (int)k; out.push_back(-1); continue; }
+                if (d == BATCH_SENTINEL) batch_in_out = true;
+                else known *= d;
+                out.push_back(d);
+            }
+            if (!is_const && batch_in_total && !batch_in_out) {
+                // The exporter wrote the batch as a literal (1 for a batch-1 trace) or as -1.
+                if (infer == 0) { out[0] = BATCH_SENTINEL; infer = -1; }
+                else if (!out.empty() && out[0] == 1 && (infer >= 0 || known == total)) out[0] = BATCH_SENTINEL;
+                else unsupported(n, "Reshape target " + dims_str(shape) + " does not keep the batch dimension leading");
+            }
+            if (infer >= 0) {
+                if (known == 0 || total % known) unsupported(n, "Reshape cannot infer -1");
+                out[infer] = total / known;
+            }
+        }
+        if (!is_const) {
+            if (out.empty() || out[0] != BATCH_SENTINEL) unsupported(n, "result does not keep the batch as the leading dimension");
+            out.erase(out.begin());
+            for (auto d : out) if (d == BATCH_SENTINEL || d < 0) unsupported(n, "batch dimension used in a non-leading position");
+            if (prod(out) != prod(dims)) unsupported(n, "element count changes from " + dims_str(dims) + " to " + dims_str(out));
+        }
+        return out;
+    }
+
+    void lower_reshape_like(const OnnxNode &n) {
+        const Val &v = get(n, 0);
+        Dims nd = reshape_target(n, v.dims, false);
+        // view if the non-unit dims are unchanged, else require row-major contiguity
+        Dims a, as, b;
+        for (size_t k = 0; k < v.dims.size(); k++) if (v.dims[k] != 1) { a.push_back(v.dims[k]); as.push_back(v.strides[k]); }
+        for (auto d : nd) if (d != 1) b.push_back(d);
+        Val o = v;
+        o.dims = nd;
+        if (a == b) {
+            o.strides.assign(nd.size(), 0);
+            size_t j = 0;
+            for (size_t k = 0; k < nd.size(); k++) if (nd[k] != 1) o.strides[k] = as[j++];
+        } else {
+            Val src = v.contiguous() ? v : materialize(v, row_major(v.dims), n.name);
+            o = src;
+            o.dims = nd;
+            o.strides = row_major(nd);
+        }
+        define(n.outputs[0], o);
+    }
+
+    void lower_transpose(const OnnxNode &n) {
+        const Val &v = get(n, 0);
+        auto perm = n.attr_ints("perm");
+        size_t r = v.dims.size() + 1;
+        if (perm.empty()) for (size_t k = 0; k < r; k++) perm.push_back((int64_t)(r - 1 - k));
+        if (perm.size() != r || perm[0] != 0) unsupported(n, "Transpose must keep the batch as the leading dimension");
+        Val o = v;
+        for (size_t k = 1; k < r; k++) { o.dims[k - 1] = v.dims[perm[k] - 1]; o.strides[k - 1] = v.strides[perm[k] - 1]; }
+        define(n.outputs[0], o);
+    }
+
+    void slice_params(const OnnxNode &n, const Dims &dims, const Dims &strides, Dims &nd, Dims &ns, int64_t &off, bool batched) {
+        std::vector<int64_t> starts, ends, axes, steps;
+        if (n.has("starts")) { starts = n.attr_ints("starts"); ends = n.attr_ints("ends"); axes = n.attr_ints("axes"); }
+        else {
+            starts = const_ints(n, get(n, 1));
+            ends = const_ints(n, get(n, 2));
+            if (has_input(n, 3)) axes = const_ints(n, get(n, 3));
+            if (has_input(n, 4)) steps = const_ints(n, get(n, 4));
+        }
+        int64_t r = (int64_t)dims.size() + (batched ? 1 : 0);
+        if (axes.empty()) for (size_t k = 0; k < starts.size(); k++) axes.push_back((int64_t)k);
+        if (steps.empty()) steps.assign(starts.size(), 1);
+        nd = dims; ns = strides; off = 0;
+        for (size_t k = 0; k < starts.size(); k++) {
+            int64_t ax = axes[k] < 0 ? axes[k] + r : axes[k];
+            if (batched) { if (ax == 0) unsupported(n, "Slice along the batch dimension"); ax -= 1; }
+            int64_t d = dims[ax], st = steps[k], s = starts[k], e = ends[k];
+            if (st == 0) unsupported(n, "Slice step 0");
+            if (s < 0) s += d;
+            if (e < 0) e += d;
+            int64_t cnt;
+            if (st > 0) { s = std::clamp<int64_t>(s, 0, d); e = std::clamp<int64_t>(e, 0, d); cnt = e > s ? (e - s + st - 1) / st : 0; }
+            else {
+                // ONNX: clamp start to [0, d-1], end to [-1, d-1] for negative steps
+                int64_t s0 = starts[k] < 0 ? starts[k] + d : starts[k];
+                int64_t e0 = ends[k];
+                if (e0 < -d - 1) e0 = -1; else if (e0 < 0) e0 += d;
+                s = std::clamp<int64_t>(s0, 0, d - 1);
+                e = std::clamp<int64_t>(e0, -1, d - 1);
+                cnt = s > e ? (s - e + (-st) - 1) / (-st) : 0;
+            }
+            if (cnt <= 0) unsupported(n, "Slice produces an empty tensor");
+            off += s * strides[ax];
+            nd[ax] = cnt;
+            ns[ax] = strides[ax] * st;
+        }
+    }
+    void lower_slice(const OnnxNode &n) {
+        const Val &v = get(n, 0);
+        Val o = v;
+        int64_t off;
+        slice_params(n, v.dims, v.strides, o.dims, o.strides, off, true);
+        o.offset = v.offset + off;
+        define(n.outputs[0], o);
+    }
+
+    void lower_concat(const OnnxNode &n) {
+        std::vector<Val> ins;
+        for (size_t k = 0; k < n.inputs.size(); k++) {
+            Val v = get(n, k);
+            if (v.is_const) v = upload_as_activation(v);
+            ins.push_back(v);
+        }
+        int64_t r = (int64_t)ins[0].dims.size() + 1;
+        int64_t axis = n.attr_i("axis", 0);
+        if (axis < 0) axis += r;
+        if (axis == 0) unsupported(n, "Concat along the batch dimension");
+        axis -= 1;
+        Dims od = ins[0].dims;
+        od[axis] = 0;
+        for (auto &v : ins) {
+            if (v.dims.size() != od.size()) unsupported(n, "rank mismatch");
+            od[axis] += v.dims[axis];
+        }
+        // layout: follow the first input's physical order
+        Val probe = ins[0];
+        probe.dims = od;
+        Val out = new_act(od, strides_for_order(od, phys_order(ins[0])));
+        int64_t pos = 0;
+        for (auto &v : ins) {
+            Val slot = out;
+            slot.dims = v.dims;
+            slot.offset = out.offset + pos * out.strides[axis];
+            emit_elt("concat:" + n.name, slot, ref_of(v), v.strides, batch_stride(v), Ref{}, {}, 0, BIN_NONE, ActSpec{});
+            pos += v.dims[axis];
+        }
+        define(n.outputs[0], out);
+    }
+
+    bool unary_spec(const OnnxNode &n, ActSpec &a) {
+        const std::string &t = n.op_type;
+        if (t == "Relu") a.act = ACT_RELU;
+        else if (t == "Sigmoid") a.act = ACT_SIGMOID;
+        else if (t == "Tanh") a.act = ACT_TANH;
+        else if (t == "Exp") a.act = ACT_EXP;
+        else if (t == "Log") a.act = ACT_LOG;
+        else if (t == "Sqrt") a.act = ACT_SQRT;
+        else if (t == "Abs") a.act = ACT_ABS;
+        else if (t == "Neg") a.act = ACT_NEG;
+        else if (t == "Reciprocal") a.act = ACT_RECIP;
+        else if (t == "Floor") a.act = ACT_FLOOR;
+        else if (t == "Ceil") a.act = ACT_CEIL;
+        else if (t == "Erf") a.act = ACT_ERF;
+        else if (t == "Softplus") a.act = ACT_SOFTPLUS;
+        else if (t == "HardSwish") a.act = ACT_HSWISH;
+        else if (t == "HardSigmoid") { a.act = ACT_HSIGMOID; a.p0 = n.attr_f("alpha", 0.2f); a.p1 = n.attr_f("beta", 0.5f); }
+        else if (t == "LeakyRelu") { a.act = ACT_LEAKY; a.p0 = n.attr_f("alpha", 0.01f); }
+        else if (t == "Clip") {
+            float lo = -INFINITY, hi = INFINITY;
+            if (n.has("min")) lo = n.attr_f("min", lo);
+            if (n.has("max")) hi = n.attr_f("max", hi);
+            if (has_input(n, 1)) { if (!const_scalar(get(n, 1), lo)) return false; }
+            if (has_input(n, 2)) { if (!const_scalar(get(n, 2), hi)) return false; }
+            a.act = ACT_CLIP; a.p0 = lo; a.p1 = hi;
+        } else return false;
+        return true;
+    }
+    // activation pattern starting at tensor `cur`: returns true and the final tensor name if absorbed
+    bool absorb_activation(std::string &cur, ActSpec &a) {
+        auto cons = live_consumers(cur);
+        if (wanted_names_.count(cur)) return false;
+        if (cons.size() == 1) {
+            const OnnxNode &c = nodes_[cons[0]];
+            if (c.inputs.empty() || c.inputs[0] != cur) return false;
+            ActSpec s;
+            if (c.op_type == "Sigmoid" || c.op_type == "Relu" || c.op_type == "Clip" || c.op_type == "HardSwish" ||
+                c.op_type == "HardSigmoid" || c.op_type == "LeakyRelu" || c.op_type == "Tanh") {
+                if (c.op_type == "Sigmoid") {
+                    // keep a bare Sigmoid fusable too
+                }
+                if (!unary_spec(c, s)) return false;
+                a = s;
+                absorbed_[cons[0]] = true;
+                cur = c.outputs[0];
+                return true;
+            }
+            return false;
+        }
+        if (cons.size() == 2) {  // x * sigmoid(x)
+            int si = -1, mi = -1;
+            for (int k : cons) { if (nodes_[k].op_type == "Sigmoid") si = k; else if (nodes_[k].op_type == "Mul") mi = k; }
+            if (si < 0 || mi < 0) return false;
+            const OnnxNode &sg = nodes_[si], &ml = nodes_[mi];
+            if (sole_consumer(sg.outputs[0]) != mi) return false;
+            bool ok = (ml.inputs[0] == cur && ml.inputs[1] == sg.outputs[0]) || (ml.inputs[1] == cur && ml.inputs[0] == sg.outputs[0]);
+            if (!ok) return false;
+            a.act = ACT_SILU;
+            absorbed_[si] = absorbed_[mi] = true;
+            cur = ml.outputs[0];
+            return true;
+        }
+        return false;
+    }
+
+    void lower_unary(const OnnxNode &n, ActSpec a) {
+        const Val &v = get(n, 0);
+        if (v.is_const) unsupported(n, "constant operand not foldable");
+        Val out = new_act(v.dims, strides_for_order(v.dims, phys_order(v)));
+        emit_elt(n.op_type + ":" + n.name, out, ref_of(v), v.strides, batch_stride(v), Ref{}, {}, 0, BIN_NONE, a);
+        define(n.outputs[0], out);
+    }
+
+    void lower_binary(const OnnxNode &n) {
+        const Val &a = get(n, 0), &b = get(n, 1);
+        const std::string &t = n.op_type;
+        int bin = t == "Add" ? BIN_ADD : t == "Sub" ? BIN_SUB : t == "Mul" ? BIN_MUL : t == "Div" ? BIN_DIV : t == "Pow" ? BIN_POW : t == "Max" ? BIN_MAX : BIN_MIN;
+        // scalar constants become parametrised unary ops
+        float c;
+        if (!a.is_const && const_scalar(b, c)) {
+            ActSpec s;
+            bool ok = true;
+            switch (bin) {
+                case BIN_ADD: s = {ACT_AFFINE, 1.0f, c}; break;
+                case BIN_SUB: s = {ACT_AFFINE, 1.0f, -c}; break;
+                case BIN_MUL: s = {ACT_AFFINE, c, 0.0f}; break;
+                case BIN_MAX: s = {ACT_MAXC, c, 0}; break;
+                case BIN_MIN: s = {ACT_MINC, c, 0}; break;
+                case BIN_POW:
+                    if (c == 2.0f) s = {ACT_SQUARE, 0, 0};
+                    else if (c == 0.5f) s = {ACT_SQRT, 0, 0};
+                    else if (c == 1.0f) s = {ACT_AFFINE, 1.0f, 0.0f};
+                    else s = {ACT_POW, c, 0};
+                    break;
+                default: ok = false;
+            }
+            if (ok) return lower_unary(n, s);
+        }
+        if (!b.is_const && const_scalar(a, c)) {
+            ActSpec s;
+            bool ok = true;
+            switch (bin) {
+                case BIN_ADD: s = {ACT_AFFINE, 1.0f, c}; break;
+                case BIN_MUL: s = {ACT_AFFINE, c, 0.0f}; break;
+                case BIN_SUB: s = {ACT_RSUB, c, 0}; break;
+                case BIN_DIV: s = {ACT_RDIV, c, 0}; break;
+                case BIN_MAX: s = {ACT_MAXC, c, 0}; break;
+                case BIN_MIN: s = {ACT_MINC, c, 0}; break;
+                default: ok = false;
+            }
+            if (ok) {
+                OnnxNode sw = n;
+                std::swap(sw.inputs[0], sw.inputs[1]);
+                return lower_unary(sw, s);
+            }
+        }
+        // general broadcast; result dims
+        auto act_dims = [&](const Val &v) { Dims d = v.dims; if (v.is_const) { if (d.size() > 0 && (int64_t)d.size() > 0) {} } return d; };
+        (void)act_dims;
+        // Normalise both to per-sample dims: constants may carry a leading batch dim of 1.
+        auto per_sample = [&](const Val &v, size_t rank_hint) {
+            Dims d = v.dims;
+            if (v.is_const && d.size() == rank_hint + 1) {
+                if (d[0] != 1) unsupported(n, "constant operand has a non-unit batch dimension");
+                d.erase(d.begin());
+            }
+            return d;
+        };
+        size_t ra = a.is_const ? 0 : a.dims.size(), rb = b.is_const ? 0 : b.dims.size();
+        size_t rank = std::max(ra, rb);
+        Dims da = per_sample(a, rank), db = per_sample(b, rank);
+        if (da.size() > rank || db.size() > rank) {
+            // constant with more dims than the activation (e.g. [1,C,1,1] against [B,C]) is not expected
+            rank = std::max(da.size(), db.size());
+        }
+        Dims od = bcast_dims(da, db);
+        // dominant operand decides layout
+        const Val *dom = nullptr;
+        if (!a.is_const && prod(da) == prod(od) && da.size() == od.size()) dom = &a;
+        else if (!b.is_const && prod(db) == prod(od) && db.size() == od.size()) dom = &b;
+        Val out = dom ? new_act(od, strides_for_order(od, phys_order(*dom))) : new_act(od, row_major(od));
+        auto operand = [&](const Val &v, const Dims &d, Ref &r, Dims &s, int64_t &bs) {
+            if (v.is_const) {
+                std::vector<float> data = v.is_int ? std::vector<float>(v.i.begin(), v.i.end()) : v.f;
+                r = Ref{Space::CONSTS, add_const(data), 0};
+                s = bcast_strides(&n, d, row_major(d), od);
+                bs = 0;
+            } else {
+                r = ref_of(v);
+                s = bcast_strides(&n, d, v.strides, od);
+                bs = batch_stride(v);
+            }
+        };
+        Ref ra_, rb_; Dims sa, sb; int64_t ba, bb;
+        operand(a, da, ra_, sa, ba);
+        operand(b, db, rb_, sb, bb);
+        emit_elt(t + ":" + n.name, out, ra_, sa, ba, rb_, sb, bb, bin, ActSpec{});
+        define(n.outputs[0], out);
+    }
+
+    void lower_batchnorm(const OnnxNode &n) {
+        const Val &x = get(n, 0);
+        const Val &sc = get(n, 1), &bi = get(n, 2), &mu = get(n, 3), &var = get(n, 4);
+        if (!sc.is_const || !bi.is_const || !mu.is_const || !var.is_const) unsupported(n, "BatchNormalization parameters must be constants");
+        float eps = n.attr_f("epsilon", 1e-5f);
+        int64_t C = sc.numel();
+        if (x.dims.empty() || x.dims[0] != C) unsupported(n, "channel count mismatch");
+        std::vector<float> s(C), t(C);
+        for (int64_t c = 0; c < C; c++) { s[c] = sc.f[c] / std::sqrt(var.f[c] + eps); t[c] = bi.f[c] - mu.f[c] * s[c]; }
+        Dims cd(x.dims.size(), 1);
+        cd[0] = C;
+        Val mid = new_act(x.dims, strides_for_order(x.dims, phys_order(x)));
+        Ref rs{Space::CONSTS, add_const(s), 0}, rt{Space::CONSTS, add_const(t), 0};
+        Dims cs = bcast_strides(&n, cd, row_major(cd), x.dims);
+        emit_elt("bn.mul:" + n.name, mid, ref_of(x), x.strides, batch_stride(x), rs, cs, 0, BIN_MUL, ActSpec{});
+        Val out = new_act(x.dims, mid.strides);
+        emit_elt("bn.add:" + n.name, out, ref_of(mid), mid.strides, batch_stride(mid), rt, cs, 0, BIN_ADD, ActSpec{});
+        define(n.outputs[0], out);
+    }
+
+    void lower_reduce(const OnnxNode &n) {
+        const Val &v = get(n, 0);
+        const std::string &t = n.op_type;
+        if (v.is_const) unsupported(n, "reduction of a constant");
+        int op;
+        std::vector<int64_t> axes;
+        bool keep = n.attr_i("keepdims", 1) != 0;
+        int64_t r = (int64_t)v.dims.size() + 1;
+        if (t == "GlobalAveragePool" || t == "GlobalMaxPool") {
+            op = t == "GlobalAveragePool" ? RED_MEAN : RED_MAX;
+            for (int64_t k = 2; k < r; k++) axes.push_back(k);
+            keep = true;
+        } else {
+            if (t == "ReduceMean") op = RED_MEAN; else if (t == "ReduceSum") op = RED_SUM; else if (t == "ReduceMax") op = RED_MAX;
+            else if (t == "ReduceMin") op = RED_MIN; else if (t == "ReduceProd") op = RED_PROD; else if (t == "ReduceL2") op = RED_L2;
+            else if (t == "ReduceSumSquare") op = RED_SUMSQ; else unsupported(n, "unsupported reduction");
+            axes = n.attr_ints("axes");
+            if (axes.empty() && has_input(n, 1)) axes = const_ints(n, get(n, 1));
+            if (axes.empty()) {
+                if (n.attr_i("noop_with_empty_axes", 0)) { define(n.outputs[0], v); return; }
+                unsupported(n, "reduction over all axes would include the batch");
+            }
+        }
+        std::set<int> red;
+        for (auto a : axes) { if (a < 0) a += r; if (a == 0) unsupported(n, "reduction over the batch dimension"); red.insert((int)a - 1); }
+        Dims od;
+        for (size_t k = 0; k < v.dims.size(); k++) { if (red.count((int)k)) { if (keep) od.push_back(1); } else od.push_back(v.dims[k]); }
+        // kept dims in input physical order
+        std::vector<int> ord = phys_order(v);
+        PlanOp op_;
+        op_.kind = OpKind::REDUCE;
+        op_.name = t + ":" + n.name;
+        ReduceDesc &d = op_.red;
+        d.op = op;
+        Dims kept_dims_phys;
+        std::vector<int> kept_axes_phys;
+        d.kept = d.red = 1;
+        d.inner_kept = 0;
+        for (int ax : ord) {
+            if (v.dims[ax] == 1) continue;
+            if (red.count(ax)) {
+                if (d.nr >= 3) unsupported(n, "more than 3 reduced dimensions");
+                d.rsize[d.nr] = v.dims[ax]; d.rin[d.nr] = v.strides[ax]; d.nr++; d.red *= v.dims[ax];
+            } else {
+                if (d.nk >= 4) unsupported(n, "more than 4 kept dimensions");
+                d.ksize[d.nk] = v.dims[ax]; d.kin[d.nk] = v.strides[ax]; d.nk++; d.kept *= v.dims[ax];
+                kept_axes_phys.push_back(ax);
+                if (std::abs(v.strides[ax]) == 1) d.inner_kept = 1;
+            }
+        }
+        // output: contiguous over kept dims in input physical order
+        Dims ostr_phys(kept_axes_phys.size());
+        { int64_t acc = 1; for (int k = (int)kept_axes_phys.size() - 1; k >= 0; k--) { ostr_phys[k] = acc; acc *= v.dims[kept_axes_phys[k]]; } }
+        for (int k = 0; k < d.nk; k++) d.kout[k] = ostr_phys[k];
+        // logical output strides
+        Dims ostr(od.size(), 0);
+        {
+            size_t oi = 0;
+            for (size_t k = 0; k < v.dims.size(); k++) {
+                bool is_red = red.count((int)k) != 0;
+                if (is_red && !keep) continue;
+                if (!is_red && v.dims[k] != 1) {
+                    for (size_t q = 0; q < kept_axes_phys.size(); q++) if (kept_axes_phys[q] == (int)k) ostr[oi] = ostr_phys[q];
+                }
+                oi++;
+            }
+        }
+        Val out = new_act(od, ostr);
+        plan_.storages[out.storage].elems = std::max<int64_t>(d.kept, 1);
+        d.bi = batch_stride(v);
+        d.bo = plan_.storages[out.storage].elems;
+        op_.out = ref_of(out);
+        op_.a = ref_of(v);
+        op_.bytes = 4.0 * (double)(d.kept * d.red + d.kept);
+        push_op(std::move(op_));
+        define(n.outputs[0], out);
+    }
+
+    // Ensure `v` ([C,H,W] or [C,L]) is channels-last contiguous; returns the (possibly copied) value.
+    Val to_channels_last(const Val &v, const std::string &why) {
+        Dims want(v.dims.size());
+        if (v.dims.size() == 3) { want = {1, v.dims[2] * v.dims[0], v.dims[0]}; }
+        else { want = {1, v.dims[0]}; }
+        if (v.space != Space::INPUT && v.strides_equal(want)) return v;
+        if (v.space == Space::INPUT && v.strides_equal(want)) return v;
+        return materialize(v, want, why);
+    }
+
+    void lower_conv(const OnnxNode &n) {
+        Val x = get(n, 0);
+        const Val &w = get(n, 1);
+        const Val *bptr = opt(n, 2);
+        if (x.is_const || !w.is_const || (bptr && !bptr->is_const)) unsupported(n, "Conv needs an activation input and constant weights");
+        size_t sp = x.dims.size() - 1;  // spatial rank
+        if (sp != 1 && sp != 2) unsupported(n, "only 1-D and 2-D convolutions are supported");
+        if (w.dims.size() != sp + 2) unsupported(n, "weight rank mismatch");
+        int64_t groups = n.attr_i("group", 1);
+        int64_t Cin = x.dims[0], Cout = w.dims[0], cpg = w.dims[1];
+        if (cpg * groups != Cin || Cout % groups) unsupported(n, "channel/group mismatch");
+        auto get2 = [&](const char *key, int64_t dflt) {
+            auto v = n.attr_ints(key);
+            if (v.empty()) v.assign(sp, dflt);
+            if (sp == 1) v.insert(v.begin(), dflt == 0 ? 0 : 1);
+            return v;
+        };
+        int64_t H = sp == 2 ? x.dims[1] : 1, W = sp == 2 ? x.dims[2] : x.dims[1];
+        int64_t kh = sp == 2 ? w.dims[2] : 1, kw = sp == 2 ? w.dims[3] : w.dims[2];
+        auto strides = get2("strides", 1), dil = get2("dilations", 1);
+        std::vector<int64_t> pads = n.attr_ints("pads");
+        if (pads.empty()) pads.assign(2 * sp, 0);
+        int64_t pt, pl, pb, pr;
+        if (sp == 2) { pt = pads[0]; pl = pads[1]; pb = pads[2]; pr = pads[3]; }
+        else { pt = pb = 0; pl = pads[0]; pr = pads[1]; }
+        std::string auto_pad = n.attr_s("auto_pad", "NOTSET");
+        auto out_dim = [&](int64_t in, int64_t k, int64_t s, int64_t d, int64_t &p0, int64_t &p1) {
+            int64_t ke = (k - 1) * d + 1;
+            if (auto_pad == "SAME_UPPER" || auto_pad == "SAME_LOWER") {
+                int64_t o = (in + s - 1) / s;
+                int64_t tot = std::max<int64_t>((o - 1) * s + ke - in, 0);
+                p0 = auto_pad == "SAME_UPPER" ? tot / 2 : tot - tot / 2;
+                p1 = tot - p0;
+                return o;
+            }
+            if (auto_pad == "VALID") p0 = p1 = 0;
+            return (in + p0 + p1 - ke) / s + 1;
+        };
+        int64_t OH = out_dim(H, kh, strides[0], dil[0], pt, pb), OW = out_dim(W, kw, strides[1], dil[1], pl, pr);
+        if (OH <= 0 || OW <= 0) unsupported(n, "empty convolution output");
+
+        // ---- epilogue fusion: BatchNorm, activation, residual ----
+        std::vector<float> wf = w.f;
+        std::vector<float> bias(Cout, 0.0f);
+        bool has_bias = bptr != nullptr;
+        if (bptr) bias = bptr->f;
+        std::string cur = n.outputs[0];
+        int64_t per_out = wf.size() / Cout;
+        {
+            int c = sole_consumer(cur);
+            if (c >= 0 && nodes_[c].op_type == "BatchNormalization" && nodes_[c].inputs[0] == cur) {
+                const OnnxNode &bn_ = nodes_[c];
+                const Val &sc = get(bn_, 1), &bi = get(bn_, 2), &mu = get(bn_, 3), &var = get(bn_, 4);
+                if (sc.is_const && bi.is_const && mu.is_const && var.is_const && sc.numel() == Cout) {
+                    float eps = bn_.attr_f("epsilon", 1e-5f);
+                    for (int64_t o = 0; o < Cout; o++) {
+                        float s = sc.f[o] / std::sqrt(var.f[o] + eps);
+                        for (int64_t k = 0; k < per_out; k++) wf[o * per_out + k] *= s;
+                        bias[o] = (bias[o] - mu.f[o]) * s + bi.f[o];
+                    }
+                    has_bias = true;
+                    absorbed_[c] = true;
+                    cur = bn_.outputs[0];
+                }
+            }
+        }
+        ActSpec act;
+        absorb_activation(cur, act);
+        // residual: Add(cur, other) with `other` an available activation of identical shape
+        Val res;
+        bool has_res = false;
+        Dims out_dims = sp == 2 ? Dims{Cout, OH, OW} : Dims{Cout, OW};
+        Dims out_strides = sp == 2 ? Dims{1, OW * Cout, Cout} : Dims{1, Cout};
+        {
+            int c = sole_consumer(cur);
+            if (c >= 0 && nodes_[c].op_type == "Add") {
+                const OnnxNode &ad = nodes_[c];
+                const std::string &other = ad.inputs[0] == cur ? ad.inputs[1] : ad.inputs[0];
+                auto it = vals_.find(other);
+                if (it != vals_.end() && !it->second.is_const && it->second.dims == out_dims && it->second.space == Space::ARENA &&
+                    it->second.strides_equal(out_strides)) {
+                    res = it->second;
+                    has_res = true;
+                    absorbed_[c] = true;
+                    cur = ad.outputs[0];
+                }
+            }
+        }
+
+        Val out = new_act(out_dims, out_strides);
+        PlanOp op;
+        op.name = "Conv:" + n.name;
+        op.out = ref_of(out);
+        op.macs = (double)OH * OW * Cout * kh * kw * cpg;
+        op.weight_bytes = 4.0 * (wf.size() + (has_bias ? Cout : 0));
+        op.bytes = 4.0 * ((double)Cin * H * W + (double)Cout * OH * OW * (has_res ? 2 : 1));
+        if (has_bias) op.bias = Ref{Space::CONSTS, add_const(bias), 0};
+        if (has_res) op.res = ref_of(res);
+
+        bool unit_dil = dil[0] == 1 && dil[1] == 1;
+        bool no_pad = pt == 0 && pl == 0 && pb == 0 && pr == 0;
+        if (groups == 1 && kh == 1 && unit_dil && no_pad && (H == 1 || (kw == 1 && strides[0] == 1 && strides[1] == 1))) {
+            // GEMM: 1x1 conv (rows = H*W) or 1-D conv as overlapping rows (rows = OW, K = kw*Cin)
+            x = to_channels_last(x, n.name);
+            op.kind = OpKind::GEMM;
+            op.mfma = true;
+            GemmDesc &g = op.gemm;
+            g.K = (int32_t)(kw * Cin);
+            g.N = (int32_t)Cout;
+            if (H == 1) { g.rows = OW; g.lda = strides[1] * Cin; }
+            else { g.rows = H * W; g.lda = Cin; }
+            g.a_bs = batch_stride(x);
+            g.ldc = Cout; g.c_bs = plan_.storages[out.storage].elems;
+            g.act = act.act; g.p0 = act.p0; g.p1 = act.p1;
+            g.has_bias = has_bias; g.has_res = has_res;
+            if (has_res) { g.ldr = Cout; g.r_bs = batch_stride(res); }
+            // weights [Cout][Cin][kw] -> [Cout][kw][Cin]  (K index = k*Cin + c)
+            std::vector<float> wp(wf.size());
+            for (int64_t o = 0; o < Cout; o++)
+                for (int64_t c = 0; c < Cin; c++)
+                    for (int64_t k = 0; k < kw; k++) wp[(o * kw + k) * Cin + c] = wf[(o * Cin + c) * kw + k];
+            op.w = Ref{Space::CONSTS, add_const(wp), 0};
+            op.a = ref_of(x);
+        } else if (groups == Cin && cpg == 1 && Cout == Cin) {
+            x = to_channels_last(x, n.name);
+            if (has_res) {  // depthwise kernel has no residual input: undo that fusion
+                unsupported(n, "depthwise convolution followed by a fused residual is not expected");
+            }
+            op.kind = OpKind::DWCONV;
+            DwDesc &d = op.dw;
+            d.H = (int32_t)H; d.W = (int32_t)W; d.C = (int32_t)Cin; d.OH = (int32_t)OH; d.OW = (int32_t)OW;
+            d.kh = (int32_t)kh; d.kw = (int32_t)kw; d.sh = (int32_t)strides[0]; d.sw = (int32_t)strides[1];
+            d.pt = (int32_t)pt; d.pl = (int32_t)pl; d.dh = (int32_t)dil[0]; d.dw = (int32_t)dil[1];
+            d.act = act.act; d.p0 = act.p0; d.p1 = act.p1; d.has_bias = has_bias;
+            d.in_bs = batch_stride(x); d.out_bs = plan_.storages[out.storage].elems;
+            std::vector<float> wp(wf.size());  // [C][1][kh][kw] -> [kh][kw][C]
+            for (int64_t c = 0; c < Cin; c++)
+                for (int64_t k = 0; k < kh * kw; k++) wp[k * Cin + c] = wf[c * kh * kw + k];
+            op.w = Ref{Space::CONSTS, add_const(wp), 0};
+            op.a = ref_of(x);
+        } else {
+            x = to_channels_last(x, n.name);
+            op.kind = OpKind::CONV;
+            ConvDesc &d = op.conv;
+            d.H = (int32_t)H; d.W = (int32_t)W; d.Cin = (int32_t)Cin; d.OH = (int32_t)OH; d.OW = (int32_t)OW; d.Cout = (int32_t)Cout;
+            d.kh = (int32_t)kh; d.kw = (int32_t)kw; d.sh = (int32_t)strides[0]; d.sw = (int32_t)strides[1];
+            d.pt = (int32_t)pt; d.pl = (int32_t)pl; d.dh = (int32_t)dil[0]; d.dw = (int32_t)dil[1]; d.groups = (int32_t)groups;
+            d.act = act.act; d.p0 = act.p0; d.p1 = act.p1; d.has_bias = has_bias; d.has_res = has_res;
+            d.in_bs = batch_stride(x); d.out_bs = plan_.storages[out.storage].elems;
+            // [Cout][cpg][kh][kw] -> [kh][kw][cpg][Cout]
+            std::vector<float> wp(wf.size());
+            for (int64_t o = 0; o < Cout; o++)
+                for (int64_t c = 0; c < cpg; c++)
+                    for (int64_t k = 0; k < kh * kw; k++) wp[(k * cpg + c) * Cout + o] = wf[(o * cpg + c) * kh * kw + k];
+            op.w = Ref{Space::CONSTS, add_const(wp), 0};
+            op.a = ref_of(x);
+        }
+        push_op(std::move(op));
+        define(cur, out);
+    }
+
+    void lower_matmul(const OnnxNode &n) {
+        Val a = get(n, 0);
+        const Val &b = get(n, 1);
+        bool gemm = n.op_type == "Gemm";
+        if (a.is_const || !b.is_const) unsupported(n, "needs an activation left operand and a constant right operand");
+        if (b.dims.size() != 2) unsupported(n, "right operand must be a 2-D constant");
+        bool transB = gemm && n.attr_i("transB", 0);
+        if (gemm && n.attr_i("transA", 0)) unsupported(n, "transA is not supported");
+        float alpha = gemm ? n.attr_f("alpha", 1.0f) : 1.0f, beta = gemm ? n.attr_f("beta", 1.0f) : 1.0f;
+        int64_t K = transB ? b.dims[1] : b.dims[0], N = transB ? b.dims[0] : b.dims[1];
+        if (a.dims.empty() || a.dims.back() != K) unsupported(n, "inner dimensions disagree: " + dims_str(a.dims) + " x " + dims_str(b.dims));
+        // A must be row-major contiguous so rows collapse to (rows, K) with lda = K
+        if (!a.contiguous()) a = materialize(a, row_major(a.dims), n.name);
+        int64_t rows = a.numel() / K;
+        std::vector<float> wp((size_t)(N * K));  // [N][K]
+        for (int64_t nn = 0; nn < N; nn++)
+            for (int64_t k = 0; k < K; k++) wp[nn * K + k] = alpha * (transB ? b.f[nn * K + k] : b.f[k * N + nn]);
+        std::vector<float> bias;
+        bool has_bias = false;
+        if (gemm && has_input(n, 2)) {
+            const Val &c = get(n, 2);
+            if (!c.is_const) unsupported(n, "Gemm C must be constant");
+            if (c.numel() == N) bias = c.f;
+            else if (c.numel() == 1) bias.assign(N, c.f[0]);
+            else unsupported(n, "Gemm C must broadcast along rows");
+            for (auto &v : bias) v *= beta;
+            has_bias = true;
+        }
+        std::string cur = n.outputs[0];
+        if (!has_bias) {  // MatMul + Add(const [N])
+            int c = sole_consumer(cur);
+            if (c >= 0 && nodes_[c].op_type == "Add") {
+                const OnnxNode &ad = nodes_[c];
+                const std::string &other = ad.inputs[0] == cur ? ad.inputs[1] : ad.inputs[0];
+                auto it = vals_.find(other);
+                if (it != vals_.end() && it->second.is_const && !it->second.is_int && it->second.numel() == N &&
+                    (it->second.dims.empty() || it->second.dims.back() == N)) {
+                    bias = it->second.f;
+                    has_bias = true;
+                    absorbed_[c] = true;
+                    cur = ad.outputs[0];
+                }
+            }
+        }
+        ActSpec act;
+        absorb_activation(cur, act);
+        Dims od = a.dims;
+        od.back() = N;
+        Val out = new_act(od, row_major(od));
+        PlanOp op;
+        op.kind = OpKind::GEMM;
+        op.mfma = true;
+        op.name = n.op_type + ":" + n.name;
+        op.out = ref_of(out);
+        op.a = ref_of(a);
+        op.w = Ref{Space::CONSTS, add_const(wp), 0};
+        if (has_bias) op.bias = Ref{Space::CONSTS, add_const(bias), 0};
+        GemmDesc &g = op.gemm;
+        g.rows = rows; g.K = (int32_t)K; g.N = (int32_t)N;
+        g.lda = K; g.a_bs = batch_stride(a);
+        g.ldc = N; g.c_bs = plan_.storages[out.storage].elems;
+        g.act = act.act; g.p0 = act.p0; g.p1 = act.p1; g.has_bias = has_bias;
+        op.macs = (double)rows * K * N;
+        op.weight_bytes = 4.0 * (wp.size() + bias.size());
+        op.bytes = 4.0 * ((double)rows * K + (double)rows * N);
+        push_op(std::move(op));
+        define(cur, out);
+    }
+
+    // --------------------------------------------------------- memory plan
+    void plan_memory() {
+        // greedy first-fit over the linear launch order; storages are per-sample extents,
+        // rounded to 64 elements so that (offset * max_batch) stays 256-byte aligned.
+        struct Block { int64_t off, size; };
+        std::vector<Block> free_list;
+        int64_t top = 0;
+        auto alloc = [&](int64_t size) {
+            int best = -1;
+            for (size_t k = 0; k < free_list.size(); k++)
+                if (free_list[k].size >= size && (best < 0 || free_list[k].size < free_list[best].size)) best = (int)k;
+            if (best >= 0) {
+                int64_t off = free_list[best].off;
+                if (free_list[best].size == size) free_list.erase(free_list.begin() + best);
+                else { free_list[best].off += size; free_list[best].size -= size; }
+                return off;
+            }
+            int64_t off = top;
+            top += size;
+            return off;
+        };
+        auto release = [&](int64_t off, int64_t size) {
+            free_list.push_back({off, size});
+            std::sort(free_list.begin(), free_list.end(), [](const Block &a, const Block &b) { return a.off < b.off; });
+            for (size_t k = 0; k + 1 < free_list.size();) {
+                if (free_list[k].off + free_list[k].size == free_list[k + 1].off) { free_list[k].size += free_list[k + 1].size; free_list.erase(free_list.begin() + k + 1); }
+                else k++;
+            }
+            // give the tail back
+            if (!free_list.empty() && free_list.back().off + free_list.back().size == top) { top = free_list.back().off; free_list.pop_back(); }
+        };
+        auto rounded = [](int64_t e) { return (e + 63) / 64 * 64; };
+        int nops = (int)plan_.ops.size();
+        std::vector<std::vector<int>> starts(nops), ends(nops);
+        for (size_t s = 0; s < plan_.storages.size(); s++) {
+            auto &st = plan_.storages[s];
+            if (st.first < 0) continue;  // never touched
+            starts[st.first].push_back((int)s);
+            if (!st.pinned) ends[st.last].push_back((int)s);
+        }
+        int64_t peak = 0;
+        for (int k = 0; k < nops; k++) {
+            for (int s : starts[k]) plan_.storages[s].arena_off = alloc(rounded(plan_.storages[s].elems));
+            peak = std::max(peak, top);
+            for (int s : ends[k]) release(plan_.storages[s].arena_off, rounded(plan_.storages[s].elems));
+        }
+        plan_.arena_elems = std::max<int64_t>(peak, 64);
+        // constants arena
+        int64_t coff = 0;
+        plan_.const_off.resize(plan_.consts.size());
+        for (size_t k = 0; k < plan_.consts.size(); k++) { plan_.const_off[k] = coff; coff += rounded((int64_t)plan_.consts[k].size()); }
+        plan_.consts_elems = std::max<int64_t>(coff, 64);
+    }
+};
+
+}  // namespace
+
+IoMeta read_io_meta(const OnnxModel &m) {
+    IoMeta io;
+    if (!m.inputs.empty()) {
+        io.input_name = m.inputs[0].name;
+        io.input_shape = m.inputs[0].shape;
+        if (!io.input_shape.empty() && io.input_shape[0] <= 0) io.input_shape[0] = -1;
+    }
+    for (auto &o : m.outputs) {
+        io.output_names.push_back(o.name);
+        io.output_shapes.push_back(o.shape);
+    }
+    return io;
+}
+
+std::unique_ptr<Plan> build_plan(const OnnxModel &m, const std::vector<int> &wanted_outputs) {
+    auto p = std::make_unique<Plan>();
+    Builder b(m, *p);
+    b.run(wanted_outputs);
+    return p;
+}
+
+}  // namespace bn

@@ -1,0 +1,89 @@
+// Inference engine: ONNX graph -> launch plan of hand-written HIP kernels.
+// Stands in for ONNX Runtime's session (reference src/classifier.rs:340-350,
+// 637-639, 721-723, 851-853): the whole numeric hot path of the reference
+// (front end, CNN, head) is what this plan executes.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "onnx_proto.h"
+
+namespace bn {
+
+struct UnsupportedModel : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// Where an operand lives.
+enum class Space : int32_t { NONE = 0, INPUT, ARENA, CONSTS };
+struct Ref {
+    Space space = Space::NONE;
+    int32_t id = -1;     // ARENA: storage id; CONSTS: constant-buffer id
+    int64_t offset = 0;  // elements (per sample for INPUT/ARENA)
+};
+
+enum class OpKind : int32_t { ELT, REDUCE, GEMM, CONV, DWCONV };
+
+struct PlanOp {
+    OpKind kind;
+    std::string name;
+    Ref out, a, b, w, bias, res, scale;
+    EltDesc elt{};
+    ReduceDesc red{};
+    GemmDesc gemm{};
+    ConvDesc conv{};
+    DwDesc dw{};
+    double macs = 0;        // per sample
+    double bytes = 0;       // algorithmic bytes read+written per sample (weights excluded)
+    double weight_bytes = 0;
+    bool mfma = false;
+};
+
+struct Storage {
+    int64_t elems = 0;  // per sample
+    int32_t first = -1, last = -1;  // op indices
+    bool pinned = false;            // graph output: never recycled
+    int64_t arena_off = -1;         // elements per sample
+};
+
+struct OutputInfo {
+    std::string name;
+    std::vector<int64_t> dims;  // per sample (without batch)
+    int64_t row_elems = 0;
+    Ref ref;
+    bool computed = false;
+};
+
+struct IoMeta {
+    std::string input_name;
+    std::vector<int64_t> input_shape;  // ONNX shape, -1 = dynamic
+    std::vector<std::string> output_names;
+    std::vector<std::vector<int64_t>> output_shapes;
+};
+
+// Immutable after build(): shared by every context of a model.
+struct Plan {
+    int64_t sample_count = 0;
+    std::vector<PlanOp> ops;
+    std::vector<Storage> storages;
+    std::vector<std::vector<float>> consts;  // host copies, uploaded once per model
+    std::vector<int64_t> const_off;          // element offsets inside the weights arena
+    int64_t consts_elems = 0;
+    int64_t arena_elems = 0;  // per sample
+    std::vector<OutputInfo> outputs;
+    IoMeta io;
+    double macs_mfma = 0, macs_valu = 0, act_bytes = 0, weight_bytes = 0;
+};
+
+// wanted_outputs: graph output indices that must be computed (others are dead code).
+std::unique_ptr<Plan> build_plan(const OnnxModel &m, const std::vector<int> &wanted_outputs);
+// Graph I/O metadata without planning (for detection before the wanted set is known).
+IoMeta read_io_meta(const OnnxModel &m);
+
+}  // namespace bn

@@ -1,0 +1,198 @@
+// Flat C ABI (bnh_*) over the C++ host mirror, for the ctypes test/bench harness.
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/birdnet_host.h"
+
+using namespace birdnet;
+
+struct bnh_classifier {
+    Classifier cl;
+};
+struct bnh_context {
+    std::unique_ptr<BatchInferenceContext> ctx;
+};
+struct bnh_results {
+    std::vector<PredictionResult> v;
+};
+
+namespace {
+
+int32_t set_err(bnh_error *err, const Error &e) {
+    const int32_t kind = (int32_t)e.kind + 1;
+    if (err) {
+        err->kind = kind;
+        err->index = e.index;
+        err->expected = e.expected;
+        err->got = e.got;
+        err->duration_ns = e.duration_ns;
+        snprintf(err->message, sizeof(err->message), "%s", e.what());
+    }
+    return kind;
+}
+int32_t set_other(bnh_error *err, const char *what) {
+    if (err) {
+        memset(err, 0, sizeof(*err));
+        err->kind = BNH_ERR_OTHER;
+        snprintf(err->message, sizeof(err->message), "%s", what);
+    }
+    return BNH_ERR_OTHER;
+}
+// timeout_ns < 0 => None.  A non-NULL cancel flag becomes a CancellationToken aliasing it, so
+// "cancel from another thread" is observed while the batch runs.
+InferenceOptions make_opts(int64_t timeout_ns, const volatile int32_t *cancel) {
+    InferenceOptions o;
+    if (timeout_ns >= 0) o.timeout = std::chrono::nanoseconds(timeout_ns);
+    if (cancel) o.cancellation_token = CancellationToken::alias(const_cast<volatile int32_t *>(cancel));
+    return o;
+}
+
+template <class F>
+int32_t guarded(bnh_error *err, F &&f) {
+    try {
+        f();
+        if (err) memset(err, 0, sizeof(*err));
+        return BNH_OK;
+    } catch (const Error &e) {
+        return set_err(err, e);
+    } catch (const std::exception &e) {
+        return set_other(err, e.what());
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t bnh_classifier_build(const char *model_path, const char *labels_path, const char *const *labels, size_t n_labels, int32_t model_type,
+                             int64_t top_k, int32_t has_min, float min_conf, int32_t device, bnh_classifier **out, bnh_error *err) {
+    if (out) *out = nullptr;
+    return guarded(err, [&] {
+        ClassifierBuilder b;
+        if (model_path) b.model_path(model_path);
+        if (labels) {
+            std::vector<std::string> l;
+            for (size_t i = 0; i < n_labels; i++) l.emplace_back(labels[i]);
+            b.labels(std::move(l));
+        } else if (labels_path) b.labels_path(labels_path);
+        if (model_type >= 0) b.model_type((ModelType)model_type);
+        if (top_k >= 0) b.top_k((size_t)top_k);
+        else b.top_k((size_t)-1);  // usize::MAX
+        if (has_min) b.min_confidence(min_conf);
+        b.with_rocm(device);
+        auto *c = new bnh_classifier{b.build()};
+        *out = c;
+    });
+}
+
+void bnh_classifier_free(bnh_classifier *c) { delete c; }
+
+void bnh_classifier_config(const bnh_classifier *c, bn_model_config *out) {
+    const ModelConfig &m = c->cl.config();
+    memset(out, 0, sizeof(*out));
+    out->model_type = (int32_t)m.model_type;
+    out->sample_rate = m.sample_rate;
+    out->segment_duration = m.segment_duration;
+    out->sample_count = m.sample_count;
+    out->num_species = m.num_species;
+    out->has_embedding = m.embedding_dim ? 1 : 0;
+    out->embedding_dim = m.embedding_dim.value_or(0);
+    out->logits_output = m.model_type == ModelType::BirdNetV24 ? 0 : m.model_type == ModelType::BirdNetV30 ? 1 : 3;
+    out->embedding_output = m.model_type == ModelType::BirdNetV24 ? -1 : 0;
+}
+
+const char *bnh_classifier_provider(const bnh_classifier *c) { return as_str(c->cl.requested_provider()); }
+size_t bnh_classifier_label_count(const bnh_classifier *c) { return c->cl.labels().size(); }
+const char *bnh_classifier_label(const bnh_classifier *c, size_t i) { return i < c->cl.labels().size() ? c->cl.labels()[i].c_str() : nullptr; }
+
+int32_t bnh_predict(const bnh_classifier *c, const float *segment, size_t len, int64_t timeout_ns, const volatile int32_t *cancel, bnh_results **out,
+                    bnh_error *err) {
+    if (out) *out = nullptr;
+    return guarded(err, [&] {
+        InferenceOptions o = make_opts(timeout_ns, cancel);
+        auto r = std::make_unique<bnh_results>();
+        r->v.push_back(c->cl.predict(segment, len, o));
+        *out = r.release();
+    });
+}
+
+int32_t bnh_predict_batch(const bnh_classifier *c, const float *const *segments, const size_t *lens, size_t n, int64_t timeout_ns,
+                          const volatile int32_t *cancel, bnh_results **out, bnh_error *err) {
+    if (out) *out = nullptr;
+    return guarded(err, [&] {
+        InferenceOptions o = make_opts(timeout_ns, cancel);
+        auto r = std::make_unique<bnh_results>();
+        r->v = c->cl.predict_batch(segments, lens, n, o);
+        *out = r.release();
+    });
+}
+
+int32_t bnh_create_batch_context(const bnh_classifier *c, size_t max_batch, bnh_context **out, bnh_error *err) {
+    if (out) *out = nullptr;
+    return guarded(err, [&] {
+        auto x = std::make_unique<bnh_context>();
+        x->ctx = c->cl.create_batch_context(max_batch);
+        *out = x.release();
+    });
+}
+
+void bnh_context_free(bnh_context *ctx) { delete ctx; }
+size_t bnh_context_max_batch_size(const bnh_context *ctx) { return ctx->ctx->max_batch_size(); }
+size_t bnh_context_sample_count(const bnh_context *ctx) { return ctx->ctx->sample_count(); }
+size_t bnh_context_input_buffer_capacity(const bnh_context *ctx) { return ctx->ctx->input_buffer_capacity(); }
+size_t bnh_context_input_buffer_bytes(const bnh_context *ctx) { return ctx->ctx->input_buffer_bytes(); }
+int32_t bnh_context_model_type(const bnh_context *ctx) { return (int32_t)ctx->ctx->model_type(); }
+
+int32_t bnh_predict_batch_with_context(const bnh_classifier *c, bnh_context *ctx, const float *const *segments, const size_t *lens, size_t n,
+                                       int64_t timeout_ns, const volatile int32_t *cancel, bnh_results **out, bnh_error *err) {
+    if (out) *out = nullptr;
+    return guarded(err, [&] {
+        InferenceOptions o = make_opts(timeout_ns, cancel);
+        auto r = std::make_unique<bnh_results>();
+        r->v = c->cl.predict_batch_with_context(*ctx->ctx, segments, lens, n, o);
+        *out = r.release();
+    });
+}
+
+size_t bnh_results_len(const bnh_results *r) { return r ? r->v.size() : 0; }
+int32_t bnh_result_model_type(const bnh_results *r, size_t i) { return (int32_t)r->v[i].model_type; }
+size_t bnh_result_n_predictions(const bnh_results *r, size_t i) { return r->v[i].predictions.size(); }
+const char *bnh_result_species(const bnh_results *r, size_t i, size_t j) { return r->v[i].predictions[j].species.c_str(); }
+float bnh_result_confidence(const bnh_results *r, size_t i, size_t j) { return r->v[i].predictions[j].confidence; }
+size_t bnh_result_index(const bnh_results *r, size_t i, size_t j) { return r->v[i].predictions[j].index; }
+size_t bnh_result_raw_scores(const bnh_results *r, size_t i, const float **data) {
+    *data = r->v[i].raw_scores.data();
+    return r->v[i].raw_scores.size();
+}
+size_t bnh_result_embeddings(const bnh_results *r, size_t i, const float **data) {
+    *data = nullptr;
+    if (!r->v[i].embeddings) return 0;
+    *data = r->v[i].embeddings->data();
+    return r->v[i].embeddings->size();
+}
+void bnh_results_free(bnh_results *r) { delete r; }
+
+size_t bnh_parse_labels(const char *content, int32_t csv, char *out, size_t cap) {
+    std::vector<std::string> l;
+    try {
+        l = csv ? parse_csv_labels(content ? content : "") : parse_text_labels(content ? content : "");
+    } catch (...) {
+        return 0;
+    }
+    std::string joined;
+    for (size_t i = 0; i < l.size(); i++) joined += (i ? "\n" : "") + l[i];
+    if (out && cap) snprintf(out, cap, "%s", joined.c_str());
+    return joined.size() + 1;
+}
+
+size_t bnh_chunk_plan(size_t n_samples, size_t segment_samples, float overlap_secs, uint32_t sample_rate, uint64_t *starts, float *start_times,
+                      size_t cap) {
+    auto v = chunk_plan(n_samples, segment_samples, overlap_secs, sample_rate);
+    for (size_t i = 0; i < v.size() && i < cap; i++) {
+        if (starts) starts[i] = v[i].start;
+        if (start_times) start_times[i] = v[i].start_time;
+    }
+    return v.size();
+}
+
+}  // extern "C"

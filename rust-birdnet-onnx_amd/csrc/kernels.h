@@ -1,0 +1,125 @@
+// Launch descriptors shared by the planner (engine.cpp, host C++) and the HIP
+// kernels (kernels.hip, topk.hip).  All tensors are f32.  "Batch" is always the
+// outermost dimension and is the only run-time-variable size.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace bn {
+
+// Epilogue / unary function codes.
+enum Act : int32_t {
+    ACT_NONE = 0,
+    ACT_RELU,
+    ACT_CLIP,      // p0 = lo, p1 = hi
+    ACT_SIGMOID,
+    ACT_SILU,      // x * sigmoid(x)
+    ACT_HSIGMOID,  // max(0, min(1, p0*x + p1))
+    ACT_HSWISH,    // x * max(0, min(1, x/6 + 0.5))
+    ACT_LEAKY,     // x >= 0 ? x : p0*x
+    ACT_TANH,
+    ACT_EXP,
+    ACT_LOG,
+    ACT_SQRT,
+    ACT_ABS,
+    ACT_NEG,
+    ACT_RECIP,
+    ACT_POW,       // pow(x, p0)
+    ACT_AFFINE,    // p0*x + p1
+    ACT_MAXC,      // max(x, p0)
+    ACT_MINC,      // min(x, p0)
+    ACT_RSUB,      // p0 - x
+    ACT_RDIV,      // p0 / x
+    ACT_SQUARE,
+    ACT_FLOOR,
+    ACT_CEIL,
+    ACT_ERF,
+    ACT_SOFTPLUS,
+};
+
+enum BinOp : int32_t { BIN_NONE = 0, BIN_ADD, BIN_SUB, BIN_MUL, BIN_DIV, BIN_POW, BIN_MAX, BIN_MIN };
+enum RedOp : int32_t { RED_SUM = 0, RED_MEAN, RED_MAX, RED_MIN, RED_PROD, RED_L2, RED_SUMSQ };
+
+constexpr int ELT_MAX_DIMS = 5;  // per-sample loop dims (batch is separate)
+
+// out[b, i...] = act(bin(a[b, i...], b[b, i...])) over a per-sample index space
+// of nd dims, outermost first.  Strides are in elements; 0 broadcasts.
+struct EltDesc {
+    int32_t nd;
+    int64_t size[ELT_MAX_DIMS];
+    int64_t so[ELT_MAX_DIMS], sa[ELT_MAX_DIMS], sb[ELT_MAX_DIMS];
+    int64_t bo, ba, bb;  // batch strides (bb == 0 for constants)
+    int32_t bin;         // BinOp (BIN_NONE => unary)
+    int32_t act;         // applied after bin
+    float p0, p1;
+    int64_t per_sample;  // product of size[]
+    int32_t flat;        // 1: all operands contiguous with identical indexing -> vectorised path
+};
+
+// Generic reduction: kept dims (<=4, per sample) x reduced dims (<=3).
+struct ReduceDesc {
+    int32_t nk, nr;
+    int64_t ksize[4], kin[4], kout[4];
+    int64_t rsize[3], rin[3];
+    int64_t bi, bo;  // batch strides
+    int64_t kept, red;  // products
+    int32_t op;
+    int32_t inner_kept;  // 1: some kept dim has input stride 1 (threads map to kept index)
+};
+
+// C[r, n] = act(sum_k A[r, k] * W[n, k] + bias[n]) (+ res[r, n]) where row
+// r = b * rows + m addresses A at b*a_bs + m*lda (rows may overlap: conv1d
+// framing) and C / res at b*c_bs + m*ldc.  W is [N][K], K contiguous.
+struct GemmDesc {
+    int64_t rows;  // per sample
+    int32_t K, N;
+    int64_t lda, a_bs, ldc, c_bs, ldr, r_bs;
+    int32_t act;
+    float p0, p1;
+    int32_t has_bias, has_res;
+    int32_t has_scale;    // A is multiplied by scale[b, k] on load (squeeze-excite gate)
+    int64_t s_bs;         // batch stride of scale
+};
+
+// Direct NHWC convolution, weights [kh][kw][cin/groups][cout].
+struct ConvDesc {
+    int32_t H, W, Cin, OH, OW, Cout;
+    int32_t kh, kw, sh, sw, pt, pl, dh, dw, groups;
+    int32_t act;
+    float p0, p1;
+    int32_t has_bias, has_res;
+    int64_t in_bs, out_bs;
+};
+
+// Depthwise NHWC convolution, weights [kh][kw][C]; optionally accumulates the
+// per-(sample, channel) sum of the activated output (squeeze of squeeze-excite).
+struct DwDesc {
+    int32_t H, W, C, OH, OW;
+    int32_t kh, kw, sh, sw, pt, pl, dh, dw;
+    int32_t act;
+    float p0, p1;
+    int32_t has_bias;
+    int64_t in_bs, out_bs;
+};
+
+void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a, const float *b,
+                    int64_t batch);
+void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *in, int64_t batch);
+void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W,
+                 const float *bias, const float *res, const float *scale, int64_t batch);
+void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w,
+                 const float *bias, const float *res, int64_t batch);
+void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w,
+                   const float *bias, int64_t batch);
+
+// top-K + sigmoid + filter + stable sort, bit-exact with the reference's
+// BinaryHeap semantics (topk.hip).  idx/conf/count are device buffers with row
+// stride k_stride.
+void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, int64_t k,
+                 int has_min, float min_conf, int64_t k_stride, uint32_t *idx, float *conf,
+                 uint32_t *count);
+// LDS bytes the top-K kernel needs for (n, k); 0 if it cannot run (too large).
+size_t topk_lds_bytes(int64_t n, int64_t k);
+
+}  // namespace bn

@@ -1,0 +1,582 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the inference plan.
+//
+//  gemm_mfma_kernel   pointwise conv / conv1d framing / MatMul / FC on the matrix
+//                     cores with exact-f32 MFMA (v_mfma_f32_32x32x2_f32), LDS
+//                     staged, fused bias + activation + residual epilogue
+//  dwconv_kernel      NHWC depthwise KxK, 4 channels per lane (float4), fused
+//                     bias + activation
+//  conv_direct_kernel NHWC direct convolution (stem conv, grouped conv fallback)
+//  reduce_*_kernel    strided reductions (global pooling, per-segment min/max)
+//  elt_*_kernel       strided elementwise / broadcast / copy
+//
+// All tensors are f32, the batch is the outermost dimension.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "kernels.h"
+
+namespace bn {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_apply(int act, float x, float p0, float p1) {
+    switch (act) {
+        case ACT_NONE: return x;
+        case ACT_RELU: return fmaxf(x, 0.0f);
+        case ACT_CLIP: return fminf(fmaxf(x, p0), p1);
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+        case ACT_SILU: return x / (1.0f + expf(-x));
+        case ACT_HSIGMOID: return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f);
+        case ACT_HSWISH: return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case ACT_LEAKY: return x >= 0.0f ? x : p0 * x;
+        case ACT_TANH: return tanhf(x);
+        case ACT_EXP: return expf(x);
+        case ACT_LOG: return logf(x);
+        case ACT_SQRT: return sqrtf(x);
+        case ACT_ABS: return fabsf(x);
+        case ACT_NEG: return -x;
+        case ACT_RECIP: return 1.0f / x;
+        case ACT_POW: return powf(x, p0);
+        case ACT_AFFINE: return p0 * x + p1;
+        case ACT_MAXC: return fmaxf(x, p0);
+        case ACT_MINC: return fminf(x, p0);
+        case ACT_RSUB: return p0 - x;
+        case ACT_RDIV: return p0 / x;
+        case ACT_SQUARE: return x * x;
+        case ACT_FLOOR: return floorf(x);
+        case ACT_CEIL: return ceilf(x);
+        case ACT_ERF: return erff(x);
+        case ACT_SOFTPLUS: return log1pf(expf(x));
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float bin_apply(int bin, float a, float b) {
+    switch (bin) {
+        case BIN_ADD: return a + b;
+        case BIN_SUB: return a - b;
+        case BIN_MUL: return a * b;
+        case BIN_DIV: return a / b;
+        case BIN_POW: return powf(a, b);
+        case BIN_MAX: return fmaxf(a, b);
+        case BIN_MIN: return fminf(a, b);
+        default: return a;
+    }
+}
+
+// ------------------------------------------------------------------ elementwise
+// grid: (ceil(per_sample / (256*UNROLL)), batch)
+__global__ __launch_bounds__(256) void elt_strided_kernel(EltDesc d, float *__restrict__ out,
+                                                          const float *__restrict__ a,
+                                                          const float *__restrict__ b) {
+    const int64_t bidx = blockIdx.y;
+    const uint32_t per = (uint32_t)d.per_sample;
+    float *o = out + bidx * d.bo;
+    const float *pa = a + bidx * d.ba;
+    const float *pb = b ? b + bidx * d.bb : nullptr;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < per; i += gridDim.x * 256u) {
+        uint32_t rem = i;
+        int64_t oo = 0, oa = 0, ob = 0;
+#pragma unroll
+        for (int k = ELT_MAX_DIMS - 1; k >= 0; k--) {
+            if (k < d.nd) {
+                const uint32_t sz = (uint32_t)d.size[k];
+                const uint32_t idx = rem % sz;
+                rem /= sz;
+                oo += (int64_t)idx * d.so[k];
+                oa += (int64_t)idx * d.sa[k];
+                ob += (int64_t)idx * d.sb[k];
+            }
+        }
+        float v = pa[oa];
+        if (d.bin != BIN_NONE) v = bin_apply(d.bin, v, pb[ob]);
+        o[oo] = act_apply(d.act, v, d.p0, d.p1);
+    }
+}
+
+// contiguous operands, 4 elements per lane
+__global__ __launch_bounds__(256) void elt_flat4_kernel(EltDesc d, float *__restrict__ out,
+                                                        const float *__restrict__ a,
+                                                        const float *__restrict__ b) {
+    const int64_t bidx = blockIdx.y;
+    const uint32_t per4 = (uint32_t)(d.per_sample >> 2);
+    float4 *o = reinterpret_cast<float4 *>(out + bidx * d.bo);
+    const float4 *pa = reinterpret_cast<const float4 *>(a + bidx * d.ba);
+    const float4 *pb = b ? reinterpret_cast<const float4 *>(b + bidx * d.bb) : nullptr;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < per4; i += gridDim.x * 256u) {
+        float4 v = pa[i];
+        if (d.bin != BIN_NONE) {
+            const float4 w = pb[i];
+            v.x = bin_apply(d.bin, v.x, w.x);
+            v.y = bin_apply(d.bin, v.y, w.y);
+            v.z = bin_apply(d.bin, v.z, w.z);
+            v.w = bin_apply(d.bin, v.w, w.w);
+        }
+        v.x = act_apply(d.act, v.x, d.p0, d.p1);
+        v.y = act_apply(d.act, v.y, d.p0, d.p1);
+        v.z = act_apply(d.act, v.z, d.p0, d.p1);
+        v.w = act_apply(d.act, v.w, d.p0, d.p1);
+        o[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ float red_init(int op) {
+    switch (op) {
+        case RED_MAX: return -INFINITY;
+        case RED_MIN: return INFINITY;
+        case RED_PROD: return 1.0f;
+        default: return 0.0f;
+    }
+}
+__device__ __forceinline__ float red_step(int op, float acc, float x) {
+    switch (op) {
+        case RED_MAX: return fmaxf(acc, x);
+        case RED_MIN: return fminf(acc, x);
+        case RED_PROD: return acc * x;
+        case RED_L2:
+        case RED_SUMSQ: return acc + x * x;
+        default: return acc + x;
+    }
+}
+__device__ __forceinline__ float red_merge(int op, float a, float b) {
+    switch (op) {
+        case RED_MAX: return fmaxf(a, b);
+        case RED_MIN: return fminf(a, b);
+        case RED_PROD: return a * b;
+        default: return a + b;
+    }
+}
+__device__ __forceinline__ float red_finish(int op, float acc, int64_t n) {
+    if (op == RED_MEAN) return acc / (float)n;
+    if (op == RED_L2) return sqrtf(acc);
+    return acc;
+}
+__device__ __forceinline__ int64_t red_offset(const ReduceDesc &d, uint32_t r) {
+    int64_t off = 0;
+#pragma unroll
+    for (int k = 2; k >= 0; k--) {
+        if (k < d.nr) {
+            const uint32_t sz = (uint32_t)d.rsize[k];
+            off += (int64_t)(r % sz) * d.rin[k];
+            r /= sz;
+        }
+    }
+    return off;
+}
+__device__ __forceinline__ void kept_offsets(const ReduceDesc &d, uint32_t kidx, int64_t &in_off,
+                                             int64_t &out_off) {
+    in_off = 0;
+    out_off = 0;
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+        if (k < d.nk) {
+            const uint32_t sz = (uint32_t)d.ksize[k];
+            const uint32_t idx = kidx % sz;
+            kidx /= sz;
+            in_off += (int64_t)idx * d.kin[k];
+            out_off += (int64_t)idx * d.kout[k];
+        }
+    }
+}
+
+// kept index on threadIdx.x (coalesced along the innermost kept dim), the reduced
+// range split over threadIdx.y.  block (64, 16); grid (ceil(kept/64), batch)
+__global__ __launch_bounds__(1024) void reduce_inner_kept_kernel(ReduceDesc d, float *__restrict__ out,
+                                                                 const float *__restrict__ in) {
+    __shared__ float part[16][64];
+    const int64_t bidx = blockIdx.y;
+    const uint32_t kidx = blockIdx.x * 64u + threadIdx.x;
+    const bool valid = kidx < (uint32_t)d.kept;
+    float acc = red_init(d.op);
+    int64_t in_off = 0, out_off = 0;
+    if (valid) {
+        kept_offsets(d, kidx, in_off, out_off);
+        const float *p = in + bidx * d.bi + in_off;
+        for (uint32_t r = threadIdx.y; r < (uint32_t)d.red; r += 16u) acc = red_step(d.op, acc, p[red_offset(d, r)]);
+    }
+    part[threadIdx.y][threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.y == 0 && valid) {
+        for (int y = 1; y < 16; y++) acc = red_merge(d.op, acc, part[y][threadIdx.x]);
+        out[bidx * d.bo + out_off] = red_finish(d.op, acc, d.red);
+    }
+}
+
+// one block per (kept index, sample): threads stride over the reduced range
+// block 256; grid (kept, batch)
+__global__ __launch_bounds__(256) void reduce_row_kernel(ReduceDesc d, float *__restrict__ out,
+                                                         const float *__restrict__ in) {
+    __shared__ float part[4];
+    const int64_t bidx = blockIdx.y;
+    int64_t in_off, out_off;
+    kept_offsets(d, blockIdx.x, in_off, out_off);
+    const float *p = in + bidx * d.bi + in_off;
+    float acc = red_init(d.op);
+    if (d.nr == 1) {
+        const int64_t st = d.rin[0];
+        for (uint32_t r = threadIdx.x; r < (uint32_t)d.red; r += 256u) acc = red_step(d.op, acc, p[(int64_t)r * st]);
+    } else {
+        for (uint32_t r = threadIdx.x; r < (uint32_t)d.red; r += 256u) acc = red_step(d.op, acc, p[red_offset(d, r)]);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc = red_merge(d.op, acc, __shfl_down(acc, off));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        acc = red_merge(d.op, red_merge(d.op, part[0], part[1]), red_merge(d.op, part[2], part[3]));
+        out[bidx * d.bo + out_off] = red_finish(d.op, acc, d.red);
+    }
+}
+
+// ------------------------------------------------------------------ MFMA GEMM
+// Block tile 128 x BN, K step 32, 256 threads = 4 waves stacked along M.  Each
+// wave owns a 32 x BN strip: BN/32 accumulators of v_mfma_f32_32x32x2_f32.
+// LDS rows are padded to 36 floats so the b128 fragment reads are conflict free.
+//
+// Fragment trick: one ds_read_b128 per operand feeds four MFMAs.  The MFMA sums
+// over two k-slots (lane>>5); slot h of MFMA j carries k = 8g + 4h + j, the same
+// assignment for A and B, so every k of the 8-wide group is used exactly once.
+constexpr int GEMM_BM = 128, GEMM_BK = 32, GEMM_LD = 36;
+
+template <int AVEC>
+__device__ __forceinline__ void load_a_tile(const GemmDesc &d, const float *__restrict__ A, int64_t total_rows,
+                                            int64_t row0, int k0, int tid, float (&regs)[16]) {
+    // 128 rows x 32 floats = 4096 floats, 16 per thread
+    constexpr int PER_ROW = GEMM_BK / AVEC;        // vectors per row
+    constexpr int ITERS = 16 / AVEC;               // vector loads per thread
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
+        const int f = tid + i * 256;
+        const int row = f / PER_ROW, cv = f % PER_ROW;
+        const int64_t r = row0 + row;
+        const int k = k0 + cv * AVEC;
+        float v[AVEC];
+#pragma unroll
+        for (int j = 0; j < AVEC; j++) v[j] = 0.0f;
+        if (r < total_rows && k < d.K) {
+            const int64_t b = r / d.rows, m = r - b * d.rows;
+            const float *p = A + b * d.a_bs + m * d.lda + k;
+            if constexpr (AVEC == 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(p);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else if constexpr (AVEC == 2) {
+                const float2 t = *reinterpret_cast<const float2 *>(p);
+                v[0] = t.x; v[1] = t.y;
+            } else {
+                v[0] = *p;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < AVEC; j++) regs[i * AVEC + j] = v[j];
+    }
+}
+
+template <int AVEC>
+__device__ __forceinline__ void store_a_tile(float *__restrict__ As, int tid, const float (&regs)[16]) {
+    constexpr int PER_ROW = GEMM_BK / AVEC;
+    constexpr int ITERS = 16 / AVEC;
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
+        const int f = tid + i * 256;
+        const int row = f / PER_ROW, cv = f % PER_ROW;
+        float *p = As + row * GEMM_LD + cv * AVEC;
+        if constexpr (AVEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(regs[i * 4], regs[i * 4 + 1], regs[i * 4 + 2], regs[i * 4 + 3]);
+        else if constexpr (AVEC == 2) *reinterpret_cast<float2 *>(p) = make_float2(regs[i * 2], regs[i * 2 + 1]);
+        else *p = regs[i];
+    }
+}
+
+template <int BN, int WVEC>
+__device__ __forceinline__ void load_w_tile(const GemmDesc &d, const float *__restrict__ W, int n0, int k0, int tid,
+                                            float (&regs)[BN / 8]) {
+    // BN rows x 32 floats = BN*32 floats, BN/8 per thread
+    constexpr int PER_ROW = GEMM_BK / WVEC;
+    constexpr int ITERS = BN / 8 / WVEC;
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
+        const int f = tid + i * 256;
+        const int row = f / PER_ROW, cv = f % PER_ROW;
+        const int n = n0 + row, k = k0 + cv * WVEC;
+        float v[WVEC];
+#pragma unroll
+        for (int j = 0; j < WVEC; j++) v[j] = 0.0f;
+        if (n < d.N && k < d.K) {
+            const float *p = W + (int64_t)n * d.K + k;
+            if constexpr (WVEC == 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(p);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                v[0] = *p;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WVEC; j++) regs[i * WVEC + j] = v[j];
+    }
+}
+
+template <int BN, int WVEC>
+__device__ __forceinline__ void store_w_tile(float *__restrict__ Ws, int tid, const float (&regs)[BN / 8]) {
+    constexpr int PER_ROW = GEMM_BK / WVEC;
+    constexpr int ITERS = BN / 8 / WVEC;
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
+        const int f = tid + i * 256;
+        const int row = f / PER_ROW, cv = f % PER_ROW;
+        float *p = Ws + row * GEMM_LD + cv * WVEC;
+        if constexpr (WVEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(regs[i * 4], regs[i * 4 + 1], regs[i * 4 + 2], regs[i * 4 + 3]);
+        else *p = regs[i];
+    }
+}
+
+template <int BN, int AVEC, int WVEC>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__restrict__ C,
+                                                        const float *__restrict__ A,
+                                                        const float *__restrict__ W,
+                                                        const float *__restrict__ bias,
+                                                        const float *__restrict__ res, int64_t total_rows) {
+    constexpr int NT = BN / 32;
+    __shared__ __align__(16) float As[GEMM_BM * GEMM_LD];
+    __shared__ __align__(16) float Ws[BN * GEMM_LD];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * GEMM_BM;
+    const int n0 = blockIdx.y * BN;
+
+    floatx16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+
+    float ra[16];
+    float rw[BN / 8];
+    load_a_tile<AVEC>(d, A, total_rows, row0, 0, tid, ra);
+    load_w_tile<BN, WVEC>(d, W, n0, 0, tid, rw);
+    const bool wave_active = row0 + wave * 32 < total_rows;
+
+    for (int k0 = 0; k0 < d.K; k0 += GEMM_BK) {
+        __syncthreads();  // previous tile fully consumed
+        store_a_tile<AVEC>(As, tid, ra);
+        store_w_tile<BN, WVEC>(Ws, tid, rw);
+        __syncthreads();
+        if (k0 + GEMM_BK < d.K) {  // prefetch the next tile into registers while computing
+            load_a_tile<AVEC>(d, A, total_rows, row0, k0 + GEMM_BK, tid, ra);
+            load_w_tile<BN, WVEC>(d, W, n0, k0 + GEMM_BK, tid, rw);
+        }
+        if (wave_active) {
+            const float *ap = As + (wave * 32 + lr) * GEMM_LD + 4 * lh;
+            const float *wp = Ws + lr * GEMM_LD + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < GEMM_BK / 8; g++) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const float4 b4 = *reinterpret_cast<const float4 *>(wp + t * 32 * GEMM_LD + 8 * g);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!wave_active) return;
+    // epilogue: acc[t][reg] is C[row = (reg&3) + 8*(reg>>2) + 4*lh][col = lr] of the 32x32 tile
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int64_t r = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (r >= total_rows) continue;
+        const int64_t b = r / d.rows, m = r - b * d.rows;
+        float *crow = C + b * d.c_bs + m * d.ldc;
+        const float *rrow = d.has_res ? res + b * d.r_bs + m * d.ldr : nullptr;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int n = n0 + t * 32 + lr;
+            if (n < d.N) {
+                float v = acc[t][reg];
+                if (d.has_bias) v += bias[n];
+                v = act_apply(d.act, v, d.p0, d.p1);
+                if (d.has_res) v += rrow[n];
+                crow[n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ depthwise conv
+// one lane = one output pixel x 4 channels.  grid (ceil(OH*OW*C4/256), batch)
+template <int VEC>
+__global__ __launch_bounds__(256) void dwconv_kernel(DwDesc d, float *__restrict__ out,
+                                                     const float *__restrict__ in,
+                                                     const float *__restrict__ w,
+                                                     const float *__restrict__ bias) {
+    const int64_t bidx = blockIdx.y;
+    const uint32_t CV = (uint32_t)d.C / VEC;
+    const uint32_t total = (uint32_t)d.OH * d.OW * CV;
+    const float *ip = in + bidx * d.in_bs;
+    float *op = out + bidx * d.out_bs;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t cv = i % CV;
+        const uint32_t pix = i / CV;
+        const int ow = pix % d.OW, oh = pix / d.OW;
+        const int c = cv * VEC;
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) acc[j] = d.has_bias ? bias[c + j] : 0.0f;
+        const int ih0 = oh * d.sh - d.pt, iw0 = ow * d.sw - d.pl;
+        for (int ky = 0; ky < d.kh; ky++) {
+            const int ih = ih0 + ky * d.dh;
+            if (ih < 0 || ih >= d.H) continue;
+            for (int kx = 0; kx < d.kw; kx++) {
+                const int iw = iw0 + kx * d.dw;
+                if (iw < 0 || iw >= d.W) continue;
+                const float *px = ip + ((int64_t)ih * d.W + iw) * d.C + c;
+                const float *pw = w + (ky * d.kw + kx) * d.C + c;
+                if constexpr (VEC == 4) {
+                    const float4 x = *reinterpret_cast<const float4 *>(px);
+                    const float4 k = *reinterpret_cast<const float4 *>(pw);
+                    acc[0] = fmaf(x.x, k.x, acc[0]);
+                    acc[1] = fmaf(x.y, k.y, acc[1]);
+                    acc[2] = fmaf(x.z, k.z, acc[2]);
+                    acc[3] = fmaf(x.w, k.w, acc[3]);
+                } else {
+                    acc[0] = fmaf(px[0], pw[0], acc[0]);
+                }
+            }
+        }
+        float *po = op + (int64_t)pix * d.C + c;
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4 *>(po) = make_float4(act_apply(d.act, acc[0], d.p0, d.p1), act_apply(d.act, acc[1], d.p0, d.p1),
+                                                          act_apply(d.act, acc[2], d.p0, d.p1), act_apply(d.act, acc[3], d.p0, d.p1));
+        } else {
+            po[0] = act_apply(d.act, acc[0], d.p0, d.p1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ direct conv
+// one lane = one output element (oc fastest).  grid (ceil(OH*OW*Cout/256), batch)
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvDesc d, float *__restrict__ out,
+                                                          const float *__restrict__ in,
+                                                          const float *__restrict__ w,
+                                                          const float *__restrict__ bias,
+                                                          const float *__restrict__ res) {
+    const int64_t bidx = blockIdx.y;
+    const uint32_t total = (uint32_t)d.OH * d.OW * d.Cout;
+    const int cpg = d.Cin / d.groups, opg = d.Cout / d.groups;
+    const float *ip = in + bidx * d.in_bs;
+    float *op = out + bidx * d.out_bs;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int oc = i % d.Cout;
+        const uint32_t pix = i / d.Cout;
+        const int ow = pix % d.OW, oh = pix / d.OW;
+        const int g = oc / opg;
+        float acc = d.has_bias ? bias[oc] : 0.0f;
+        const int ih0 = oh * d.sh - d.pt, iw0 = ow * d.sw - d.pl;
+        for (int ky = 0; ky < d.kh; ky++) {
+            const int ih = ih0 + ky * d.dh;
+            if (ih < 0 || ih >= d.H) continue;
+            for (int kx = 0; kx < d.kw; kx++) {
+                const int iw = iw0 + kx * d.dw;
+                if (iw < 0 || iw >= d.W) continue;
+                const float *px = ip + ((int64_t)ih * d.W + iw) * d.Cin + g * cpg;
+                const float *pw = w + (int64_t)((ky * d.kw + kx) * cpg) * d.Cout + oc;
+                for (int ci = 0; ci < cpg; ci++) acc = fmaf(px[ci], pw[(int64_t)ci * d.Cout], acc);
+            }
+        }
+        acc = act_apply(d.act, acc, d.p0, d.p1);
+        if (d.has_res) acc += res[bidx * d.out_bs + i];
+        op[i] = acc;
+    }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline unsigned cap_blocks(int64_t want, int64_t cap) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, cap)); }
+
+}  // namespace
+
+void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a, const float *b, int64_t batch) {
+    if (batch <= 0 || d.per_sample <= 0) return;
+    const bool vec4 = d.flat && (d.per_sample % 4 == 0) && (d.bo % 4 == 0) && (d.ba % 4 == 0) && (b == nullptr || d.bb % 4 == 0) &&
+                      aligned16(out) && aligned16(a) && (b == nullptr || aligned16(b));
+    if (vec4) {
+        dim3 grid(cap_blocks((d.per_sample / 4 + 255) / 256, 4096), (unsigned)batch);
+        hipLaunchKernelGGL(elt_flat4_kernel, grid, dim3(256), 0, s, d, out, a, b);
+    } else {
+        dim3 grid(cap_blocks((d.per_sample + 255) / 256, 4096), (unsigned)batch);
+        hipLaunchKernelGGL(elt_strided_kernel, grid, dim3(256), 0, s, d, out, a, b);
+    }
+}
+
+void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *in, int64_t batch) {
+    if (batch <= 0) return;
+    if (d.inner_kept) {
+        dim3 grid((unsigned)((d.kept + 63) / 64), (unsigned)batch);
+        hipLaunchKernelGGL(reduce_inner_kept_kernel, grid, dim3(64, 16), 0, s, d, out, in);
+    } else {
+        dim3 grid((unsigned)d.kept, (unsigned)batch);
+        hipLaunchKernelGGL(reduce_row_kernel, grid, dim3(256), 0, s, d, out, in);
+    }
+}
+
+template <int BN>
+static void launch_gemm_bn(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
+                           const float *res, int64_t total_rows) {
+    dim3 grid((unsigned)((total_rows + GEMM_BM - 1) / GEMM_BM), (unsigned)((d.N + BN - 1) / BN));
+    const bool w4 = (d.K % 4 == 0) && aligned16(W);
+    int avec = 1;
+    if (d.K % 4 == 0 && d.lda % 4 == 0 && d.a_bs % 4 == 0 && aligned16(A)) avec = 4;
+    else if (d.K % 2 == 0 && d.lda % 2 == 0 && d.a_bs % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 7u) == 0) avec = 2;
+#define BN_LAUNCH(AV, WV) hipLaunchKernelGGL((gemm_mfma_kernel<BN, AV, WV>), grid, dim3(256), 0, s, d, C, A, W, bias, res, total_rows)
+    if (w4) {
+        if (avec == 4) BN_LAUNCH(4, 4);
+        else if (avec == 2) BN_LAUNCH(2, 4);
+        else BN_LAUNCH(1, 4);
+    } else {
+        if (avec == 4) BN_LAUNCH(4, 1);
+        else if (avec == 2) BN_LAUNCH(2, 1);
+        else BN_LAUNCH(1, 1);
+    }
+#undef BN_LAUNCH
+}
+
+void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
+                 const float *res, const float *scale, int64_t batch) {
+    (void)scale;
+    if (batch <= 0) return;
+    const int64_t total_rows = batch * d.rows;
+    const int64_t mblocks = (total_rows + GEMM_BM - 1) / GEMM_BM;
+    // widest N tile that still fills the 256 CUs a couple of times over
+    if (d.N > 64 && mblocks * ((d.N + 127) / 128) >= 512) launch_gemm_bn<128>(s, d, C, A, W, bias, res, total_rows);
+    else if (d.N > 32 && mblocks * ((d.N + 63) / 64) >= 256) launch_gemm_bn<64>(s, d, C, A, W, bias, res, total_rows);
+    else launch_gemm_bn<32>(s, d, C, A, W, bias, res, total_rows);
+}
+
+void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w, const float *bias,
+                 const float *res, int64_t batch) {
+    if (batch <= 0) return;
+    const int64_t total = (int64_t)d.OH * d.OW * d.Cout;
+    dim3 grid(cap_blocks((total + 255) / 256, 8192), (unsigned)batch);
+    hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, d, out, in, w, bias, res);
+}
+
+void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w, const float *bias,
+                   int64_t batch) {
+    if (batch <= 0) return;
+    const bool v4 = d.C % 4 == 0 && d.in_bs % 4 == 0 && d.out_bs % 4 == 0 && aligned16(in) && aligned16(out) && aligned16(w);
+    if (v4) {
+        const int64_t total = (int64_t)d.OH * d.OW * (d.C / 4);
+        dim3 grid(cap_blocks((total + 255) / 256, 8192), (unsigned)batch);
+        hipLaunchKernelGGL(dwconv_kernel<4>, grid, dim3(256), 0, s, d, out, in, w, bias);
+    } else {
+        const int64_t total = (int64_t)d.OH * d.OW * d.C;
+        dim3 grid(cap_blocks((total + 255) / 256, 8192), (unsigned)batch);
+        hipLaunchKernelGGL(dwconv_kernel<1>, grid, dim3(256), 0, s, d, out, in, w, bias);
+    }
+}
+
+}  // namespace bn

@@ -1,0 +1,289 @@
+// top_k_predictions on the device: one wavefront (64 lanes) per logits row.
+//
+// Reference behaviour being reproduced (file:line under the reference tree):
+//   src/postprocess.rs:8-35   ScoreEntry ordering = reversed f32::total_cmp
+//   src/postprocess.rs:40-87  push every logit into a BinaryHeap capped at k,
+//                             sigmoid the survivors in Vec order, filter
+//                             `confidence >= min`, stable sort descending
+//   src/postprocess.rs:91-93  sigmoid(x) = 1 / (1 + exp(-x))
+//
+// The result must be identical to the reference INCLUDING which index survives
+// a tie and the order of equal confidences, both of which are decided by Rust
+// std's BinaryHeap arrangement.  So the kernel runs the very same heap
+// algorithm (sift_up / sift_down_to_bottom with the Hole idiom) on an LDS
+// resident heap, and gets its speed from skipping, 64 logits at a time, the
+// pushes that are provably no-ops:
+//
+//   push(x) followed by pop() leaves the heap array bit-for-bit unchanged when
+//   (1) key(x) < key(root) strictly, and
+//   (2) along the fixed root->slot-k path every on-path node is strictly
+//       smaller than the sibling of its on-path child (and than slot k-1 when
+//       k is even).
+//   Under (1) x sifts up to the root, shifting the path down one level; pop()
+//   then drops x, and sift_down_to_bottom walks the same path back because (2)
+//   makes the on-path child the unique minimum at every level.
+//
+// Condition (2) only involves O(log k) fixed slots, so it is re-evaluated by
+// lane 0 after every real heap update.  On typical logits ~k*ln(n/k) of the n
+// elements are real updates; fully tied rows degrade to the serial algorithm
+// but stay exact.
+//
+// exp(): Rust's f32::exp is the platform libm expf.  glibc 2.35's expf (the
+// ARM optimized-routines algorithm: 32-entry 2^(i/32) table, cubic in double
+// precision) is restated here operation for operation, in the fused form its
+// x86-64 FMA build executes, so confidences are bit-identical to the
+// reference on an FMA-capable host.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.h"
+
+namespace bn {
+namespace {
+
+__device__ __forceinline__ uint32_t total_key(uint32_t b) {
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__constant__ uint64_t kExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+// glibc 2.35 expf, FMA build.  Compiled with -ffp-contract=off so only the
+// explicit fma() calls fuse.
+__device__ float expf_glibc(float x) {
+    const uint32_t ix = __float_as_uint(x);
+    const uint32_t abstop = (ix >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {  // |x| >= 88 or NaN
+        if (ix == 0xff800000u) return 0.0f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);  // overflow
+        if (x < -0x1.9fe368p6f) return 0.0f;                         // underflow
+    }
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0;
+    const double Shift = 0x1.8p52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    const double xd = (double)x;
+    double kd = fma(InvLn2N, xd, Shift);
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd = kd - Shift;
+    const double r = fma(InvLn2N, xd, -kd);
+    const uint64_t t = kExp2fTab[ki & 31u] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    const double z = fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = fma(r, C2, 1.0);
+    y = fma(z, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
+__device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf_glibc(-x)); }
+
+struct Heap {
+    uint32_t *key;  // total_cmp keys
+    uint32_t *idx;
+};
+
+// heap_le(a, b) <=> ScoreEntry a <= b <=> key(a) >= key(b)
+__device__ __forceinline__ void sift_up(Heap h, uint32_t start, uint32_t pos) {
+    const uint32_t ek = h.key[pos], ei = h.idx[pos];
+    while (pos > start) {
+        const uint32_t parent = (pos - 1) >> 1;
+        if (ek >= h.key[parent]) break;
+        h.key[pos] = h.key[parent];
+        h.idx[pos] = h.idx[parent];
+        pos = parent;
+    }
+    h.key[pos] = ek;
+    h.idx[pos] = ei;
+}
+
+__device__ __forceinline__ void sift_down_to_bottom(Heap h, uint32_t end, uint32_t pos) {
+    const uint32_t start = pos;
+    const uint32_t ek = h.key[pos], ei = h.idx[pos];
+    uint32_t child = 2 * pos + 1;
+    const uint32_t lim = end >= 2 ? end - 2 : 0;
+    while (child <= lim) {
+        child += (h.key[child] >= h.key[child + 1]) ? 1u : 0u;
+        h.key[pos] = h.key[child];
+        h.idx[pos] = h.idx[child];
+        pos = child;
+        child = 2 * pos + 1;
+    }
+    if (child == end - 1) {
+        h.key[pos] = h.key[child];
+        h.idx[pos] = h.idx[child];
+        pos = child;
+    }
+    h.key[pos] = ek;
+    h.idx[pos] = ei;
+    sift_up(h, start, pos);
+}
+
+// Condition (2) of the header comment for a full heap of k entries.
+__device__ bool path_is_strict(Heap h, uint32_t k) {
+    uint32_t node = k;  // slot the next push lands in
+    while (node > 0) {
+        const uint32_t parent = (node - 1) >> 1;
+        const uint32_t sib = (node & 1u) ? node + 1 : node - 1;
+        // sibling of the on-path child; slot k itself is not in the heap yet
+        if (sib < k && !(h.key[parent] < h.key[sib])) return false;
+        node = parent;
+    }
+    return true;
+}
+
+// LDS layout: key[k+1] | idx[k+1] | conf[k] (conf reuses nothing: kept separate for clarity)
+__global__ __launch_bounds__(64) void topk_kernel(const float *__restrict__ logits, int64_t n,
+                                                  uint32_t k, int has_min, float min_conf,
+                                                  int64_t k_stride, uint32_t *__restrict__ idx_out,
+                                                  float *__restrict__ conf_out,
+                                                  uint32_t *__restrict__ count_out) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    Heap h{lds, lds + (k + 1)};
+    float *conf = reinterpret_cast<float *>(lds + 2 * (size_t)(k + 1));
+    uint32_t *oidx = lds + 2 * (size_t)(k + 1) + k;
+    __shared__ uint32_t s_strict, s_root, s_cnt;
+
+    const int64_t row = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const float *x = logits + row * n;
+
+    // ---- phase 1: the first k pushes (no pops) ----
+    if (lane == 0) {
+        for (uint32_t i = 0; i < k; i++) {
+            h.key[i] = total_key(__float_as_uint(x[i]));
+            h.idx[i] = i;
+            sift_up(h, 0, i);
+        }
+        s_strict = path_is_strict(h, k) ? 1u : 0u;
+        s_root = h.key[0];
+    }
+    __syncthreads();
+
+    // ---- phase 2: remaining elements, 64 per step, skipping provable no-ops ----
+    for (int64_t base = k; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const bool valid = i < n;
+        const uint32_t myk = valid ? total_key(__float_as_uint(x[i])) : 0u;
+        uint64_t pending = __ballot(valid);
+        while (pending) {
+            const uint32_t strict = s_strict, root = s_root;
+            const bool mine = (pending >> lane) & 1ull;
+            const uint64_t cand = __ballot(mine && (!strict || myk >= root));
+            if (!cand) break;
+            const int l = __ffsll((long long)cand) - 1;  // lowest index first: sequential order
+            const uint32_t xk = __shfl(myk, l);
+            if (lane == 0) {
+                // heap.push(x); heap.pop()
+                h.key[k] = xk;
+                h.idx[k] = (uint32_t)(base + l);
+                sift_up(h, 0, k);
+                // pop: item = data.pop(); swap(item, data[0]); sift_down_to_bottom(0)
+                h.key[0] = h.key[k];
+                h.idx[0] = h.idx[k];
+                sift_down_to_bottom(h, k, 0);
+                s_strict = path_is_strict(h, k) ? 1u : 0u;
+                s_root = h.key[0];
+            }
+            __syncthreads();
+            pending &= ~((2ull << l) - 1ull);  // lanes <= l are done
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 3: sigmoid in Vec order, filter, stable sort descending ----
+    for (uint32_t j = lane; j < k; j += 64) {
+        const uint32_t kk = h.key[j];
+        const uint32_t bits = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;
+        conf[j] = sigmoid_ref(__uint_as_float(bits));
+    }
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t m = 0;
+        for (uint32_t j = 0; j < k; j++) {
+            const float c = conf[j];
+            if (has_min && !(c >= min_conf)) continue;
+            conf[m] = c;  // m <= j: in-place compaction
+            oidx[m] = h.idx[j];
+            m++;
+        }
+        s_cnt = m;
+    }
+    __syncthreads();
+    const uint32_t m = s_cnt;
+    uint32_t *io = idx_out + row * k_stride;
+    float *co = conf_out + row * k_stride;
+    if (m <= 64) {
+        // insertion sort, exactly what slice::sort_by runs for len <= 20 (and the
+        // oracle for every len): move left while strictly greater.
+        if (lane == 0) {
+            for (uint32_t i = 1; i < m; i++) {
+                const float tc = conf[i];
+                const uint32_t ti = oidx[i];
+                uint32_t j = i;
+                while (j > 0 && tc > conf[j - 1]) {
+                    conf[j] = conf[j - 1];
+                    oidx[j] = oidx[j - 1];
+                    j--;
+                }
+                conf[j] = tc;
+                oidx[j] = ti;
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = lane; j < m; j += 64) {
+            io[j] = oidx[j];
+            co[j] = conf[j];
+        }
+    } else {
+        // stable rank sort (identical to any stable sort when confidences are
+        // totally ordered, the only case std::sort_by specifies for len > 20)
+        for (uint32_t i = lane; i < m; i += 64) {
+            const float ci = conf[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m; j++) {
+                const float cj = conf[j];
+                rank += (cj > ci || (j < i && !(ci > cj))) ? 1u : 0u;
+            }
+            io[rank] = oidx[i];
+            co[rank] = ci;
+        }
+    }
+    if (lane == 0) count_out[row] = m;
+}
+
+}  // namespace
+
+size_t topk_lds_bytes(int64_t n, int64_t k) {
+    (void)n;
+    size_t b = (size_t)(2 * (k + 1) + 2 * k) * 4;
+    return b <= 150 * 1024 ? b : 0;
+}
+
+void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, int64_t k,
+                 int has_min, float min_conf, int64_t k_stride, uint32_t *idx, float *conf,
+                 uint32_t *count) {
+    if (rows <= 0 || k <= 0 || n <= 0) return;
+    const size_t lds = topk_lds_bytes(n, k);
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3((unsigned)rows), dim3(64), lds, s, logits, n, (uint32_t)k,
+                       has_min, min_conf, k_stride, idx, conf, count);
+}
+
+}  // namespace bn

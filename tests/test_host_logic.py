@@ -1,0 +1,165 @@
+"""CPU tests of the host-side logic behind the C ABI: detection rules, label parsing,
+chunking, the ONNX reader and the launch planner (no GPU compute)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle
+
+synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+writer = importlib.import_module("rust-birdnet-onnx_amd.onnx_writer")
+
+
+def detect(bn, in_shape, out_shapes, override=-1):
+    ins = np.asarray(in_shape, dtype=np.int64)
+    flat = np.asarray([d for s in out_shapes for d in s] or [0], dtype=np.int64)
+    ranks = (C.c_size_t * max(len(out_shapes), 1))(*[len(s) for s in out_shapes])
+    cfg = bn.BnModelConfig()
+    i64p = C.POINTER(C.c_int64)
+    st = bn.lib.bn_detect_model_type(ins.ctypes.data_as(i64p), len(ins), flat.ctypes.data_as(i64p), ranks,
+                                     len(out_shapes), override, C.byref(cfg))
+    return (cfg if st == 0 else None), bn.last_error()
+
+
+CASES = [
+    ([1, 144000], [[1, 6522]], -1),
+    ([1, 160000], [[1, 1024], [1, 1000]], -1),
+    ([1, 160000], [[1, 1536], [1, 16, 4, 1536], [1, 500, 128], [1, 14795]], -1),
+    ([1, 160000], [[1, 512], [1, 16, 4, 512], [1, 500, 128], [1, 500]], 2),
+    ([1, 160000], [[1, 1024], [1, 1000]], 0),
+    ([1, 100000], [[1, 1000]], -1),
+    ([1, 1, 144000], [[1, 10]], -1),
+    ([-1, 144000], [[-1, 10]], -1),
+    ([144000], [[1, 10]], -1),
+    ([1, 144000], [[1, 5], [1, 6]], 0),
+    ([1, 160000], [[1, 5]], 1),
+    ([1, 160000], [[1, 5], [1, 6]], 2),
+    ([1, 144000], [[]], -1),
+]
+
+
+@pytest.mark.parametrize("in_shape,out_shapes,override", CASES)
+def test_detection_matches_oracle(bn, in_shape, out_shapes, override):
+    # detection.rs:183-284 KATs + error paths; the oracle is pinned by the same KATs
+    got, msg = detect(bn, in_shape, out_shapes, override)
+    want = oracle.detect_model_type(in_shape, out_shapes, None if override < 0 else override)
+    assert (got is None) == (want is None), msg
+    if got is not None:
+        for f in ("model_type", "sample_rate", "segment_duration", "sample_count", "num_species", "has_embedding",
+                  "embedding_dim"):
+            assert getattr(got, f) == getattr(want, f), f
+        assert got.logits_output == {0: 0, 1: 1, 2: 3}[got.model_type]
+        assert got.embedding_output == (-1 if got.model_type == 0 else 0)
+
+
+def test_detection_error_text(bn):
+    _, msg = detect(bn, [1, 100000], [[1, 1000]])
+    assert "unsupported model: 100000 samples, 1 outputs" in msg  # detection.rs:73-78, tested at :279-280
+    _, msg = detect(bn, [1, 160000], [[1, 1024], [1, 1000]], 0)
+    assert "BirdNetV24 expects 144000 samples, but model has 160000" in msg  # detection.rs:90-96
+
+
+def test_parse_text_labels(bn):  # labels.rs:42-48
+    assert bn.parse_labels("a\n  b  \n\n\nc\r\n", False) == ["a", "b", "c"]
+    assert bn.parse_labels("", False) == []
+
+
+def test_parse_csv_labels(bn):  # labels.rs:51-95
+    assert bn.parse_labels("label,other\nfoo,1\nbar,2\n", True) == ["foo", "bar"]
+    assert bn.parse_labels("inat2024_fsd50k\nx\ny\n", True) == ["x", "y"]
+    assert bn.parse_labels("robin,1\nwren,2\n", True) == ["robin", "wren"]          # no header
+    assert bn.parse_labels('"a, b",1\nc,2\n', True) == ["a, b", "c"]                  # quoted first column
+
+
+def test_reference_label_files_parse_to_the_pinned_counts(bn):
+    import os
+    base = "/root/reference/data/labels"
+    if not os.path.isdir(base):
+        pytest.skip("reference tree not present (GPU box)")
+    txt = open(os.path.join(base, "birdnet_v2.4", "BirdNET_GLOBAL_6K_V2.4_Labels_en_uk.txt"), encoding="utf-8").read()
+    assert len(bn.parse_labels(txt, False)) == 6522
+    csv = open(os.path.join(base, "perch_v2", "labels.csv"), encoding="utf-8").read()
+    assert len(bn.parse_labels(csv, True)) == 14795
+
+
+@pytest.mark.parametrize("n,seg,ov,sr", [(144000 * 3 + 10, 144000, 0.0, 48000), (300000, 144000, 1.5, 48000),
+                                         (1000, 144000, 3.0, 48000), (1000, 144000, 4.0, 48000), (0, 144000, 0.0, 48000),
+                                         (160000 * 7, 160000, 2.5, 32000), (999999, 144000, 2.999, 48000)])
+def test_chunk_plan_matches_oracle(bn, n, seg, ov, sr):  # birdnet-analyze.rs:707-743
+    s, t = bn.chunk_plan(n, seg, ov, sr)
+    so, to = oracle.chunk_plan(n, seg, ov, sr)
+    assert s.tolist() == so.tolist()
+    assert t.tobytes() == to.tobytes()
+
+
+def test_plan_of_v24_model(bn, tmp_path):
+    p = tmp_path / "m.onnx"
+    p.write_bytes(synth.birdnet_v24(num_species=100, width=0.5, depth=0.5, head=128))
+    text = bn.plan_describe(str(p))
+    lines = text.splitlines()
+    kinds = [l.split()[1] for l in lines if l[:3].strip().isdigit()]
+    # Conv+BN+ReLU fused: no standalone BN/Relu launches beyond the explicit spectrogram BN (2 ELT ops)
+    assert kinds.count("DWCONV") >= 7 and kinds.count("GEMM") >= 20 and kinds.count("CONV") == 1
+    assert "OUTPUT 0 output computed=1 row_elems=100" in text
+    # mel filterbank zero rows pruned the DFT conv: 1025 -> <200 bins and 513 -> <400
+    gemm_n = [int(l.split("N=")[1].split()[0]) for l in lines if " K=2048 " in l or " K=1024 " in l and "lda=28" in l]
+    assert gemm_n and max(gemm_n) < 400, gemm_n
+
+
+def test_dead_outputs_are_not_planned(bn, tmp_path):
+    p = tmp_path / "p.onnx"
+    p.write_bytes(synth.perch_v2(num_species=50, width=0.25, depth=0.25, emb=64))
+    main = bn.plan_describe(str(p))
+    full = bn.plan_describe(str(p), all_outputs=True)
+    assert "OUTPUT 1 spatial_embedding computed=0" in main and "OUTPUT 2 spectrogram computed=0" in main
+    assert "OUTPUT 1 spatial_embedding computed=1" in full and "OUTPUT 2 spectrogram computed=1" in full
+    assert "OUTPUT 0 embedding computed=1 row_elems=64" in main and "OUTPUT 3 label computed=1 row_elems=50" in main
+
+
+def test_malformed_and_unsupported_models(bn, tmp_path):
+    bad = tmp_path / "bad.onnx"
+    bad.write_bytes(b"\x00\x01garbage that is not a protobuf")
+    with pytest.raises(bn.EngineError) as e:
+        bn.plan_describe(str(bad))
+    assert e.value.status == 6  # BN_ERR_MODEL_LOAD
+    with pytest.raises(bn.EngineError):
+        bn.plan_describe(str(tmp_path / "missing.onnx"))
+    g = writer.GraphBuilder()
+    g.add_input("input", [None, 144000])
+    y = g.node("LSTM", ["input"], outputs=["output"])
+    g.add_output("output", [None, 10])
+    un = tmp_path / "un.onnx"
+    un.write_bytes(g.serialize())
+    with pytest.raises(bn.EngineError) as e:
+        bn.plan_describe(str(un))
+    assert e.value.status == 7 and "LSTM" in str(e.value)  # BN_ERR_UNSUPPORTED_MODEL names the node
+
+
+def test_builder_required_fields(bn):  # classifier.rs:336-337, tests :1105-1125
+    with pytest.raises(bn.Error) as e:
+        bn.Classifier.builder().labels(["a"]).build()
+    assert e.value.kind == bn.ErrorKind.ModelPathRequired and str(e.value) == "model path required"
+    with pytest.raises(bn.Error) as e:
+        bn.Classifier.builder().model_path("x.onnx").build()
+    assert e.value.kind == bn.ErrorKind.LabelsRequired and str(e.value) == "labels required (provide path or vec)"
+
+
+def test_inference_options(bn):  # inference_options.rs:116-199
+    o = bn.InferenceOptions()
+    assert not o.needs_monitor() and o.timeout is None and o.cancellation_token is None
+    assert bn.InferenceOptions.with_timeout_of(30).needs_monitor()
+    t = bn.CancellationToken()
+    assert not t.is_cancelled()
+    o = bn.InferenceOptions().with_timeout(1.0).with_cancellation_token(t)
+    t.cancel()
+    assert o.cancellation_token.is_cancelled() and o.needs_monitor()
+
+
+def test_model_type_constants(bn):  # types.rs:14-44, tests :194-235
+    M = bn.ModelType
+    assert (M.BirdNetV24.sample_rate(), M.BirdNetV24.segment_duration(), M.BirdNetV24.sample_count()) == (48000, 3.0, 144000)
+    assert (M.BirdNetV30.sample_rate(), M.BirdNetV30.segment_duration(), M.BirdNetV30.sample_count()) == (32000, 5.0, 160000)
+    assert (M.PerchV2.sample_rate(), M.PerchV2.sample_count()) == (32000, 160000)
+    assert not M.BirdNetV24.has_embeddings() and M.BirdNetV30.has_embeddings() and M.PerchV2.has_embeddings()
