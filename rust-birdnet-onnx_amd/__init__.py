@@ -499,8 +499,10 @@ class Context:
         cfg = self.model.config
         f32p = C.POINTER(C.c_float)
         ptrs = (f32p * max(b, 1))(*[x[i].ctypes.data_as(f32p) for i in range(b)])
-        logits = np.empty((b, cfg.num_species), dtype=np.float32)
-        emb = np.empty((b, cfg.embedding_dim), dtype=np.float32) if (cfg.has_embedding and want_embeddings) else None
+        logits = np.empty((b, self.output_device(cfg.logits_output)[1]), dtype=np.float32)
+        emb = None
+        if cfg.has_embedding and want_embeddings:
+            emb = np.empty((b, self.output_device(cfg.embedding_output)[1]), dtype=np.float32)
         st = lib.bn_infer(self._h, ptrs, b, logits.ctypes.data_as(f32p),
                           None if emb is None else emb.ctypes.data_as(f32p), cancel, timeout_ns)
         if st:

@@ -125,9 +125,19 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
+            (void)hipGetLastError();  // drop stale sticky errors of unrelated earlier calls
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            for (auto &op : p.ops) launch_op(c, op, d_in, (int64_t)batch);
+            hipError_t le = hipSuccess;
+            std::string bad;
+            for (auto &op : p.ops) {
+                launch_op(c, op, d_in, (int64_t)batch);
+                if (le == hipSuccess && (le = hipGetLastError()) != hipSuccess) bad = op.name;
+            }
             hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (le != hipSuccess) {
+                if (g) (void)hipGraphDestroy(g);
+                return fail(BN_ERR_BACKEND, "launch of '" + bad + "' failed during capture: " + hipGetErrorString(le));
+            }
             if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
             hipGraphExec_t ge = nullptr;
             e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
@@ -141,11 +151,13 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
         }
         HIP_TRY(hipGraphLaunch(it->second, c->stream));
     } else {
+        (void)hipGetLastError();  // drop stale sticky errors of unrelated earlier calls
         for (auto &op : p.ops) {
             if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
             launch_op(c, op, d_in, (int64_t)batch);
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return fail(BN_ERR_BACKEND, "launch of '" + op.name + "' failed: " + hipGetErrorString(le));
         }
-        HIP_TRY(hipGetLastError());
     }
     return BN_OK;
 }
@@ -360,7 +372,11 @@ bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **
     HIP_TRY(hipMalloc(&c->d_arena, arena_b));
     HIP_TRY(hipMalloc(&c->d_input, in_b));
     HIP_TRY(hipHostMalloc(&c->h_input, in_b, hipHostMallocDefault));
-    c->h_out_elems = (size_t)(m->cfg.num_species + m->cfg.embedding_dim) * max_batch;
+    {
+        size_t row = (size_t)p.outputs[m->cfg.logits_output].row_elems;
+        if (m->cfg.embedding_output >= 0) row += (size_t)p.outputs[m->cfg.embedding_output].row_elems;
+        c->h_out_elems = row * max_batch;
+    }
     HIP_TRY(hipHostMalloc(&c->h_out, c->h_out_elems * sizeof(float), hipHostMallocDefault));
     c->device_bytes = arena_b + in_b;
     *out = c.release();
@@ -509,6 +525,7 @@ static bn_status topk_run(int device, hipStream_t stream, const float *d_logits,
     const size_t k = std::min(top_k, n);
     if (k_stride < k) return fail(BN_ERR_INVALID_ARG, "k_stride smaller than min(top_k, n)");
     if (topk_lds_bytes((int64_t)n, (int64_t)k) == 0) return fail(BN_ERR_INVALID_ARG, "top_k too large for the on-chip heap (k <= 9000)");
+    (void)hipGetLastError();
     launch_topk(stream, d_logits, (int64_t)rows, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, d_idx, d_conf, d_cnt);
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> h_idx(rows * k), h_cnt(rows);

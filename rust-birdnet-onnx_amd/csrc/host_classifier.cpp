@@ -103,8 +103,14 @@ constexpr size_t kDefaultCtxCap = 1024;
 
 // process_batch_outputs_from_flat (classifier.rs:872-911): slice rows, top-K, copy raw scores.
 std::vector<PredictionResult> run_on_ctx(ClassifierInner &in, bn_ctx *ctx, const float *const *segs, size_t n, const InferenceOptions &opt) {
-    const size_t N = in.config.num_species;
-    const size_t E = in.config.embedding_dim.value_or(0);
+    // row lengths as planned (equal to num_species / embedding_dim for every 2-D output)
+    size_t N = in.config.num_species, E = in.config.embedding_dim.value_or(0);
+    {
+        const float *dp = nullptr;
+        size_t row = 0;
+        if (bn_ctx_output_device(ctx, in.raw_cfg.logits_output, &dp, &row) == BN_OK) N = row;
+        if (E && bn_ctx_output_device(ctx, in.raw_cfg.embedding_output, &dp, &row) == BN_OK) E = row;
+    }
     std::vector<float> logits(n * N), emb(n * E);
     const volatile int32_t *cancel = opt.cancellation_token ? opt.cancellation_token->raw() : nullptr;
     const uint64_t timeout_ns = opt.timeout ? std::max<uint64_t>((uint64_t)opt.timeout->count(), 1) : 0;

@@ -1,0 +1,195 @@
+"""GPU parity of individual kernels: single-operator ONNX graphs through the C ABI vs the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import onnx_ref
+from gpu_helpers import assert_close, op_graph, write_model
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(bn, data, batch=3, seed=0, all_outputs=False, scale=1.0):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((batch, 144000)) * scale).astype(np.float32)
+    path = write_model(data)
+    m = bn.Model(path)
+    ctx = bn.Context(m, batch + 1, bn.BN_CTX_ALL_OUTPUTS if all_outputs else 0)
+    logits, _ = ctx.infer(x)
+    ref = onnx_ref.run_model(data, x)["output"]
+    return logits.reshape(ref.shape), ref
+
+
+def conv_case(cin, h, w, cout, k, stride, pad, groups=1, bias=True, act=None, dil=1, seed=0):
+    rng = np.random.default_rng(seed)
+    assert cin * h * w <= 144000
+    wgt = (rng.standard_normal((cout, cin // groups, k, k)) / np.sqrt(cin // groups * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    oh = (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    ow = (w + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(cin * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, cin, h, w)])
+        ins = [x, g.const(wgt)] + ([g.const(b)] if bias else [])
+        y = g.node("Conv", ins, kernel_shape=[k, k], strides=[stride, stride], pads=[pad] * 4, group=groups,
+                   dilations=[dil, dil])
+        if act == "relu":
+            y = g.node("Relu", [y])
+        elif act == "silu":
+            y = g.node("Mul", [y, g.node("Sigmoid", [y])])
+        elif act == "relu6":
+            y = g.node("Clip", [y, g.const(np.float32(0)), g.const(np.float32(6))])
+        return y
+    return op_graph(build, [cout, oh, ow])
+
+
+@pytest.mark.parametrize("cin,h,w,cout", [(16, 12, 20, 96), (96, 12, 20, 24), (24, 7, 9, 144), (144, 6, 8, 40),
+                                          (40, 5, 7, 33), (8, 3, 5, 7), (320, 3, 16, 128), (13, 4, 6, 130)])
+def test_pointwise_conv_gemm(bn, cin, h, w, cout):
+    got, ref = run_both(bn, conv_case(cin, h, w, cout, 1, 1, 0, act="relu"))
+    assert_close(got, ref, f"1x1 conv {cin}->{cout}")
+
+
+@pytest.mark.parametrize("c,h,w,k,stride,act", [(32, 24, 30, 3, 1, "relu"), (96, 24, 30, 3, 2, "relu"),
+                                                (144, 12, 17, 5, 2, "silu"), (240, 6, 9, 5, 1, "relu6"),
+                                                (30, 9, 11, 3, 1, None), (8, 5, 5, 7, 1, None)])
+def test_depthwise_conv(bn, c, h, w, k, stride, act):
+    got, ref = run_both(bn, conv_case(c, h, w, c, k, stride, k // 2, groups=c, act=act))
+    assert_close(got, ref, f"depthwise {c} k{k} s{stride}")
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,groups,dil", [(2, 32, 3, 2, 1, 1, 1), (3, 8, 3, 1, 1, 1, 1),
+                                                              (8, 16, 3, 1, 1, 2, 1), (4, 6, 5, 2, 2, 1, 1),
+                                                              (6, 6, 3, 1, 2, 3, 2), (1, 4, 3, 1, 0, 1, 1)])
+def test_direct_conv(bn, cin, cout, k, stride, pad, groups, dil):
+    got, ref = run_both(bn, conv_case(cin, 20, 31, cout, k, stride, pad, groups=groups, dil=dil, act="relu"))
+    assert_close(got, ref, f"conv {cin}->{cout} k{k} s{stride} g{groups}")
+
+
+def test_conv_bn_residual_fusion(bn):
+    rng = np.random.default_rng(5)
+    c = 24
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(c * 10 * 12), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, c, 10, 12)])
+        w0 = (rng.standard_normal((c, c, 1, 1)) / np.sqrt(c)).astype(np.float32)
+        x = g.node("Relu", [g.node("Conv", [x, g.const(w0)], kernel_shape=[1, 1])])   # makes an NHWC arena tensor
+        w1 = (rng.standard_normal((c, c, 1, 1)) / np.sqrt(c)).astype(np.float32)
+        y = g.node("Conv", [x, g.const(w1)], kernel_shape=[1, 1])
+        y = g.node("BatchNormalization", [y, g.const(rng.uniform(0.5, 1.5, c).astype(np.float32)),
+                                          g.const(rng.standard_normal(c).astype(np.float32)),
+                                          g.const(rng.standard_normal(c).astype(np.float32)),
+                                          g.const(rng.uniform(0.5, 1.5, c).astype(np.float32))], epsilon=1e-3)
+        return g.node("Add", [y, x])
+    data = op_graph(build, [c, 10, 12])
+    got, ref = run_both(bn, data)
+    assert_close(got, ref, "conv+bn+residual")
+    import tempfile
+    text = bn.plan_describe(write_model(data))
+    assert "res=1" in text and "bn." not in text  # BatchNorm and the residual Add were folded into the GEMM
+
+
+@pytest.mark.parametrize("n_fft,hop,bins", [(2048, 278, 40), (1024, 280, 129), (640, 320, 65), (512, 1, 5)])
+def test_conv1d_framing_as_gemm(bn, n_fft, hop, bins):
+    rng = np.random.default_rng(6)
+    w = (rng.standard_normal((bins, 1, n_fft)) / np.sqrt(n_fft)).astype(np.float32)
+    L = 144000 if hop > 1 else 4000
+    frames = (L - n_fft) // hop + 1
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        if L != 144000:
+            x = g.node("Slice", [x, i64(0), i64(L), i64(1), i64(1)])
+        u = g.node("Unsqueeze", [x, i64(1)])
+        return g.node("Conv", [u, g.const(w)], kernel_shape=[n_fft], strides=[hop])
+    got, ref = run_both(bn, op_graph(build, [bins, frames]), batch=2)
+    assert_close(got, ref, f"conv1d n_fft={n_fft} hop={hop}")
+
+
+def test_conv1d_with_padding(bn):
+    rng = np.random.default_rng(7)
+    w = (rng.standard_normal((9, 1, 640)) / 25.0).astype(np.float32)
+
+    def build(g, x):
+        u = g.node("Unsqueeze", [x, g.const(np.array([1], dtype=np.int64))])
+        return g.node("Conv", [u, g.const(w)], kernel_shape=[640], strides=[320], pads=[160, 160])
+    got, ref = run_both(bn, op_graph(build, [9, 450]), batch=2)
+    assert_close(got, ref, "padded conv1d")
+
+
+@pytest.mark.parametrize("k,n,style", [(1024, 6522, "gemm"), (96, 10, "matmul"), (130, 33, "matmul_bias"), (7, 5, "gemm_nt")])
+def test_dense_head(bn, k, n, style):
+    rng = np.random.default_rng(8)
+    w = (rng.standard_normal((n, k)) / np.sqrt(k)).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(k), i64(1), i64(1)])
+        if style == "gemm":
+            return g.node("Gemm", [x, g.const(w), g.const(b)], transB=1)
+        if style == "gemm_nt":
+            return g.node("Gemm", [x, g.const(np.ascontiguousarray(w.T)), g.const(b)], alpha=0.5, beta=2.0)
+        y = g.node("MatMul", [x, g.const(np.ascontiguousarray(w.T))])
+        return g.node("Add", [y, g.const(b)]) if style == "matmul_bias" else y
+    got, ref = run_both(bn, op_graph(build, [n]), batch=5)
+    assert_close(got, ref, f"dense {k}->{n} {style}")
+
+
+def test_reductions_and_broadcast(bn):
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Reshape", [x, i64(-1, 30, 48, 100)])
+        gap = g.node("GlobalAveragePool", [x])                          # [B,30,1,1]
+        mx = g.node("ReduceMax", [x], axes=[1], keepdims=1)             # [B,1,48,100]
+        mn = g.node("ReduceMin", [x], axes=[3], keepdims=1)             # [B,30,48,1]
+        sm = g.node("ReduceSum", [x], axes=[2, 3], keepdims=1)          # [B,30,1,1]
+        y = g.node("Add", [g.node("Mul", [x, gap]), mx])
+        y = g.node("Sub", [y, mn])
+        y = g.node("Div", [y, g.node("Add", [g.node("Abs", [sm]), g.const(np.float32(1.0))])])
+        return g.node("ReduceMean", [y], axes=[2], keepdims=0)          # [B,30,100]
+    got, ref = run_both(bn, op_graph(build, [30, 100]))
+    assert_close(got, ref, "reductions", atol=1e-4, rtol=1e-4)
+
+
+def test_views_concat_and_unary(bn):
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Reshape", [x, i64(-1, 4, 60, 600)])
+        t = g.node("Transpose", [x], perm=[0, 2, 3, 1])                                   # [B,60,600,4]
+        rev = g.node("Slice", [t, i64(-1), i64(-(2 ** 62)), i64(2), i64(-1)])             # reverse axis 2
+        ev = g.node("Slice", [rev, i64(0), i64(600), i64(2), i64(2)])                     # every 2nd -> 300
+        a = g.node("Sigmoid", [ev])
+        b = g.node("Tanh", [g.node("Slice", [t, i64(10), i64(310), i64(2), i64(1)])])     # [B,60,300,4]
+        c = g.node("Concat", [a, b, g.node("Exp", [g.node("Neg", [g.node("Abs", [a])])])], axis=3)  # [B,60,300,12]
+        c = g.node("Pow", [g.node("Abs", [c]), g.const(np.float32(0.3))])
+        c = g.node("Log", [g.node("Add", [c, g.const(np.float32(1e-3))])])
+        c = g.node("Max", [c, g.const(np.float32(-2.0))])
+        c = g.node("LeakyRelu", [c], alpha=0.1)
+        c = g.node("Transpose", [c], perm=[0, 3, 1, 2])                                   # [B,12,60,300]
+        return g.node("Flatten", [g.node("ReduceMean", [c], axes=[3], keepdims=1)], axis=1)  # [B,720]
+    got, ref = run_both(bn, op_graph(build, [720]))
+    assert_close(got, ref, "views/concat/unary", atol=1e-4, rtol=1e-4)
+
+
+def test_standalone_batchnorm_and_hard_activations(bn):
+    rng = np.random.default_rng(9)
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Reshape", [x, i64(-1, 6, 40, 600)])
+        y = g.node("BatchNormalization", [x, g.const(rng.uniform(0.5, 1.5, 6).astype(np.float32)),
+                                          g.const(rng.standard_normal(6).astype(np.float32)),
+                                          g.const(rng.standard_normal(6).astype(np.float32)),
+                                          g.const(rng.uniform(0.5, 1.5, 6).astype(np.float32))])
+        y = g.node("HardSwish", [y])
+        y = g.node("HardSigmoid", [y], alpha=0.25, beta=0.4)
+        y = g.node("Mul", [y, g.const(rng.standard_normal((1, 6, 1, 1)).astype(np.float32))])
+        y = g.node("Add", [y, g.const(rng.standard_normal((600,)).astype(np.float32))])
+        return g.node("ReduceMax", [y], axes=[2], keepdims=0)
+    got, ref = run_both(bn, op_graph(build, [6, 600]))
+    assert_close(got, ref, "bn/hard activations", atol=1e-5, rtol=1e-5)
