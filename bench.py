@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: BirdNET-v2.4-style model, batch of 32 synthetic 48 kHz 3 s segments
+per GPU (BASELINE.json configs[1]), inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one whole pass of the hot path over one batch per GPU: the launch plan (front end,
+CNN, head), the top-K kernel, and the device-to-host copies of the logits rows and top-K results
+(bn_step_device).  With N > 1 the segments of a step are sharded contiguously over the ranks
+(weak scaling: 32 per GPU) and the per-rank logits are all-gathered with RCCL.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").  The roofline / per-kernel numbers
+come from HIP events recorded on the context's stream around every launch (bn_ctx_time_kernels);
+cpu_baseline times the CPU oracle (torch CPU, fp32) on a bounded sample on rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: f32-input MFMA peak (= vector peak)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="segments per GPU per step (BASELINE configs[1]: 32)")
+    ap.add_argument("--streams", type=int, default=1, help="contexts (HIP streams) in flight per GPU")
+    ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="segments the CPU oracle is timed on")
+    ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    bn = importlib.import_module("rust-birdnet-onnx_amd")
+    synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+
+    S, SR, B = 144000, 48000, args.batch
+    model_bytes = synth.birdnet_v24()  # full-size hypothesised topology, seeded synthetic weights
+    with tempfile.NamedTemporaryFile(suffix=".onnx", delete=False) as f:
+        f.write(model_bytes)
+        path = f.name
+    model = bn.Model(path, device=local_rank)
+    os.unlink(path)
+    cfg = model.config
+    N = cfg.num_species
+    ctxs = [bn.Context(model, B) for _ in range(max(1, args.streams))]
+
+    # synthetic inputs, resident in HBM before the timed region: this rank's contiguous shard of
+    # NBUF global batches (global segment index = (buffer * world + rank) * B + i)
+    NBUF = 4
+    bufs = []
+    for b in range(NBUF):
+        x = synth.synthetic_segments(B, S, SR, first_index=(b * world + rank) * B)
+        bufs.append(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+
+    gathered = None
+    if world > 1:
+        gathered = torch.empty((world * B, N), dtype=torch.float32, device="cuda")
+
+    class _DevView:  # zero-copy torch view of the context's device logits
+        def __init__(self, ptr, shape):
+            self.__cuda_array_interface__ = {"data": (ptr, False), "shape": shape, "typestr": "<f4", "version": 2}
+
+    logit_views = []
+    for c in ctxs:
+        ptr, n = c.output_device(cfg.logits_output)
+        logit_views.append(torch.as_tensor(_DevView(ptr, (B, n)), device="cuda") if world > 1 else None)
+
+    def step(i):
+        c = ctxs[i % len(ctxs)]
+        if len(ctxs) > 1:
+            c.synchronize()  # results of this context's previous step are consumed before reuse
+        c.step_device(bufs[i % NBUF].data_ptr(), B, args.top_k, 0.1, sync=(len(ctxs) == 1 and world == 1))
+        if world > 1:
+            c.synchronize()
+            dist.all_gather_into_tensor(gathered, logit_views[i % len(ctxs)])
+
+    def fence():
+        for c in ctxs:
+            c.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity of the last step's results (not timed): top-1 of the device top-K == argmax of the logits
+    lg, ix, cf, ct = ctxs[(args.warmup + args.steps - 1) % len(ctxs)].step_results(B)
+    assert np.isfinite(lg).all()
+    for r in range(B):
+        if ct[r]:
+            assert ix[r, 0] == int(np.argmax(lg[r]))
+
+    total_segments = args.steps * B * world
+    value = total_segments / dt
+
+    out = {
+        "metric": "audio-segments/sec (batch) BirdNET v2.4 3s@48kHz",
+        "value": round(value, 2),
+        "unit": "segments/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BirdNET v2.4 (synthetic-weights hypothesised topology), batch=32 synthetic 48 kHz 3 s segments per GPU, inputs resident in HBM, logits+top-10 copied to host",
+            "global_batch": B * world,
+            "segments_per_gpu_per_step": B,
+            "streams_per_gpu": len(ctxs),
+            "num_species": int(N),
+            "x_realtime": round(value * 3.0, 1),
+            "parallelism": f"segment-sharded x{world}" + (" + RCCL all-gather of logits" if world > 1 else ""),
+        },
+    }
+
+    if rank == 0:
+        # ---- per-kernel device times (HIP events on the context's stream), roofline of the dominant kernel
+        ctxs[0].infer(bufs[0].cpu().numpy())  # puts a real batch into the context's own input buffer
+        rows = ctxs[0].time_kernels(B)
+        for _ in range(4):  # average a few passes
+            more = ctxs[0].time_kernels(B)
+            rows = [(a[0], a[1] + b[1], a[2], a[3]) for a, b in zip(rows, more)]
+        rows = [(n_, us / 5.0, m_, by_) for n_, us, m_, by_ in rows]
+        # classify launches by the kernel that executes them (plan_describe gives the op kind per launch)
+        desc = bn.plan_describe(path_for_describe(model_bytes))
+        kind_of = [l.split()[1] for l in desc.splitlines() if l[:3].strip().isdigit()]
+        fam_name = {"GEMM": "gemm_mfma_kernel", "DWCONV": "dwconv_kernel", "CONV": "conv_direct_kernel",
+                    "REDUCE": "reduce_kernel", "ELT": "elt_kernel"}
+        fam = {}
+        for (name, us, macs, byts), k in zip(rows, kind_of):
+            f_ = fam.setdefault(fam_name[k], {"us": 0.0, "macs": 0.0, "bytes": 0.0, "launches": 0})
+            f_["us"] += us
+            f_["macs"] += macs
+            f_["bytes"] += byts
+            f_["launches"] += 1
+        total_us = sum(v["us"] for v in fam.values())
+        dom = max(fam.items(), key=lambda kv: kv[1]["us"])
+        dname, d = dom
+        tf = 2.0 * d["macs"] / (d["us"] * 1e-6) / 1e12
+        gbs = d["bytes"] / (d["us"] * 1e-6) / 1e9
+        frac_mfma, frac_hbm = tf / MFMA_F32_PEAK_TF, gbs / HBM_PEAK_GBS
+        if frac_hbm >= frac_mfma:
+            roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
+        else:
+            roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
+        roof.update({"traffic": None, "kernel": dname, "launches_per_step": d["launches"],
+                     "avg_launch_us": round(d["us"] / d["launches"], 2), "share_of_step": round(d["us"] / total_us, 3),
+                     "alt_frac": {"hbm": round(frac_hbm, 4), "mfma_f32": round(frac_mfma, 4)}})
+        out["roofline"] = roof
+        out["kernel_families"] = {k: {"us_per_step": round(v["us"], 1), "launches": v["launches"],
+                                      "TFLOPs": round(2 * v["macs"] / (v["us"] * 1e-6) / 1e12, 2),
+                                      "GBs": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1)} for k, v in fam.items()}
+        out["device_us_per_step_sum_of_launches"] = round(total_us, 1)
+        if args.kernel_table:
+            for (name, us, macs, byts), k in sorted(zip(rows, kind_of), key=lambda t: -t[0][1])[:40]:
+                print(f"{us:9.1f} us  {k:7s} {name:42s} {2 * macs / us / 1e6:8.2f} TF/s {byts / us / 1e3:8.1f} GB/s", file=sys.stderr)
+
+        # ---- CPU baseline: the oracle (port), bounded sample, rank 0, N=1 only
+        if world == 1 and not args.no_cpu_baseline:
+            import torch as _t
+            from oracle import onnx_ref
+
+            g = onnx_ref.load_graph(model_bytes)
+            xs = synth.synthetic_segments(args.cpu_sample, S, SR)
+            onnx_ref.run_graph(g, xs[:2])  # warm
+            t1 = time.perf_counter()
+            done = 0
+            for k in range(0, args.cpu_sample, 8):  # the reference CLI's CPU batch size is 8 (birdnet-analyze.rs:38-39)
+                onnx_ref.run_graph(g, xs[k:k + 8])
+                done += len(xs[k:k + 8])
+            cdt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(done / cdt, 3), "unit": "segments/s", "cores": int(_t.get_num_threads()),
+                                   "kind": "port",
+                                   "sample": f"{done} segments (batches of 8) of the same synthetic workload through oracle/onnx_ref.py (torch CPU fp32, unfused ONNX graph incl. full DFT conv), {cdt:.1f} s"}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+_describe_path = None
+
+
+def path_for_describe(model_bytes: bytes) -> str:
+    global _describe_path
+    if _describe_path is None:
+        f = tempfile.NamedTemporaryFile(suffix=".onnx", delete=False)
+        f.write(model_bytes)
+        f.close()
+        _describe_path = f.name
+    return _describe_path
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,21 @@ bn_status bn_topk_host(int32_t device, const float *logits, size_t rows, size_t 
                        int32_t has_min, float min_conf, size_t k_stride, uint32_t *idx_out,
                        float *conf_out, uint32_t *count_out);
 
+/*
+ * One whole pass of the hot path over a device-resident batch, fully asynchronous
+ * on the context's stream: the plan (bn_infer_device), the top-K kernel
+ * (bn_topk), and the device-to-host copies of the logits rows (raw_scores,
+ * classifier.rs:907,948) and of the top-K results into pinned buffers owned by
+ * the context.  With sync == 0 the caller overlaps host work and calls
+ * bn_ctx_synchronize() before reading bn_step_results().
+ */
+bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch_size, size_t top_k,
+                         int32_t has_min, float min_conf, int32_t sync);
+/* Pinned host views of the last bn_step_device: logits [batch, num_species], idx/conf
+ * [batch, k_stride], count [batch].  Valid until the next step on this context. */
+bn_status bn_step_results(const bn_ctx *c, const float **logits, const uint32_t **idx,
+                          const float **conf, const uint32_t **count, size_t *k_stride);
+
 /* Diagnostic, needs no device: parse the file, build the launch plan (all graph
  * outputs when all_outputs != 0, else logits + embeddings only) and write a
  * text description (one line per launch, then totals) into buf.  Returns the

@@ -34,7 +34,8 @@ ENGINE_SYMBOLS = [
     "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create",
     "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_device",
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
-    "bn_topk", "bn_topk_device", "bn_topk_host", "bn_plan_describe", "bn_last_error",
+    "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
+    "bn_last_error",
 ]
 HOST_SYMBOLS = [
     "bnh_classifier_build", "bnh_classifier_free", "bnh_classifier_config", "bnh_classifier_provider",
@@ -103,6 +104,8 @@ def _load() -> C.CDLL:
         "bn_topk": (i32, [vp, sz, sz, i32, C.c_float, sz, u32p, f32p, u32p]),
         "bn_topk_device": (i32, [i32, vp, sz, sz, sz, i32, C.c_float, sz, u32p, f32p, u32p]),
         "bn_topk_host": (i32, [i32, f32p, sz, sz, sz, i32, C.c_float, sz, u32p, f32p, u32p]),
+        "bn_step_device": (i32, [vp, vp, sz, sz, i32, C.c_float, i32]),
+        "bn_step_results": (i32, [vp, C.POINTER(f32p), C.POINTER(u32p), C.POINTER(f32p), C.POINTER(u32p), C.POINTER(sz)]),
         "bn_plan_describe": (sz, [C.c_char_p, i32, i32, C.c_char_p, sz, C.POINTER(i32)]),
         "bn_last_error": (sz, [C.c_char_p, sz]),
         # host mirror
@@ -513,6 +516,25 @@ class Context:
         st = lib.bn_infer_device(self._h, C.c_void_p(d_ptr), batch, 1 if sync else 0)
         if st:
             raise EngineError(st)
+
+    def step_device(self, d_ptr: int, batch: int, top_k: int = 10, min_confidence: Optional[float] = None,
+                    sync: bool = False):
+        """One whole hot-path pass (plan + top-K + D2H of logits / top-K) on a device-resident batch."""
+        st = lib.bn_step_device(self._h, C.c_void_p(d_ptr), batch, top_k, 0 if min_confidence is None else 1,
+                                C.c_float(min_confidence or 0.0), 1 if sync else 0)
+        if st:
+            raise EngineError(st)
+
+    def step_results(self, batch: int):
+        lg, ix, cf, ct = C.POINTER(C.c_float)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)(), C.POINTER(C.c_uint32)()
+        ks = C.c_size_t()
+        st = lib.bn_step_results(self._h, C.byref(lg), C.byref(ix), C.byref(cf), C.byref(ct), C.byref(ks))
+        if st:
+            raise EngineError(st)
+        n = self.output_device(self.model.config.logits_output)[1]
+        k = ks.value
+        return (np.ctypeslib.as_array(lg, shape=(batch, n)).copy(), np.ctypeslib.as_array(ix, shape=(batch, k)).copy(),
+                np.ctypeslib.as_array(cf, shape=(batch, k)).copy(), np.ctypeslib.as_array(ct, shape=(batch,)).copy())
 
     def synchronize(self):
         st = lib.bn_ctx_synchronize(self._h)

@@ -79,6 +79,10 @@ struct bn_ctx {
     uint32_t *d_tk_idx = nullptr, *d_tk_cnt = nullptr;
     float *d_tk_conf = nullptr;
     size_t tk_cap = 0;  // elements of idx/conf
+    // pinned mirrors for bn_step_device
+    uint32_t *h_tk_idx = nullptr, *h_tk_cnt = nullptr;
+    float *h_tk_conf = nullptr;
+    size_t h_tk_cap = 0, step_k = 0;
     struct GraphKey {
         size_t batch;
         const float *in;
@@ -395,6 +399,9 @@ void bn_ctx_destroy(bn_ctx *c) {
     if (c->d_tk_idx) (void)hipFree(c->d_tk_idx);
     if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
     if (c->d_tk_cnt) (void)hipFree(c->d_tk_cnt);
+    if (c->h_tk_idx) (void)hipHostFree(c->h_tk_idx);
+    if (c->h_tk_conf) (void)hipHostFree(c->h_tk_conf);
+    if (c->h_tk_cnt) (void)hipHostFree(c->h_tk_cnt);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -572,6 +579,71 @@ bn_status bn_topk(bn_ctx *c, size_t batch, size_t top_k, int32_t has_min, float 
     if (!c->d_tk_cnt) HIP_TRY(hipMalloc(&c->d_tk_cnt, c->max_batch * sizeof(uint32_t)));
     return topk_run(c->model->device, c->stream, resolve(c, lo.ref, c->d_input), batch, n, top_k, has_min, min_conf, k_stride, c->d_tk_idx,
                     c->d_tk_conf, c->d_tk_cnt, idx_out, conf_out, count_out);
+}
+
+static bn_status ensure_topk_buffers(bn_ctx *c, size_t k) {
+    const size_t need = c->max_batch * k;
+    if (need > c->tk_cap) {
+        if (c->d_tk_idx) (void)hipFree(c->d_tk_idx);
+        if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
+        c->d_tk_idx = nullptr;
+        c->d_tk_conf = nullptr;
+        HIP_TRY(hipMalloc(&c->d_tk_idx, need * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_tk_conf, need * sizeof(float)));
+        c->tk_cap = need;
+    }
+    if (!c->d_tk_cnt) HIP_TRY(hipMalloc(&c->d_tk_cnt, c->max_batch * sizeof(uint32_t)));
+    return BN_OK;
+}
+
+bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch, size_t top_k, int32_t has_min, float min_conf, int32_t sync) {
+    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
+    if (batch == 0) return BN_OK;
+    if (!d_pcm || batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "bad input / batch size exceeds context max");
+    const Plan &p = *c->pd->plan;
+    const OutputInfo &lo = p.outputs[c->model->cfg.logits_output];
+    const size_t n = (size_t)lo.row_elems;
+    const size_t k = std::min(top_k, n);
+    if (k == 0 || topk_lds_bytes((int64_t)n, (int64_t)k) == 0) return fail(BN_ERR_INVALID_ARG, "top_k must be in 1..9000");
+    HIP_TRY(hipSetDevice(c->model->device));
+    bn_status st = drain_if_needed(c);
+    if (st != BN_OK) return st;
+    st = ensure_topk_buffers(c, k);
+    if (st != BN_OK) return st;
+    if (c->max_batch * k > c->h_tk_cap) {
+        if (c->h_tk_idx) (void)hipHostFree(c->h_tk_idx);
+        if (c->h_tk_conf) (void)hipHostFree(c->h_tk_conf);
+        c->h_tk_idx = nullptr;
+        c->h_tk_conf = nullptr;
+        HIP_TRY(hipHostMalloc(&c->h_tk_idx, c->max_batch * k * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&c->h_tk_conf, c->max_batch * k * sizeof(float), hipHostMallocDefault));
+        c->h_tk_cap = c->max_batch * k;
+    }
+    if (!c->h_tk_cnt) HIP_TRY(hipHostMalloc(&c->h_tk_cnt, c->max_batch * sizeof(uint32_t), hipHostMallocDefault));
+    st = enqueue_plan(c, d_pcm, batch, nullptr);
+    if (st != BN_OK) return st;
+    c->last_batch = batch;
+    const float *d_logits = resolve(c, lo.ref, d_pcm);
+    (void)hipGetLastError();
+    launch_topk(c->stream, d_logits, (int64_t)batch, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, c->d_tk_idx, c->d_tk_conf, c->d_tk_cnt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_out, d_logits, batch * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_tk_idx, c->d_tk_idx, batch * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_tk_conf, c->d_tk_conf, batch * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_tk_cnt, c->d_tk_cnt, batch * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    c->step_k = k;
+    if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
+    return BN_OK;
+}
+
+bn_status bn_step_results(const bn_ctx *c, const float **logits, const uint32_t **idx, const float **conf, const uint32_t **count, size_t *k_stride) {
+    if (!c || !c->h_tk_idx) return fail(BN_ERR_INVALID_ARG, "no step has run on this context");
+    if (logits) *logits = c->h_out;
+    if (idx) *idx = c->h_tk_idx;
+    if (conf) *conf = c->h_tk_conf;
+    if (count) *count = c->h_tk_cnt;
+    if (k_stride) *k_stride = c->step_k;
+    return BN_OK;
 }
 
 bn_status bn_topk_device(int32_t device, const float *d_logits, size_t rows, size_t n, size_t top_k, int32_t has_min, float min_conf,
