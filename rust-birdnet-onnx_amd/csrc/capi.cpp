@@ -117,6 +117,11 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
             launch_conv(c->stream, op.conv, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in), batch);
             break;
         case OpKind::DWCONV: launch_dwconv(c->stream, op.dw, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), batch); break;
+        case OpKind::GAP: launch_gap_partial(c->stream, op.gap, out, a, batch); break;
+        case OpKind::SEFC:
+            launch_se_fc(c->stream, op.se, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
+                         resolve(c, op.bias2, d_in), batch);
+            break;
     }
 }
 
@@ -718,13 +723,13 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
             if (cfg.embedding_output >= 0) wanted.push_back(cfg.embedding_output);
         }
         auto p = build_plan(om, wanted);
-        static const char *kinds[] = {"ELT", "REDUCE", "GEMM", "CONV", "DWCONV"};
+        static const char *kinds[] = {"ELT", "REDUCE", "GEMM", "CONV", "DWCONV", "GAP", "SEFC"};
         char line[512];
         for (size_t k = 0; k < p->ops.size(); k++) {
             const PlanOp &op = p->ops[k];
             std::string extra;
             if (op.kind == OpKind::GEMM) {
-                snprintf(line, sizeof(line), " rows=%lld K=%d N=%d lda=%lld act=%d bias=%d res=%d", (long long)op.gemm.rows, op.gemm.K, op.gemm.N, (long long)op.gemm.lda, op.gemm.act, op.gemm.has_bias, op.gemm.has_res);
+                snprintf(line, sizeof(line), " rows=%lld K=%d N=%d lda=%lld act=%d bias=%d res=%d gate=%d", (long long)op.gemm.rows, op.gemm.K, op.gemm.N, (long long)op.gemm.lda, op.gemm.act, op.gemm.has_bias, op.gemm.has_res, op.gemm.has_scale);
                 extra = line;
             } else if (op.kind == OpKind::DWCONV) {
                 snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%d act=%d", op.dw.H, op.dw.W, op.dw.C, op.dw.OH, op.dw.OW, op.dw.kh, op.dw.kw, op.dw.sh, op.dw.act);
@@ -734,6 +739,12 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 extra = line;
             } else if (op.kind == OpKind::ELT) {
                 snprintf(line, sizeof(line), " n=%lld nd=%d bin=%d act=%d flat=%d", (long long)op.elt.per_sample, op.elt.nd, op.elt.bin, op.elt.act, op.elt.flat);
+                extra = line;
+            } else if (op.kind == OpKind::GAP) {
+                snprintf(line, sizeof(line), " HW=%lld C=%d splits=%d", (long long)op.gap.HW, op.gap.C, op.gap.splits);
+                extra = line;
+            } else if (op.kind == OpKind::SEFC) {
+                snprintf(line, sizeof(line), " C=%d Cr=%d act1=%d act2=%d", op.se.C, op.se.Cr, op.se.act1, op.se.act2);
                 extra = line;
             } else {
                 snprintf(line, sizeof(line), " kept=%lld red=%lld op=%d inner_kept=%d", (long long)op.red.kept, (long long)op.red.red, op.red.op, op.red.inner_kept);

@@ -58,6 +58,10 @@ struct Val {
     int64_t offset = 0;
     std::vector<float> f;
     std::vector<int64_t> i;
+    // squeeze-excite: `is_gate` marks the per-channel gate vector produced by the fused SE kernel;
+    // `gate_storage >= 0` marks "x * gate" not yet applied (the consuming 1x1 conv applies it on load)
+    bool is_gate = false;
+    int32_t gate_storage = -1;
     int64_t numel() const { return prod(dims); }
     bool contiguous() const { return !is_const && strides_equal(row_major(dims)); }
     bool strides_equal(const Dims &s) const {
@@ -184,7 +188,19 @@ class Builder {
         if (idx >= n.inputs.size() || n.inputs[idx].empty()) unsupported(n, "missing input " + std::to_string(idx));
         auto it = vals_.find(n.inputs[idx]);
         if (it == vals_.end()) unsupported(n, "input '" + n.inputs[idx] + "' is not defined (graph not topologically sorted?)");
+        if (it->second.gate_storage >= 0 && !(n.op_type == "Conv" && idx == 0)) it->second = apply_gate(it->second, n.inputs[idx]);
         return it->second;
+    }
+    // x * gate as an explicit elementwise launch (fallback when the consumer cannot fold the gate)
+    Val apply_gate(const Val &x, const std::string &why) {
+        Val plain = x;
+        plain.gate_storage = -1;
+        Val out = new_act(x.dims, x.strides_equal(row_major(x.dims)) ? row_major(x.dims) : strides_for_order(x.dims, phys_order(x)));
+        Dims gs(x.dims.size(), 0);
+        gs[0] = 1;  // gate is [C] along logical dim 0
+        emit_elt("se.mul:" + why, out, ref_of(plain), plain.strides, batch_stride(plain), Ref{Space::ARENA, x.gate_storage, 0}, gs,
+                 plan_.storages[x.gate_storage].elems, BIN_MUL, ActSpec{});
+        return out;
     }
     bool has_input(const OnnxNode &n, size_t idx) const { return idx < n.inputs.size() && !n.inputs[idx].empty(); }
     const Val *opt(const OnnxNode &n, size_t idx) {
@@ -257,6 +273,8 @@ class Builder {
         touch(op.b, idx);
         touch(op.res, idx);
         touch(op.scale, idx);
+        touch(op.w2, idx);
+        touch(op.bias2, idx);
         plan_.ops.push_back(std::move(op));
     }
 
@@ -926,6 +944,19 @@ class Builder {
     void lower_binary(const OnnxNode &n) {
         const Val &a = get(n, 0), &b = get(n, 1);
         const std::string &t = n.op_type;
+        if (t == "Mul" && (a.is_gate != b.is_gate)) {
+            // x * se_gate: leave it pending on the value; the consuming 1x1 conv folds it into its
+            // operand load, any other consumer triggers apply_gate() in get()
+            const Val &x = a.is_gate ? b : a;
+            const Val &g = a.is_gate ? a : b;
+            if (!x.is_const && x.gate_storage < 0 && x.dims.size() == 3 && x.dims[0] == g.dims[0] && x.space == Space::ARENA) {
+                Val o = x;
+                o.gate_storage = g.storage;
+                if (wanted_names_.count(n.outputs[0])) o = apply_gate(o, n.name);
+                define(n.outputs[0], o);
+                return;
+            }
+        }
         int bin = t == "Add" ? BIN_ADD : t == "Sub" ? BIN_SUB : t == "Mul" ? BIN_MUL : t == "Div" ? BIN_DIV : t == "Pow" ? BIN_POW : t == "Max" ? BIN_MAX : BIN_MIN;
         // scalar constants become parametrised unary ops
         float c;
@@ -1030,10 +1061,116 @@ class Builder {
         define(n.outputs[0], out);
     }
 
+    // GlobalAveragePool -> Conv1x1 -> act -> Conv1x1 -> Sigmoid/HardSigmoid -> Mul(x, .) : squeeze-excite.
+    // Emits the two SE launches and defines the gate; returns false if the pattern does not match.
+    bool try_squeeze_excite(const OnnxNode &n, const Val &x) {
+        if (x.dims.size() != 3 || x.space != Space::ARENA || x.gate_storage >= 0) return false;
+        const int64_t C = x.dims[0], H = x.dims[1], W = x.dims[2];
+        if (C % 4 || C > 4096 || !x.strides_equal(Dims{1, W * C, C}) || x.offset != 0) return false;
+        if (plan_.storages[x.storage].elems % 4) return false;
+        // spatial mean?
+        if (n.op_type == "ReduceMean") {
+            auto axes = n.attr_ints("axes");
+            if (axes.empty() && has_input(n, 1)) axes = const_ints(n, get(n, 1));
+            std::set<int64_t> ax;
+            for (auto a : axes) ax.insert(a < 0 ? a + 4 : a);
+            if (ax != std::set<int64_t>{2, 3} || n.attr_i("keepdims", 1) == 0) return false;
+        } else if (n.op_type != "GlobalAveragePool") return false;
+        int c1 = sole_consumer(n.outputs[0]);
+        if (c1 < 0 || nodes_[c1].op_type != "Conv") return false;
+        auto conv_1x1 = [&](const OnnxNode &cv, int64_t cin, int64_t &cout, std::vector<float> &w, std::vector<float> &b) {
+            auto wi = vals_.find(cv.inputs[1]);
+            if (wi == vals_.end() || !wi->second.is_const || wi->second.dims.size() != 4) return false;
+            const Val &wv = wi->second;
+            if (wv.dims[1] != cin || wv.dims[2] != 1 || wv.dims[3] != 1 || cv.attr_i("group", 1) != 1) return false;
+            for (auto p : cv.attr_ints("pads")) if (p) return false;
+            for (auto p : cv.attr_ints("strides")) if (p != 1) return false;
+            cout = wv.dims[0];
+            w = wv.f;
+            b.clear();
+            if (cv.inputs.size() > 2 && !cv.inputs[2].empty()) {
+                auto bi = vals_.find(cv.inputs[2]);
+                if (bi == vals_.end() || !bi->second.is_const) return false;
+                b = bi->second.f;
+            }
+            return true;
+        };
+        int64_t Cr = 0, C2 = 0;
+        std::vector<float> w1, b1, w2, b2;
+        if (nodes_[c1].inputs[0] != n.outputs[0] || !conv_1x1(nodes_[c1], C, Cr, w1, b1) || Cr > 1024) return false;
+        // dry-run the chain before absorbing anything
+        std::vector<bool> saved = absorbed_;
+        auto bail = [&]() { absorbed_ = saved; return false; };
+        absorbed_[c1] = true;
+        std::string cur = nodes_[c1].outputs[0];
+        ActSpec act1;
+        absorb_activation(cur, act1);
+        int c2 = sole_consumer(cur);
+        if (c2 < 0 || nodes_[c2].op_type != "Conv" || nodes_[c2].inputs[0] != cur || !conv_1x1(nodes_[c2], Cr, C2, w2, b2) || C2 != C) return bail();
+        absorbed_[c2] = true;
+        cur = nodes_[c2].outputs[0];
+        int sg = sole_consumer(cur);
+        ActSpec act2;
+        if (sg < 0 || nodes_[sg].inputs[0] != cur || (nodes_[sg].op_type != "Sigmoid" && nodes_[sg].op_type != "HardSigmoid") || !unary_spec(nodes_[sg], act2)) return bail();
+        absorbed_[sg] = true;
+        const std::string gate_name = nodes_[sg].outputs[0];
+        if (wanted_names_.count(gate_name)) return bail();
+        // the gate must only feed Mul(x, gate)
+        for (int k : live_consumers(gate_name)) {
+            const OnnxNode &m = nodes_[k];
+            if (m.op_type != "Mul") return bail();
+            const std::string &other = m.inputs[0] == gate_name ? m.inputs[1] : m.inputs[0];
+            if (other != n.inputs[0]) return bail();
+        }
+        // ---- emit
+        const int64_t HW = H * W;
+        int32_t splits = (int32_t)std::min<int64_t>(64, std::max<int64_t>(1, (HW + 31) / 32));
+        Val partial = new_act(Dims{(int64_t)splits, C}, Dims{C, 1});
+        {
+            PlanOp op;
+            op.kind = OpKind::GAP;
+            op.name = "se.squeeze:" + n.name;
+            op.out = ref_of(partial);
+            op.a = ref_of(x);
+            op.gap.HW = HW; op.gap.C = (int32_t)C; op.gap.splits = splits;
+            op.gap.in_bs = batch_stride(x); op.gap.out_bs = plan_.storages[partial.storage].elems;
+            op.bytes = 4.0 * (double)(HW * C + splits * C);
+            push_op(std::move(op));
+        }
+        Val gate = new_act(Dims{C, 1, 1}, Dims{1, 0, 0});
+        plan_.storages[gate.storage].elems = (C + 3) / 4 * 4;
+        {
+            PlanOp op;
+            op.kind = OpKind::SEFC;
+            op.name = "se.excite:" + n.name;
+            op.out = ref_of(gate);
+            op.a = ref_of(partial);
+            op.w = Ref{Space::CONSTS, add_const(w1), 0};
+            if (!b1.empty()) op.bias = Ref{Space::CONSTS, add_const(b1), 0};
+            std::vector<float> w2t(w2.size());  // [C][Cr] -> [Cr][C]: coalesced reads in the excite product
+            for (int64_t c = 0; c < C; c++)
+                for (int64_t j = 0; j < Cr; j++) w2t[j * C + c] = w2[c * Cr + j];
+            op.w2 = Ref{Space::CONSTS, add_const(w2t), 0};
+            if (!b2.empty()) op.bias2 = Ref{Space::CONSTS, add_const(b2), 0};
+            op.se.C = (int32_t)C; op.se.Cr = (int32_t)Cr; op.se.splits = splits; op.se.inv_hw = 1.0f / (float)HW;
+            op.se.act1 = act1.act; op.se.p0_1 = act1.p0; op.se.p1_1 = act1.p1;
+            op.se.act2 = act2.act; op.se.p0_2 = act2.p0; op.se.p1_2 = act2.p1;
+            op.se.in_bs = plan_.storages[partial.storage].elems; op.se.out_bs = plan_.storages[gate.storage].elems;
+            op.macs = 2.0 * (double)C * Cr;
+            op.weight_bytes = 4.0 * (w1.size() + w2.size() + b1.size() + b2.size());
+            op.bytes = 4.0 * (double)(splits * C + C);
+            push_op(std::move(op));
+        }
+        gate.is_gate = true;
+        define(gate_name, gate);
+        return true;
+    }
+
     void lower_reduce(const OnnxNode &n) {
         const Val &v = get(n, 0);
         const std::string &t = n.op_type;
         if (v.is_const) unsupported(n, "reduction of a constant");
+        if (try_squeeze_excite(n, v)) return;
         int op;
         std::vector<int64_t> axes;
         bool keep = n.attr_i("keepdims", 1) != 0;
@@ -1120,6 +1257,8 @@ class Builder {
 
     void lower_conv(const OnnxNode &n) {
         Val x = get(n, 0);
+        int32_t gate_storage = x.gate_storage;
+        x.gate_storage = -1;
         const Val &w = get(n, 1);
         const Val *bptr = opt(n, 2);
         if (x.is_const || !w.is_const || (bptr && !bptr->is_const)) unsupported(n, "Conv needs an activation input and constant weights");
@@ -1219,9 +1358,21 @@ class Builder {
 
         bool unit_dil = dil[0] == 1 && dil[1] == 1;
         bool no_pad = pt == 0 && pl == 0 && pb == 0 && pr == 0;
-        if (groups == 1 && kh == 1 && unit_dil && no_pad && (H == 1 || (kw == 1 && strides[0] == 1 && strides[1] == 1))) {
+        const bool gemm_path = groups == 1 && kh == 1 && unit_dil && no_pad && (H == 1 || (kw == 1 && strides[0] == 1 && strides[1] == 1));
+        if (gate_storage >= 0 && !(gemm_path && kw == 1)) {  // only the 1x1 GEMM folds the SE gate
+            Val gx = x;
+            gx.gate_storage = gate_storage;
+            x = apply_gate(gx, n.name);
+            gate_storage = -1;
+        }
+        if (gemm_path) {
             // GEMM: 1x1 conv (rows = H*W) or 1-D conv as overlapping rows (rows = OW, K = kw*Cin)
             x = to_channels_last(x, n.name);
+            if (gate_storage >= 0) {
+                op.scale = Ref{Space::ARENA, gate_storage, 0};
+                op.gemm.has_scale = 1;
+                op.gemm.s_bs = plan_.storages[gate_storage].elems;
+            }
             op.kind = OpKind::GEMM;
             op.mfma = true;
             GemmDesc &g = op.gemm;

@@ -28,17 +28,19 @@ struct Ref {
     int64_t offset = 0;  // elements (per sample for INPUT/ARENA)
 };
 
-enum class OpKind : int32_t { ELT, REDUCE, GEMM, CONV, DWCONV };
+enum class OpKind : int32_t { ELT, REDUCE, GEMM, CONV, DWCONV, GAP, SEFC };
 
 struct PlanOp {
     OpKind kind;
     std::string name;
-    Ref out, a, b, w, bias, res, scale;
+    Ref out, a, b, w, bias, res, scale, w2, bias2;
     EltDesc elt{};
     ReduceDesc red{};
     GemmDesc gemm{};
     ConvDesc conv{};
     DwDesc dw{};
+    GapDesc gap{};
+    SeFcDesc se{};
     double macs = 0;        // per sample
     double bytes = 0;       // algorithmic bytes read+written per sample (weights excluded)
     double weight_bytes = 0;

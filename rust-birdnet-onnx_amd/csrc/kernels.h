@@ -103,6 +103,28 @@ struct DwDesc {
     int64_t in_bs, out_bs;
 };
 
+// Squeeze-excite, stage 1: per-(sample, split) channel sums of an NHWC tensor [HW][C]
+// -> partial [splits][C].  Stage 2 (SeFcDesc) sums the splits in a fixed order (deterministic).
+struct GapDesc {
+    int64_t HW;
+    int32_t C, splits;
+    int64_t in_bs, out_bs;
+};
+// Squeeze-excite, stage 2, one workgroup per sample:
+//   s = mean over HW (from the partial sums); h = act1(W1 s + b1); gate = act2(W2 h + b2)
+// W1 is [Cr][C], W2 is [C][Cr].
+struct SeFcDesc {
+    int32_t C, Cr, splits;
+    float inv_hw;
+    int32_t act1, act2;
+    float p0_1, p1_1, p0_2, p1_2;
+    int64_t in_bs, out_bs;
+};
+
+void launch_gap_partial(hipStream_t s, const GapDesc &d, float *partial, const float *in, int64_t batch);
+void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, const float *partial, const float *w1,
+                  const float *b1, const float *w2, const float *b2, int64_t batch);
+
 void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a, const float *b,
                     int64_t batch);
 void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *in, int64_t batch);

@@ -206,27 +206,36 @@ __global__ __launch_bounds__(1024) void reduce_inner_kept_kernel(ReduceDesc d, f
     }
 }
 
-// one block per (kept index, sample): threads stride over the reduced range
-// block 256; grid (kept, batch)
-__global__ __launch_bounds__(256) void reduce_row_kernel(ReduceDesc d, float *__restrict__ out,
-                                                         const float *__restrict__ in) {
-    __shared__ float part[4];
+// one block per (kept index, sample): threads stride over the reduced range (float4 when the
+// reduced dim is contiguous and aligned).  block = blockDim.x (256 or 1024); grid (kept, batch)
+__global__ __launch_bounds__(1024) void reduce_row_kernel(ReduceDesc d, float *__restrict__ out,
+                                                          const float *__restrict__ in, int vec4) {
+    __shared__ float part[16];
     const int64_t bidx = blockIdx.y;
+    const uint32_t nt = blockDim.x;
     int64_t in_off, out_off;
     kept_offsets(d, blockIdx.x, in_off, out_off);
     const float *p = in + bidx * d.bi + in_off;
     float acc = red_init(d.op);
-    if (d.nr == 1) {
+    if (vec4) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(p);
+        const uint32_t n4 = (uint32_t)(d.red >> 2);
+        for (uint32_t r = threadIdx.x; r < n4; r += nt) {
+            const float4 v = p4[r];
+            acc = red_step(d.op, red_step(d.op, red_step(d.op, red_step(d.op, acc, v.x), v.y), v.z), v.w);
+        }
+        for (uint32_t r = (n4 << 2) + threadIdx.x; r < (uint32_t)d.red; r += nt) acc = red_step(d.op, acc, p[r]);
+    } else if (d.nr == 1) {
         const int64_t st = d.rin[0];
-        for (uint32_t r = threadIdx.x; r < (uint32_t)d.red; r += 256u) acc = red_step(d.op, acc, p[(int64_t)r * st]);
+        for (uint32_t r = threadIdx.x; r < (uint32_t)d.red; r += nt) acc = red_step(d.op, acc, p[(int64_t)r * st]);
     } else {
-        for (uint32_t r = threadIdx.x; r < (uint32_t)d.red; r += 256u) acc = red_step(d.op, acc, p[red_offset(d, r)]);
+        for (uint32_t r = threadIdx.x; r < (uint32_t)d.red; r += nt) acc = red_step(d.op, acc, p[red_offset(d, r)]);
     }
     for (int off = 32; off > 0; off >>= 1) acc = red_merge(d.op, acc, __shfl_down(acc, off));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        acc = red_merge(d.op, red_merge(d.op, part[0], part[1]), red_merge(d.op, part[2], part[3]));
+        for (uint32_t w = 1; w < (nt >> 6); w++) acc = red_merge(d.op, acc, part[w]);
         out[bidx * d.bo + out_off] = red_finish(d.op, acc, d.red);
     }
 }
@@ -242,8 +251,8 @@ __global__ __launch_bounds__(256) void reduce_row_kernel(ReduceDesc d, float *__
 constexpr int GEMM_BM = 128, GEMM_BK = 32, GEMM_LD = 36;
 
 template <int AVEC>
-__device__ __forceinline__ void load_a_tile(const GemmDesc &d, const float *__restrict__ A, int64_t total_rows,
-                                            int64_t row0, int k0, int tid, float (&regs)[16]) {
+__device__ __forceinline__ void load_a_tile(const GemmDesc &d, const float *__restrict__ A, const float *__restrict__ scale,
+                                            int64_t total_rows, int64_t row0, int k0, int tid, float (&regs)[16]) {
     // 128 rows x 32 floats = 4096 floats, 16 per thread
     constexpr int PER_ROW = GEMM_BK / AVEC;        // vectors per row
     constexpr int ITERS = 16 / AVEC;               // vector loads per thread
@@ -267,6 +276,11 @@ __device__ __forceinline__ void load_a_tile(const GemmDesc &d, const float *__re
                 v[0] = t.x; v[1] = t.y;
             } else {
                 v[0] = *p;
+            }
+            if (d.has_scale) {  // squeeze-excite gate folded into the operand load
+                const float *sp = scale + b * d.s_bs + k;
+#pragma unroll
+                for (int j = 0; j < AVEC; j++) v[j] *= sp[j];
             }
         }
 #pragma unroll
@@ -336,7 +350,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
                                                         const float *__restrict__ A,
                                                         const float *__restrict__ W,
                                                         const float *__restrict__ bias,
-                                                        const float *__restrict__ res, int64_t total_rows) {
+                                                        const float *__restrict__ res,
+                                                        const float *__restrict__ scale, int64_t total_rows) {
     constexpr int NT = BN / 32;
     __shared__ __align__(16) float As[GEMM_BM * GEMM_LD];
     __shared__ __align__(16) float Ws[BN * GEMM_LD];
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
 
     float ra[16];
     float rw[BN / 8];
-    load_a_tile<AVEC>(d, A, total_rows, row0, 0, tid, ra);
+    load_a_tile<AVEC>(d, A, scale, total_rows, row0, 0, tid, ra);
     load_w_tile<BN, WVEC>(d, W, n0, 0, tid, rw);
     const bool wave_active = row0 + wave * 32 < total_rows;
 
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
         store_w_tile<BN, WVEC>(Ws, tid, rw);
         __syncthreads();
         if (k0 + GEMM_BK < d.K) {  // prefetch the next tile into registers while computing
-            load_a_tile<AVEC>(d, A, total_rows, row0, k0 + GEMM_BK, tid, ra);
+            load_a_tile<AVEC>(d, A, scale, total_rows, row0, k0 + GEMM_BK, tid, ra);
             load_w_tile<BN, WVEC>(d, W, n0, k0 + GEMM_BK, tid, rw);
         }
         if (wave_active) {
@@ -404,6 +419,216 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
                 crow[n] = v;
             }
         }
+    }
+}
+
+
+// ------------------------------------------------------------------ small-M GEMM: intra-block split-K
+// When the output has few 128-row tiles (late CNN stages, FC head) the kernel above leaves most
+// CUs idle.  Here a block owns one 32 x BN tile and its 4 waves split K between them (k-steps
+// interleaved), each wave staging its own operand slices through a private LDS region with no
+// block barrier in the main loop; the four partial accumulators are then summed through LDS in a
+// fixed order (deterministic) and the epilogue is shared between the waves.
+template <int BN, int AVEC, int WVEC>
+__global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__restrict__ C,
+                                                          const float *__restrict__ A,
+                                                          const float *__restrict__ W,
+                                                          const float *__restrict__ bias,
+                                                          const float *__restrict__ res,
+                                                          const float *__restrict__ scale, int64_t total_rows) {
+    constexpr int NT = BN / 32;
+    constexpr int STAGE = (32 + BN) * GEMM_LD;                 // floats of operand staging per wave
+    constexpr int RED = 32 * BN;                               // floats of one wave's accumulator tile
+    constexpr int LDS_FLOATS = (4 * STAGE > 4 * RED) ? 4 * STAGE : 4 * RED;
+    __shared__ __align__(16) float lds[LDS_FLOATS];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    const int n0 = blockIdx.y * BN;
+    float *As = lds + wave * STAGE;
+    float *Ws = As + 32 * GEMM_LD;
+
+    floatx16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+
+    const int ksteps = (d.K + GEMM_BK - 1) / GEMM_BK;
+    for (int ks = wave; ks < ksteps; ks += 4) {
+        const int k0 = ks * GEMM_BK;
+        // A slice: 32 rows x 32 floats = 1024 floats, 16 per lane
+        {
+            constexpr int PER_ROW = GEMM_BK / AVEC;
+            constexpr int ITERS = 16 / AVEC;
+#pragma unroll
+            for (int i = 0; i < ITERS; i++) {
+                const int f = lane + i * 64;
+                const int row = f / PER_ROW, cv = f % PER_ROW;
+                const int64_t r = row0 + row;
+                const int k = k0 + cv * AVEC;
+                float v[AVEC];
+#pragma unroll
+                for (int j = 0; j < AVEC; j++) v[j] = 0.0f;
+                if (r < total_rows && k < d.K) {
+                    const int64_t b = r / d.rows, m = r - b * d.rows;
+                    const float *p = A + b * d.a_bs + m * d.lda + k;
+                    if constexpr (AVEC == 4) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(p);
+                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                    } else if constexpr (AVEC == 2) {
+                        const float2 t2 = *reinterpret_cast<const float2 *>(p);
+                        v[0] = t2.x; v[1] = t2.y;
+                    } else {
+                        v[0] = *p;
+                    }
+                    if (d.has_scale) {
+                        const float *sp = scale + b * d.s_bs + k;
+#pragma unroll
+                        for (int j = 0; j < AVEC; j++) v[j] *= sp[j];
+                    }
+                }
+                float *q = As + row * GEMM_LD + cv * AVEC;
+#pragma unroll
+                for (int j = 0; j < AVEC; j++) q[j] = v[j];
+            }
+        }
+        // W slice: BN rows x 32 floats
+        {
+            constexpr int PER_ROW = GEMM_BK / WVEC;
+            constexpr int ITERS = BN * GEMM_BK / 64 / WVEC;
+#pragma unroll
+            for (int i = 0; i < ITERS; i++) {
+                const int f = lane + i * 64;
+                const int row = f / PER_ROW, cv = f % PER_ROW;
+                const int n = n0 + row, k = k0 + cv * WVEC;
+                float v[WVEC];
+#pragma unroll
+                for (int j = 0; j < WVEC; j++) v[j] = 0.0f;
+                if (n < d.N && k < d.K) {
+                    const float *p = W + (int64_t)n * d.K + k;
+                    if constexpr (WVEC == 4) {
+                        const float4 t4 = *reinterpret_cast<const float4 *>(p);
+                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+                    } else {
+                        v[0] = *p;
+                    }
+                }
+                float *q = Ws + row * GEMM_LD + cv * WVEC;
+#pragma unroll
+                for (int j = 0; j < WVEC; j++) q[j] = v[j];
+            }
+        }
+        // the staging region is private to this wave; LDS ops of one wave complete in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float *ap = As + lr * GEMM_LD + 4 * lh;
+        const float *wp = Ws + lr * GEMM_LD + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < GEMM_BK / 8; g++) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const float4 b4 = *reinterpret_cast<const float4 *>(wp + t * 32 * GEMM_LD + 8 * g);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // reads done before the next iteration overwrites the slices
+    }
+    // cross-wave reduction in a fixed order: red[wave][t*16+reg][lane]
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) lds[wave * RED + (t * 16 + reg) * 64 + lane] = acc[t][reg];
+    __syncthreads();
+    // wave w finishes accumulator registers 4w .. 4w+3 of every N tile
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int reg = wave * 4 + q;
+        const int64_t r = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (r >= total_rows) continue;
+        const int64_t b = r / d.rows, m = r - b * d.rows;
+        float *crow = C + b * d.c_bs + m * d.ldc;
+        const float *rrow = d.has_res ? res + b * d.r_bs + m * d.ldr : nullptr;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int n = n0 + t * 32 + lr;
+            if (n < d.N) {
+                const int e = (t * 16 + reg) * 64 + lane;
+                float v = ((lds[e] + lds[RED + e]) + lds[2 * RED + e]) + lds[3 * RED + e];
+                if (d.has_bias) v += bias[n];
+                v = act_apply(d.act, v, d.p0, d.p1);
+                if (d.has_res) v += rrow[n];
+                crow[n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ squeeze-excite
+// stage 1: block = CV*R threads (CV = C/4 channel vectors, R row lanes); thread (r, cv) walks rows
+// r, r+R, ... of its split with fully coalesced float4 loads.  grid (splits, batch)
+__global__ void gap_partial_kernel(GapDesc d, float *__restrict__ partial, const float *__restrict__ in, int R) {
+    extern __shared__ __align__(16) float4 gsm[];
+    const int CV = d.C >> 2;
+    const int cv = threadIdx.x % CV, r = threadIdx.x / CV;
+    const int64_t b = blockIdx.y;
+    const int64_t rows_per = (d.HW + d.splits - 1) / d.splits;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per;
+    const int64_t r1 = r0 + rows_per < d.HW ? r0 + rows_per : d.HW;
+    const float4 *p = reinterpret_cast<const float4 *>(in + b * d.in_bs) + cv;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t row = r0 + r; row < r1; row += R) {
+        const float4 v = p[row * CV];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    gsm[r * CV + cv] = acc;
+    __syncthreads();
+    if (r == 0) {
+        for (int y = 1; y < R; y++) {
+            const float4 v = gsm[y * CV + cv];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4 *>(partial + b * d.out_bs + (int64_t)blockIdx.x * d.C)[cv] = acc;
+    }
+}
+
+// stage 2: one block (1024 threads = 16 waves) per sample.  W1 is [Cr][C], W2T is [Cr][C]
+// (the excite weights transposed at plan time) so both matrix-vector products read coalesced.
+__global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restrict__ gate, const float *__restrict__ partial,
+                                                     const float *__restrict__ w1, const float *__restrict__ b1,
+                                                     const float *__restrict__ w2t, const float *__restrict__ b2) {
+    extern __shared__ __align__(16) float ssm[];
+    float *s = ssm;          // [C]
+    float *h = ssm + d.C;    // [Cr]
+    const int64_t b = blockIdx.x;
+    const float *pp = partial + b * d.in_bs;
+    for (int c = threadIdx.x; c < d.C; c += 1024) {
+        float acc = 0.f;
+        for (int sp = 0; sp < d.splits; sp++) acc += pp[(int64_t)sp * d.C + c];
+        s[c] = acc * d.inv_hw;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave; j < d.Cr; j += 16) {
+        const float *wr = w1 + (int64_t)j * d.C;
+        float acc = 0.f;
+        for (int c = lane; c < d.C; c += 64) acc = fmaf(s[c], wr[c], acc);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) h[j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d.C; c += 1024) {
+        float acc = b2 ? b2[c] : 0.f;
+        for (int j = 0; j < d.Cr; j++) acc = fmaf(h[j], w2t[(int64_t)j * d.C + c], acc);
+        gate[b * d.out_bs + c] = act_apply(d.act2, acc, d.p0_2, d.p1_2);
     }
 }
 
@@ -519,19 +744,26 @@ void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *
         hipLaunchKernelGGL(reduce_inner_kept_kernel, grid, dim3(64, 16), 0, s, d, out, in);
     } else {
         dim3 grid((unsigned)d.kept, (unsigned)batch);
-        hipLaunchKernelGGL(reduce_row_kernel, grid, dim3(256), 0, s, d, out, in);
+        const int vec4 = d.nr == 1 && d.rin[0] == 1 && d.bi % 4 == 0 && aligned16(in) && d.nk == 0;
+        hipLaunchKernelGGL(reduce_row_kernel, grid, dim3(d.red >= 8192 ? 1024 : 256), 0, s, d, out, in, vec4);
     }
 }
 
-template <int BN>
+template <int BN, bool SPLITK>
 static void launch_gemm_bn(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
-                           const float *res, int64_t total_rows) {
-    dim3 grid((unsigned)((total_rows + GEMM_BM - 1) / GEMM_BM), (unsigned)((d.N + BN - 1) / BN));
+                           const float *res, const float *scale, int64_t total_rows) {
+    constexpr int BM = SPLITK ? 32 : GEMM_BM;
+    dim3 grid((unsigned)((total_rows + BM - 1) / BM), (unsigned)((d.N + BN - 1) / BN));
     const bool w4 = (d.K % 4 == 0) && aligned16(W);
     int avec = 1;
-    if (d.K % 4 == 0 && d.lda % 4 == 0 && d.a_bs % 4 == 0 && aligned16(A)) avec = 4;
+    const bool s4 = !d.has_scale || (d.s_bs % 4 == 0 && aligned16(scale));
+    if (d.K % 4 == 0 && d.lda % 4 == 0 && d.a_bs % 4 == 0 && aligned16(A) && s4) avec = 4;
     else if (d.K % 2 == 0 && d.lda % 2 == 0 && d.a_bs % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 7u) == 0) avec = 2;
-#define BN_LAUNCH(AV, WV) hipLaunchKernelGGL((gemm_mfma_kernel<BN, AV, WV>), grid, dim3(256), 0, s, d, C, A, W, bias, res, total_rows)
+#define BN_LAUNCH(AV, WV)                                                                                                      \
+    do {                                                                                                                       \
+        if constexpr (SPLITK) hipLaunchKernelGGL((gemm_splitk_kernel<BN, AV, WV>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows); \
+        else hipLaunchKernelGGL((gemm_mfma_kernel<BN, AV, WV>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows); \
+    } while (0)
     if (w4) {
         if (avec == 4) BN_LAUNCH(4, 4);
         else if (avec == 2) BN_LAUNCH(2, 4);
@@ -544,16 +776,52 @@ static void launch_gemm_bn(hipStream_t s, const GemmDesc &d, float *C, const flo
 #undef BN_LAUNCH
 }
 
-void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
-                 const float *res, const float *scale, int64_t batch) {
-    (void)scale;
-    if (batch <= 0) return;
-    const int64_t total_rows = batch * d.rows;
+static void launch_gemm_tiled(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
+                              const float *res, const float *scale, int64_t total_rows) {
     const int64_t mblocks = (total_rows + GEMM_BM - 1) / GEMM_BM;
     // widest N tile that still fills the 256 CUs a couple of times over
-    if (d.N > 64 && mblocks * ((d.N + 127) / 128) >= 512) launch_gemm_bn<128>(s, d, C, A, W, bias, res, total_rows);
-    else if (d.N > 32 && mblocks * ((d.N + 63) / 64) >= 256) launch_gemm_bn<64>(s, d, C, A, W, bias, res, total_rows);
-    else launch_gemm_bn<32>(s, d, C, A, W, bias, res, total_rows);
+    if (d.N > 64 && mblocks * ((d.N + 127) / 128) >= 512) launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    else if (d.N > 32 && mblocks * ((d.N + 63) / 64) >= 256) launch_gemm_bn<64, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    else launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
+}
+
+// Which of the two GEMM kernels runs is decided from per-sample quantities only, so that the
+// summation order of every output element -- and with it the result bits -- does not depend on
+// how many segments share a batch (a shard's last, shorter batch matches the single-GPU run).
+static bool gemm_use_splitk(const GemmDesc &d) { return d.K >= 256 && d.rows <= 256; }
+
+static void launch_gemm_splitk(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
+                               const float *res, const float *scale, int64_t total_rows) {
+    {
+        // few output tiles and a deep K: 32-row tiles with the 4 waves of a block splitting K
+        const int64_t m32 = (total_rows + 31) / 32;
+        if (d.N > 32 && m32 * ((d.N + 63) / 64) >= 512) launch_gemm_bn<64, true>(s, d, C, A, W, bias, res, scale, total_rows);
+        else launch_gemm_bn<32, true>(s, d, C, A, W, bias, res, scale, total_rows);
+    }
+}
+
+void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
+                 const float *res, const float *scale, int64_t batch) {
+    if (batch <= 0) return;
+    const int64_t total_rows = batch * d.rows;
+    if (gemm_use_splitk(d)) launch_gemm_splitk(s, d, C, A, W, bias, res, scale, total_rows);
+    else launch_gemm_tiled(s, d, C, A, W, bias, res, scale, total_rows);
+}
+
+void launch_gap_partial(hipStream_t s, const GapDesc &d, float *partial, const float *in, int64_t batch) {
+    if (batch <= 0) return;
+    const int CV = d.C / 4;
+    int R = 256 / CV;
+    if (R < 1) R = 1;
+    dim3 grid((unsigned)d.splits, (unsigned)batch);
+    hipLaunchKernelGGL(gap_partial_kernel, grid, dim3(CV * R), (size_t)CV * R * sizeof(float4), s, d, partial, in, R);
+}
+
+void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, const float *partial, const float *w1, const float *b1,
+                  const float *w2, const float *b2, int64_t batch) {
+    if (batch <= 0) return;
+    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)batch), dim3(1024), (size_t)(d.C + d.Cr) * sizeof(float), s, d, gate, partial, w1, b1,
+                       w2, b2);
 }
 
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w, const float *bias,

@@ -278,7 +278,7 @@ void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, in
     const size_t lds = topk_lds_bytes(n, k);
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(topk_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
