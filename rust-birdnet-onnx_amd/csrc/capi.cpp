@@ -76,7 +76,7 @@ struct bn_ctx {
     bool in_flight = false;  // a cancelled/timed-out run may still be executing
     size_t last_batch = 0;
     // top-K scratch
-    uint32_t *d_tk_idx = nullptr, *d_tk_cnt = nullptr;
+    uint32_t *d_tk_idx = nullptr, *d_tk_cnt = nullptr, *d_tk_flags = nullptr;
     float *d_tk_conf = nullptr;
     size_t tk_cap = 0;  // elements of idx/conf
     // pinned mirrors for bn_step_device
@@ -119,7 +119,7 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
         case OpKind::DWCONV: launch_dwconv(c->stream, op.dw, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), batch); break;
         case OpKind::GAP: launch_gap_partial(c->stream, op.gap, out, a, batch); break;
         case OpKind::SEFC:
-            launch_se_fc(c->stream, op.se, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
+            launch_se_fc(c->stream, op.se, out, resolve(c, op.b, d_in), a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
                          resolve(c, op.bias2, d_in), batch);
             break;
     }
@@ -404,6 +404,7 @@ void bn_ctx_destroy(bn_ctx *c) {
     if (c->d_tk_idx) (void)hipFree(c->d_tk_idx);
     if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
     if (c->d_tk_cnt) (void)hipFree(c->d_tk_cnt);
+    if (c->d_tk_flags) (void)hipFree(c->d_tk_flags);
     if (c->h_tk_idx) (void)hipHostFree(c->h_tk_idx);
     if (c->h_tk_conf) (void)hipHostFree(c->h_tk_conf);
     if (c->h_tk_cnt) (void)hipHostFree(c->h_tk_cnt);
@@ -531,14 +532,14 @@ size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch, char (*names)[BN_NAME_LEN], 
 }
 
 static bn_status topk_run(int device, hipStream_t stream, const float *d_logits, size_t rows, size_t n, size_t top_k, int32_t has_min,
-                          float min_conf, size_t k_stride, uint32_t *d_idx, float *d_conf, uint32_t *d_cnt, uint32_t *idx_out,
-                          float *conf_out, uint32_t *count_out) {
+                          float min_conf, size_t k_stride, uint32_t *d_idx, float *d_conf, uint32_t *d_cnt, uint32_t *d_flags,
+                          uint32_t *idx_out, float *conf_out, uint32_t *count_out) {
     (void)device;
     const size_t k = std::min(top_k, n);
     if (k_stride < k) return fail(BN_ERR_INVALID_ARG, "k_stride smaller than min(top_k, n)");
     if (topk_lds_bytes((int64_t)n, (int64_t)k) == 0) return fail(BN_ERR_INVALID_ARG, "top_k too large for the on-chip heap (k <= 9000)");
     (void)hipGetLastError();
-    launch_topk(stream, d_logits, (int64_t)rows, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, d_idx, d_conf, d_cnt);
+    launch_topk(stream, d_logits, (int64_t)rows, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, d_idx, d_conf, d_cnt, d_flags);
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> h_idx(rows * k), h_cnt(rows);
     std::vector<float> h_conf(rows * k);
@@ -556,6 +557,8 @@ static bn_status topk_run(int device, hipStream_t stream, const float *d_logits,
     return BN_OK;
 }
 
+static bn_status ensure_topk_buffers(bn_ctx *c, size_t k);
+
 bn_status bn_topk(bn_ctx *c, size_t batch, size_t top_k, int32_t has_min, float min_conf, size_t k_stride, uint32_t *idx_out, float *conf_out,
                   uint32_t *count_out) {
     if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
@@ -571,19 +574,12 @@ bn_status bn_topk(bn_ctx *c, size_t batch, size_t top_k, int32_t has_min, float 
     }
     if (!idx_out || !conf_out) return fail(BN_ERR_INVALID_ARG, "null output");
     HIP_TRY(hipSetDevice(c->model->device));
-    const size_t need = c->max_batch * k;
-    if (need > c->tk_cap) {
-        if (c->d_tk_idx) (void)hipFree(c->d_tk_idx);
-        if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
-        c->d_tk_idx = nullptr;
-        c->d_tk_conf = nullptr;
-        HIP_TRY(hipMalloc(&c->d_tk_idx, need * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&c->d_tk_conf, need * sizeof(float)));
-        c->tk_cap = need;
+    {
+        bn_status est = ensure_topk_buffers(c, k);
+        if (est != BN_OK) return est;
     }
-    if (!c->d_tk_cnt) HIP_TRY(hipMalloc(&c->d_tk_cnt, c->max_batch * sizeof(uint32_t)));
     return topk_run(c->model->device, c->stream, resolve(c, lo.ref, c->d_input), batch, n, top_k, has_min, min_conf, k_stride, c->d_tk_idx,
-                    c->d_tk_conf, c->d_tk_cnt, idx_out, conf_out, count_out);
+                    c->d_tk_conf, c->d_tk_cnt, c->d_tk_flags, idx_out, conf_out, count_out);
 }
 
 static bn_status ensure_topk_buffers(bn_ctx *c, size_t k) {
@@ -598,6 +594,7 @@ static bn_status ensure_topk_buffers(bn_ctx *c, size_t k) {
         c->tk_cap = need;
     }
     if (!c->d_tk_cnt) HIP_TRY(hipMalloc(&c->d_tk_cnt, c->max_batch * sizeof(uint32_t)));
+    if (!c->d_tk_flags) HIP_TRY(hipMalloc(&c->d_tk_flags, c->max_batch * sizeof(uint32_t)));
     return BN_OK;
 }
 
@@ -630,7 +627,7 @@ bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch, size_t top
     c->last_batch = batch;
     const float *d_logits = resolve(c, lo.ref, d_pcm);
     (void)hipGetLastError();
-    launch_topk(c->stream, d_logits, (int64_t)batch, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, c->d_tk_idx, c->d_tk_conf, c->d_tk_cnt);
+    launch_topk(c->stream, d_logits, (int64_t)batch, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, c->d_tk_idx, c->d_tk_conf, c->d_tk_cnt, c->d_tk_flags);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_out, d_logits, batch * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(c->h_tk_idx, c->d_tk_idx, batch * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -664,15 +661,18 @@ bn_status bn_topk_device(int32_t device, const float *d_logits, size_t rows, siz
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BN_ERR_NO_DEVICE, "no HIP device is visible; this path has no CPU fallback");
     HIP_TRY(hipSetDevice(device));
-    uint32_t *d_idx = nullptr, *d_cnt = nullptr;
+    uint32_t *d_idx = nullptr, *d_cnt = nullptr, *d_flags = nullptr;
     float *d_conf = nullptr;
     HIP_TRY(hipMalloc(&d_idx, rows * k * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&d_conf, rows * k * sizeof(float)));
     HIP_TRY(hipMalloc(&d_cnt, rows * sizeof(uint32_t)));
-    bn_status st = topk_run(device, nullptr, d_logits, rows, n, top_k, has_min, min_conf, k_stride, d_idx, d_conf, d_cnt, idx_out, conf_out, count_out);
+    HIP_TRY(hipMalloc(&d_flags, rows * sizeof(uint32_t)));
+    bn_status st = topk_run(device, nullptr, d_logits, rows, n, top_k, has_min, min_conf, k_stride, d_idx, d_conf, d_cnt, d_flags, idx_out, conf_out,
+                            count_out);
     (void)hipFree(d_idx);
     (void)hipFree(d_conf);
     (void)hipFree(d_cnt);
+    (void)hipFree(d_flags);
     return st;
 }
 

@@ -1141,10 +1141,12 @@ class Builder {
         plan_.storages[gate.storage].elems = (C + 3) / 4 * 4;
         {
             PlanOp op;
+            Val hidden = new_act(Dims{Cr}, Dims{1});
             op.kind = OpKind::SEFC;
             op.name = "se.excite:" + n.name;
             op.out = ref_of(gate);
             op.a = ref_of(partial);
+            op.b = ref_of(hidden);  // scratch between the two excite launches
             op.w = Ref{Space::CONSTS, add_const(w1), 0};
             if (!b1.empty()) op.bias = Ref{Space::CONSTS, add_const(b1), 0};
             std::vector<float> w2t(w2.size());  // [C][Cr] -> [Cr][C]: coalesced reads in the excite product

@@ -122,8 +122,9 @@ struct SeFcDesc {
 };
 
 void launch_gap_partial(hipStream_t s, const GapDesc &d, float *partial, const float *in, int64_t batch);
-void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, const float *partial, const float *w1,
-                  const float *b1, const float *w2, const float *b2, int64_t batch);
+// hidden: scratch [batch][Cr]
+void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, const float *partial,
+                  const float *w1, const float *b1, const float *w2, const float *b2, int64_t batch);
 
 void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a, const float *b,
                     int64_t batch);
@@ -138,9 +139,10 @@ void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, 
 // top-K + sigmoid + filter + stable sort, bit-exact with the reference's
 // BinaryHeap semantics (topk.hip).  idx/conf/count are device buffers with row
 // stride k_stride.
+// `flags` is a device scratch of `rows` uint32 (may be NULL: exact kernel only).
 void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, int64_t k,
                  int has_min, float min_conf, int64_t k_stride, uint32_t *idx, float *conf,
-                 uint32_t *count);
+                 uint32_t *count, uint32_t *flags);
 // LDS bytes the top-K kernel needs for (n, k); 0 if it cannot run (too large).
 size_t topk_lds_bytes(int64_t n, int64_t k);
 

@@ -250,24 +250,43 @@ __global__ __launch_bounds__(1024) void reduce_row_kernel(ReduceDesc d, float *_
 // assignment for A and B, so every k of the 8-wide group is used exactly once.
 constexpr int GEMM_BM = 128, GEMM_BK = 32, GEMM_LD = 36;
 
-template <int AVEC>
-__device__ __forceinline__ void load_a_tile(const GemmDesc &d, const float *__restrict__ A, const float *__restrict__ scale,
-                                            int64_t total_rows, int64_t row0, int k0, int tid, float (&regs)[16]) {
-    // 128 rows x 32 floats = 4096 floats, 16 per thread
-    constexpr int PER_ROW = GEMM_BK / AVEC;        // vectors per row
-    constexpr int ITERS = 16 / AVEC;               // vector loads per thread
+// Row addressing is resolved once per thread before the K loop: aoff[i] is the element offset of
+// the i-th row this thread stages (or -1 past the end), soff[i] the offset of its sample's gate.
+__device__ __forceinline__ void row_split(const GemmDesc &d, int64_t r, int64_t &b, int64_t &m) {
+    // rows and row counts fit 32 bits for every supported batch; 32-bit division is ~5x cheaper
+    const uint32_t bb = (uint32_t)r / (uint32_t)d.rows;
+    b = bb;
+    m = r - (int64_t)bb * d.rows;
+}
+
+template <int AVEC, int ROWS_PER_PASS, int ITERS>
+__device__ __forceinline__ void a_offsets(const GemmDesc &d, int64_t total_rows, int64_t row0, int row_first,
+                                          int64_t (&aoff)[ITERS], int64_t (&soff)[ITERS]) {
 #pragma unroll
     for (int i = 0; i < ITERS; i++) {
-        const int f = tid + i * 256;
-        const int row = f / PER_ROW, cv = f % PER_ROW;
-        const int64_t r = row0 + row;
-        const int k = k0 + cv * AVEC;
+        const int64_t r = row0 + row_first + i * ROWS_PER_PASS;
+        if (r < total_rows) {
+            int64_t b, m;
+            row_split(d, r, b, m);
+            aoff[i] = b * d.a_bs + m * d.lda;
+            soff[i] = b * d.s_bs;
+        } else {
+            aoff[i] = -1;
+            soff[i] = 0;
+        }
+    }
+}
+
+template <int AVEC, int ITERS>
+__device__ __forceinline__ void load_a_regs(const GemmDesc &d, const float *__restrict__ A, const float *__restrict__ scale,
+                                            const int64_t (&aoff)[ITERS], const int64_t (&soff)[ITERS], int k, float (&regs)[ITERS * AVEC]) {
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
         float v[AVEC];
 #pragma unroll
         for (int j = 0; j < AVEC; j++) v[j] = 0.0f;
-        if (r < total_rows && k < d.K) {
-            const int64_t b = r / d.rows, m = r - b * d.rows;
-            const float *p = A + b * d.a_bs + m * d.lda + k;
+        if (aoff[i] >= 0 && k < d.K) {
+            const float *p = A + aoff[i] + k;
             if constexpr (AVEC == 4) {
                 const float4 t = *reinterpret_cast<const float4 *>(p);
                 v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -278,7 +297,7 @@ __device__ __forceinline__ void load_a_tile(const GemmDesc &d, const float *__re
                 v[0] = *p;
             }
             if (d.has_scale) {  // squeeze-excite gate folded into the operand load
-                const float *sp = scale + b * d.s_bs + k;
+                const float *sp = scale + soff[i] + k;
 #pragma unroll
                 for (int j = 0; j < AVEC; j++) v[j] *= sp[j];
             }
@@ -288,32 +307,11 @@ __device__ __forceinline__ void load_a_tile(const GemmDesc &d, const float *__re
     }
 }
 
-template <int AVEC>
-__device__ __forceinline__ void store_a_tile(float *__restrict__ As, int tid, const float (&regs)[16]) {
-    constexpr int PER_ROW = GEMM_BK / AVEC;
-    constexpr int ITERS = 16 / AVEC;
+template <int WVEC, int ROWS_PER_PASS, int ITERS>
+__device__ __forceinline__ void load_w_regs(const GemmDesc &d, const float *__restrict__ W, int n_first, int k, float (&regs)[ITERS * WVEC]) {
 #pragma unroll
     for (int i = 0; i < ITERS; i++) {
-        const int f = tid + i * 256;
-        const int row = f / PER_ROW, cv = f % PER_ROW;
-        float *p = As + row * GEMM_LD + cv * AVEC;
-        if constexpr (AVEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(regs[i * 4], regs[i * 4 + 1], regs[i * 4 + 2], regs[i * 4 + 3]);
-        else if constexpr (AVEC == 2) *reinterpret_cast<float2 *>(p) = make_float2(regs[i * 2], regs[i * 2 + 1]);
-        else *p = regs[i];
-    }
-}
-
-template <int BN, int WVEC>
-__device__ __forceinline__ void load_w_tile(const GemmDesc &d, const float *__restrict__ W, int n0, int k0, int tid,
-                                            float (&regs)[BN / 8]) {
-    // BN rows x 32 floats = BN*32 floats, BN/8 per thread
-    constexpr int PER_ROW = GEMM_BK / WVEC;
-    constexpr int ITERS = BN / 8 / WVEC;
-#pragma unroll
-    for (int i = 0; i < ITERS; i++) {
-        const int f = tid + i * 256;
-        const int row = f / PER_ROW, cv = f % PER_ROW;
-        const int n = n0 + row, k = k0 + cv * WVEC;
+        const int n = n_first + i * ROWS_PER_PASS;
         float v[WVEC];
 #pragma unroll
         for (int j = 0; j < WVEC; j++) v[j] = 0.0f;
@@ -331,17 +329,30 @@ __device__ __forceinline__ void load_w_tile(const GemmDesc &d, const float *__re
     }
 }
 
-template <int BN, int WVEC>
-__device__ __forceinline__ void store_w_tile(float *__restrict__ Ws, int tid, const float (&regs)[BN / 8]) {
-    constexpr int PER_ROW = GEMM_BK / WVEC;
-    constexpr int ITERS = BN / 8 / WVEC;
+template <int VEC, int ROWS_PER_PASS, int ITERS>
+__device__ __forceinline__ void store_tile_regs(float *__restrict__ T, int row_first, int col, const float (&regs)[ITERS * VEC]) {
 #pragma unroll
     for (int i = 0; i < ITERS; i++) {
-        const int f = tid + i * 256;
-        const int row = f / PER_ROW, cv = f % PER_ROW;
-        float *p = Ws + row * GEMM_LD + cv * WVEC;
-        if constexpr (WVEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(regs[i * 4], regs[i * 4 + 1], regs[i * 4 + 2], regs[i * 4 + 3]);
+        float *p = T + (row_first + i * ROWS_PER_PASS) * GEMM_LD + col;
+        if constexpr (VEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(regs[i * 4], regs[i * 4 + 1], regs[i * 4 + 2], regs[i * 4 + 3]);
+        else if constexpr (VEC == 2) *reinterpret_cast<float2 *>(p) = make_float2(regs[i * 2], regs[i * 2 + 1]);
         else *p = regs[i];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void mfma_ktile(const float *__restrict__ ap, const float *__restrict__ wp, floatx16 (&acc)[NT]) {
+#pragma unroll
+    for (int g = 0; g < GEMM_BK / 8; g++) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(wp + t * 32 * GEMM_LD + 8 * g);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);
+        }
     }
 }
 
@@ -353,6 +364,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
                                                         const float *__restrict__ res,
                                                         const float *__restrict__ scale, int64_t total_rows) {
     constexpr int NT = BN / 32;
+    // staging geometry: a pass of 256 threads covers 256*VEC/32 rows of 32 floats
+    constexpr int A_RPP = 256 * AVEC / GEMM_BK, A_IT = GEMM_BM / A_RPP;
+    constexpr int W_RPP = 256 * WVEC / GEMM_BK, W_IT = BN / W_RPP;
     __shared__ __align__(16) float As[GEMM_BM * GEMM_LD];
     __shared__ __align__(16) float Ws[BN * GEMM_LD];
     const int tid = threadIdx.x;
@@ -360,6 +374,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
     const int lr = lane & 31, lh = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * GEMM_BM;
     const int n0 = blockIdx.y * BN;
+    const int a_row = tid / (GEMM_BK / AVEC), a_col = (tid % (GEMM_BK / AVEC)) * AVEC;
+    const int w_row = tid / (GEMM_BK / WVEC), w_col = (tid % (GEMM_BK / WVEC)) * WVEC;
 
     floatx16 acc[NT];
 #pragma unroll
@@ -367,37 +383,24 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
 
-    float ra[16];
-    float rw[BN / 8];
-    load_a_tile<AVEC>(d, A, scale, total_rows, row0, 0, tid, ra);
-    load_w_tile<BN, WVEC>(d, W, n0, 0, tid, rw);
+    int64_t aoff[A_IT], soff[A_IT];
+    a_offsets<AVEC, A_RPP, A_IT>(d, total_rows, row0, a_row, aoff, soff);
+    float ra[A_IT * AVEC];
+    float rw[W_IT * WVEC];
+    load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, a_col, ra);
+    load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, w_col, rw);
     const bool wave_active = row0 + wave * 32 < total_rows;
 
     for (int k0 = 0; k0 < d.K; k0 += GEMM_BK) {
         __syncthreads();  // previous tile fully consumed
-        store_a_tile<AVEC>(As, tid, ra);
-        store_w_tile<BN, WVEC>(Ws, tid, rw);
+        store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra);
+        store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw);
         __syncthreads();
         if (k0 + GEMM_BK < d.K) {  // prefetch the next tile into registers while computing
-            load_a_tile<AVEC>(d, A, scale, total_rows, row0, k0 + GEMM_BK, tid, ra);
-            load_w_tile<BN, WVEC>(d, W, n0, k0 + GEMM_BK, tid, rw);
+            load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, k0 + GEMM_BK + a_col, ra);
+            load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, k0 + GEMM_BK + w_col, rw);
         }
-        if (wave_active) {
-            const float *ap = As + (wave * 32 + lr) * GEMM_LD + 4 * lh;
-            const float *wp = Ws + lr * GEMM_LD + 4 * lh;
-#pragma unroll
-            for (int g = 0; g < GEMM_BK / 8; g++) {
-                const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const float4 b4 = *reinterpret_cast<const float4 *>(wp + t * 32 * GEMM_LD + 8 * g);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);
-                }
-            }
-        }
+        if (wave_active) mfma_ktile<NT>(As + (wave * 32 + lr) * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, acc);
     }
     if (!wave_active) return;
     // epilogue: acc[t][reg] is C[row = (reg&3) + 8*(reg>>2) + 4*lh][col = lr] of the 32x32 tile
@@ -405,7 +408,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
     for (int reg = 0; reg < 16; reg++) {
         const int64_t r = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
         if (r >= total_rows) continue;
-        const int64_t b = r / d.rows, m = r - b * d.rows;
+        int64_t b, m;
+        row_split(d, r, b, m);
         float *crow = C + b * d.c_bs + m * d.ldc;
         const float *rrow = d.has_res ? res + b * d.r_bs + m * d.ldr : nullptr;
 #pragma unroll
@@ -421,7 +425,6 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
         }
     }
 }
-
 
 // ------------------------------------------------------------------ small-M GEMM: intra-block split-K
 // When the output has few 128-row tiles (late CNN stages, FC head) the kernel above leaves most
@@ -455,89 +458,31 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__r
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
 
+    // a pass of one wave (64 lanes) covers 64*VEC/32 rows of 32 floats
+    constexpr int A_RPP = 64 * AVEC / GEMM_BK, A_IT = 32 / A_RPP;
+    constexpr int W_RPP = 64 * WVEC / GEMM_BK, W_IT = BN / W_RPP;
+    const int a_row = lane / (GEMM_BK / AVEC), a_col = (lane % (GEMM_BK / AVEC)) * AVEC;
+    const int w_row = lane / (GEMM_BK / WVEC), w_col = (lane % (GEMM_BK / WVEC)) * WVEC;
+    int64_t aoff[A_IT], soff[A_IT];
+    a_offsets<AVEC, A_RPP, A_IT>(d, total_rows, row0, a_row, aoff, soff);
     const int ksteps = (d.K + GEMM_BK - 1) / GEMM_BK;
     for (int ks = wave; ks < ksteps; ks += 4) {
         const int k0 = ks * GEMM_BK;
-        // A slice: 32 rows x 32 floats = 1024 floats, 16 per lane
         {
-            constexpr int PER_ROW = GEMM_BK / AVEC;
-            constexpr int ITERS = 16 / AVEC;
-#pragma unroll
-            for (int i = 0; i < ITERS; i++) {
-                const int f = lane + i * 64;
-                const int row = f / PER_ROW, cv = f % PER_ROW;
-                const int64_t r = row0 + row;
-                const int k = k0 + cv * AVEC;
-                float v[AVEC];
-#pragma unroll
-                for (int j = 0; j < AVEC; j++) v[j] = 0.0f;
-                if (r < total_rows && k < d.K) {
-                    const int64_t b = r / d.rows, m = r - b * d.rows;
-                    const float *p = A + b * d.a_bs + m * d.lda + k;
-                    if constexpr (AVEC == 4) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(p);
-                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
-                    } else if constexpr (AVEC == 2) {
-                        const float2 t2 = *reinterpret_cast<const float2 *>(p);
-                        v[0] = t2.x; v[1] = t2.y;
-                    } else {
-                        v[0] = *p;
-                    }
-                    if (d.has_scale) {
-                        const float *sp = scale + b * d.s_bs + k;
-#pragma unroll
-                        for (int j = 0; j < AVEC; j++) v[j] *= sp[j];
-                    }
-                }
-                float *q = As + row * GEMM_LD + cv * AVEC;
-#pragma unroll
-                for (int j = 0; j < AVEC; j++) q[j] = v[j];
-            }
+            float ra[A_IT * AVEC];
+            load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, k0 + a_col, ra);
+            store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra);
         }
-        // W slice: BN rows x 32 floats
         {
-            constexpr int PER_ROW = GEMM_BK / WVEC;
-            constexpr int ITERS = BN * GEMM_BK / 64 / WVEC;
-#pragma unroll
-            for (int i = 0; i < ITERS; i++) {
-                const int f = lane + i * 64;
-                const int row = f / PER_ROW, cv = f % PER_ROW;
-                const int n = n0 + row, k = k0 + cv * WVEC;
-                float v[WVEC];
-#pragma unroll
-                for (int j = 0; j < WVEC; j++) v[j] = 0.0f;
-                if (n < d.N && k < d.K) {
-                    const float *p = W + (int64_t)n * d.K + k;
-                    if constexpr (WVEC == 4) {
-                        const float4 t4 = *reinterpret_cast<const float4 *>(p);
-                        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
-                    } else {
-                        v[0] = *p;
-                    }
-                }
-                float *q = Ws + row * GEMM_LD + cv * WVEC;
-#pragma unroll
-                for (int j = 0; j < WVEC; j++) q[j] = v[j];
-            }
+            float rw[W_IT * WVEC];
+            load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, k0 + w_col, rw);
+            store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw);
         }
         // the staging region is private to this wave; LDS ops of one wave complete in order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float *ap = As + lr * GEMM_LD + 4 * lh;
-        const float *wp = Ws + lr * GEMM_LD + 4 * lh;
-#pragma unroll
-        for (int g = 0; g < GEMM_BK / 8; g++) {
-            const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float4 b4 = *reinterpret_cast<const float4 *>(wp + t * 32 * GEMM_LD + 8 * g);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);
-            }
-        }
+        mfma_ktile<NT>(As + lr * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, acc);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // reads done before the next iteration overwrites the slices
     }
@@ -554,7 +499,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__r
         const int reg = wave * 4 + q;
         const int64_t r = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
         if (r >= total_rows) continue;
-        const int64_t b = r / d.rows, m = r - b * d.rows;
+        int64_t b, m;
+        row_split(d, r, b, m);
         float *crow = C + b * d.c_bs + m * d.ldc;
         const float *rrow = d.has_res ? res + b * d.r_bs + m * d.ldr : nullptr;
 #pragma unroll
@@ -600,36 +546,43 @@ __global__ void gap_partial_kernel(GapDesc d, float *__restrict__ partial, const
     }
 }
 
-// stage 2: one block (1024 threads = 16 waves) per sample.  W1 is [Cr][C], W2T is [Cr][C]
-// (the excite weights transposed at plan time) so both matrix-vector products read coalesced.
-__global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restrict__ gate, const float *__restrict__ partial,
-                                                     const float *__restrict__ w1, const float *__restrict__ b1,
-                                                     const float *__restrict__ w2t, const float *__restrict__ b2) {
-    extern __shared__ __align__(16) float ssm[];
-    float *s = ssm;          // [C]
-    float *h = ssm + d.C;    // [Cr]
-    const int64_t b = blockIdx.x;
+// stage 2a (squeeze finish + reduce FC): grid (ceil(Cr/8), batch), 512 threads = 8 waves, one
+// hidden unit per wave.  Spread over many CUs because a single CU streams weights at only
+// ~10 B/clk.  W1 is [Cr][C].
+__global__ __launch_bounds__(512) void se_fc1_kernel(SeFcDesc d, float *__restrict__ hidden, const float *__restrict__ partial,
+                                                     const float *__restrict__ w1, const float *__restrict__ b1) {
+    extern __shared__ __align__(16) float ssm[];  // s[C]
+    const int64_t b = blockIdx.y;
     const float *pp = partial + b * d.in_bs;
-    for (int c = threadIdx.x; c < d.C; c += 1024) {
+    for (int c = threadIdx.x; c < d.C; c += 512) {
         float acc = 0.f;
         for (int sp = 0; sp < d.splits; sp++) acc += pp[(int64_t)sp * d.C + c];
-        s[c] = acc * d.inv_hw;
+        ssm[c] = acc * d.inv_hw;
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int j = wave; j < d.Cr; j += 16) {
-        const float *wr = w1 + (int64_t)j * d.C;
-        float acc = 0.f;
-        for (int c = lane; c < d.C; c += 64) acc = fmaf(s[c], wr[c], acc);
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        if (lane == 0) h[j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
-    }
+    const int j = blockIdx.x * 8 + wave;
+    if (j >= d.Cr) return;
+    const float *wr = w1 + (int64_t)j * d.C;
+    float acc = 0.f;
+    for (int c = lane; c < d.C; c += 64) acc = fmaf(ssm[c], wr[c], acc);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) hidden[b * d.Cr + j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
+}
+
+// stage 2b (excite FC + gate activation): grid (ceil(C/256), batch), 256 threads, one channel per
+// thread.  W2T is [Cr][C] (transposed at plan time) so the reads are coalesced.
+__global__ __launch_bounds__(256) void se_fc2_kernel(SeFcDesc d, float *__restrict__ gate, const float *__restrict__ hidden,
+                                                     const float *__restrict__ w2t, const float *__restrict__ b2) {
+    extern __shared__ __align__(16) float hsm[];  // h[Cr]
+    const int64_t b = blockIdx.y;
+    for (int j = threadIdx.x; j < d.Cr; j += 256) hsm[j] = hidden[b * d.Cr + j];
     __syncthreads();
-    for (int c = threadIdx.x; c < d.C; c += 1024) {
-        float acc = b2 ? b2[c] : 0.f;
-        for (int j = 0; j < d.Cr; j++) acc = fmaf(h[j], w2t[(int64_t)j * d.C + c], acc);
-        gate[b * d.out_bs + c] = act_apply(d.act2, acc, d.p0_2, d.p1_2);
-    }
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d.C) return;
+    float acc = b2 ? b2[c] : 0.f;
+    for (int j = 0; j < d.Cr; j++) acc = fmaf(hsm[j], w2t[(int64_t)j * d.C + c], acc);
+    gate[b * d.out_bs + c] = act_apply(d.act2, acc, d.p0_2, d.p1_2);
 }
 
 // ------------------------------------------------------------------ depthwise conv
@@ -716,6 +669,58 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvDesc d, float *__r
         acc = act_apply(d.act, acc, d.p0, d.p1);
         if (d.has_res) acc += res[bidx * d.out_bs + i];
         op[i] = acc;
+    }
+}
+
+// Dense conv with a small weight tensor (stem conv): weights [kh][kw][Cin][Cout] staged in LDS,
+// one lane = one output pixel x 4 output channels.  grid (ceil(OH*OW*Cout/4/256), batch)
+__global__ __launch_bounds__(256) void conv_small_kernel(ConvDesc d, float *__restrict__ out, const float *__restrict__ in,
+                                                         const float *__restrict__ w, const float *__restrict__ bias,
+                                                         const float *__restrict__ res) {
+    extern __shared__ __align__(16) float wsm[];
+    const int wn = d.kh * d.kw * d.Cin * d.Cout;
+    for (int i = threadIdx.x * 4; i < wn; i += 1024) *reinterpret_cast<float4 *>(wsm + i) = *reinterpret_cast<const float4 *>(w + i);
+    __syncthreads();
+    const int64_t bidx = blockIdx.y;
+    const uint32_t OC4 = (uint32_t)d.Cout >> 2;
+    const uint32_t total = (uint32_t)d.OH * d.OW * OC4;
+    const float *ip = in + bidx * d.in_bs;
+    float *op = out + bidx * d.out_bs;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const uint32_t o4 = i % OC4;
+        const uint32_t pix = i / OC4;
+        const int ow = pix % d.OW, oh = pix / d.OW;
+        const int oc = o4 * 4;
+        float4 acc = d.has_bias ? *reinterpret_cast<const float4 *>(bias + oc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int ih0 = oh * d.sh - d.pt, iw0 = ow * d.sw - d.pl;
+        for (int ky = 0; ky < d.kh; ky++) {
+            const int ih = ih0 + ky * d.dh;
+            if (ih < 0 || ih >= d.H) continue;
+            for (int kx = 0; kx < d.kw; kx++) {
+                const int iw = iw0 + kx * d.dw;
+                if (iw < 0 || iw >= d.W) continue;
+                const float *px = ip + ((int64_t)ih * d.W + iw) * d.Cin;
+                const float *pw = wsm + ((ky * d.kw + kx) * d.Cin) * d.Cout + oc;
+                for (int ci = 0; ci < d.Cin; ci++) {
+                    const float x = px[ci];
+                    const float4 k4 = *reinterpret_cast<const float4 *>(pw + ci * d.Cout);
+                    acc.x = fmaf(x, k4.x, acc.x);
+                    acc.y = fmaf(x, k4.y, acc.y);
+                    acc.z = fmaf(x, k4.z, acc.z);
+                    acc.w = fmaf(x, k4.w, acc.w);
+                }
+            }
+        }
+        acc.x = act_apply(d.act, acc.x, d.p0, d.p1);
+        acc.y = act_apply(d.act, acc.y, d.p0, d.p1);
+        acc.z = act_apply(d.act, acc.z, d.p0, d.p1);
+        acc.w = act_apply(d.act, acc.w, d.p0, d.p1);
+        const int64_t o = (int64_t)pix * d.Cout + oc;
+        if (d.has_res) {
+            const float4 r4 = *reinterpret_cast<const float4 *>(res + bidx * d.out_bs + o);
+            acc.x += r4.x; acc.y += r4.y; acc.z += r4.z; acc.w += r4.w;
+        }
+        *reinterpret_cast<float4 *>(op + o) = acc;
     }
 }
 
@@ -817,16 +822,26 @@ void launch_gap_partial(hipStream_t s, const GapDesc &d, float *partial, const f
     hipLaunchKernelGGL(gap_partial_kernel, grid, dim3(CV * R), (size_t)CV * R * sizeof(float4), s, d, partial, in, R);
 }
 
-void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, const float *partial, const float *w1, const float *b1,
-                  const float *w2, const float *b2, int64_t batch) {
+void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, const float *partial, const float *w1,
+                  const float *b1, const float *w2, const float *b2, int64_t batch) {
     if (batch <= 0) return;
-    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)batch), dim3(1024), (size_t)(d.C + d.Cr) * sizeof(float), s, d, gate, partial, w1, b1,
-                       w2, b2);
+    hipLaunchKernelGGL(se_fc1_kernel, dim3((unsigned)((d.Cr + 7) / 8), (unsigned)batch), dim3(512), (size_t)d.C * sizeof(float), s, d, hidden,
+                       partial, w1, b1);
+    hipLaunchKernelGGL(se_fc2_kernel, dim3((unsigned)((d.C + 255) / 256), (unsigned)batch), dim3(256), (size_t)d.Cr * sizeof(float), s, d, gate,
+                       hidden, w2, b2);
 }
 
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w, const float *bias,
                  const float *res, int64_t batch) {
     if (batch <= 0) return;
+    const int64_t wfloats = (int64_t)d.kh * d.kw * d.Cin * d.Cout;
+    if (d.groups == 1 && d.Cout % 4 == 0 && wfloats <= 12288 && d.out_bs % 4 == 0 && aligned16(out) && aligned16(w) &&
+        (!d.has_res || aligned16(res))) {
+        const int64_t total = (int64_t)d.OH * d.OW * (d.Cout / 4);
+        dim3 grid(cap_blocks((total + 255) / 256, 8192), (unsigned)batch);
+        hipLaunchKernelGGL(conv_small_kernel, grid, dim3(256), (size_t)wfloats * sizeof(float), s, d, out, in, w, bias, res);
+        return;
+    }
     const int64_t total = (int64_t)d.OH * d.OW * d.Cout;
     dim3 grid(cap_blocks((total + 255) / 256, 8192), (unsigned)batch);
     hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, d, out, in, w, bias, res);

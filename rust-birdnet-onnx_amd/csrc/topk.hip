@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -148,8 +149,10 @@ __global__ __launch_bounds__(64) void topk_kernel(const float *__restrict__ logi
                                                   uint32_t k, int has_min, float min_conf,
                                                   int64_t k_stride, uint32_t *__restrict__ idx_out,
                                                   float *__restrict__ conf_out,
-                                                  uint32_t *__restrict__ count_out) {
+                                                  uint32_t *__restrict__ count_out,
+                                                  const uint32_t *__restrict__ flags) {
     extern __shared__ __align__(16) uint32_t lds[];
+    if (flags && flags[blockIdx.x] == 0) return;  // the fast kernel already produced this row
     Heap h{lds, lds + (k + 1)};
     float *conf = reinterpret_cast<float *>(lds + 2 * (size_t)(k + 1));
     uint32_t *oidx = lds + 2 * (size_t)(k + 1) + k;
@@ -263,6 +266,105 @@ __global__ __launch_bounds__(64) void topk_kernel(const float *__restrict__ logi
     if (lane == 0) count_out[row] = m;
 }
 
+
+// ---------------------------------------------------------------------------
+// Fast path.  When the k+1 largest keys of a row are pairwise distinct and the k
+// confidences are pairwise distinct and not NaN, the reference's result does not
+// depend on the heap's internal arrangement at all: it is the k largest logits
+// in descending order (sigmoid is monotone), cut where `confidence >= min`
+// stops holding.  This kernel computes exactly that, one wavefront per row:
+//   pass 1  per-lane maximum; the (k+1)-th largest of the 64 lane maxima is a lower
+//           bound T0 of the row's (k+1)-th largest key
+//   pass 2  ballot-compact every element with key >= T0 into LDS (typically < 100)
+//   rank    each candidate counts the candidates that beat it -> sorted top k+1
+// and raises flags[row] = 1 for every row it cannot decide (ties, NaN, too many
+// candidates); those rows are then redone by the exact heap kernel above.
+constexpr int FAST_CAP = 1024;
+
+__global__ __launch_bounds__(64) void topk_fast_kernel(const float *__restrict__ logits, int64_t n, uint32_t k, int has_min,
+                                                       float min_conf, int64_t k_stride, uint32_t *__restrict__ idx_out,
+                                                       float *__restrict__ conf_out, uint32_t *__restrict__ count_out,
+                                                       uint32_t *__restrict__ flags) {
+    __shared__ uint32_t ckey[FAST_CAP], cidx[FAST_CAP];
+    __shared__ uint32_t skey[64], sidx[64];
+    __shared__ float sconf[64];
+    const int64_t row = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *x = reinterpret_cast<const uint32_t *>(logits + row * n);
+
+    uint32_t mk = 0;
+    for (int64_t i = lane; i < n; i += 64) {
+        const uint32_t kk = total_key(x[i]);
+        mk = kk > mk ? kk : mk;
+    }
+    // rank of this lane's maximum among the 64 (ties by lane id): the lane of rank k holds T0
+    uint32_t rank = 0;
+    for (int l = 0; l < 64; l++) {
+        const uint32_t o = __shfl(mk, l);
+        rank += (o > mk || (o == mk && (uint32_t)l < lane)) ? 1u : 0u;
+    }
+    const uint64_t who = __ballot(rank == k);
+    const uint32_t T0 = __shfl(mk, __ffsll((long long)who) - 1);
+
+    uint32_t cnt = 0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const uint32_t kk = i < n ? total_key(x[i]) : 0u;
+        const bool pred = i < n && kk >= T0;
+        const uint64_t m = __ballot(pred);
+        const uint32_t pos = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pred && pos < FAST_CAP) {
+            ckey[pos] = kk;
+            cidx[pos] = (uint32_t)i;
+        }
+        cnt += (uint32_t)__popcll(m);
+    }
+    if (cnt > FAST_CAP) {  // heavy ties around the threshold: exact kernel
+        if (lane == 0) flags[row] = 1;
+        return;
+    }
+    __syncthreads();
+    for (uint32_t c = lane; c < cnt; c += 64) {
+        const uint32_t kc = ckey[c], ic = cidx[c];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t kj = ckey[j];
+            r += (kj > kc || (kj == kc && cidx[j] < ic)) ? 1u : 0u;
+        }
+        if (r <= k) {
+            skey[r] = kc;
+            sidx[r] = ic;
+        }
+    }
+    __syncthreads();
+    bool bad = false;
+    float c0 = 0.f;
+    if (lane <= k) {
+        const uint32_t kk = skey[lane];
+        const uint32_t bits = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;
+        const float v = __uint_as_float(bits);
+        c0 = sigmoid_ref(v);
+        sconf[lane] = c0;
+        if (lane < k) bad = (kk == skey[lane + 1]) || (v != v);  // adjacent equal keys / NaN
+    }
+    __syncthreads();
+    if (lane + 1 < k) bad = bad || (c0 == sconf[lane + 1]);      // equal confidences among the survivors
+    if (__ballot(bad)) {
+        if (lane == 0) flags[row] = 1;
+        return;
+    }
+    const bool keep = lane < k && (!has_min || c0 >= min_conf);  // a prefix: confidences are descending
+    const uint64_t km = __ballot(keep);
+    if (keep) {
+        idx_out[row * k_stride + lane] = sidx[lane];
+        conf_out[row * k_stride + lane] = c0;
+    }
+    if (lane == 0) {
+        count_out[row] = (uint32_t)__popcll(km);
+        flags[row] = 0;
+    }
+}
+
 }  // namespace
 
 size_t topk_lds_bytes(int64_t n, int64_t k) {
@@ -273,8 +375,13 @@ size_t topk_lds_bytes(int64_t n, int64_t k) {
 
 void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, int64_t k,
                  int has_min, float min_conf, int64_t k_stride, uint32_t *idx, float *conf,
-                 uint32_t *count) {
+                 uint32_t *count, uint32_t *flags) {
     if (rows <= 0 || k <= 0 || n <= 0) return;
+    // fast path needs k+1 lane maxima; BN_TOPK_EXACT=1 forces the exact heap kernel (tests)
+    if (flags && (k > 62 || n < 64 || getenv("BN_TOPK_EXACT"))) flags = nullptr;
+    if (flags)
+        hipLaunchKernelGGL(topk_fast_kernel, dim3((unsigned)rows), dim3(64), 0, s, logits, n, (uint32_t)k, has_min, min_conf, k_stride, idx,
+                           conf, count, flags);
     const size_t lds = topk_lds_bytes(n, k);
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
@@ -283,7 +390,7 @@ void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, in
         attr_set = true;
     }
     hipLaunchKernelGGL(topk_kernel, dim3((unsigned)rows), dim3(64), lds, s, logits, n, (uint32_t)k,
-                       has_min, min_conf, k_stride, idx, conf, count);
+                       has_min, min_conf, k_stride, idx, conf, count, (const uint32_t *)flags);
 }
 
 }  // namespace bn

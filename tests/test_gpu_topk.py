@@ -14,6 +14,18 @@ INF, NAN = float("inf"), float("nan")
 
 
 def check_rows(bn, logits, top_k, min_conf=None):
+    """Both device paths must reproduce the oracle: the fast kernel (with its exact-kernel fallback
+    for undecidable rows) and the exact BinaryHeap kernel alone (BN_TOPK_EXACT=1)."""
+    import os
+    _check_rows(bn, logits, top_k, min_conf)
+    os.environ["BN_TOPK_EXACT"] = "1"
+    try:
+        _check_rows(bn, logits, top_k, min_conf)
+    finally:
+        del os.environ["BN_TOPK_EXACT"]
+
+
+def _check_rows(bn, logits, top_k, min_conf=None):
     a = np.ascontiguousarray(logits, dtype=np.float32)
     if a.ndim == 1:
         a = a[None, :]
