@@ -340,8 +340,10 @@ __device__ __forceinline__ void store_tile_regs(float *__restrict__ T, int row_f
     }
 }
 
+// ng = number of 8-wide k groups of this K step that hold real data, nt = number of 32-wide N
+// tiles of this block that exist; padded groups / tiles are skipped (both are wave-uniform).
 template <int NT>
-__device__ __forceinline__ void mfma_ktile(const float *__restrict__ ap, const float *__restrict__ wp, floatx16 (&acc)[NT]) {
+__device__ __forceinline__ void mfma_ktile_full(const float *__restrict__ ap, const float *__restrict__ wp, floatx16 (&acc)[NT]) {
 #pragma unroll
     for (int g = 0; g < GEMM_BK / 8; g++) {
         const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
@@ -352,6 +354,95 @@ __device__ __forceinline__ void mfma_ktile(const float *__restrict__ ap, const f
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);
+        }
+    }
+}
+
+// K tail: only the first ng 8-wide groups of the step hold data (wave-uniform).
+template <int NT>
+__device__ __forceinline__ void mfma_ktile_partial(const float *__restrict__ ap, const float *__restrict__ wp, floatx16 (&acc)[NT], int ng) {
+    for (int g = 0; g < ng; g++) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(wp + t * 32 * GEMM_LD + 8 * g);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[t], 0, 0, 0);
+        }
+    }
+}
+
+// Activation over a whole accumulator tile with ONE dispatch on the (wave-uniform) code.
+template <int NT, class F>
+__device__ __forceinline__ void map_tile(floatx16 (&acc)[NT], F f) {
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = f(acc[t][r]);
+}
+template <int NT>
+__device__ __forceinline__ void act_tile(int act, float p0, float p1, floatx16 (&acc)[NT]) {
+    if (act == ACT_NONE) return;
+    if (act == ACT_RELU) map_tile<NT>(acc, [](float x) { return fmaxf(x, 0.0f); });
+    else if (act == ACT_CLIP) map_tile<NT>(acc, [=](float x) { return fminf(fmaxf(x, p0), p1); });
+    else if (act == ACT_SILU) map_tile<NT>(acc, [](float x) { return x / (1.0f + expf(-x)); });
+    else if (act == ACT_SIGMOID) map_tile<NT>(acc, [](float x) { return 1.0f / (1.0f + expf(-x)); });
+    else if (act == ACT_HSWISH) map_tile<NT>(acc, [](float x) { return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f); });
+    else if (act == ACT_HSIGMOID) map_tile<NT>(acc, [=](float x) { return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f); });
+    else if (act == ACT_LEAKY) map_tile<NT>(acc, [=](float x) { return x >= 0.0f ? x : p0 * x; });
+    else if (act == ACT_TANH) map_tile<NT>(acc, [](float x) { return tanhf(x); });
+}
+
+// Shared epilogue: bias, activation, residual, store.  Lane (lr, lh) of a wave holds, in
+// acc[t][reg], C[rbase + (reg&3) + 8*(reg>>2) + 4*lh][n0 + 32*t + lr].  Output (and residual) rows
+// of one launch are contiguous across samples (ldc == N-stride of a dense [rows*batch, ldc]
+// array) whenever c_bs == rows*ldc, which the planner guarantees for its own allocations; then no
+// per-row division is needed.
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue(const GemmDesc &d, float *__restrict__ C, const float *__restrict__ bias,
+                                              const float *__restrict__ res, floatx16 (&acc)[NT], int64_t rbase, int64_t total_rows,
+                                              int n0, int lr, int lh, int reg_lo, int reg_hi) {
+    float bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int n = n0 + t * 32 + lr;
+        bv[t] = (d.has_bias && n < d.N) ? bias[n] : 0.0f;
+    }
+    if (d.has_bias) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] += bv[t];
+    }
+    act_tile<NT>(d.act, d.p0, d.p1, acc);
+    const bool flat_c = d.c_bs == d.rows * d.ldc;
+    const bool flat_r = !d.has_res || d.r_bs == d.rows * d.ldr;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int64_t r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (reg >= reg_lo && reg < reg_hi && r < total_rows) {
+            float *crow;
+            const float *rrow = nullptr;
+            if (flat_c && flat_r) {
+                crow = C + r * d.ldc;
+                if (d.has_res) rrow = res + r * d.ldr;
+            } else {
+                int64_t b, m;
+                row_split(d, r, b, m);
+                crow = C + b * d.c_bs + m * d.ldc;
+                if (d.has_res) rrow = res + b * d.r_bs + m * d.ldr;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int n = n0 + t * 32 + lr;
+                if (n < d.N) {
+                    float v = acc[t][reg];
+                    if (d.has_res) v += rrow[n];
+                    crow[n] = v;
+                }
+            }
         }
     }
 }
@@ -391,7 +482,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
     load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, w_col, rw);
     const bool wave_active = row0 + wave * 32 < total_rows;
 
-    for (int k0 = 0; k0 < d.K; k0 += GEMM_BK) {
+    const float *ap = As + (wave * 32 + lr) * GEMM_LD + 4 * lh, *wp = Ws + lr * GEMM_LD + 4 * lh;
+    int k0 = 0;
+    for (; k0 + GEMM_BK <= d.K; k0 += GEMM_BK) {  // full K steps
         __syncthreads();  // previous tile fully consumed
         store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra);
         store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw);
@@ -400,30 +493,17 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
             load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, k0 + GEMM_BK + a_col, ra);
             load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, k0 + GEMM_BK + w_col, rw);
         }
-        if (wave_active) mfma_ktile<NT>(As + (wave * 32 + lr) * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, acc);
+        if (wave_active) mfma_ktile_full<NT>(ap, wp, acc);
+    }
+    if (k0 < d.K) {  // K tail: zero-filled past K, only the groups holding data are multiplied
+        __syncthreads();
+        store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra);
+        store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw);
+        __syncthreads();
+        if (wave_active) mfma_ktile_partial<NT>(ap, wp, acc, (d.K - k0 + 7) / 8);
     }
     if (!wave_active) return;
-    // epilogue: acc[t][reg] is C[row = (reg&3) + 8*(reg>>2) + 4*lh][col = lr] of the 32x32 tile
-#pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-        const int64_t r = row0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (r >= total_rows) continue;
-        int64_t b, m;
-        row_split(d, r, b, m);
-        float *crow = C + b * d.c_bs + m * d.ldc;
-        const float *rrow = d.has_res ? res + b * d.r_bs + m * d.ldr : nullptr;
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const int n = n0 + t * 32 + lr;
-            if (n < d.N) {
-                float v = acc[t][reg];
-                if (d.has_bias) v += bias[n];
-                v = act_apply(d.act, v, d.p0, d.p1);
-                if (d.has_res) v += rrow[n];
-                crow[n] = v;
-            }
-        }
-    }
+    gemm_epilogue<NT>(d, C, bias, res, acc, row0 + wave * 32, total_rows, n0, lr, lh, 0, 16);
 }
 
 // ------------------------------------------------------------------ small-M GEMM: intra-block split-K
@@ -482,7 +562,11 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__r
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        mfma_ktile<NT>(As + lr * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, acc);
+        {
+            const int kleft = d.K - k0;
+            if (kleft >= GEMM_BK) mfma_ktile_full<NT>(As + lr * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, acc);
+            else mfma_ktile_partial<NT>(As + lr * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, acc, (kleft + 7) / 8);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // reads done before the next iteration overwrites the slices
     }
@@ -493,29 +577,16 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__r
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) lds[wave * RED + (t * 16 + reg) * 64 + lane] = acc[t][reg];
     __syncthreads();
-    // wave w finishes accumulator registers 4w .. 4w+3 of every N tile
+    // wave w finishes accumulator registers 4w .. 4w+3 of every N tile: gather the four partial
+    // sums (fixed order) back into those registers, then the shared epilogue stores them
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int reg = wave * 4 + q;
-        const int64_t r = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (r >= total_rows) continue;
-        int64_t b, m;
-        row_split(d, r, b, m);
-        float *crow = C + b * d.c_bs + m * d.ldc;
-        const float *rrow = d.has_res ? res + b * d.r_bs + m * d.ldr : nullptr;
+    for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const int n = n0 + t * 32 + lr;
-            if (n < d.N) {
-                const int e = (t * 16 + reg) * 64 + lane;
-                float v = ((lds[e] + lds[RED + e]) + lds[2 * RED + e]) + lds[3 * RED + e];
-                if (d.has_bias) v += bias[n];
-                v = act_apply(d.act, v, d.p0, d.p1);
-                if (d.has_res) v += rrow[n];
-                crow[n] = v;
-            }
+        for (int reg = 0; reg < 16; reg++) {
+            const int e = (t * 16 + reg) * 64 + lane;
+            if ((reg >> 2) == wave) acc[t][reg] = ((lds[e] + lds[RED + e]) + lds[2 * RED + e]) + lds[3 * RED + e];
         }
-    }
+    gemm_epilogue<NT>(d, C, bias, res, acc, row0, total_rows, n0, lr, lh, wave * 4, wave * 4 + 4);
 }
 
 // ------------------------------------------------------------------ squeeze-excite
@@ -785,7 +856,11 @@ static void launch_gemm_tiled(hipStream_t s, const GemmDesc &d, float *C, const 
                               const float *res, const float *scale, int64_t total_rows) {
     const int64_t mblocks = (total_rows + GEMM_BM - 1) / GEMM_BM;
     // widest N tile that still fills the 256 CUs a couple of times over
-    if (d.N > 64 && mblocks * ((d.N + 127) / 128) >= 512) launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    // N tile: the least padded of {128, 96, 64, 32} that still fills the 256 CUs a couple of times over
+    auto waste = [&](int bn) { return (int64_t)((d.N + bn - 1) / bn) * bn - d.N; };
+    if (d.N > 64 && mblocks * ((d.N + 95) / 96) >= 512 && waste(96) < waste(128) && waste(96) <= waste(64))
+        launch_gemm_bn<96, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    else if (d.N > 64 && mblocks * ((d.N + 127) / 128) >= 512 && waste(128) <= waste(64)) launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
     else if (d.N > 32 && mblocks * ((d.N + 63) / 64) >= 256) launch_gemm_bn<64, false>(s, d, C, A, W, bias, res, scale, total_rows);
     else launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
 }
