@@ -107,7 +107,12 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
     float *out = resolve(c, op.out, d_in);
     const float *a = resolve(c, op.a, d_in);
     switch (op.kind) {
-        case OpKind::ELT: launch_eltwise(c->stream, op.elt, out, a, resolve(c, op.b, d_in), batch); break;
+        case OpKind::ELT: {
+            const float *eb[ELT_MAX_STAGES];
+            for (int k = 0; k < ELT_MAX_STAGES; k++) eb[k] = resolve(c, op.eb[k], d_in);
+            launch_eltwise(c->stream, op.elt, out, a, eb, batch);
+            break;
+        }
         case OpKind::REDUCE: launch_reduce(c->stream, op.red, out, a, batch); break;
         case OpKind::GEMM:
             launch_gemm(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in),
@@ -738,7 +743,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 snprintf(line, sizeof(line), " %dx%dx%d->%dx%dx%d k=%dx%d s=%d g=%d act=%d", op.conv.H, op.conv.W, op.conv.Cin, op.conv.OH, op.conv.OW, op.conv.Cout, op.conv.kh, op.conv.kw, op.conv.sh, op.conv.groups, op.conv.act);
                 extra = line;
             } else if (op.kind == OpKind::ELT) {
-                snprintf(line, sizeof(line), " n=%lld nd=%d bin=%d act=%d flat=%d", (long long)op.elt.per_sample, op.elt.nd, op.elt.bin, op.elt.act, op.elt.flat);
+                snprintf(line, sizeof(line), " n=%lld nd=%d stages=%d bin0=%d act0=%d", (long long)op.elt.per_sample, op.elt.nd, op.elt.nstages, op.elt.st[0].bin, op.elt.st[0].act);
                 extra = line;
             } else if (op.kind == OpKind::GAP) {
                 snprintf(line, sizeof(line), " HW=%lld C=%d splits=%d", (long long)op.gap.HW, op.gap.C, op.gap.splits);

@@ -165,6 +165,7 @@ class Builder {
             oi.computed = true;
             plan_.storages[v.storage].pinned = true;
         }
+        fuse_elementwise_chains();
         plan_memory();
         for (auto &op : plan_.ops) {
             (op.mfma ? plan_.macs_mfma : plan_.macs_valu) += op.macs;
@@ -275,6 +276,7 @@ class Builder {
         touch(op.scale, idx);
         touch(op.w2, idx);
         touch(op.bias2, idx);
+        for (auto &r : op.eb) touch(r, idx);
         plan_.ops.push_back(std::move(op));
     }
 
@@ -343,18 +345,19 @@ class Builder {
         op.name = name;
         op.out = ref_of(out);
         op.a = a;
-        op.b = b;
+        op.eb[0] = b;
         EltDesc &d = op.elt;
         d.nd = (int)loops.size();
         d.per_sample = 1;
+        d.nstages = 1;
+        EltStage &st = d.st[0];
         for (int k = 0; k < d.nd; k++) {
-            d.size[k] = loops[k].n; d.so[k] = loops[k].so; d.sa[k] = loops[k].sa; d.sb[k] = loops[k].sb;
+            d.size[k] = loops[k].n; d.so[k] = loops[k].so; d.sa[k] = loops[k].sa; st.sb[k] = loops[k].sb;
             d.per_sample *= loops[k].n;
         }
         int64_t out_ext = plan_.storages[out.storage].elems;
-        d.bo = out_ext; d.ba = a_bs; d.bb = b_bs;
-        d.bin = bin; d.act = act.act; d.p0 = act.p0; d.p1 = act.p1;
-        d.flat = (d.nd == 1 && d.so[0] == 1 && d.sa[0] == 1 && (bin == BIN_NONE || d.sb[0] == 1)) ? 1 : 0;
+        d.bo = out_ext; d.ba = a_bs; st.bb = b_bs;
+        st.bin = bin; st.act = act.act; st.p0 = act.p0; st.p1 = act.p1;
         op.bytes = 4.0 * (double)d.per_sample * (bin == BIN_NONE ? 2 : 3);
         push_op(std::move(op));
     }
@@ -853,10 +856,27 @@ class Builder {
             if (v.dims.size() != od.size()) unsupported(n, "rank mismatch");
             od[axis] += v.dims[axis];
         }
-        // layout: follow the first input's physical order
-        Val probe = ins[0];
-        probe.dims = od;
-        Val out = new_act(od, strides_for_order(od, phys_order(ins[0])));
+        // layout: channels-last when the result (through elementwise ops) feeds a convolution,
+        // else follow the first input's physical order
+        bool to_conv = false;
+        {
+            std::string cur = n.outputs[0];
+            for (int hop = 0; hop < 6 && !to_conv; hop++) {
+                int c = sole_consumer(cur);
+                if (c < 0) break;
+                const OnnxNode &cn = nodes_[c];
+                if (cn.op_type == "Conv" && cn.inputs[0] == cur) to_conv = true;
+                else if (cn.inputs[0] == cur && (cn.op_type == "BatchNormalization" || cn.op_type == "Relu" || cn.op_type == "Clip" ||
+                                                 cn.op_type == "Mul" || cn.op_type == "Add" || cn.op_type == "Sub" || cn.op_type == "Div" ||
+                                                 cn.op_type == "Sigmoid" || cn.op_type == "Pow" || cn.op_type == "Log" || cn.op_type == "Sqrt"))
+                    cur = cn.outputs[0];
+                else break;
+            }
+        }
+        Dims ostr = strides_for_order(od, phys_order(ins[0]));
+        if (to_conv && od.size() == 3) ostr = Dims{1, od[2] * od[0], od[0]};
+        else if (to_conv && od.size() == 2) ostr = Dims{1, od[0]};
+        Val out = new_act(od, ostr);
         int64_t pos = 0;
         for (auto &v : ins) {
             Val slot = out;
@@ -1499,6 +1519,93 @@ class Builder {
         op.bytes = 4.0 * ((double)rows * K + (double)rows * N);
         push_op(std::move(op));
         define(cur, out);
+    }
+
+    // --------------------------------------------------------- elementwise chain fusion
+    void all_refs(PlanOp &op, std::vector<Ref *> &out) {
+        out = {&op.out, &op.a, &op.b, &op.res, &op.scale, &op.w2, &op.bias2};
+        for (auto &r : op.eb) out.push_back(&r);
+    }
+    void recompute_liveness() {
+        for (auto &st : plan_.storages) { st.first = -1; st.last = -1; }
+        std::vector<Ref *> refs;
+        for (size_t k = 0; k < plan_.ops.size(); k++) {
+            all_refs(plan_.ops[k], refs);
+            for (Ref *r : refs) touch(*r, (int)k);
+        }
+    }
+    // An ELT launch whose result is read by exactly one later ELT launch, as that launch's primary
+    // operand over the very same index space, is folded into it (its stages are prepended).
+    void fuse_elementwise_chains() {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            recompute_liveness();
+            // users per storage
+            std::vector<std::vector<int>> users(plan_.storages.size());
+            std::vector<Ref *> refs;
+            for (size_t k = 0; k < plan_.ops.size(); k++) {
+                all_refs(plan_.ops[k], refs);
+                for (Ref *r : refs)
+                    if (r->space == Space::ARENA && (users[r->id].empty() || users[r->id].back() != (int)k)) users[r->id].push_back((int)k);
+            }
+            for (size_t j = 0; j < plan_.ops.size() && !changed; j++) {
+                PlanOp &cons = plan_.ops[j];
+                if (cons.kind != OpKind::ELT || cons.a.space != Space::ARENA) continue;
+                const auto &u = users[cons.a.id];
+                if (u.size() != 2 || u[1] != (int)j || plan_.storages[cons.a.id].pinned) continue;
+                PlanOp &prod = plan_.ops[u[0]];
+                if (prod.kind != OpKind::ELT || prod.out.space != Space::ARENA || prod.out.id != cons.a.id) continue;
+                const int64_t delta = cons.a.offset - prod.out.offset;  // consumer may read a shifted / reversed view
+                if (prod.elt.nstages + cons.elt.nstages > ELT_MAX_STAGES) continue;
+                // (A) same index space: the consumer reads exactly what the producer wrote, or
+                // (B) the producer is a flat map over a dense buffer (offset in == offset out), so the
+                //     consumer's own strides address the producer's operands directly
+                const EltDesc &pe = prod.elt, &ce = cons.elt;
+                if (pe.bo != ce.ba) continue;
+                bool same = pe.nd == ce.nd && delta == 0;
+                for (int k = 0; same && k < pe.nd; k++) same = pe.size[k] == ce.size[k] && pe.so[k] == ce.sa[k];
+                bool flat_prod = pe.nd == 1 && pe.so[0] == 1 && pe.sa[0] == 1 && pe.per_sample == ce.per_sample;
+                for (int k = 0; flat_prod && k < pe.nstages; k++)
+                    flat_prod = pe.st[k].bin == BIN_NONE || pe.st[k].sb[0] == 0 || pe.st[k].sb[0] == 1;
+                if (!same && !flat_prod) continue;
+                // the consumer must not also use the intermediate as a stage operand
+                {
+                    bool clash = false;
+                    for (int k = 0; k < ce.nstages; k++) clash = clash || (cons.eb[k].space == Space::ARENA && cons.eb[k].id == cons.a.id);
+                    if (clash) continue;
+                }
+                // nothing between the two may overwrite the producer's inputs: storages are single-assignment
+                // except concat targets, which are only read after all their writers ran -> safe.
+                PlanOp fused = cons;
+                fused.name = prod.name + "+" + cons.name;
+                fused.a = prod.a;
+                EltDesc &fe = fused.elt;
+                fe.ba = pe.ba;
+                fe.nstages = pe.nstages + ce.nstages;
+                if (same) {
+                    for (int k = 0; k < pe.nd; k++) fe.sa[k] = pe.sa[k];
+                    for (int k = 0; k < pe.nstages; k++) { fe.st[k] = pe.st[k]; fused.eb[k] = prod.eb[k]; }
+                } else {
+                    // flat producer: its primary operand and every full-size stage operand are addressed
+                    // with the strides the consumer used for the intermediate (fe.sa is already ce.sa)
+                    fused.a.offset += delta;
+                    for (int k = 0; k < pe.nstages; k++) {
+                        fe.st[k] = pe.st[k];
+                        fused.eb[k] = prod.eb[k];
+                        const bool full = pe.st[k].bin != BIN_NONE && pe.st[k].sb[0] == 1;
+                        if (full) fused.eb[k].offset += delta;
+                        for (int q = 0; q < ELT_MAX_DIMS; q++) fe.st[k].sb[q] = (q < ce.nd && full) ? ce.sa[q] : 0;
+                    }
+                }
+                for (int k = 0; k < ce.nstages; k++) { fe.st[pe.nstages + k] = ce.st[k]; fused.eb[pe.nstages + k] = cons.eb[k]; }
+                fused.bytes = prod.bytes + cons.bytes - 8.0 * (double)pe.per_sample;  // the intermediate never touches memory
+                plan_.ops[j] = fused;
+                plan_.ops.erase(plan_.ops.begin() + u[0]);
+                changed = true;
+            }
+        }
+        recompute_liveness();
     }
 
     // --------------------------------------------------------- memory plan

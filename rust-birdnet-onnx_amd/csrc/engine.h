@@ -34,6 +34,7 @@ struct PlanOp {
     OpKind kind;
     std::string name;
     Ref out, a, b, w, bias, res, scale, w2, bias2;
+    Ref eb[ELT_MAX_STAGES];  // ELT: second operand of each chain stage
     EltDesc elt{};
     ReduceDesc red{};
     GemmDesc gemm{};

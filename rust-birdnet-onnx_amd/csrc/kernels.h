@@ -43,18 +43,26 @@ enum RedOp : int32_t { RED_SUM = 0, RED_MEAN, RED_MAX, RED_MIN, RED_PROD, RED_L2
 
 constexpr int ELT_MAX_DIMS = 5;  // per-sample loop dims (batch is separate)
 
-// out[b, i...] = act(bin(a[b, i...], b[b, i...])) over a per-sample index space
-// of nd dims, outermost first.  Strides are in elements; 0 broadcasts.
+// Elementwise chain over a per-sample index space of nd dims (outermost first):
+//   v = a[b, i...];  for each stage s: v = act_s(bin_s(v, operand_s[b, i...]));  out[b, i...] = v
+// Strides are in elements; 0 broadcasts.  Chains are built at plan time by fusing consecutive
+// elementwise launches (normalisation, power-law compression, BatchNorm, layout copies).
+constexpr int ELT_MAX_STAGES = 4;
+struct EltStage {
+    int32_t bin;  // BinOp (BIN_NONE => no second operand)
+    int32_t act;  // applied after bin
+    float p0, p1;
+    int64_t sb[ELT_MAX_DIMS];
+    int64_t bb;   // batch stride of the operand (0 for constants)
+};
 struct EltDesc {
     int32_t nd;
     int64_t size[ELT_MAX_DIMS];
-    int64_t so[ELT_MAX_DIMS], sa[ELT_MAX_DIMS], sb[ELT_MAX_DIMS];
-    int64_t bo, ba, bb;  // batch strides (bb == 0 for constants)
-    int32_t bin;         // BinOp (BIN_NONE => unary)
-    int32_t act;         // applied after bin
-    float p0, p1;
+    int64_t so[ELT_MAX_DIMS], sa[ELT_MAX_DIMS];
+    int64_t bo, ba;      // batch strides
     int64_t per_sample;  // product of size[]
-    int32_t flat;        // 1: all operands contiguous with identical indexing -> vectorised path
+    int32_t nstages;
+    EltStage st[ELT_MAX_STAGES];
 };
 
 // Generic reduction: kept dims (<=4, per sample) x reduced dims (<=3).
@@ -126,8 +134,8 @@ void launch_gap_partial(hipStream_t s, const GapDesc &d, float *partial, const f
 void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, const float *partial,
                   const float *w1, const float *b1, const float *w2, const float *b2, int64_t batch);
 
-void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a, const float *b,
-                    int64_t batch);
+void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a,
+                    const float *const (&b)[ELT_MAX_STAGES], int64_t batch);
 void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *in, int64_t batch);
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W,
                  const float *bias, const float *res, const float *scale, int64_t batch);

@@ -67,58 +67,86 @@ __device__ __forceinline__ float bin_apply(int bin, float a, float b) {
     }
 }
 
-// ------------------------------------------------------------------ elementwise
-// grid: (ceil(per_sample / (256*UNROLL)), batch)
-__global__ __launch_bounds__(256) void elt_strided_kernel(EltDesc d, float *__restrict__ out,
-                                                          const float *__restrict__ a,
-                                                          const float *__restrict__ b) {
+// ------------------------------------------------------------------ elementwise chains
+struct EltPtrs {
+    const float *b[ELT_MAX_STAGES];
+};
+
+// generic strided form.  grid: (ceil(per_sample / 256) capped, batch)
+__global__ __launch_bounds__(256) void elt_strided_kernel(EltDesc d, float *__restrict__ out, const float *__restrict__ a, EltPtrs bp) {
     const int64_t bidx = blockIdx.y;
     const uint32_t per = (uint32_t)d.per_sample;
     float *o = out + bidx * d.bo;
     const float *pa = a + bidx * d.ba;
-    const float *pb = b ? b + bidx * d.bb : nullptr;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < per; i += gridDim.x * 256u) {
         uint32_t rem = i;
-        int64_t oo = 0, oa = 0, ob = 0;
+        uint32_t idx[ELT_MAX_DIMS];
 #pragma unroll
         for (int k = ELT_MAX_DIMS - 1; k >= 0; k--) {
+            idx[k] = 0;
             if (k < d.nd) {
                 const uint32_t sz = (uint32_t)d.size[k];
-                const uint32_t idx = rem % sz;
+                idx[k] = rem % sz;
                 rem /= sz;
-                oo += (int64_t)idx * d.so[k];
-                oa += (int64_t)idx * d.sa[k];
-                ob += (int64_t)idx * d.sb[k];
             }
         }
+        int64_t oo = 0, oa = 0;
+#pragma unroll
+        for (int k = 0; k < ELT_MAX_DIMS; k++)
+            if (k < d.nd) {
+                oo += (int64_t)idx[k] * d.so[k];
+                oa += (int64_t)idx[k] * d.sa[k];
+            }
         float v = pa[oa];
-        if (d.bin != BIN_NONE) v = bin_apply(d.bin, v, pb[ob]);
-        o[oo] = act_apply(d.act, v, d.p0, d.p1);
+#pragma unroll
+        for (int s = 0; s < ELT_MAX_STAGES; s++) {
+            if (s < d.nstages) {
+                const EltStage &st = d.st[s];
+                if (st.bin != BIN_NONE) {
+                    int64_t ob = bidx * st.bb;
+#pragma unroll
+                    for (int k = 0; k < ELT_MAX_DIMS; k++)
+                        if (k < d.nd) ob += (int64_t)idx[k] * st.sb[k];
+                    v = bin_apply(st.bin, v, bp.b[s][ob]);
+                }
+                v = act_apply(st.act, v, st.p0, st.p1);
+            }
+        }
+        o[oo] = v;
     }
 }
 
-// contiguous operands, 4 elements per lane
-__global__ __launch_bounds__(256) void elt_flat4_kernel(EltDesc d, float *__restrict__ out,
-                                                        const float *__restrict__ a,
-                                                        const float *__restrict__ b) {
+// out and a contiguous; every stage operand either contiguous like them or one scalar per sample.
+__global__ __launch_bounds__(256) void elt_flat4_kernel(EltDesc d, float *__restrict__ out, const float *__restrict__ a, EltPtrs bp) {
     const int64_t bidx = blockIdx.y;
     const uint32_t per4 = (uint32_t)(d.per_sample >> 2);
     float4 *o = reinterpret_cast<float4 *>(out + bidx * d.bo);
     const float4 *pa = reinterpret_cast<const float4 *>(a + bidx * d.ba);
-    const float4 *pb = b ? reinterpret_cast<const float4 *>(b + bidx * d.bb) : nullptr;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < per4; i += gridDim.x * 256u) {
         float4 v = pa[i];
-        if (d.bin != BIN_NONE) {
-            const float4 w = pb[i];
-            v.x = bin_apply(d.bin, v.x, w.x);
-            v.y = bin_apply(d.bin, v.y, w.y);
-            v.z = bin_apply(d.bin, v.z, w.z);
-            v.w = bin_apply(d.bin, v.w, w.w);
+#pragma unroll
+        for (int s = 0; s < ELT_MAX_STAGES; s++) {
+            if (s < d.nstages) {
+                const EltStage &st = d.st[s];
+                if (st.bin != BIN_NONE) {
+                    float4 w;
+                    if (st.sb[0] == 0) {
+                        const float x = bp.b[s][bidx * st.bb];
+                        w = make_float4(x, x, x, x);
+                    } else {
+                        w = reinterpret_cast<const float4 *>(bp.b[s] + bidx * st.bb)[i];
+                    }
+                    v.x = bin_apply(st.bin, v.x, w.x);
+                    v.y = bin_apply(st.bin, v.y, w.y);
+                    v.z = bin_apply(st.bin, v.z, w.z);
+                    v.w = bin_apply(st.bin, v.w, w.w);
+                }
+                v.x = act_apply(st.act, v.x, st.p0, st.p1);
+                v.y = act_apply(st.act, v.y, st.p0, st.p1);
+                v.z = act_apply(st.act, v.z, st.p0, st.p1);
+                v.w = act_apply(st.act, v.w, st.p0, st.p1);
+            }
         }
-        v.x = act_apply(d.act, v.x, d.p0, d.p1);
-        v.y = act_apply(d.act, v.y, d.p0, d.p1);
-        v.z = act_apply(d.act, v.z, d.p0, d.p1);
-        v.w = act_apply(d.act, v.w, d.p0, d.p1);
         o[i] = v;
     }
 }
@@ -546,17 +574,19 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__r
     int64_t aoff[A_IT], soff[A_IT];
     a_offsets<AVEC, A_RPP, A_IT>(d, total_rows, row0, a_row, aoff, soff);
     const int ksteps = (d.K + GEMM_BK - 1) / GEMM_BK;
+    float ra[A_IT * AVEC];
+    float rw[W_IT * WVEC];
+    if (wave < ksteps) {
+        load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, wave * GEMM_BK + a_col, ra);
+        load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, wave * GEMM_BK + w_col, rw);
+    }
     for (int ks = wave; ks < ksteps; ks += 4) {
         const int k0 = ks * GEMM_BK;
-        {
-            float ra[A_IT * AVEC];
-            load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, k0 + a_col, ra);
-            store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra);
-        }
-        {
-            float rw[W_IT * WVEC];
-            load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, k0 + w_col, rw);
-            store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw);
+        store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra);
+        store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw);
+        if (ks + 4 < ksteps) {  // next slice of this wave in flight while the MFMAs run
+            load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, k0 + 4 * GEMM_BK + a_col, ra);
+            load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, k0 + 4 * GEMM_BK + w_col, rw);
         }
         // the staging region is private to this wave; LDS ops of one wave complete in order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -800,16 +830,23 @@ inline unsigned cap_blocks(int64_t want, int64_t cap) { return (unsigned)std::ma
 
 }  // namespace
 
-void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a, const float *b, int64_t batch) {
+void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a, const float *const (&b)[ELT_MAX_STAGES], int64_t batch) {
     if (batch <= 0 || d.per_sample <= 0) return;
-    const bool vec4 = d.flat && (d.per_sample % 4 == 0) && (d.bo % 4 == 0) && (d.ba % 4 == 0) && (b == nullptr || d.bb % 4 == 0) &&
-                      aligned16(out) && aligned16(a) && (b == nullptr || aligned16(b));
+    EltPtrs bp;
+    for (int k = 0; k < ELT_MAX_STAGES; k++) bp.b[k] = b[k];
+    bool vec4 = d.nd == 1 && d.so[0] == 1 && d.sa[0] == 1 && d.per_sample % 4 == 0 && d.bo % 4 == 0 && d.ba % 4 == 0 && aligned16(out) && aligned16(a);
+    for (int k = 0; k < d.nstages && vec4; k++) {
+        const EltStage &st = d.st[k];
+        if (st.bin == BIN_NONE) continue;
+        if (st.sb[0] == 1) vec4 = st.bb % 4 == 0 && aligned16(b[k]);
+        else if (st.sb[0] != 0) vec4 = false;
+    }
     if (vec4) {
         dim3 grid(cap_blocks((d.per_sample / 4 + 255) / 256, 4096), (unsigned)batch);
-        hipLaunchKernelGGL(elt_flat4_kernel, grid, dim3(256), 0, s, d, out, a, b);
+        hipLaunchKernelGGL(elt_flat4_kernel, grid, dim3(256), 0, s, d, out, a, bp);
     } else {
         dim3 grid(cap_blocks((d.per_sample + 255) / 256, 4096), (unsigned)batch);
-        hipLaunchKernelGGL(elt_strided_kernel, grid, dim3(256), 0, s, d, out, a, b);
+        hipLaunchKernelGGL(elt_strided_kernel, grid, dim3(256), 0, s, d, out, a, bp);
     }
 }
 
