@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="segments per GPU per step (BASELINE configs[1]: 32)")
-    ap.add_argument("--streams", type=int, default=1, help="contexts (HIP streams) in flight per GPU")
+    ap.add_argument("--streams", type=int, default=3, help="contexts (HIP streams) in flight per GPU")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="segments the CPU oracle is timed on")

@@ -121,7 +121,7 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
         case OpKind::CONV:
             launch_conv(c->stream, op.conv, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in), batch);
             break;
-        case OpKind::DWCONV: launch_dwconv(c->stream, op.dw, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), batch); break;
+        case OpKind::DWCONV: launch_dwconv(c->stream, op.dw, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.b, d_in), batch); break;
         case OpKind::GAP: launch_gap_partial(c->stream, op.gap, out, a, batch); break;
         case OpKind::SEFC:
             launch_se_fc(c->stream, op.se, out, resolve(c, op.b, d_in), a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
@@ -737,7 +737,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 snprintf(line, sizeof(line), " rows=%lld K=%d N=%d lda=%lld act=%d bias=%d res=%d gate=%d", (long long)op.gemm.rows, op.gemm.K, op.gemm.N, (long long)op.gemm.lda, op.gemm.act, op.gemm.has_bias, op.gemm.has_res, op.gemm.has_scale);
                 extra = line;
             } else if (op.kind == OpKind::DWCONV) {
-                snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%d act=%d", op.dw.H, op.dw.W, op.dw.C, op.dw.OH, op.dw.OW, op.dw.kh, op.dw.kw, op.dw.sh, op.dw.act);
+                snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%d act=%d tiled=%d squeeze=%d nblk=%d", op.dw.H, op.dw.W, op.dw.C, op.dw.OH, op.dw.OW, op.dw.kh, op.dw.kw, op.dw.sh, op.dw.act, op.dw.tiled, op.dw.has_gap, op.dw.nblk);
                 extra = line;
             } else if (op.kind == OpKind::CONV) {
                 snprintf(line, sizeof(line), " %dx%dx%d->%dx%dx%d k=%dx%d s=%d g=%d act=%d", op.conv.H, op.conv.W, op.conv.Cin, op.conv.OH, op.conv.OW, op.conv.Cout, op.conv.kh, op.conv.kw, op.conv.sh, op.conv.groups, op.conv.act);

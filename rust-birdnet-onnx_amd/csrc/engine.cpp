@@ -1145,8 +1145,21 @@ class Builder {
         // ---- emit
         const int64_t HW = H * W;
         int32_t splits = (int32_t)std::min<int64_t>(64, std::max<int64_t>(1, (HW + 31) / 32));
+        // produced by the tiled depthwise kernel just before? then it emits the channel sums itself
+        PlanOp *dwp = nullptr;
+        if (!plan_.ops.empty()) {
+            PlanOp &last = plan_.ops.back();
+            if (last.kind == OpKind::DWCONV && last.dw.tiled && last.out.space == Space::ARENA && last.out.id == x.storage && last.out.offset == 0)
+                dwp = &last;
+        }
+        if (dwp) splits = dwp->dw.nblk;
         Val partial = new_act(Dims{(int64_t)splits, C}, Dims{C, 1});
-        {
+        if (dwp) {
+            dwp->dw.has_gap = 1;
+            dwp->dw.gap_bs = plan_.storages[partial.storage].elems;
+            dwp->b = ref_of(partial);
+            touch(dwp->b, (int)plan_.ops.size() - 1);
+        } else {
             PlanOp op;
             op.kind = OpKind::GAP;
             op.name = "se.squeeze:" + n.name;
@@ -1426,6 +1439,14 @@ class Builder {
             d.pt = (int32_t)pt; d.pl = (int32_t)pl; d.dh = (int32_t)dil[0]; d.dw = (int32_t)dil[1];
             d.act = act.act; d.p0 = act.p0; d.p1 = act.p1; d.has_bias = has_bias;
             d.in_bs = batch_stride(x); d.out_bs = plan_.storages[out.storage].elems;
+            if (Cin % 4 == 0 && Cin / 4 <= 1024 && (kw == 3 || kw == 5) && (strides[1] == 1 || strides[1] == 2) && unit_dil && x.offset % 4 == 0 &&
+                d.in_bs % 4 == 0 && d.out_bs % 4 == 0) {
+                d.tiled = 1;
+                d.tw = 4;
+                d.rpb = (int32_t)std::max<int64_t>(1, 256 / (Cin / 4));
+                const int64_t tiles = OH * ((OW + d.tw - 1) / d.tw);
+                d.nblk = (int32_t)((tiles + d.rpb - 1) / d.rpb);
+            }
             std::vector<float> wp(wf.size());  // [C][1][kh][kw] -> [kh][kw][C]
             for (int64_t c = 0; c < Cin; c++)
                 for (int64_t k = 0; k < kh * kw; k++) wp[k * Cin + c] = wf[c * kh * kw + k];

@@ -109,6 +109,12 @@ struct DwDesc {
     float p0, p1;
     int32_t has_bias;
     int64_t in_bs, out_bs;
+    // tiled kernel (kernel 3/5, stride 1/2, no dilation, C % 4 == 0): each lane produces `tw`
+    // adjacent output pixels of 4 channels; a block is (C/4) x rpb lanes = rpb pixel tiles.
+    int32_t tiled, tw, rpb, nblk;
+    // squeeze of a following squeeze-excite: per-block channel sums -> gap[b][nblk][C]
+    int32_t has_gap;
+    int64_t gap_bs;
 };
 
 // Squeeze-excite, stage 1: per-(sample, split) channel sums of an NHWC tensor [HW][C]
@@ -142,7 +148,7 @@ void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, con
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w,
                  const float *bias, const float *res, int64_t batch);
 void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w,
-                   const float *bias, int64_t batch);
+                   const float *bias, float *gap, int64_t batch);
 
 // top-K + sigmoid + filter + stable sort, bit-exact with the reference's
 // BinaryHeap semantics (topk.hip).  idx/conf/count are device buffers with row

@@ -652,13 +652,32 @@ __global__ void gap_partial_kernel(GapDesc d, float *__restrict__ partial, const
 // ~10 B/clk.  W1 is [Cr][C].
 __global__ __launch_bounds__(512) void se_fc1_kernel(SeFcDesc d, float *__restrict__ hidden, const float *__restrict__ partial,
                                                      const float *__restrict__ w1, const float *__restrict__ b1) {
-    extern __shared__ __align__(16) float ssm[];  // s[C]
+    extern __shared__ __align__(16) float ssm[];  // s[C] followed by the [P][C] partial-sum scratch
     const int64_t b = blockIdx.y;
     const float *pp = partial + b * d.in_bs;
-    for (int c = threadIdx.x; c < d.C; c += 512) {
-        float acc = 0.f;
-        for (int sp = 0; sp < d.splits; sp++) acc += pp[(int64_t)sp * d.C + c];
-        ssm[c] = acc * d.inv_hw;
+    // finish the squeeze: sum the per-block partials.  P = 512 / C thread groups share the splits
+    // (group p takes splits p, p+P, ...); the P results are then added in a fixed order.
+    const int P = d.C >= 512 ? 1 : 512 / d.C;
+    float *red = ssm + d.C;
+    if (P == 1) {
+        for (int c = threadIdx.x; c < d.C; c += 512) {
+            float acc = 0.f;
+            for (int sp = 0; sp < d.splits; sp++) acc += pp[(int64_t)sp * d.C + c];
+            ssm[c] = acc * d.inv_hw;
+        }
+    } else {
+        const int p = threadIdx.x / d.C, c = threadIdx.x - p * d.C;
+        if (p < P) {
+            float acc = 0.f;
+            for (int sp = p; sp < d.splits; sp += P) acc += pp[(int64_t)sp * d.C + c];
+            red[p * d.C + c] = acc;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < d.C) {
+            float acc = red[threadIdx.x];
+            for (int q = 1; q < P; q++) acc += red[q * d.C + threadIdx.x];
+            ssm[threadIdx.x] = acc * d.inv_hw;
+        }
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -733,6 +752,86 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwDesc d, float *__restrict
                                                           act_apply(d.act, acc[2], d.p0, d.p1), act_apply(d.act, acc[3], d.p0, d.p1));
         } else {
             po[0] = act_apply(d.act, acc[0], d.p0, d.p1);
+        }
+    }
+}
+
+// Tiled depthwise conv: lane (r, cv) of a block computes TW adjacent output pixels (one row) for
+// channels 4cv..4cv+3, loading each needed input column once per kernel row (NC = (TW-1)*S + KW
+// float4 loads feed TW*KW float4 FMAs).  Optionally emits the per-block channel sums of the
+// activated output (the squeeze of a squeeze-excite) with a fixed-order LDS reduction.
+// block = CV * RPB lanes, grid (nblk, batch)
+template <int KW, int S, int TW>
+__global__ void dwconv_tiled_kernel(DwDesc d, float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w,
+                                    const float *__restrict__ bias, float *__restrict__ gap) {
+    extern __shared__ __align__(16) float4 dsm[];
+    constexpr int NC = (TW - 1) * S + KW;
+    const int CV = d.C >> 2;
+    const int cv = threadIdx.x % CV, r = threadIdx.x / CV;
+    const int64_t b = blockIdx.y;
+    const int OWT = (d.OW + TW - 1) / TW;
+    const int tile = blockIdx.x * d.rpb + r;
+    const bool live = tile < d.OH * OWT;
+    const int oh = live ? tile / OWT : 0;
+    const int ow0 = live ? (tile - oh * OWT) * TW : 0;
+    const int c = cv * 4;
+    float4 acc[TW];
+    const float4 bz = d.has_bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < TW; p++) acc[p] = bz;
+    if (live) {
+        const float *ip = in + b * d.in_bs + c;
+        const int iw0 = ow0 * S - d.pl;
+        for (int ky = 0; ky < d.kh; ky++) {
+            const int ih = oh * d.sh - d.pt + ky;
+            if (ih < 0 || ih >= d.H) continue;
+            float4 wv[KW];
+#pragma unroll
+            for (int kx = 0; kx < KW; kx++) wv[kx] = *reinterpret_cast<const float4 *>(w + (ky * KW + kx) * d.C + c);
+            float4 xv[NC];
+            const float *rowp = ip + (int64_t)ih * d.W * d.C;
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                const int iw = iw0 + j;
+                xv[j] = (iw >= 0 && iw < d.W) ? *reinterpret_cast<const float4 *>(rowp + (int64_t)iw * d.C) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int p = 0; p < TW; p++)
+#pragma unroll
+                for (int kx = 0; kx < KW; kx++) {
+                    const float4 x = xv[p * S + kx];
+                    acc[p].x = fmaf(x.x, wv[kx].x, acc[p].x);
+                    acc[p].y = fmaf(x.y, wv[kx].y, acc[p].y);
+                    acc[p].z = fmaf(x.z, wv[kx].z, acc[p].z);
+                    acc[p].w = fmaf(x.w, wv[kx].w, acc[p].w);
+                }
+        }
+    }
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        float *op = out + b * d.out_bs + ((int64_t)oh * d.OW + ow0) * d.C + c;
+#pragma unroll
+        for (int p = 0; p < TW; p++) {
+            if (ow0 + p < d.OW) {
+                float4 v = acc[p];
+                v.x = act_apply(d.act, v.x, d.p0, d.p1);
+                v.y = act_apply(d.act, v.y, d.p0, d.p1);
+                v.z = act_apply(d.act, v.z, d.p0, d.p1);
+                v.w = act_apply(d.act, v.w, d.p0, d.p1);
+                *reinterpret_cast<float4 *>(op + (int64_t)p * d.C) = v;
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+        }
+    }
+    if (d.has_gap) {
+        dsm[r * CV + cv] = sum;
+        __syncthreads();
+        if (r == 0) {
+            for (int y = 1; y < d.rpb; y++) {
+                const float4 v = dsm[y * CV + cv];
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
+            reinterpret_cast<float4 *>(gap + b * d.gap_bs + (int64_t)blockIdx.x * d.C)[cv] = sum;
         }
     }
 }
@@ -937,7 +1036,7 @@ void launch_gap_partial(hipStream_t s, const GapDesc &d, float *partial, const f
 void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, const float *partial, const float *w1,
                   const float *b1, const float *w2, const float *b2, int64_t batch) {
     if (batch <= 0) return;
-    hipLaunchKernelGGL(se_fc1_kernel, dim3((unsigned)((d.Cr + 7) / 8), (unsigned)batch), dim3(512), (size_t)d.C * sizeof(float), s, d, hidden,
+    hipLaunchKernelGGL(se_fc1_kernel, dim3((unsigned)((d.Cr + 7) / 8), (unsigned)batch), dim3(512), (size_t)(d.C + 512) * sizeof(float), s, d, hidden,
                        partial, w1, b1);
     hipLaunchKernelGGL(se_fc2_kernel, dim3((unsigned)((d.C + 255) / 256), (unsigned)batch), dim3(256), (size_t)d.Cr * sizeof(float), s, d, gate,
                        hidden, w2, b2);
@@ -959,9 +1058,21 @@ void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, 
     hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, d, out, in, w, bias, res);
 }
 
-void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w, const float *bias,
+void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w, const float *bias, float *gap,
                    int64_t batch) {
     if (batch <= 0) return;
+    if (d.tiled) {
+        const int CV = d.C / 4;
+        dim3 grid((unsigned)d.nblk, (unsigned)batch), block((unsigned)(CV * d.rpb));
+        const size_t lds = d.has_gap ? (size_t)CV * d.rpb * sizeof(float4) : 0;
+#define DW_LAUNCH(KW, S) hipLaunchKernelGGL((dwconv_tiled_kernel<KW, S, 4>), grid, block, lds, s, d, out, in, w, bias, gap)
+        if (d.kw == 3 && d.sw == 1) DW_LAUNCH(3, 1);
+        else if (d.kw == 3 && d.sw == 2) DW_LAUNCH(3, 2);
+        else if (d.kw == 5 && d.sw == 1) DW_LAUNCH(5, 1);
+        else DW_LAUNCH(5, 2);
+#undef DW_LAUNCH
+        return;
+    }
     const bool v4 = d.C % 4 == 0 && d.in_bs % 4 == 0 && d.out_bs % 4 == 0 && aligned16(in) && aligned16(out) && aligned16(w);
     if (v4) {
         const int64_t total = (int64_t)d.OH * d.OW * (d.C / 4);
