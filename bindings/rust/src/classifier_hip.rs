@@ -1,0 +1,74 @@
+//! `predict_batch_with_context` of the reference (src/classifier.rs:826-867) on top of the C ABI.
+//! Source only -- see ../README.md.
+use crate::ffi::*;
+use crate::{BatchInferenceContext, Error, InferenceOptions, Prediction, PredictionResult, Result};
+use std::sync::atomic::Ordering;
+
+impl crate::Classifier {
+    pub fn predict_batch_with_context(
+        &self,
+        context: &mut BatchInferenceContext,
+        segments: &[&[f32]],
+        options: &InferenceOptions,
+    ) -> Result<Vec<PredictionResult>> {
+        if segments.is_empty() {
+            return Ok(Vec::new());
+        }
+        let n = segments.len();
+        // batch_context.rs:191-206: batch limit first, then per-segment sizes
+        if n > context.max_batch_size() {
+            return Err(Error::Inference(format!("batch size {} exceeds context max {}", n, context.max_batch_size())));
+        }
+        for (i, s) in segments.iter().enumerate() {
+            if s.len() != context.sample_count() {
+                return Err(Error::BatchInputSize { index: i, expected: context.sample_count(), got: s.len() });
+            }
+        }
+        let cfg = &self.inner.config;
+        let (nsp, emb_dim) = (cfg.num_species, cfg.embedding_dim.unwrap_or(0));
+        let ptrs: Vec<*const f32> = segments.iter().map(|s| s.as_ptr()).collect();
+        let mut logits = vec![0f32; n * nsp];
+        let mut emb = vec![0f32; n * emb_dim];
+        let cancel = options.cancellation_token.as_ref().map_or(std::ptr::null(), |t| t.cancelled.as_ptr() as *const i32);
+        let timeout_ns = options.timeout.map_or(0, |d| d.as_nanos().max(1) as u64);
+        let st = unsafe {
+            bn_infer(context.ctx, ptrs.as_ptr(), n, logits.as_mut_ptr(),
+                     if emb_dim > 0 { emb.as_mut_ptr() } else { std::ptr::null_mut() }, cancel, timeout_ns)
+        };
+        match st {
+            BN_OK => {}
+            BN_ERR_TIMEOUT => return Err(Error::Timeout { duration: options.timeout.unwrap_or_default() }),
+            BN_ERR_CANCELLED => return Err(Error::Cancelled),
+            _ => return Err(Error::Inference(last_error())),
+        }
+        let k = self.inner.top_k.min(nsp);
+        let (mut idx, mut conf, mut cnt) = (vec![0u32; n * k.max(1)], vec![0f32; n * k.max(1)], vec![0u32; n]);
+        let (has_min, min) = self.inner.min_confidence.map_or((0, 0.0), |m| (1, m));
+        if unsafe { bn_topk(context.ctx, n, self.inner.top_k, has_min, min, k.max(1), idx.as_mut_ptr(), conf.as_mut_ptr(), cnt.as_mut_ptr()) } != BN_OK {
+            return Err(Error::Inference(last_error()));
+        }
+        Ok((0..n)
+            .map(|i| PredictionResult {
+                model_type: cfg.model_type,
+                predictions: (0..cnt[i] as usize)
+                    .map(|j| {
+                        let index = idx[i * k.max(1) + j] as usize;
+                        Prediction {
+                            species: self.inner.labels.get(index).cloned().unwrap_or_else(|| format!("unknown_{index}")),
+                            confidence: conf[i * k.max(1) + j],
+                            index,
+                        }
+                    })
+                    .collect(),
+                embeddings: cfg.embedding_dim.map(|d| emb[i * d..(i + 1) * d].to_vec()),
+                raw_scores: logits[i * nsp..(i + 1) * nsp].to_vec(),
+            })
+            .collect())
+    }
+}
+
+fn last_error() -> String {
+    let mut buf = vec![0u8; 1024];
+    unsafe { bn_last_error(buf.as_mut_ptr() as *mut _, buf.len()) };
+    String::from_utf8_lossy(&buf).trim_end_matches('\0').to_string()
+}

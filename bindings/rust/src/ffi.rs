@@ -1,0 +1,43 @@
+//! Raw bindings of include/birdnet_hip.h (BN_ABI_VERSION 1).  Source only -- see ../README.md.
+#![allow(non_camel_case_types)]
+use std::os::raw::c_char;
+
+#[repr(C)]
+pub struct bn_model { _p: [u8; 0] }
+#[repr(C)]
+pub struct bn_ctx { _p: [u8; 0] }
+
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct bn_model_config {
+    pub model_type: i32,
+    pub sample_rate: u32,
+    pub segment_duration: f32,
+    pub sample_count: u64,
+    pub num_species: u64,
+    pub has_embedding: i32,
+    pub embedding_dim: u64,
+    pub logits_output: i32,
+    pub embedding_output: i32,
+}
+
+pub const BN_OK: i32 = 0;
+pub const BN_ERR_TIMEOUT: i32 = 3;
+pub const BN_ERR_CANCELLED: i32 = 4;
+pub const BN_ERR_MODEL_DETECTION: i32 = 8;
+pub const BN_ERR_NO_DEVICE: i32 = 9;
+
+#[link(name = "birdnet_hip")]
+extern "C" {
+    pub fn bn_abi_version() -> i32;
+    pub fn bn_model_load(path: *const c_char, device: i32, model_type_override: i32, out: *mut *mut bn_model) -> i32;
+    pub fn bn_model_free(m: *mut bn_model);
+    pub fn bn_model_get_config(m: *const bn_model, out: *mut bn_model_config) -> i32;
+    pub fn bn_ctx_create(m: *mut bn_model, max_batch: usize, flags: u32, out: *mut *mut bn_ctx) -> i32;
+    pub fn bn_ctx_destroy(c: *mut bn_ctx);
+    pub fn bn_infer(c: *mut bn_ctx, segs: *const *const f32, batch: usize, logits_out: *mut f32, emb_out: *mut f32,
+                    cancel: *const i32, timeout_ns: u64) -> i32;
+    pub fn bn_topk(c: *mut bn_ctx, batch: usize, top_k: usize, has_min: i32, min_conf: f32, k_stride: usize,
+                   idx_out: *mut u32, conf_out: *mut f32, count_out: *mut u32) -> i32;
+    pub fn bn_last_error(buf: *mut c_char, cap: usize) -> usize;
+}

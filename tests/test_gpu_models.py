@@ -242,3 +242,35 @@ def test_size_independent_properties_at_bench_size(bn, v24_full):
     for r in range(32):
         want = oracle.top_k(b[r], 10, 0.01)
         assert idx[r, :cnt[r]].tolist() == [w[0] for w in want]
+
+
+def test_sharded_recording_equals_single_pass(bn, v24_small):
+    """BASELINE.json configs[4] at reduced length: a continuous recording cut by chunk_audio rules,
+    processed as R contiguous shards with a different batch size per shard, concatenated, must be
+    bit-identical to one pass over all windows (what the RCCL all-gather reassembles)."""
+    import torch
+    dmod = importlib.import_module("rust-birdnet-onnx_amd.distributed")
+    data, path = v24_small
+    m = bn.Model(path)
+    S, sr = 144000, 48000
+    rec = synth.synthetic_segments(1, S * 9 + 5000, sr)[0]           # 9.03 windows -> 10 windows, last padded
+    starts = dmod.chunk_starts(rec.shape[0], S, 0.0, sr)
+    so, _ = oracle.chunk_plan(rec.shape[0], S, 0.0, sr)
+    assert starts.tolist() == so.tolist() and len(starts) == 10
+    ctx_all = bn.Context(m, 16)
+    want, _ = ctx_all.infer(dmod.fill_windows(rec, starts, S))
+    for world, batches in ((2, (3, 5)), (4, (1, 2, 3, 2))):
+        parts = []
+        for r in range(world):
+            lo, hi = dmod.shard_range(len(starts), r, world)
+            ctx = bn.Context(m, batches[r])
+            rows = [ctx.infer(dmod.fill_windows(rec, starts[s:min(hi, s + batches[r])], S))[0] for s in range(lo, hi, batches[r])]
+            parts.append(torch.from_numpy(np.concatenate(rows)) if rows else torch.zeros((0, want.shape[1])))
+        got = torch.cat(parts).numpy()
+        assert got.tobytes() == want.tobytes()
+    # overlap > 0 re-uses samples between windows; still window-independent
+    starts = dmod.chunk_starts(rec.shape[0], S, 1.5, sr)
+    w = dmod.fill_windows(rec, starts, S)
+    a, _ = ctx_all.infer(w[:16])
+    b, _ = bn.Context(m, 4).infer(w[4:8])
+    assert a[4:8].tobytes() == b.tobytes()
