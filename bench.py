@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="segments the CPU oracle is timed on")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -55,15 +57,20 @@ def main():
     import torch
 
     dist = None
+    dev = local_rank if args.device is None else args.device
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=args.backend)
     else:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev)
+    local_rank = dev
 
     bn = importlib.import_module("rust-birdnet-onnx_amd")
     synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
@@ -101,14 +108,41 @@ def main():
         ptr, n = c.output_device(cfg.logits_output)
         logit_views.append(torch.as_tensor(_DevView(ptr, (B, n)), device="cuda") if world > 1 else None)
 
-    def step(i):
-        c = ctxs[i % len(ctxs)]
-        if len(ctxs) > 1:
-            c.synchronize()  # results of this context's previous step are consumed before reuse
-        c.step_device(bufs[i % NBUF].data_ptr(), B, args.top_k, 0.1, sync=(len(ctxs) == 1 and world == 1))
+    S_ = len(ctxs)
+    LAG = S_ - 1 if world > 1 else S_  # N > 1: consume one step early so the collective overlaps compute
+    gather_done = [None] * S_  # per context: event after the collective that read its logits
+
+    def finish(j):
+        """Results of step j are complete on the host side; with N > 1 all-gather its logits."""
+        c = ctxs[j % S_]
+        c.synchronize()
         if world > 1:
-            c.synchronize()
-            dist.all_gather_into_tensor(gathered, logit_views[i % len(ctxs)])
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(gathered, logit_views[j % S_])
+                ev = torch.cuda.Event()
+                ev.record()
+                gather_done[j % S_] = ev
+            else:  # rehearsal backends gather on the host
+                parts = [torch.empty((B, N), dtype=torch.float32) for _ in range(world)]
+                dist.all_gather(parts, logit_views[j % S_].cpu())
+
+    def step(i):
+        # contexts are used round-robin; a context's previous results are consumed one step before
+        # it is reused so that the collective overlaps the next step's kernels
+        if S_ > 1 and i >= LAG:
+            finish(i - LAG)
+        c = ctxs[i % S_]
+        if gather_done[i % S_] is not None:
+            gather_done[i % S_].synchronize()  # the collective no longer reads this context's logits
+            gather_done[i % S_] = None
+        c.step_device(bufs[i % NBUF].data_ptr(), B, args.top_k, 0.1, sync=False)
+        if S_ == 1:
+            finish(i)
+
+    def drain(total):
+        if S_ > 1:
+            for j in range(max(0, total - LAG), total):
+                finish(j)
 
     def fence():
         for c in ctxs:
@@ -119,19 +153,21 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain(args.warmup)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(i)
+    drain(args.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     # sanity of the last step's results (not timed): top-1 of the device top-K == argmax of the logits
-    lg, ix, cf, ct = ctxs[(args.warmup + args.steps - 1) % len(ctxs)].step_results(B)
+    lg, ix, cf, ct = ctxs[(args.steps - 1) % len(ctxs)].step_results(B)
     assert np.isfinite(lg).all()
     for r in range(B):
         if ct[r]:
