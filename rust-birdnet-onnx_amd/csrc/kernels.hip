@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -248,11 +249,22 @@ __global__ __launch_bounds__(1024) void reduce_row_kernel(ReduceDesc d, float *_
     if (vec4) {
         const float4 *p4 = reinterpret_cast<const float4 *>(p);
         const uint32_t n4 = (uint32_t)(d.red >> 2);
-        for (uint32_t r = threadIdx.x; r < n4; r += nt) {
+        // four loads in flight per lane (independent accumulators); exact for min/max, fixed order for sums
+        float a1 = red_init(d.op), a2 = a1, a3 = a1;
+        uint32_t r = threadIdx.x;
+        for (; r + 3 * nt < n4; r += 4 * nt) {
+            const float4 v0 = p4[r], v1 = p4[r + nt], v2 = p4[r + 2 * nt], v3 = p4[r + 3 * nt];
+            acc = red_step(d.op, red_step(d.op, red_step(d.op, red_step(d.op, acc, v0.x), v0.y), v0.z), v0.w);
+            a1 = red_step(d.op, red_step(d.op, red_step(d.op, red_step(d.op, a1, v1.x), v1.y), v1.z), v1.w);
+            a2 = red_step(d.op, red_step(d.op, red_step(d.op, red_step(d.op, a2, v2.x), v2.y), v2.z), v2.w);
+            a3 = red_step(d.op, red_step(d.op, red_step(d.op, red_step(d.op, a3, v3.x), v3.y), v3.z), v3.w);
+        }
+        for (; r < n4; r += nt) {
             const float4 v = p4[r];
             acc = red_step(d.op, red_step(d.op, red_step(d.op, red_step(d.op, acc, v.x), v.y), v.z), v.w);
         }
-        for (uint32_t r = (n4 << 2) + threadIdx.x; r < (uint32_t)d.red; r += nt) acc = red_step(d.op, acc, p[r]);
+        acc = red_merge(d.op, red_merge(d.op, acc, a1), red_merge(d.op, a2, a3));
+        for (uint32_t t = (n4 << 2) + threadIdx.x; t < (uint32_t)d.red; t += nt) acc = red_step(d.op, acc, p[t]);
     } else if (d.nr == 1) {
         const int64_t st = d.rin[0];
         for (uint32_t r = threadIdx.x; r < (uint32_t)d.red; r += nt) acc = red_step(d.op, acc, p[(int64_t)r * st]);
@@ -277,6 +289,9 @@ __global__ __launch_bounds__(1024) void reduce_row_kernel(ReduceDesc d, float *_
 // over two k-slots (lane>>5); slot h of MFMA j carries k = 8g + 4h + j, the same
 // assignment for A and B, so every k of the 8-wide group is used exactly once.
 constexpr int GEMM_BM = 128, GEMM_BK = 32, GEMM_LD = 36;
+#ifndef GEMM_PF
+#define GEMM_PF 1
+#endif
 
 // Row addressing is resolved once per thread before the K loop: aoff[i] is the element offset of
 // the i-th row this thread stages (or -1 past the end), soff[i] the offset of its sample's gate.
@@ -287,74 +302,87 @@ __device__ __forceinline__ void row_split(const GemmDesc &d, int64_t r, int64_t 
     m = r - (int64_t)bb * d.rows;
 }
 
+// Every staging load is UNCONDITIONAL and UNMASKED: out-of-range rows / columns read a clamped
+// (valid) address and whatever lands there is simply never used -- rows past the end and weight
+// rows past N only feed output elements the epilogue does not store, and columns past K are
+// excluded by the K-tail step (mfma_ktile_partial multiplies only the 8-wide groups that hold
+// data; a ragged K % 8 is zeroed explicitly in that one step).  Guarding or masking a load makes
+// hipcc wait for it on the spot, which serialises the memory latency of the whole tile.
 template <int AVEC, int ROWS_PER_PASS, int ITERS>
 __device__ __forceinline__ void a_offsets(const GemmDesc &d, int64_t total_rows, int64_t row0, int row_first,
                                           int64_t (&aoff)[ITERS], int64_t (&soff)[ITERS]) {
 #pragma unroll
     for (int i = 0; i < ITERS; i++) {
-        const int64_t r = row0 + row_first + i * ROWS_PER_PASS;
-        if (r < total_rows) {
-            int64_t b, m;
-            row_split(d, r, b, m);
-            aoff[i] = b * d.a_bs + m * d.lda;
-            soff[i] = b * d.s_bs;
+        int64_t r = row0 + row_first + i * ROWS_PER_PASS;
+        r = r < total_rows ? r : total_rows - 1;
+        int64_t b, m;
+        row_split(d, r, b, m);
+        aoff[i] = b * d.a_bs + m * d.lda;
+        soff[i] = b * d.s_bs;
+    }
+}
+
+// Squeeze-excite gate values for the same elements load_a_regs fetches.  They are multiplied in when
+// the tile is written to LDS: multiplying right after the load would put an s_waitcnt behind every
+// single load.
+template <int AVEC, int ITERS>
+__device__ __forceinline__ void load_gate_regs(const GemmDesc &d, const float *__restrict__ scale, const int64_t (&soff)[ITERS], int k,
+                                               float (&regs)[ITERS * AVEC]) {
+    const int kc = k < d.K ? k : 0;
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
+        const float *sp = scale + soff[i] + kc;
+        if constexpr (AVEC == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(sp);
+            regs[i * 4] = t.x; regs[i * 4 + 1] = t.y; regs[i * 4 + 2] = t.z; regs[i * 4 + 3] = t.w;
         } else {
-            aoff[i] = -1;
-            soff[i] = 0;
+#pragma unroll
+            for (int j = 0; j < AVEC; j++) regs[i * AVEC + j] = sp[j];
         }
     }
 }
 
 template <int AVEC, int ITERS>
-__device__ __forceinline__ void load_a_regs(const GemmDesc &d, const float *__restrict__ A, const float *__restrict__ scale,
-                                            const int64_t (&aoff)[ITERS], const int64_t (&soff)[ITERS], int k, float (&regs)[ITERS * AVEC]) {
+__device__ __forceinline__ void load_a_regs(const GemmDesc &d, const float *__restrict__ A, const int64_t (&aoff)[ITERS], int k,
+                                            float (&regs)[ITERS * AVEC]) {
+    const int kc = k < d.K ? k : 0;  // K % AVEC == 0 for AVEC > 1, so a vector never straddles K
 #pragma unroll
     for (int i = 0; i < ITERS; i++) {
-        float v[AVEC];
-#pragma unroll
-        for (int j = 0; j < AVEC; j++) v[j] = 0.0f;
-        if (aoff[i] >= 0 && k < d.K) {
-            const float *p = A + aoff[i] + k;
-            if constexpr (AVEC == 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(p);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else if constexpr (AVEC == 2) {
-                const float2 t = *reinterpret_cast<const float2 *>(p);
-                v[0] = t.x; v[1] = t.y;
-            } else {
-                v[0] = *p;
-            }
-            if (d.has_scale) {  // squeeze-excite gate folded into the operand load
-                const float *sp = scale + soff[i] + k;
-#pragma unroll
-                for (int j = 0; j < AVEC; j++) v[j] *= sp[j];
-            }
+        const float *p = A + aoff[i] + kc;
+        if constexpr (AVEC == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(p);
+            regs[i * 4] = t.x; regs[i * 4 + 1] = t.y; regs[i * 4 + 2] = t.z; regs[i * 4 + 3] = t.w;
+        } else if constexpr (AVEC == 2) {
+            const float2 t = *reinterpret_cast<const float2 *>(p);
+            regs[i * 2] = t.x; regs[i * 2 + 1] = t.y;
+        } else {
+            regs[i] = *p;
         }
-#pragma unroll
-        for (int j = 0; j < AVEC; j++) regs[i * AVEC + j] = v[j];
     }
 }
 
 template <int WVEC, int ROWS_PER_PASS, int ITERS>
 __device__ __forceinline__ void load_w_regs(const GemmDesc &d, const float *__restrict__ W, int n_first, int k, float (&regs)[ITERS * WVEC]) {
+    const int kc = k < d.K ? k : 0;
 #pragma unroll
     for (int i = 0; i < ITERS; i++) {
         const int n = n_first + i * ROWS_PER_PASS;
-        float v[WVEC];
-#pragma unroll
-        for (int j = 0; j < WVEC; j++) v[j] = 0.0f;
-        if (n < d.N && k < d.K) {
-            const float *p = W + (int64_t)n * d.K + k;
-            if constexpr (WVEC == 4) {
-                const float4 t = *reinterpret_cast<const float4 *>(p);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else {
-                v[0] = *p;
-            }
+        const float *p = W + (int64_t)(n < d.N ? n : d.N - 1) * d.K + kc;
+        if constexpr (WVEC == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(p);
+            regs[i * 4] = t.x; regs[i * 4 + 1] = t.y; regs[i * 4 + 2] = t.z; regs[i * 4 + 3] = t.w;
+        } else {
+            regs[i] = *p;
         }
-#pragma unroll
-        for (int j = 0; j < WVEC; j++) regs[i * WVEC + j] = v[j];
     }
+}
+
+// zero the staged elements whose column index is >= K (ragged K tail only)
+template <int VEC, int N>
+__device__ __forceinline__ void zero_past_k(int k_col, int K, float (&regs)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        if (k_col + (i % VEC) >= K) regs[i] = 0.0f;
 }
 
 template <int VEC, int ROWS_PER_PASS, int ITERS>
@@ -475,7 +503,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc &d, float *__restri
     }
 }
 
-template <int BN, int AVEC, int WVEC>
+template <int BN, int AVEC, int WVEC, bool GATED>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__restrict__ C,
                                                         const float *__restrict__ A,
                                                         const float *__restrict__ W,
@@ -504,31 +532,64 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
 
     int64_t aoff[A_IT], soff[A_IT];
     a_offsets<AVEC, A_RPP, A_IT>(d, total_rows, row0, a_row, aoff, soff);
-    float ra[A_IT * AVEC];
-    float rw[W_IT * WVEC];
-    load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, a_col, ra);
-    load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, w_col, rw);
-    const bool wave_active = row0 + wave * 32 < total_rows;
-
-    const float *ap = As + (wave * 32 + lr) * GEMM_LD + 4 * lh, *wp = Ws + lr * GEMM_LD + 4 * lh;
-    int k0 = 0;
-    for (; k0 + GEMM_BK <= d.K; k0 += GEMM_BK) {  // full K steps
-        __syncthreads();  // previous tile fully consumed
-        store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra);
-        store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw);
-        __syncthreads();
-        if (k0 + GEMM_BK < d.K) {  // prefetch the next tile into registers while computing
-            load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, k0 + GEMM_BK + a_col, ra);
-            load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, k0 + GEMM_BK + w_col, rw);
+    // PF K tiles are kept in flight in registers: a load round trip costs ~2 us on this part while
+    // the MFMAs of one K step take 0.2-0.9 us, so a one-deep prefetch leaves the waves waiting
+    constexpr int PF = GEMM_PF;
+    float ra[PF][A_IT * AVEC];
+    float rg[PF][GATED ? A_IT * AVEC : 1];
+    float rw[PF][W_IT * WVEC];
+    const int ksteps = (d.K + GEMM_BK - 1) / GEMM_BK;
+#pragma unroll
+    for (int p = 0; p < PF; p++)
+        if (p < ksteps) {
+            load_a_regs<AVEC, A_IT>(d, A, aoff, p * GEMM_BK + a_col, ra[p]);
+            if constexpr (GATED) load_gate_regs<AVEC, A_IT>(d, scale, soff, p * GEMM_BK + a_col, rg[p]);
+            load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, p * GEMM_BK + w_col, rw[p]);
         }
-        if (wave_active) mfma_ktile_full<NT>(ap, wp, acc);
+    const bool wave_active = row0 + wave * 32 < total_rows;
+    const float *ap = As + (wave * 32 + lr) * GEMM_LD + 4 * lh, *wp = Ws + lr * GEMM_LD + 4 * lh;
+    const int kfull = d.K / GEMM_BK;  // K steps with all 32 columns present
+    for (int ks0 = 0; ks0 < kfull; ks0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            const int ks = ks0 + p;
+            if (ks < kfull) {  // block-uniform
+                __syncthreads();  // previous tile fully consumed
+                if constexpr (GATED) {
+#pragma unroll
+                    for (int i = 0; i < A_IT * AVEC; i++) ra[p][i] *= rg[p][i];
+                }
+                store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra[p]);
+                store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw[p]);
+                __syncthreads();
+                if (ks + PF < ksteps) {  // refill this slot with the tile PF steps ahead
+                    load_a_regs<AVEC, A_IT>(d, A, aoff, (ks + PF) * GEMM_BK + a_col, ra[p]);
+                    if constexpr (GATED) load_gate_regs<AVEC, A_IT>(d, scale, soff, (ks + PF) * GEMM_BK + a_col, rg[p]);
+                    load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, (ks + PF) * GEMM_BK + w_col, rw[p]);
+                }
+                mfma_ktile_full<NT>(ap, wp, acc);  // waves past the last row multiply clamped rows; their results are never stored
+            }
+        }
     }
-    if (k0 < d.K) {  // K tail: zero-filled past K, only the groups holding data are multiplied
+    if (kfull < ksteps) {  // K tail: zero-filled past K, only the 8-wide groups holding data are multiplied
+        const int slot = kfull % PF;
         __syncthreads();
-        store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra);
-        store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw);
+#pragma unroll
+        for (int p = 0; p < PF; p++)
+            if (p == slot) {
+                if constexpr (GATED) {
+#pragma unroll
+                    for (int i = 0; i < A_IT * AVEC; i++) ra[p][i] *= rg[p][i];
+                }
+                if (d.K % 8) {  // ragged K: the last multiplied group reaches past K
+                    zero_past_k<AVEC>(kfull * GEMM_BK + a_col, d.K, ra[p]);
+                    zero_past_k<WVEC>(kfull * GEMM_BK + w_col, d.K, rw[p]);
+                }
+                store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra[p]);
+                store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw[p]);
+            }
         __syncthreads();
-        if (wave_active) mfma_ktile_partial<NT>(ap, wp, acc, (d.K - k0 + 7) / 8);
+        mfma_ktile_partial<NT>(ap, wp, acc, (d.K - kfull * GEMM_BK + 7) / 8);
     }
     if (!wave_active) return;
     gemm_epilogue<NT>(d, C, bias, res, acc, row0 + wave * 32, total_rows, n0, lr, lh, 0, 16);
@@ -540,7 +601,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
 // interleaved), each wave staging its own operand slices through a private LDS region with no
 // block barrier in the main loop; the four partial accumulators are then summed through LDS in a
 // fixed order (deterministic) and the epilogue is shared between the waves.
-template <int BN, int AVEC, int WVEC>
+template <int BN, int AVEC, int WVEC, bool GATED>
 __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__restrict__ C,
                                                           const float *__restrict__ A,
                                                           const float *__restrict__ W,
@@ -574,31 +635,45 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__r
     int64_t aoff[A_IT], soff[A_IT];
     a_offsets<AVEC, A_RPP, A_IT>(d, total_rows, row0, a_row, aoff, soff);
     const int ksteps = (d.K + GEMM_BK - 1) / GEMM_BK;
-    float ra[A_IT * AVEC];
-    float rw[W_IT * WVEC];
-    if (wave < ksteps) {
-        load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, wave * GEMM_BK + a_col, ra);
-        load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, wave * GEMM_BK + w_col, rw);
-    }
-    for (int ks = wave; ks < ksteps; ks += 4) {
-        const int k0 = ks * GEMM_BK;
-        store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra);
-        store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw);
-        if (ks + 4 < ksteps) {  // next slice of this wave in flight while the MFMAs run
-            load_a_regs<AVEC, A_IT>(d, A, scale, aoff, soff, k0 + 4 * GEMM_BK + a_col, ra);
-            load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, k0 + 4 * GEMM_BK + w_col, rw);
+    constexpr int PF = GEMM_PF;
+    float ra[PF][A_IT * AVEC];
+    float rg[PF][GATED ? A_IT * AVEC : 1];
+    float rw[PF][W_IT * WVEC];
+#pragma unroll
+    for (int p = 0; p < PF; p++)
+        if (wave + 4 * p < ksteps) {
+            load_a_regs<AVEC, A_IT>(d, A, aoff, (wave + 4 * p) * GEMM_BK + a_col, ra[p]);
+            if constexpr (GATED) load_gate_regs<AVEC, A_IT>(d, scale, soff, (wave + 4 * p) * GEMM_BK + a_col, rg[p]);
+            load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, (wave + 4 * p) * GEMM_BK + w_col, rw[p]);
         }
-        // the staging region is private to this wave; LDS ops of one wave complete in order
+    auto sync_wave = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {
-            const int kleft = d.K - k0;
-            if (kleft >= GEMM_BK) mfma_ktile_full<NT>(As + lr * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, acc);
-            else mfma_ktile_partial<NT>(As + lr * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, acc, (kleft + 7) / 8);
+    };
+    // (no K tail: only shapes with K % 32 == 0 are routed here, see gemm_use_splitk)
+    for (int ks0 = wave; ks0 < ksteps; ks0 += 4 * PF) {
+#pragma unroll
+        for (int p = 0; p < PF; p++) {
+            const int ks = ks0 + 4 * p;
+            if (ks < ksteps) {  // wave-uniform
+                const int k0 = ks * GEMM_BK;
+                if constexpr (GATED) {
+#pragma unroll
+                    for (int i = 0; i < A_IT * AVEC; i++) ra[p][i] *= rg[p][i];
+                }
+                store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra[p]);
+                store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw[p]);
+                if (ks + 4 * PF < ksteps) {  // refill this slot with the slice PF rounds ahead
+                    load_a_regs<AVEC, A_IT>(d, A, aoff, k0 + 4 * PF * GEMM_BK + a_col, ra[p]);
+                    if constexpr (GATED) load_gate_regs<AVEC, A_IT>(d, scale, soff, k0 + 4 * PF * GEMM_BK + a_col, rg[p]);
+                    load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, k0 + 4 * PF * GEMM_BK + w_col, rw[p]);
+                }
+                sync_wave();  // the staging region is private to this wave; LDS ops of one wave complete in order
+                mfma_ktile_full<NT>(As + lr * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, acc);
+                sync_wave();  // reads done before the next slice overwrites the region
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // reads done before the next iteration overwrites the slices
     }
     // cross-wave reduction in a fixed order: red[wave][t*16+reg][lane]
     __syncthreads();
@@ -647,20 +722,24 @@ __global__ void gap_partial_kernel(GapDesc d, float *__restrict__ partial, const
     }
 }
 
-// stage 2a (squeeze finish + reduce FC): grid (ceil(Cr/8), batch), 512 threads = 8 waves, one
-// hidden unit per wave.  Spread over many CUs because a single CU streams weights at only
-// ~10 B/clk.  W1 is [Cr][C].
-__global__ __launch_bounds__(512) void se_fc1_kernel(SeFcDesc d, float *__restrict__ hidden, const float *__restrict__ partial,
-                                                     const float *__restrict__ w1, const float *__restrict__ b1) {
-    extern __shared__ __align__(16) float ssm[];  // s[C] followed by the [P][C] partial-sum scratch
+// stage 2 (squeeze finish + reduce FC + excite FC + gate activation) in ONE launch:
+// grid (ceil(C/256), batch), 1024 threads.  Every block of a sample redoes the cheap first half
+// (the C-vector sum and the Cr hidden units, 16 waves in parallel) and then produces its own
+// 256-channel slice of the gate; the work is spread over several CUs per sample because one CU
+// streams weights at only ~10 B/clk.  W1 is [Cr][C]; W2T is [Cr][C] (transposed at plan time).
+__global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restrict__ gate, const float *__restrict__ partial,
+                                                     const float *__restrict__ w1, const float *__restrict__ b1,
+                                                     const float *__restrict__ w2t, const float *__restrict__ b2) {
+    extern __shared__ __align__(16) float ssm[];  // s[C] | h[Cr] | red[P*C <= 1024]
+    float *hid = ssm + d.C;
+    float *red = hid + d.Cr;
     const int64_t b = blockIdx.y;
     const float *pp = partial + b * d.in_bs;
-    // finish the squeeze: sum the per-block partials.  P = 512 / C thread groups share the splits
-    // (group p takes splits p, p+P, ...); the P results are then added in a fixed order.
-    const int P = d.C >= 512 ? 1 : 512 / d.C;
-    float *red = ssm + d.C;
+    // squeeze finish: P = 1024 / C thread groups share the splits (group p takes p, p+P, ...),
+    // the P results are added in a fixed order (deterministic)
+    const int P = d.C >= 1024 ? 1 : 1024 / d.C;
     if (P == 1) {
-        for (int c = threadIdx.x; c < d.C; c += 512) {
+        for (int c = threadIdx.x; c < d.C; c += 1024) {
             float acc = 0.f;
             for (int sp = 0; sp < d.splits; sp++) acc += pp[(int64_t)sp * d.C + c];
             ssm[c] = acc * d.inv_hw;
@@ -668,9 +747,14 @@ __global__ __launch_bounds__(512) void se_fc1_kernel(SeFcDesc d, float *__restri
     } else {
         const int p = threadIdx.x / d.C, c = threadIdx.x - p * d.C;
         if (p < P) {
-            float acc = 0.f;
-            for (int sp = p; sp < d.splits; sp += P) acc += pp[(int64_t)sp * d.C + c];
-            red[p * d.C + c] = acc;
+            float a0 = 0.f, a1 = 0.f;
+            int sp = p;
+            for (; sp + P < d.splits; sp += 2 * P) {
+                a0 += pp[(int64_t)sp * d.C + c];
+                a1 += pp[(int64_t)(sp + P) * d.C + c];
+            }
+            if (sp < d.splits) a0 += pp[(int64_t)sp * d.C + c];
+            red[p * d.C + c] = a0 + a1;
         }
         __syncthreads();
         if ((int)threadIdx.x < d.C) {
@@ -681,28 +765,26 @@ __global__ __launch_bounds__(512) void se_fc1_kernel(SeFcDesc d, float *__restri
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 8 + wave;
-    if (j >= d.Cr) return;
-    const float *wr = w1 + (int64_t)j * d.C;
-    float acc = 0.f;
-    for (int c = lane; c < d.C; c += 64) acc = fmaf(ssm[c], wr[c], acc);
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if (lane == 0) hidden[b * d.Cr + j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
-}
-
-// stage 2b (excite FC + gate activation): grid (ceil(C/256), batch), 256 threads, one channel per
-// thread.  W2T is [Cr][C] (transposed at plan time) so the reads are coalesced.
-__global__ __launch_bounds__(256) void se_fc2_kernel(SeFcDesc d, float *__restrict__ gate, const float *__restrict__ hidden,
-                                                     const float *__restrict__ w2t, const float *__restrict__ b2) {
-    extern __shared__ __align__(16) float hsm[];  // h[Cr]
-    const int64_t b = blockIdx.y;
-    for (int j = threadIdx.x; j < d.Cr; j += 256) hsm[j] = hidden[b * d.Cr + j];
+    for (int j = wave; j < d.Cr; j += 16) {
+        const float *wr = w1 + (int64_t)j * d.C;
+        float acc = 0.f;
+        for (int c = lane; c < d.C; c += 64) acc = fmaf(ssm[c], wr[c], acc);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) hid[j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
+    }
     __syncthreads();
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d.C) return;
-    float acc = b2 ? b2[c] : 0.f;
-    for (int j = 0; j < d.Cr; j++) acc = fmaf(hsm[j], w2t[(int64_t)j * d.C + c], acc);
-    gate[b * d.out_bs + c] = act_apply(d.act2, acc, d.p0_2, d.p1_2);
+    // excite: 256 channels per block, 4 thread groups split the Cr terms (fixed-order combine)
+    const int cl = threadIdx.x & 255, q = threadIdx.x >> 8;
+    const int c = blockIdx.x * 256 + cl;
+    float acc = 0.f;
+    if (c < d.C)
+        for (int j = q; j < d.Cr; j += 4) acc = fmaf(hid[j], w2t[(int64_t)j * d.C + c], acc);
+    red[q * 256 + cl] = acc;
+    __syncthreads();
+    if (q == 0 && c < d.C) {
+        const float v = ((red[cl] + red[256 + cl]) + red[512 + cl]) + red[768 + cl] + (b2 ? b2[c] : 0.f);
+        gate[b * d.out_bs + c] = act_apply(d.act2, v, d.p0_2, d.p1_2);
+    }
 }
 
 // ------------------------------------------------------------------ depthwise conv
@@ -971,10 +1053,15 @@ static void launch_gemm_bn(hipStream_t s, const GemmDesc &d, float *C, const flo
     const bool s4 = !d.has_scale || (d.s_bs % 4 == 0 && aligned16(scale));
     if (d.K % 4 == 0 && d.lda % 4 == 0 && d.a_bs % 4 == 0 && aligned16(A) && s4) avec = 4;
     else if (d.K % 2 == 0 && d.lda % 2 == 0 && d.a_bs % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 7u) == 0) avec = 2;
-#define BN_LAUNCH(AV, WV)                                                                                                      \
+#define BN_LAUNCH2(AV, WV, G)                                                                                                  \
     do {                                                                                                                       \
-        if constexpr (SPLITK) hipLaunchKernelGGL((gemm_splitk_kernel<BN, AV, WV>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows); \
-        else hipLaunchKernelGGL((gemm_mfma_kernel<BN, AV, WV>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows); \
+        if constexpr (SPLITK) hipLaunchKernelGGL((gemm_splitk_kernel<BN, AV, WV, G>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows); \
+        else hipLaunchKernelGGL((gemm_mfma_kernel<BN, AV, WV, G>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows); \
+    } while (0)
+#define BN_LAUNCH(AV, WV)                   \
+    do {                                    \
+        if (d.has_scale) BN_LAUNCH2(AV, WV, true); \
+        else BN_LAUNCH2(AV, WV, false);     \
     } while (0)
     if (w4) {
         if (avec == 4) BN_LAUNCH(4, 4);
@@ -986,6 +1073,7 @@ static void launch_gemm_bn(hipStream_t s, const GemmDesc &d, float *C, const flo
         else BN_LAUNCH(1, 1);
     }
 #undef BN_LAUNCH
+#undef BN_LAUNCH2
 }
 
 static void launch_gemm_tiled(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
@@ -1004,7 +1092,11 @@ static void launch_gemm_tiled(hipStream_t s, const GemmDesc &d, float *C, const 
 // Which of the two GEMM kernels runs is decided from per-sample quantities only, so that the
 // summation order of every output element -- and with it the result bits -- does not depend on
 // how many segments share a batch (a shard's last, shorter batch matches the single-GPU run).
-static bool gemm_use_splitk(const GemmDesc &d) { return d.K >= 256 && d.rows <= 256; }
+static bool gemm_use_splitk(const GemmDesc &d) {
+    static const int min_k = getenv("BN_SPLITK_MINK") ? atoi(getenv("BN_SPLITK_MINK")) : 256;
+    static const int max_rows = getenv("BN_SPLITK_MAXROWS") ? atoi(getenv("BN_SPLITK_MAXROWS")) : 256;
+    return d.K >= min_k && d.rows <= max_rows && d.K % GEMM_BK == 0;  // the split-K kernel has no K-tail step
+}
 
 static void launch_gemm_splitk(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
                                const float *res, const float *scale, int64_t total_rows) {
@@ -1035,11 +1127,10 @@ void launch_gap_partial(hipStream_t s, const GapDesc &d, float *partial, const f
 
 void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, const float *partial, const float *w1,
                   const float *b1, const float *w2, const float *b2, int64_t batch) {
+    (void)hidden;
     if (batch <= 0) return;
-    hipLaunchKernelGGL(se_fc1_kernel, dim3((unsigned)((d.Cr + 7) / 8), (unsigned)batch), dim3(512), (size_t)(d.C + 512) * sizeof(float), s, d, hidden,
-                       partial, w1, b1);
-    hipLaunchKernelGGL(se_fc2_kernel, dim3((unsigned)((d.C + 255) / 256), (unsigned)batch), dim3(256), (size_t)d.Cr * sizeof(float), s, d, gate,
-                       hidden, w2, b2);
+    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)((d.C + 255) / 256), (unsigned)batch), dim3(1024),
+                       (size_t)(d.C + d.Cr + 1024) * sizeof(float), s, d, gate, partial, w1, b1, w2, b2);
 }
 
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w, const float *bias,

@@ -293,9 +293,24 @@ __global__ __launch_bounds__(64) void topk_fast_kernel(const float *__restrict__
     const uint32_t *x = reinterpret_cast<const uint32_t *>(logits + row * n);
 
     uint32_t mk = 0;
-    for (int64_t i = lane; i < n; i += 64) {
-        const uint32_t kk = total_key(x[i]);
-        mk = kk > mk ? kk : mk;
+    {
+        // four loads in flight per lane (the row is read twice, both passes are latency-bound)
+        int64_t i = lane;
+        uint32_t m1 = 0, m2 = 0, m3 = 0;
+        for (; i + 192 < n; i += 256) {
+            const uint32_t k0 = total_key(x[i]), k1 = total_key(x[i + 64]), k2 = total_key(x[i + 128]), k3 = total_key(x[i + 192]);
+            mk = k0 > mk ? k0 : mk;
+            m1 = k1 > m1 ? k1 : m1;
+            m2 = k2 > m2 ? k2 : m2;
+            m3 = k3 > m3 ? k3 : m3;
+        }
+        for (; i < n; i += 64) {
+            const uint32_t kk = total_key(x[i]);
+            mk = kk > mk ? kk : mk;
+        }
+        m1 = m1 > m2 ? m1 : m2;
+        mk = mk > m3 ? mk : m3;
+        mk = mk > m1 ? mk : m1;
     }
     // rank of this lane's maximum among the 64 (ties by lane id): the lane of rank k holds T0
     uint32_t rank = 0;
@@ -307,17 +322,26 @@ __global__ __launch_bounds__(64) void topk_fast_kernel(const float *__restrict__
     const uint32_t T0 = __shfl(mk, __ffsll((long long)who) - 1);
 
     uint32_t cnt = 0;
-    for (int64_t base = 0; base < n; base += 64) {
-        const int64_t i = base + lane;
-        const uint32_t kk = i < n ? total_key(x[i]) : 0u;
-        const bool pred = i < n && kk >= T0;
-        const uint64_t m = __ballot(pred);
-        const uint32_t pos = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (pred && pos < FAST_CAP) {
-            ckey[pos] = kk;
-            cidx[pos] = (uint32_t)i;
+    for (int64_t base = 0; base < n; base += 256) {
+        // element order (base+lane, base+64+lane, ...) is preserved: candidates stay in index order
+        uint32_t kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = base + 64 * u + lane;
+            kk[u] = i < n ? total_key(x[i]) : 0u;
         }
-        cnt += (uint32_t)__popcll(m);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = base + 64 * u + lane;
+            const bool pred = i < n && kk[u] >= T0;
+            const uint64_t m = __ballot(pred);
+            const uint32_t pos = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (pred && pos < FAST_CAP) {
+                ckey[pos] = kk[u];
+                cidx[pos] = (uint32_t)i;
+            }
+            cnt += (uint32_t)__popcll(m);
+        }
     }
     if (cnt > FAST_CAP) {  // heavy ties around the threshold: exact kernel
         if (lane == 0) flags[row] = 1;
