@@ -1082,10 +1082,18 @@ static void launch_gemm_tiled(hipStream_t s, const GemmDesc &d, float *C, const 
     // widest N tile that still fills the 256 CUs a couple of times over
     // N tile: the least padded of {128, 96, 64, 32} that still fills the 256 CUs a couple of times over
     auto waste = [&](int bn) { return (int64_t)((d.N + bn - 1) / bn) * bn - d.N; };
-    if (d.N > 64 && mblocks * ((d.N + 95) / 96) >= 512 && waste(96) < waste(128) && waste(96) <= waste(64))
-        launch_gemm_bn<96, false>(s, d, C, A, W, bias, res, scale, total_rows);
-    else if (d.N > 64 && mblocks * ((d.N + 127) / 128) >= 512 && waste(128) <= waste(64)) launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
-    else if (d.N > 32 && mblocks * ((d.N + 63) / 64) >= 256) launch_gemm_bn<64, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    static const int force_bn = getenv("BN_FORCE_BN") ? atoi(getenv("BN_FORCE_BN")) : 0;  // experiments only
+    if (force_bn == 128) return launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    if (force_bn == 96) return launch_gemm_bn<96, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    if (force_bn == 64) return launch_gemm_bn<64, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    if (force_bn == 32) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    // Measured on MI355X (tools/gemm_bench): 32-wide N tiles win or tie almost everywhere -- more,
+    // smaller blocks hide the load latency better than wider tiles save operand re-reads.  Wider
+    // tiles only pay once the grid is several thousand blocks deep (high-resolution expand convs).
+    const int64_t blocks32 = mblocks * ((d.N + 31) / 32);
+    if (blocks32 > 6000 && d.N > 64 && waste(96) < waste(128) && waste(96) <= waste(64)) launch_gemm_bn<96, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    else if (blocks32 > 6000 && d.N > 64 && waste(128) <= waste(64)) launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    else if (blocks32 > 6000 && d.N > 32) launch_gemm_bn<64, false>(s, d, C, A, W, bias, res, scale, total_rows);
     else launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
 }
 
@@ -1095,7 +1103,10 @@ static void launch_gemm_tiled(hipStream_t s, const GemmDesc &d, float *C, const 
 static bool gemm_use_splitk(const GemmDesc &d) {
     static const int min_k = getenv("BN_SPLITK_MINK") ? atoi(getenv("BN_SPLITK_MINK")) : 256;
     static const int max_rows = getenv("BN_SPLITK_MAXROWS") ? atoi(getenv("BN_SPLITK_MAXROWS")) : 256;
-    return d.K >= min_k && d.rows <= max_rows && d.K % GEMM_BK == 0;  // the split-K kernel has no K-tail step
+    // deep K, few output tiles per sample (measured: pays below ~8 tiles of 128x32 per sample);
+    // the split-K kernel has no K-tail step
+    const double tiles = (double)d.rows / GEMM_BM * ((d.N + 31) / 32);
+    return d.K >= min_k && d.rows <= max_rows && d.K % GEMM_BK == 0 && tiles < 8.0;
 }
 
 static void launch_gemm_splitk(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
