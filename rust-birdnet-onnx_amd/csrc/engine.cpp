@@ -1443,8 +1443,10 @@ class Builder {
                 d.in_bs % 4 == 0 && d.out_bs % 4 == 0) {
                 d.tiled = 1;
                 d.tw = 4;
-                d.rpb = (int32_t)std::max<int64_t>(1, 256 / (Cin / 4));
+                // pixel tiles per block: up to 1024 lanes, but keep >= 8 blocks per sample; fewer, larger
+                // blocks also mean fewer squeeze partials for the SE excite kernel to add up
                 const int64_t tiles = OH * ((OW + d.tw - 1) / d.tw);
+                d.rpb = (int32_t)std::max<int64_t>(1, std::min<int64_t>(1024 / (Cin / 4), (tiles + 7) / 8));
                 d.nblk = (int32_t)((tiles + d.rpb - 1) / d.rpb);
             }
             std::vector<float> wp(wf.size());  // [C][1][kh][kw] -> [kh][kw][C]

@@ -740,9 +740,17 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
     const int P = d.C >= 1024 ? 1 : 1024 / d.C;
     if (P == 1) {
         for (int c = threadIdx.x; c < d.C; c += 1024) {
-            float acc = 0.f;
-            for (int sp = 0; sp < d.splits; sp++) acc += pp[(int64_t)sp * d.C + c];
-            ssm[c] = acc * d.inv_hw;
+            // four partials in flight (independent accumulators, combined in a fixed order)
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int sp = 0;
+            for (; sp + 3 < d.splits; sp += 4) {
+                a0 += pp[(int64_t)sp * d.C + c];
+                a1 += pp[(int64_t)(sp + 1) * d.C + c];
+                a2 += pp[(int64_t)(sp + 2) * d.C + c];
+                a3 += pp[(int64_t)(sp + 3) * d.C + c];
+            }
+            for (; sp < d.splits; sp++) a0 += pp[(int64_t)sp * d.C + c];
+            ssm[c] = ((a0 + a1) + (a2 + a3)) * d.inv_hw;
         }
     } else {
         const int p = threadIdx.x / d.C, c = threadIdx.x - p * d.C;
