@@ -169,6 +169,7 @@ class Builder {
         plan_memory();
         for (auto &op : plan_.ops) {
             (op.mfma ? plan_.macs_mfma : plan_.macs_valu) += op.macs;
+            plan_.macs_mfma += op.macs_mfma_extra;
             plan_.act_bytes += op.bytes;
             plan_.weight_bytes += op.weight_bytes;
         }
@@ -1152,9 +1153,20 @@ class Builder {
             if (last.kind == OpKind::DWCONV && last.dw.tiled && last.out.space == Space::ARENA && last.out.id == x.storage && last.out.offset == 0)
                 dwp = &last;
         }
+        PlanOp *mbp = nullptr;
+        if (!dwp && !plan_.ops.empty()) {
+            PlanOp &last = plan_.ops.back();
+            if (last.kind == OpKind::MBCONV && last.out.space == Space::ARENA && last.out.id == x.storage && last.out.offset == 0) mbp = &last;
+        }
         if (dwp) splits = dwp->dw.nblk;
+        if (mbp) splits = mbp->mb.tiles_x * mbp->mb.tiles_y;
         Val partial = new_act(Dims{(int64_t)splits, C}, Dims{C, 1});
-        if (dwp) {
+        if (mbp) {
+            mbp->mb.has_gap = 1;
+            mbp->mb.gap_bs = plan_.storages[partial.storage].elems;
+            mbp->b = ref_of(partial);
+            touch(mbp->b, (int)plan_.ops.size() - 1);
+        } else if (dwp) {
             dwp->dw.has_gap = 1;
             dwp->dw.gap_bs = plan_.storages[partial.storage].elems;
             dwp->b = ref_of(partial);
@@ -1454,6 +1466,49 @@ class Builder {
                 for (int64_t k = 0; k < kh * kw; k++) wp[k * Cin + c] = wf[c * kh * kw + k];
             op.w = Ref{Space::CONSTS, add_const(wp), 0};
             op.a = ref_of(x);
+            // expand 1x1 conv immediately before, consumed only here?  Then both can run in one launch
+            // with the expanded tensor kept in LDS (mbconv_expand_dw_kernel).  Measured on MI355X at
+            // batch 32 the fused kernel is still ~2x slower than the two separate launches (one
+            // (tile, 32-channel chunk) per block is latency-bound at 2 blocks/CU), so it is opt-in
+            // (BN_MBFUSE=1) until it keeps the X tile resident across channel chunks.
+            if (d.tiled && kh == kw && strides[0] == strides[1] && getenv("BN_MBFUSE") && !plan_.ops.empty()) {
+                PlanOp &pe = plan_.ops.back();
+                const bool producer = pe.kind == OpKind::GEMM && pe.out.space == Space::ARENA && pe.out.id == x.storage && pe.out.offset == 0 &&
+                                      x.offset == 0 && !pe.gemm.has_scale && !pe.gemm.has_res && pe.gemm.rows == H * W && pe.gemm.N == Cin &&
+                                      pe.gemm.lda == pe.gemm.K && pe.gemm.K % 4 == 0 && pe.a.offset % 4 == 0 &&
+                                      (pe.a.space != Space::ARENA || plan_.storages[pe.a.id].elems % 4 == 0);
+                // halo recompute factor of the expand conv: staged halo pixels / image pixels
+                const int toh0 = strides[1] == 1 ? 8 : 4, tow0 = strides[1] == 1 ? 16 : 8;
+                const int64_t hp = ((toh0 - 1) * strides[1] + kw) * ((tow0 - 1) * strides[1] + kw);
+                const double halo_factor = (double)((hp + 31) / 32 * 32) * ((OW + tow0 - 1) / tow0) * ((OH + toh0 - 1) / toh0) / (double)(H * W);
+                if (producer && halo_factor <= 2.0 && sole_consumer(n.inputs[0]) == cur_) {
+                    PlanOp mb;
+                    mb.kind = OpKind::MBCONV;
+                    mb.name = "mbconv:" + pe.name.substr(pe.name.find(':') + 1) + "+" + n.name;
+                    mb.out = op.out;
+                    mb.a = pe.a;
+                    mb.w = pe.w; mb.bias = pe.bias;
+                    mb.w2 = op.w; mb.bias2 = op.bias;
+                    MbDesc &m = mb.mb;
+                    m.H = (int32_t)H; m.W = (int32_t)W; m.Cin = pe.gemm.K; m.C = (int32_t)Cin; m.OH = (int32_t)OH; m.OW = (int32_t)OW;
+                    m.k = (int32_t)kw; m.s = (int32_t)strides[1]; m.pt = (int32_t)pt; m.pl = (int32_t)pl;
+                    m.act1 = pe.gemm.act; m.p0_1 = pe.gemm.p0; m.p1_1 = pe.gemm.p1; m.has_bias1 = pe.gemm.has_bias;
+                    m.act2 = act.act; m.p0_2 = act.p0; m.p1_2 = act.p1; m.has_bias2 = has_bias;
+                    m.in_bs = pe.gemm.a_bs; m.out_bs = d.out_bs;
+                    const int toh = m.s == 1 ? 8 : 4, tow = m.s == 1 ? 16 : 8;
+                    m.tiles_x = (int32_t)((OW + tow - 1) / tow); m.tiles_y = (int32_t)((OH + toh - 1) / toh);
+                    const double halo = (double)((toh - 1) * m.s + m.k) * ((tow - 1) * m.s + m.k) * m.tiles_x * m.tiles_y;
+                    mb.macs = op.macs;                                   // depthwise part (VALU)
+                    mb.weight_bytes = op.weight_bytes + pe.weight_bytes;
+                    mb.bytes = 4.0 * ((double)H * W * pe.gemm.K + (double)OH * OW * Cin);
+                    mb.mfma = false;
+                    mb.macs_mfma_extra = halo * pe.gemm.K * Cin;          // expand part incl. halo recompute
+                    plan_.ops.pop_back();
+                    push_op(std::move(mb));
+                    define(cur, out);
+                    return;
+                }
+            }
         } else {
             x = to_channels_last(x, n.name);
             op.kind = OpKind::CONV;

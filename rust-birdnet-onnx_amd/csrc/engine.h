@@ -28,7 +28,7 @@ struct Ref {
     int64_t offset = 0;  // elements (per sample for INPUT/ARENA)
 };
 
-enum class OpKind : int32_t { ELT, REDUCE, GEMM, CONV, DWCONV, GAP, SEFC };
+enum class OpKind : int32_t { ELT, REDUCE, GEMM, CONV, DWCONV, GAP, SEFC, MBCONV };
 
 struct PlanOp {
     OpKind kind;
@@ -42,7 +42,9 @@ struct PlanOp {
     DwDesc dw{};
     GapDesc gap{};
     SeFcDesc se{};
+    MbDesc mb{};
     double macs = 0;        // per sample
+    double macs_mfma_extra = 0;  // MBCONV: the expand part runs on the matrix cores
     double bytes = 0;       // algorithmic bytes read+written per sample (weights excluded)
     double weight_bytes = 0;
     bool mfma = false;

@@ -117,6 +117,23 @@ struct DwDesc {
     int64_t gap_bs;
 };
 
+// Fused MBConv front half: expand 1x1 conv (+bias+act) -> depthwise KxK (+bias+act) [+ SE squeeze],
+// the expanded tensor lives only in LDS.  x is NHWC [H][W][Cin]; expand weights [C][Cin];
+// depthwise weights [k][k][C]; output NHWC [OH][OW][C].
+struct MbDesc {
+    int32_t H, W, Cin, C, OH, OW;
+    int32_t k, s, pt, pl;
+    int32_t act1, act2;
+    float p0_1, p1_1, p0_2, p1_2;
+    int32_t has_bias1, has_bias2;
+    int64_t in_bs, out_bs;
+    int32_t tiles_x, tiles_y;  // output tiles of (8x16 at stride 1, 4x8 at stride 2)
+    int32_t has_gap;
+    int64_t gap_bs;
+};
+void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1,
+                   const float *b1, const float *w2, const float *b2, float *gap, int64_t batch);
+
 // Squeeze-excite, stage 1: per-(sample, split) channel sums of an NHWC tensor [HW][C]
 // -> partial [splits][C].  Stage 2 (SeFcDesc) sums the splits in a fixed order (deterministic).
 struct GapDesc {

@@ -795,6 +795,145 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
     }
 }
 
+// ------------------------------------------------------------------ fused expand + depthwise
+// One block = one output tile (TOH x TOW pixels) x one chunk of 32 mid channels:
+//   1. the input halo tile ((TOH-1)*S+K) x ((TOW-1)*S+K) pixels x Cin is staged through LDS in
+//      32-wide K chunks and multiplied with the chunk's 32 expand filters on the matrix cores
+//      (rows = halo pixels, same fragment scheme as gemm_mfma_kernel)
+//   2. bias + activation, halo pixels outside the image forced to 0 (the depthwise conv pads the
+//      EXPANDED tensor), result written to LDS as [halo pixel][32 channels]
+//   3. depthwise K x K from LDS (lane = channel, conflict free), bias + activation, NHWC store,
+//      per-block channel sums for a following squeeze-excite (fixed-order LDS reduction)
+// grid (tiles, ceil(C/32), batch), 256 threads.
+template <int K, int S>
+__global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
+                                                               const float *__restrict__ w1, const float *__restrict__ b1,
+                                                               const float *__restrict__ w2, const float *__restrict__ b2,
+                                                               float *__restrict__ gap) {
+    constexpr int TOH = S == 1 ? 8 : 4, TOW = S == 1 ? 16 : 8;
+    constexpr int IHT = (TOH - 1) * S + K, IWT = (TOW - 1) * S + K, HP = IHT * IWT;
+    constexpr int MT = (HP + 31) / 32, MP = MT * 32;
+    constexpr int TPW = (MT + 3) / 4;  // m-tiles per wave
+    __shared__ __align__(16) float Xs[MP * GEMM_LD];
+    __shared__ __align__(16) float Ws[32 * GEMM_LD];
+    __shared__ __align__(16) float Es[MP * 32];
+    __shared__ float red[8][32];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
+    const int oh0 = ty * TOH, ow0 = tx * TOW;
+    const int ih0 = oh0 * S - d.pt, iw0 = ow0 * S - d.pl;
+    const int c0 = blockIdx.y * 32;
+    const int64_t b = blockIdx.z;
+    const float *xin = in + b * d.in_bs;
+
+    floatx16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+
+    for (int kc = 0; kc < d.Cin; kc += GEMM_BK) {
+        __syncthreads();  // previous chunk consumed
+        // X chunk: MP rows (halo pixels) x 32 floats; rows outside the image / past HP and columns
+        // past Cin are zero
+        {
+            // all loads of the chunk are issued before the first one is consumed
+            constexpr int NIT = MP * 8 / 256;
+            float4 xv[NIT];
+            bool okv[NIT];
+#pragma unroll
+            for (int i = 0; i < NIT; i++) {
+                const int f = tid + i * 256;
+                const int r = f >> 3, cv = f & 7;
+                const int iy = r / IWT, ix = r - iy * IWT;
+                const int ih = ih0 + iy, iw = iw0 + ix, k = kc + cv * 4;
+                okv[i] = r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W && k < d.Cin;
+                const int ihc = ih < 0 ? 0 : (ih >= d.H ? d.H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= d.W ? d.W - 1 : iw);
+                xv[i] = *reinterpret_cast<const float4 *>(xin + ((int64_t)ihc * d.W + iwc) * d.Cin + (k < d.Cin ? k : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < NIT; i++) {
+                const int f = tid + i * 256;
+                *reinterpret_cast<float4 *>(Xs + (f >> 3) * GEMM_LD + (f & 7) * 4) = okv[i] ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        {
+            const int n = tid >> 3, cv = tid & 7, k = kc + cv * 4;
+            const int cn = c0 + n < d.C ? c0 + n : d.C - 1;
+            const float4 v = *reinterpret_cast<const float4 *>(w1 + (int64_t)cn * d.Cin + (k < d.Cin ? k : 0));
+            *reinterpret_cast<float4 *>(Ws + n * GEMM_LD + cv * 4) = (k < d.Cin && c0 + n < d.C) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TPW; t++) {
+            const int mt = wave + 4 * t;
+            if (mt < MT) {
+                floatx16 one[1] = {acc[t]};
+                mfma_ktile_full<1>(Xs + (mt * 32 + lr) * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, one);
+                acc[t] = one[0];
+            }
+        }
+    }
+    // expand epilogue -> Es[halo pixel][channel]
+    {
+        const int cg = c0 + lr;
+        const float bv = (d.has_bias1 && cg < d.C) ? b1[cg] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < TPW; t++) {
+            const int mt = wave + 4 * t;
+            if (mt < MT) {
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const int r = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    const int iy = r / IWT, ix = r - iy * IWT;
+                    const int ih = ih0 + iy, iw = iw0 + ix;
+                    const bool ok = r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+                    const float v = act_apply(d.act1, acc[t][reg] + bv, d.p0_1, d.p1_1);
+                    Es[r * 32 + lr] = ok ? v : 0.0f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // depthwise from LDS: lane = channel, 8 lane groups share the tile's pixels
+    const int c = tid & 31, g = tid >> 5;
+    const int cg = c0 + c;
+    const bool cact = cg < d.C;
+    float wd[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; q++) wd[q] = cact ? w2[q * d.C + cg] : 0.0f;
+    const float bias2 = (d.has_bias2 && cact) ? b2[cg] : 0.0f;
+    constexpr int PPG = TOH * TOW / 8;  // output pixels per lane group
+    float sum = 0.0f;
+    float *ob = out + b * d.out_bs;
+#pragma unroll
+    for (int q = 0; q < PPG; q++) {
+        const int p = g * PPG + q;          // pixel index inside the tile, row-major
+        const int oy = p / TOW, ox = p - oy * TOW;
+        float a = bias2;
+#pragma unroll
+        for (int ky = 0; ky < K; ky++)
+#pragma unroll
+            for (int kx = 0; kx < K; kx++) a = fmaf(Es[((oy * S + ky) * IWT + ox * S + kx) * 32 + c], wd[ky * K + kx], a);
+        a = act_apply(d.act2, a, d.p0_2, d.p1_2);
+        const int oh = oh0 + oy, ow = ow0 + ox;
+        if (cact && oh < d.OH && ow < d.OW) {
+            ob[((int64_t)oh * d.OW + ow) * d.C + cg] = a;
+            sum += a;
+        }
+    }
+    if (d.has_gap) {
+        red[g][c] = sum;
+        __syncthreads();
+        if (g == 0 && cact) {
+            float t = red[0][c];
+#pragma unroll
+            for (int y = 1; y < 8; y++) t += red[y][c];
+            gap[b * d.gap_bs + (int64_t)blockIdx.x * d.C + cg] = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ depthwise conv
 // one lane = one output pixel x 4 channels.  grid (ceil(OH*OW*C4/256), batch)
 template <int VEC>
@@ -1166,6 +1305,18 @@ void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, 
     const int64_t total = (int64_t)d.OH * d.OW * d.Cout;
     dim3 grid(cap_blocks((total + 255) / 256, 8192), (unsigned)batch);
     hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, d, out, in, w, bias, res);
+}
+
+void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
+                   const float *b2, float *gap, int64_t batch) {
+    if (batch <= 0) return;
+    dim3 grid((unsigned)(d.tiles_x * d.tiles_y), (unsigned)((d.C + 31) / 32), (unsigned)batch);
+#define MB_LAUNCH(K, S) hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap)
+    if (d.k == 3 && d.s == 1) MB_LAUNCH(3, 1);
+    else if (d.k == 3 && d.s == 2) MB_LAUNCH(3, 2);
+    else if (d.k == 5 && d.s == 1) MB_LAUNCH(5, 1);
+    else MB_LAUNCH(5, 2);
+#undef MB_LAUNCH
 }
 
 void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w, const float *bias, float *gap,

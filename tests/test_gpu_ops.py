@@ -193,3 +193,46 @@ def test_standalone_batchnorm_and_hard_activations(bn):
         return g.node("ReduceMax", [y], axes=[2], keepdims=0)
     got, ref = run_both(bn, op_graph(build, [6, 600]))
     assert_close(got, ref, "bn/hard activations", atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cin,h,w,cmid,k,stride,act", [(16, 24, 40, 96, 3, 2, "relu"), (24, 12, 40, 144, 3, 1, "relu"),
+                                                       (24, 13, 37, 144, 5, 2, "silu"), (40, 9, 19, 240, 3, 2, "relu6"),
+                                                       (8, 16, 32, 48, 5, 1, "relu"), (16, 7, 9, 40, 3, 1, None)])
+def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act):
+    """expand 1x1 conv (+BN+act) -> depthwise KxK (+act): one MBCONV launch, expanded tensor only in LDS."""
+    rng = np.random.default_rng(11)
+    assert cin * h * w <= 144000
+    pad = k // 2
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+    def activation(g, y):
+        if act == "relu":
+            return g.node("Relu", [y])
+        if act == "silu":
+            return g.node("Mul", [y, g.node("Sigmoid", [y])])
+        if act == "relu6":
+            return g.node("Clip", [y, g.const(np.float32(0)), g.const(np.float32(6))])
+        return y
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(cin * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, cin, h, w)])
+        w0 = (rng.standard_normal((cin, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+        x = g.node("Conv", [x, g.const(w0)], kernel_shape=[1, 1])               # channels-last producer
+        we = (rng.standard_normal((cmid, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+        y = g.node("Conv", [x, g.const(we), g.const(rng.standard_normal(cmid).astype(np.float32))], kernel_shape=[1, 1])
+        y = activation(g, y)
+        wd = (rng.standard_normal((cmid, 1, k, k)) / k).astype(np.float32)
+        z = g.node("Conv", [y, g.const(wd), g.const(rng.standard_normal(cmid).astype(np.float32))], kernel_shape=[k, k],
+                   strides=[stride, stride], pads=[pad] * 4, group=cmid)
+        return activation(g, z)
+    data = op_graph(build, [cmid, oh, ow])
+    import os
+    os.environ["BN_MBFUSE"] = "1"   # opt-in fusion (read by the planner at model load)
+    try:
+        assert "MBCONV" in bn.plan_describe(write_model(data))
+        got, ref = run_both(bn, data)
+    finally:
+        del os.environ["BN_MBFUSE"]
+    assert_close(got, ref, f"mbconv {cin}->{cmid} k{k} s{stride}")
