@@ -1481,7 +1481,8 @@ class Builder {
                 const int toh0 = strides[1] == 1 ? 8 : 4, tow0 = strides[1] == 1 ? 16 : 8;
                 const int64_t hp = ((toh0 - 1) * strides[1] + kw) * ((tow0 - 1) * strides[1] + kw);
                 const double halo_factor = (double)((hp + 31) / 32 * 32) * ((OW + tow0 - 1) / tow0) * ((OH + toh0 - 1) / toh0) / (double)(H * W);
-                if (producer && halo_factor <= 2.0 && sole_consumer(n.inputs[0]) == cur_) {
+                const bool force = getenv("BN_MBFUSE") && std::string(getenv("BN_MBFUSE")) == "force";  // tests: small feature maps too
+                if (producer && (halo_factor <= 2.0 || force) && sole_consumer(n.inputs[0]) == cur_) {
                     PlanOp mb;
                     mb.kind = OpKind::MBCONV;
                     mb.name = "mbconv:" + pe.name.substr(pe.name.find(':') + 1) + "+" + n.name;

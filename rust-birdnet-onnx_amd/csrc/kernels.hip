@@ -288,7 +288,10 @@ __global__ __launch_bounds__(1024) void reduce_row_kernel(ReduceDesc d, float *_
 // Fragment trick: one ds_read_b128 per operand feeds four MFMAs.  The MFMA sums
 // over two k-slots (lane>>5); slot h of MFMA j carries k = 8g + 4h + j, the same
 // assignment for A and B, so every k of the 8-wide group is used exactly once.
-constexpr int GEMM_BM = 128, GEMM_BK = 32, GEMM_LD = 36;
+#ifndef GEMM_BK_VALUE
+#define GEMM_BK_VALUE 32
+#endif
+constexpr int GEMM_BM = 128, GEMM_BK = GEMM_BK_VALUE, GEMM_LD = GEMM_BK + 4;
 #ifndef GEMM_PF
 #define GEMM_PF 1
 #endif

@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles its own HIP runtime: load it BEFORE libbirdnet_hip.so pulls in the system one,
+    import torch  # noqa: F401  (two different libamdhip64 copies in one process cannot both see the GPU)
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

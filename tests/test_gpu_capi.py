@@ -1,0 +1,101 @@
+"""Engine-level C ABI entry points not reached through the Classifier mirror: load from a buffer,
+I/O metadata, cost report, device-resident inference, device/host top-K variants, step API."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle
+from gpu_helpers import write_model
+
+pytestmark = pytest.mark.gpu
+synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def small():
+    data = synth.birdnet_v30(num_species=200, width=0.5, depth=0.34, emb=1024)
+    return data, write_model(data)
+
+
+def test_load_buffer_io_info_config_cost(bn, small):
+    data, path = small
+    h = C.c_void_p()
+    buf = C.create_string_buffer(data, len(data))
+    assert bn.lib.bn_model_load_buffer(C.cast(buf, C.c_void_p), len(data), 0, -1, C.byref(h)) == 0
+    io = bn.BnIoInfo()
+    assert bn.lib.bn_model_io_info(h, C.byref(io)) == 0
+    assert io.input_name == b"input" and io.input_rank == 2 and list(io.input_shape[:2]) == [-1, 160000]
+    assert io.n_outputs == 2 and io.output_name[0].value == b"output_0" and io.output_name[1].value == b"output_1"
+    assert list(io.output_shape[0][:2]) == [-1, 1024] and list(io.output_shape[1][:2]) == [-1, 200]
+    cfg = bn.BnModelConfig()
+    assert bn.lib.bn_model_get_config(h, C.byref(cfg)) == 0
+    assert (cfg.model_type, cfg.sample_count, cfg.num_species, cfg.embedding_dim, cfg.logits_output, cfg.embedding_output) == \
+           (1, 160000, 200, 1024, 1, 0)
+    cost = bn.BnModelCost()
+    assert bn.lib.bn_model_get_cost(h, C.byref(cost)) == 0
+    assert cost.macs_mfma > 1e7 and cost.weight_bytes > 1e5 and cost.n_launches > 10
+    bn.lib.bn_model_free(h)
+    # garbage buffer -> BN_ERR_MODEL_LOAD with a message
+    bad = C.create_string_buffer(b"\xff" * 64, 64)
+    assert bn.lib.bn_model_load_buffer(C.cast(bad, C.c_void_p), 64, 0, -1, C.byref(h)) == 6
+    assert bn.last_error()
+    assert bn.lib.bn_model_load_buffer(C.cast(buf, C.c_void_p), len(data), 99, -1, C.byref(h)) == 9  # no such device
+
+
+def test_device_resident_inference_and_step(bn, small):
+    import torch
+    data, path = small
+    m = bn.Model(path)
+    ctx = bn.Context(m, 8)
+    x = synth.synthetic_segments(5, 160000, 32000)
+    want_logits, want_emb = ctx.infer(x)
+    xd = torch.from_numpy(x).cuda()
+    ctx.infer_device(xd.data_ptr(), 5, sync=True)
+    assert ctx.read_output(1, 5).tobytes() == want_logits.tobytes()
+    assert ctx.read_output(0, 5).tobytes() == want_emb.tobytes()
+    # whole-path step: plan + top-K + D2H, asynchronous then synchronised
+    ctx.step_device(xd.data_ptr(), 5, top_k=7, min_confidence=0.05)
+    ctx.synchronize()
+    lg, ix, cf, ct = ctx.step_results(5)
+    assert lg.tobytes() == want_logits.tobytes()
+    for r in range(5):
+        want = oracle.top_k(lg[r], 7, 0.05)
+        assert ix[r, :ct[r]].tolist() == [w[0] for w in want]
+        assert cf[r, :ct[r]].tobytes() == np.asarray([w[1] for w in want], np.float32).tobytes()
+    # eager (no hipGraph) context gives the same bits
+    e, _ = bn.Context(m, 8, bn.BN_CTX_NO_GRAPH).infer(x)
+    assert e.tobytes() == want_logits.tobytes()
+    # batch limits
+    with pytest.raises(bn.EngineError):
+        ctx.infer(np.zeros((9, 160000), np.float32))
+    assert bn.lib.bn_ctx_max_batch(ctx._h) == 8 and bn.lib.bn_ctx_device_bytes(ctx._h) > 8 * 160000 * 4
+    assert ctx.stream() != 0
+
+
+def test_topk_device_pointer_variant(bn):
+    import torch
+    rows = np.stack([oracle.random_logits(6522, 900 + s) for s in range(6)])
+    d = torch.from_numpy(rows).cuda()
+    k = 10
+    idx = np.zeros((6, k), np.uint32)
+    conf = np.zeros((6, k), np.float32)
+    cnt = np.zeros(6, np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    st = bn.lib.bn_topk_device(0, C.c_void_p(d.data_ptr()), 6, 6522, k, 1, C.c_float(0.2), k, idx.ctypes.data_as(u32p),
+                               conf.ctypes.data_as(C.POINTER(C.c_float)), cnt.ctypes.data_as(u32p))
+    assert st == 0
+    for r in range(6):
+        want = oracle.top_k(rows[r], k, 0.2)
+        assert idx[r, :cnt[r]].tolist() == [w[0] for w in want]
+        assert conf[r, :cnt[r]].tobytes() == np.asarray([w[1] for w in want], np.float32).tobytes()
+
+
+def test_per_kernel_timing_report(bn, small):
+    data, path = small
+    ctx = bn.Context(bn.Model(path), 4)
+    ctx.infer(synth.synthetic_segments(4, 160000, 32000))
+    rows = ctx.time_kernels(4)
+    assert len(rows) > 10 and all(us > 0 for _, us, _, _ in rows)
+    assert sum(m for _, _, m, _ in rows) > 1e7

@@ -229,7 +229,7 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act):
         return activation(g, z)
     data = op_graph(build, [cmid, oh, ow])
     import os
-    os.environ["BN_MBFUSE"] = "1"   # opt-in fusion (read by the planner at model load)
+    os.environ["BN_MBFUSE"] = "force"   # opt-in fusion, also for tiny feature maps (read by the planner at model load)
     try:
         assert "MBCONV" in bn.plan_describe(write_model(data))
         got, ref = run_both(bn, data)
