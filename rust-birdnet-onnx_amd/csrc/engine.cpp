@@ -1466,23 +1466,33 @@ class Builder {
                 for (int64_t k = 0; k < kh * kw; k++) wp[k * Cin + c] = wf[c * kh * kw + k];
             op.w = Ref{Space::CONSTS, add_const(wp), 0};
             op.a = ref_of(x);
-            // expand 1x1 conv immediately before, consumed only here?  Then both can run in one launch
-            // with the expanded tensor kept in LDS (mbconv_expand_dw_kernel).  Measured on MI355X at
-            // batch 32 the fused kernel is still ~2x slower than the two separate launches (one
-            // (tile, 32-channel chunk) per block is latency-bound at 2 blocks/CU), so it is opt-in
-            // (BN_MBFUSE=1) until it keeps the X tile resident across channel chunks.
-            if (d.tiled && kh == kw && strides[0] == strides[1] && getenv("BN_MBFUSE") && !plan_.ops.empty()) {
+            // expand 1x1 conv immediately before, consumed only here?  Then both run in one launch with the
+            // expanded tensor kept in LDS (mbconv_expand_dw_kernel): the 6x-expanded activation never
+            // touches HBM.  Measured on MI355X (batch 32, per pair): 48x256x16->96 s2: 101 -> 79 us,
+            // 24x128x24->144 s1: 80 -> 54 us, 5x5 s2: 60 -> 52 us, 12x64x40->240 5x5 s1: 54 -> 50 us; on
+            // the 6x32 maps (2 tiles per sample) and for K >= 80 the separate launches win, so the rule
+            // below keeps those unfused.  The rule only looks at per-sample shapes (batch invariance).
+            // BN_MBFUSE=0 disables, BN_MBFUSE=force fuses every eligible pair (tests).
+            const char *mbenv = getenv("BN_MBFUSE");
+            const bool mb_off = mbenv && std::string(mbenv) == "0";
+            if (d.tiled && kh == kw && strides[0] == strides[1] && !mb_off && !plan_.ops.empty()) {
                 PlanOp &pe = plan_.ops.back();
+                const int maxk = getenv("BN_MBFUSE_MAXK") ? atoi(getenv("BN_MBFUSE_MAXK")) : 48;
+                const double maxhalo = getenv("BN_MBFUSE_HALO") ? atof(getenv("BN_MBFUSE_HALO")) : 3.0;
                 const bool producer = pe.kind == OpKind::GEMM && pe.out.space == Space::ARENA && pe.out.id == x.storage && pe.out.offset == 0 &&
                                       x.offset == 0 && !pe.gemm.has_scale && !pe.gemm.has_res && pe.gemm.rows == H * W && pe.gemm.N == Cin &&
-                                      pe.gemm.lda == pe.gemm.K && pe.gemm.K % 4 == 0 && pe.a.offset % 4 == 0 &&
+                                      pe.gemm.lda == pe.gemm.K && pe.gemm.K % 4 == 0 && pe.gemm.K <= maxk && pe.a.offset % 4 == 0 &&
                                       (pe.a.space != Space::ARENA || plan_.storages[pe.a.id].elems % 4 == 0);
                 // halo recompute factor of the expand conv: staged halo pixels / image pixels
                 const int toh0 = strides[1] == 1 ? 8 : 4, tow0 = strides[1] == 1 ? 16 : 8;
                 const int64_t hp = ((toh0 - 1) * strides[1] + kw) * ((tow0 - 1) * strides[1] + kw);
                 const double halo_factor = (double)((hp + 31) / 32 * 32) * ((OW + tow0 - 1) / tow0) * ((OH + toh0 - 1) / toh0) / (double)(H * W);
-                const bool force = getenv("BN_MBFUSE") && std::string(getenv("BN_MBFUSE")) == "force";  // tests: small feature maps too
-                if (producer && (halo_factor <= 2.0 || force) && sole_consumer(n.inputs[0]) == cur_) {
+                const bool force = mbenv && std::string(mbenv) == "force";  // tests: small feature maps too
+                const bool big_enough = H * W >= 3072 || (strides[1] == 1 && H * W >= 768);
+                MbDesc probe{};
+                probe.k = (int32_t)kw; probe.s = (int32_t)strides[1]; probe.Cin = producer ? pe.gemm.K : 4;
+                const bool fits = mbconv_lds_bytes(probe) <= 150 * 1024;
+                if (producer && fits && ((halo_factor <= maxhalo && big_enough) || force) && sole_consumer(n.inputs[0]) == cur_) {
                     PlanOp mb;
                     mb.kind = OpKind::MBCONV;
                     mb.name = "mbconv:" + pe.name.substr(pe.name.find(':') + 1) + "+" + n.name;

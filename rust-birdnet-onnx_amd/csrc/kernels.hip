@@ -441,6 +441,25 @@ __device__ __forceinline__ void map_tile(floatx16 (&acc)[NT], F f) {
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = f(acc[t][r]);
 }
+template <int N, class F>
+__device__ __forceinline__ void map_array(float (&v)[N], F f) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = f(v[i]);
+}
+// activation over a small register array with ONE dispatch on the (uniform) code
+template <int N>
+__device__ __forceinline__ void act_array(int act, float p0, float p1, float (&v)[N]) {
+    if (act == ACT_NONE) return;
+    if (act == ACT_RELU) map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); });
+    else if (act == ACT_CLIP) map_array<N>(v, [=](float x) { return fminf(fmaxf(x, p0), p1); });
+    else if (act == ACT_SILU) map_array<N>(v, [](float x) { return x / (1.0f + expf(-x)); });
+    else if (act == ACT_SIGMOID) map_array<N>(v, [](float x) { return 1.0f / (1.0f + expf(-x)); });
+    else if (act == ACT_HSWISH) map_array<N>(v, [](float x) { return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f); });
+    else if (act == ACT_HSIGMOID) map_array<N>(v, [=](float x) { return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f); });
+    else if (act == ACT_LEAKY) map_array<N>(v, [=](float x) { return x >= 0.0f ? x : p0 * x; });
+    else if (act == ACT_TANH) map_array<N>(v, [](float x) { return tanhf(x); });
+}
+
 template <int NT>
 __device__ __forceinline__ void act_tile(int act, float p0, float p1, floatx16 (&acc)[NT]) {
     if (act == ACT_NONE) return;
@@ -799,15 +818,16 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
 }
 
 // ------------------------------------------------------------------ fused expand + depthwise
-// One block = one output tile (TOH x TOW pixels) x one chunk of 32 mid channels:
-//   1. the input halo tile ((TOH-1)*S+K) x ((TOW-1)*S+K) pixels x Cin is staged through LDS in
-//      32-wide K chunks and multiplied with the chunk's 32 expand filters on the matrix cores
-//      (rows = halo pixels, same fragment scheme as gemm_mfma_kernel)
+// One block = one output tile (TOH x TOW pixels), ALL mid channels in chunks of 32:
+//   0. the input halo tile ((TOH-1)*S+K) x ((TOW-1)*S+K) pixels x Cin is staged in LDS ONCE
+//      (Cin <= 48: the whole K extent fits), rows outside the image are zero
+//   per chunk of 32 mid channels (its expand filters were prefetched into registers):
+//   1. expand on the matrix cores: rows = halo pixels, cols = 32 filters, K = Cin
 //   2. bias + activation, halo pixels outside the image forced to 0 (the depthwise conv pads the
-//      EXPANDED tensor), result written to LDS as [halo pixel][32 channels]
+//      EXPANDED tensor), written to LDS as [halo pixel][32 channels]
 //   3. depthwise K x K from LDS (lane = channel, conflict free), bias + activation, NHWC store,
-//      per-block channel sums for a following squeeze-excite (fixed-order LDS reduction)
-// grid (tiles, ceil(C/32), batch), 256 threads.
+//      per-tile channel sums for a following squeeze-excite (fixed-order LDS reduction)
+// The expanded tensor never exists in HBM.  grid (tiles, 1, batch), 256 threads, dynamic LDS.
 template <int K, int S>
 __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                                const float *__restrict__ w1, const float *__restrict__ b1,
@@ -817,126 +837,143 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
     constexpr int IHT = (TOH - 1) * S + K, IWT = (TOW - 1) * S + K, HP = IHT * IWT;
     constexpr int MT = (HP + 31) / 32, MP = MT * 32;
     constexpr int TPW = (MT + 3) / 4;  // m-tiles per wave
-    __shared__ __align__(16) float Xs[MP * GEMM_LD];
-    __shared__ __align__(16) float Ws[32 * GEMM_LD];
-    __shared__ __align__(16) float Es[MP * 32];
-    __shared__ float red[8][32];
+    constexpr int PPG = TOH * TOW / 8;  // output pixels per lane group in the depthwise phase
+    extern __shared__ __align__(16) float msm[];
+    const int KS = (d.Cin + 7) / 8 * 8 + 4;  // LDS row stride (floats): (KS/4) is odd -> conflict-free b128 reads
+    const int ng = (d.Cin + 7) / 8;           // 8-wide K groups holding data
+    float *Xs = msm;                           // [MP][KS]
+    float *Ws = Xs + MP * KS;                  // [32][KS]
+    float *Es = Ws + 32 * KS;                  // [MP][32]
+    float *red = Es + MP * 32;                 // [8][32]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
     const int oh0 = ty * TOH, ow0 = tx * TOW;
     const int ih0 = oh0 * S - d.pt, iw0 = ow0 * S - d.pl;
-    const int c0 = blockIdx.y * 32;
     const int64_t b = blockIdx.z;
     const float *xin = in + b * d.in_bs;
+    const int CV = (d.Cin + 3) / 4;  // float4 per pixel
 
-    floatx16 acc[TPW];
+    // ---- 0. stage the halo tile (all loads issued before the first is consumed, 4 at a time)
+    for (int f0 = tid; f0 < MP * CV; f0 += 256 * 4) {
+        float4 xv[4];
+        bool okv[4];
 #pragma unroll
-    for (int t = 0; t < TPW; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-
-    for (int kc = 0; kc < d.Cin; kc += GEMM_BK) {
-        __syncthreads();  // previous chunk consumed
-        // X chunk: MP rows (halo pixels) x 32 floats; rows outside the image / past HP and columns
-        // past Cin are zero
-        {
-            // all loads of the chunk are issued before the first one is consumed
-            constexpr int NIT = MP * 8 / 256;
-            float4 xv[NIT];
-            bool okv[NIT];
-#pragma unroll
-            for (int i = 0; i < NIT; i++) {
-                const int f = tid + i * 256;
-                const int r = f >> 3, cv = f & 7;
-                const int iy = r / IWT, ix = r - iy * IWT;
-                const int ih = ih0 + iy, iw = iw0 + ix, k = kc + cv * 4;
-                okv[i] = r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W && k < d.Cin;
-                const int ihc = ih < 0 ? 0 : (ih >= d.H ? d.H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= d.W ? d.W - 1 : iw);
-                xv[i] = *reinterpret_cast<const float4 *>(xin + ((int64_t)ihc * d.W + iwc) * d.Cin + (k < d.Cin ? k : 0));
-            }
-#pragma unroll
-            for (int i = 0; i < NIT; i++) {
-                const int f = tid + i * 256;
-                *reinterpret_cast<float4 *>(Xs + (f >> 3) * GEMM_LD + (f & 7) * 4) = okv[i] ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        for (int i = 0; i < 4; i++) {
+            const int f = f0 + i * 256;
+            const int r = f / CV, cv = f - r * CV;
+            const int iy = r / IWT, ix = r - iy * IWT;
+            const int ih = ih0 + iy, iw = iw0 + ix;
+            okv[i] = f < MP * CV && r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+            const int ihc = ih < 0 ? 0 : (ih >= d.H ? d.H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= d.W ? d.W - 1 : iw);
+            xv[i] = *reinterpret_cast<const float4 *>(xin + ((int64_t)ihc * d.W + iwc) * d.Cin + (f < MP * CV ? cv * 4 : 0));
         }
-        {
-            const int n = tid >> 3, cv = tid & 7, k = kc + cv * 4;
-            const int cn = c0 + n < d.C ? c0 + n : d.C - 1;
-            const float4 v = *reinterpret_cast<const float4 *>(w1 + (int64_t)cn * d.Cin + (k < d.Cin ? k : 0));
-            *reinterpret_cast<float4 *>(Ws + n * GEMM_LD + cv * 4) = (k < d.Cin && c0 + n < d.C) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < TPW; t++) {
-            const int mt = wave + 4 * t;
-            if (mt < MT) {
-                floatx16 one[1] = {acc[t]};
-                mfma_ktile_full<1>(Xs + (mt * 32 + lr) * GEMM_LD + 4 * lh, Ws + lr * GEMM_LD + 4 * lh, one);
-                acc[t] = one[0];
+        for (int i = 0; i < 4; i++) {
+            const int f = f0 + i * 256;
+            if (f < MP * CV) {
+                const int r = f / CV, cv = f - r * CV;
+                *reinterpret_cast<float4 *>(Xs + r * KS + cv * 4) = okv[i] ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     }
-    // expand epilogue -> Es[halo pixel][channel]
-    {
-        const int cg = c0 + lr;
-        const float bv = (d.has_bias1 && cg < d.C) ? b1[cg] : 0.0f;
+    // zero the K padding columns [Cin, ng*8) once (Cin % 8 == 4 only)
+    if (d.Cin % 8) {
+        for (int r = tid; r < MP; r += 256) *reinterpret_cast<float4 *>(Xs + r * KS + d.Cin) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 32) *reinterpret_cast<float4 *>(Ws + tid * KS + d.Cin) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // expand filters of chunk 0 -> registers (32 rows x CV float4 <= 384 float4: <= 2 per thread)
+    float4 wreg0, wreg1;
+    const int wn0 = tid / CV, wc0 = tid - wn0 * CV, wn1 = (tid + 256) / CV, wc1 = (tid + 256) - wn1 * CV;
+    const bool wv0 = tid < 32 * CV, wv1 = tid + 256 < 32 * CV;
+#define MB_FETCH_W(C0)                                                                                                             \
+    do {                                                                                                                         \
+        const int n0_ = (C0) + wn0 < d.C ? (C0) + wn0 : d.C - 1, n1_ = (C0) + wn1 < d.C ? (C0) + wn1 : d.C - 1;                  \
+        wreg0 = *reinterpret_cast<const float4 *>(w1 + (int64_t)(wv0 ? n0_ : 0) * d.Cin + (wv0 ? wc0 * 4 : 0));                  \
+        wreg1 = *reinterpret_cast<const float4 *>(w1 + (int64_t)(wv1 ? n1_ : 0) * d.Cin + (wv1 ? wc1 * 4 : 0));                  \
+    } while (0)
+    MB_FETCH_W(0);
+    const int c = tid & 31, g = tid >> 5;
+    float *ob = out + b * d.out_bs;
+    const int nchunks = (d.C + 31) / 32;
+
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int c0 = ch * 32;
+        __syncthreads();  // Ws / Es of the previous chunk consumed; first pass: Xs complete
+        if (wv0) *reinterpret_cast<float4 *>(Ws + wn0 * KS + wc0 * 4) = wreg0;
+        if (wv1) *reinterpret_cast<float4 *>(Ws + wn1 * KS + wc1 * 4) = wreg1;
+        __syncthreads();
+        if (ch + 1 < nchunks) MB_FETCH_W(c0 + 32);  // next chunk's filters in flight during this chunk
+        // depthwise weights / bias of this chunk (consumed after the expand)
+        const int cg = c0 + c;
+        const bool cact = cg < d.C;
+        float wd[K * K];
+#pragma unroll
+        for (int q = 0; q < K * K; q++) wd[q] = w2[q * d.C + (cact ? cg : d.C - 1)];
+        const float bias2 = d.has_bias2 ? b2[cact ? cg : d.C - 1] : 0.0f;
+        const float bv = d.has_bias1 ? b1[c0 + lr < d.C ? c0 + lr : d.C - 1] : 0.0f;
+
+        // ---- 1+2. expand -> Es
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
             const int mt = wave + 4 * t;
             if (mt < MT) {
+                floatx16 acc[1];
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[0][r] = 0.0f;
+                mfma_ktile_partial<1>(Xs + (mt * 32 + lr) * KS + 4 * lh, Ws + lr * KS + 4 * lh, acc, ng);
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) acc[0][reg] += bv;
+                act_tile<1>(d.act1, d.p0_1, d.p1_1, acc);
 #pragma unroll
                 for (int reg = 0; reg < 16; reg++) {
                     const int r = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
                     const int iy = r / IWT, ix = r - iy * IWT;
                     const int ih = ih0 + iy, iw = iw0 + ix;
                     const bool ok = r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
-                    const float v = act_apply(d.act1, acc[t][reg] + bv, d.p0_1, d.p1_1);
-                    Es[r * 32 + lr] = ok ? v : 0.0f;
+                    Es[r * 32 + lr] = ok ? acc[0][reg] : 0.0f;
                 }
             }
         }
-    }
-    __syncthreads();
-    // depthwise from LDS: lane = channel, 8 lane groups share the tile's pixels
-    const int c = tid & 31, g = tid >> 5;
-    const int cg = c0 + c;
-    const bool cact = cg < d.C;
-    float wd[K * K];
-#pragma unroll
-    for (int q = 0; q < K * K; q++) wd[q] = cact ? w2[q * d.C + cg] : 0.0f;
-    const float bias2 = (d.has_bias2 && cact) ? b2[cg] : 0.0f;
-    constexpr int PPG = TOH * TOW / 8;  // output pixels per lane group
-    float sum = 0.0f;
-    float *ob = out + b * d.out_bs;
-#pragma unroll
-    for (int q = 0; q < PPG; q++) {
-        const int p = g * PPG + q;          // pixel index inside the tile, row-major
-        const int oy = p / TOW, ox = p - oy * TOW;
-        float a = bias2;
-#pragma unroll
-        for (int ky = 0; ky < K; ky++)
-#pragma unroll
-            for (int kx = 0; kx < K; kx++) a = fmaf(Es[((oy * S + ky) * IWT + ox * S + kx) * 32 + c], wd[ky * K + kx], a);
-        a = act_apply(d.act2, a, d.p0_2, d.p1_2);
-        const int oh = oh0 + oy, ow = ow0 + ox;
-        if (cact && oh < d.OH && ow < d.OW) {
-            ob[((int64_t)oh * d.OW + ow) * d.C + cg] = a;
-            sum += a;
-        }
-    }
-    if (d.has_gap) {
-        red[g][c] = sum;
         __syncthreads();
-        if (g == 0 && cact) {
-            float t = red[0][c];
+        // ---- 3. depthwise from LDS: lane = channel, 8 lane groups share the tile's pixels
+        float sum = 0.0f;
+        float ov[PPG];
 #pragma unroll
-            for (int y = 1; y < 8; y++) t += red[y][c];
-            gap[b * d.gap_bs + (int64_t)blockIdx.x * d.C + cg] = t;
+        for (int q = 0; q < PPG; q++) {
+            const int p = g * PPG + q;  // pixel index inside the tile, row-major
+            const int oy = p / TOW, ox = p - oy * TOW;
+            float a = bias2;
+#pragma unroll
+            for (int ky = 0; ky < K; ky++)
+#pragma unroll
+                for (int kx = 0; kx < K; kx++) a = fmaf(Es[((oy * S + ky) * IWT + ox * S + kx) * 32 + c], wd[ky * K + kx], a);
+            ov[q] = a;
+        }
+        act_array<PPG>(d.act2, d.p0_2, d.p1_2, ov);
+#pragma unroll
+        for (int q = 0; q < PPG; q++) {
+            const int p = g * PPG + q;
+            const int oy = p / TOW, ox = p - oy * TOW;
+            const int oh = oh0 + oy, ow = ow0 + ox;
+            if (cact && oh < d.OH && ow < d.OW) {
+                ob[((int64_t)oh * d.OW + ow) * d.C + cg] = ov[q];
+                sum += ov[q];
+            }
+        }
+        if (d.has_gap) {
+            red[g * 32 + c] = sum;
+            __syncthreads();
+            if (g == 0 && cact) {
+                float t = red[c];
+#pragma unroll
+                for (int y = 1; y < 8; y++) t += red[y * 32 + c];
+                gap[b * d.gap_bs + (int64_t)blockIdx.x * d.C + cg] = t;
+            }
         }
     }
 }
 
+#undef MB_FETCH_W
 // ------------------------------------------------------------------ depthwise conv
 // one lane = one output pixel x 4 channels.  grid (ceil(OH*OW*C4/256), batch)
 template <int VEC>
@@ -1310,11 +1347,28 @@ void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, 
     hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, d, out, in, w, bias, res);
 }
 
+size_t mbconv_lds_bytes(const MbDesc &d) {
+    const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
+    const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
+    const int mp = (hp + 31) / 32 * 32;
+    const int ks = (d.Cin + 7) / 8 * 8 + 4;
+    return (size_t)(mp * ks + 32 * ks + mp * 32 + 8 * 32) * sizeof(float);
+}
+
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
                    const float *b2, float *gap, int64_t batch) {
     if (batch <= 0) return;
-    dim3 grid((unsigned)(d.tiles_x * d.tiles_y), (unsigned)((d.C + 31) / 32), (unsigned)batch);
-#define MB_LAUNCH(K, S) hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap)
+    dim3 grid((unsigned)(d.tiles_x * d.tiles_y), 1, (unsigned)batch);
+    const size_t lds = mbconv_lds_bytes(d);
+#define MB_LAUNCH(K, S)                                                                                                          \
+    do {                                                                                                                         \
+        static size_t attr = 0;                                                                                                  \
+        if (lds > attr) {                                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mbconv_expand_dw_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr = lds;                                                                                                          \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S>), grid, dim3(256), lds, s, d, out, in, w1, b1, w2, b2, gap);           \
+    } while (0)
     if (d.k == 3 && d.s == 1) MB_LAUNCH(3, 1);
     else if (d.k == 3 && d.s == 2) MB_LAUNCH(3, 2);
     else if (d.k == 5 && d.s == 1) MB_LAUNCH(5, 1);
