@@ -1477,7 +1477,11 @@ class Builder {
             const bool mb_off = mbenv && std::string(mbenv) == "0";
             if (d.tiled && kh == kw && strides[0] == strides[1] && !mb_off && !plan_.ops.empty()) {
                 PlanOp &pe = plan_.ops.back();
-                const int maxk = getenv("BN_MBFUSE_MAXK") ? atoi(getenv("BN_MBFUSE_MAXK")) : 48;
+                const int maxk = std::min(44, getenv("BN_MBFUSE_MAXK") ? atoi(getenv("BN_MBFUSE_MAXK")) : 44);  // kernel: Cin + 1 columns in <= 6 K groups
+                // the kernel relies on act(0) == 0 for the expand activation (pixels outside the image)
+                const int a1 = pe.gemm.act;
+                const bool act_zero = a1 == ACT_NONE || a1 == ACT_RELU || (a1 == ACT_CLIP && pe.gemm.p0 <= 0.f && pe.gemm.p1 >= 0.f) ||
+                                      a1 == ACT_SILU || a1 == ACT_HSWISH || a1 == ACT_LEAKY || a1 == ACT_TANH;
                 const double maxhalo = getenv("BN_MBFUSE_HALO") ? atof(getenv("BN_MBFUSE_HALO")) : 3.0;
                 const bool producer = pe.kind == OpKind::GEMM && pe.out.space == Space::ARENA && pe.out.id == x.storage && pe.out.offset == 0 &&
                                       x.offset == 0 && !pe.gemm.has_scale && !pe.gemm.has_res && pe.gemm.rows == H * W && pe.gemm.N == Cin &&
@@ -1490,15 +1494,27 @@ class Builder {
                 const bool force = mbenv && std::string(mbenv) == "force";  // tests: small feature maps too
                 const bool big_enough = H * W >= 3072 || (strides[1] == 1 && H * W >= 768);
                 MbDesc probe{};
-                probe.k = (int32_t)kw; probe.s = (int32_t)strides[1]; probe.Cin = producer ? pe.gemm.K : 4;
+                probe.k = (int32_t)kw; probe.s = (int32_t)strides[1]; probe.Cin = producer ? pe.gemm.K : 4; probe.C = (int32_t)Cin;
                 const bool fits = mbconv_lds_bytes(probe) <= 150 * 1024;
-                if (producer && fits && ((halo_factor <= maxhalo && big_enough) || force) && sole_consumer(n.inputs[0]) == cur_) {
+                if (producer && act_zero && fits && ((halo_factor <= maxhalo && big_enough) || force) && sole_consumer(n.inputs[0]) == cur_) {
                     PlanOp mb;
                     mb.kind = OpKind::MBCONV;
                     mb.name = "mbconv:" + pe.name.substr(pe.name.find(':') + 1) + "+" + n.name;
                     mb.out = op.out;
                     mb.a = pe.a;
-                    mb.w = pe.w; mb.bias = pe.bias;
+                    // expand filters repacked for the kernel: [C][KW] rows = Cin weights | bias | zeros, KW = 8-wide
+                    // K groups covering Cin + 1 columns (the bias rides along as one more K term)
+                    {
+                        const int64_t Kc = pe.gemm.K, KW = (Kc + 8) / 8 * 8;
+                        const std::vector<float> &w0 = plan_.consts[pe.w.id];
+                        std::vector<float> wpk((size_t)(Cin * KW), 0.0f);
+                        for (int64_t nn = 0; nn < Cin; nn++) {
+                            for (int64_t k = 0; k < Kc; k++) wpk[nn * KW + k] = w0[pe.w.offset + nn * Kc + k];
+                            if (pe.gemm.has_bias) wpk[nn * KW + Kc] = plan_.consts[pe.bias.id][pe.bias.offset + nn];
+                        }
+                        mb.w = Ref{Space::CONSTS, add_const(wpk), 0};
+                    }
+                    mb.bias = pe.bias;
                     mb.w2 = op.w; mb.bias2 = op.bias;
                     MbDesc &m = mb.mb;
                     m.H = (int32_t)H; m.W = (int32_t)W; m.Cin = pe.gemm.K; m.C = (int32_t)Cin; m.OH = (int32_t)OH; m.OW = (int32_t)OW;

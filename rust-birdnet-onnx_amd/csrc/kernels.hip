@@ -795,20 +795,58 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int j = wave; j < d.Cr; j += 16) {
-        const float *wr = w1 + (int64_t)j * d.C;
-        float acc = 0.f;
-        for (int c = lane; c < d.C; c += 64) acc = fmaf(ssm[c], wr[c], acc);
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-        if (lane == 0) hid[j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
+    // hidden units: wave w owns rows w, w+16, w+32, w+48 (then +64 ...) and streams them TOGETHER, so
+    // four independent weight loads are in flight per step instead of one dependent chain per row
+    // (at C=1152, Cr=48 the row-at-a-time loop cost ~25 us of pure load latency)
+    if ((d.C & 3) == 0) {
+        const int CV = d.C >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(ssm);
+        for (int j0 = wave; j0 < d.Cr; j0 += 64) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            const float4 *wr[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int j = j0 + 16 * r < d.Cr ? j0 + 16 * r : d.Cr - 1;
+                wr[r] = reinterpret_cast<const float4 *>(w1 + (int64_t)j * d.C);
+            }
+#pragma unroll 2
+            for (int cv = lane; cv < CV; cv += 64) {
+                const float4 sv = s4[cv];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float4 wv = wr[r][cv];
+                    a[r] = fmaf(sv.x, wv.x, a[r]);
+                    a[r] = fmaf(sv.y, wv.y, a[r]);
+                    a[r] = fmaf(sv.z, wv.z, a[r]);
+                    a[r] = fmaf(sv.w, wv.w, a[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float acc = a[r];
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+                const int j = j0 + 16 * r;
+                if (lane == 0 && j < d.Cr) hid[j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
+            }
+        }
+    } else {
+        for (int j = wave; j < d.Cr; j += 16) {
+            const float *wr = w1 + (int64_t)j * d.C;
+            float acc = 0.f;
+            for (int c = lane; c < d.C; c += 64) acc = fmaf(ssm[c], wr[c], acc);
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+            if (lane == 0) hid[j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
+        }
     }
     __syncthreads();
     // excite: 256 channels per block, 4 thread groups split the Cr terms (fixed-order combine)
     const int cl = threadIdx.x & 255, q = threadIdx.x >> 8;
     const int c = blockIdx.x * 256 + cl;
     float acc = 0.f;
-    if (c < d.C)
+    if (c < d.C) {
+#pragma unroll 4
         for (int j = q; j < d.Cr; j += 4) acc = fmaf(hid[j], w2t[(int64_t)j * d.C + c], acc);
+    }
     red[q * 256 + cl] = acc;
     __syncthreads();
     if (q == 0 && c < d.C) {
@@ -820,14 +858,24 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
 // ------------------------------------------------------------------ fused expand + depthwise
 // One block = one output tile (TOH x TOW pixels), ALL mid channels in chunks of 32:
 //   0. the input halo tile ((TOH-1)*S+K) x ((TOW-1)*S+K) pixels x Cin is staged in LDS ONCE
-//      (Cin <= 48: the whole K extent fits), rows outside the image are zero
-//   per chunk of 32 mid channels (its expand filters were prefetched into registers):
-//   1. expand on the matrix cores: rows = halo pixels, cols = 32 filters, K = Cin
-//   2. bias + activation, halo pixels outside the image forced to 0 (the depthwise conv pads the
-//      EXPANDED tensor), written to LDS as [halo pixel][32 channels]
-//   3. depthwise K x K from LDS (lane = channel, conflict free), bias + activation, NHWC store,
-//      per-tile channel sums for a following squeeze-excite (fixed-order LDS reduction)
-// The expanded tensor never exists in HBM.  grid (tiles, 1, batch), 256 threads, dynamic LDS.
+//      (Cin <= 44: the whole K extent fits).  Pixels outside the image are zero rows.  Column Cin
+//      of a row holds 1 for pixels inside the image and 0 outside: the expand bias rides along as
+//      one more K term, so a pixel outside the image expands to exactly act(0) = 0 -- which is what
+//      the depthwise conv's zero padding of the EXPANDED tensor needs -- with no per-element mask
+//      or bias add in the epilogue (the planner only fuses activations with act(0) == 0)
+//   per chunk of 32 mid channels:
+//   1. expand on the matrix cores: rows = halo pixels (A from LDS), cols = 32 filters whose
+//      B operands come STRAIGHT from global memory into registers (lane = filter, one float4 per
+//      8-wide K group, bias in the slot of column Cin), prefetched one chunk ahead; the m-tiles
+//      rotate over the waves from chunk to chunk so the odd tile does not always load one SIMD
+//   2. activation, written to LDS [pixel][32]
+//   3. depthwise K x K from LDS: lane = channel (conflict free), each lane slides the window
+//      along PPG consecutive pixels of one output row, so every LDS value is read once per row
+//      tap instead of once per output; bias + activation, NHWC store
+//   after the loop: per-tile channel sums for a following squeeze-excite (fixed order)
+// The expanded tensor never exists in HBM.  grid (tiles, 1, batch), 256 threads, dynamic LDS;
+// two barriers per chunk.
+constexpr int MB_MAX_NG = 6;  // Cin + 1 <= 48
 template <int K, int S>
 __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                                const float *__restrict__ w1, const float *__restrict__ b1,
@@ -836,73 +884,82 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
     constexpr int TOH = S == 1 ? 8 : 4, TOW = S == 1 ? 16 : 8;
     constexpr int IHT = (TOH - 1) * S + K, IWT = (TOW - 1) * S + K, HP = IHT * IWT;
     constexpr int MT = (HP + 31) / 32, MP = MT * 32;
-    constexpr int TPW = (MT + 3) / 4;  // m-tiles per wave
-    constexpr int PPG = TOH * TOW / 8;  // output pixels per lane group in the depthwise phase
+    constexpr int TPW = (MT + 3) / 4;   // m-tiles per wave
+    constexpr int PPG = TOH * TOW / 8;  // consecutive output pixels (of one row) per lane group
+    constexpr int SEG = TOW / PPG;      // lane groups per output row
+    constexpr int IWS = (PPG - 1) * S + K;  // input columns one lane group touches
+    static_assert(TOW % PPG == 0, "a lane group must stay inside one output row");
     extern __shared__ __align__(16) float msm[];
-    const int KS = (d.Cin + 7) / 8 * 8 + 4;  // LDS row stride (floats): (KS/4) is odd -> conflict-free b128 reads
-    const int ng = (d.Cin + 7) / 8;           // 8-wide K groups holding data
-    float *Xs = msm;                           // [MP][KS]
-    float *Ws = Xs + MP * KS;                  // [32][KS]
-    float *Es = Ws + 32 * KS;                  // [MP][32]
-    float *red = Es + MP * 32;                 // [8][32]
+    const int ng = (d.Cin + 8) / 8;  // 8-wide K groups holding data (Cin columns + the ones column)
+    const int KS = ng * 8 + 4;       // LDS row stride (floats): (KS/4) is odd -> conflict-free b128 reads
+    float *Xs = msm;             // [MP][KS]
+    float *Es = Xs + MP * KS;    // [MP][32]
+    float *red = Es + MP * 32;   // [nchunks][8][32]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
     const int oh0 = ty * TOH, ow0 = tx * TOW;
     const int ih0 = oh0 * S - d.pt, iw0 = ow0 * S - d.pl;
     const int64_t b = blockIdx.z;
     const float *xin = in + b * d.in_bs;
-    const int CV = (d.Cin + 3) / 4;  // float4 per pixel
+    const int CV = d.Cin >> 2;  // float4 per pixel (Cin % 4 == 0)
+    const int nchunks = (d.C + 31) / 32;
 
-    // ---- 0. stage the halo tile (all loads issued before the first is consumed, 4 at a time)
-    for (int f0 = tid; f0 < MP * CV; f0 += 256 * 4) {
-        float4 xv[4];
-        bool okv[4];
+    // expand filters of a chunk: lane (lr, lh) holds columns 8g + 4lh .. +3 of filter c0 + lr for
+    // every K group g.  w1 is the planner's padded repack [C][ng*8] = weights | bias | zeros, so
+    // these are plain loads with nothing depending on them until the matrix instructions.
+    float4 bw[MB_MAX_NG], bnx[MB_MAX_NG];
+    auto fetch_b = [&](float4 (&dst)[MB_MAX_NG], int c0) {
+        const int n = c0 + lr < d.C ? c0 + lr : d.C - 1;
+        const float *wr = w1 + (int64_t)n * (ng * 8) + 4 * lh;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int f = f0 + i * 256;
-            const int r = f / CV, cv = f - r * CV;
-            const int iy = r / IWT, ix = r - iy * IWT;
-            const int ih = ih0 + iy, iw = iw0 + ix;
-            okv[i] = f < MP * CV && r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
-            const int ihc = ih < 0 ? 0 : (ih >= d.H ? d.H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= d.W ? d.W - 1 : iw);
-            xv[i] = *reinterpret_cast<const float4 *>(xin + ((int64_t)ihc * d.W + iwc) * d.Cin + (f < MP * CV ? cv * 4 : 0));
-        }
+        for (int g = 0; g < MB_MAX_NG; g++)
+            if (g < ng) dst[g] = *reinterpret_cast<const float4 *>(wr + 8 * g);
+    };
+    fetch_b(bw, 0);
+
+    // ---- 0. stage the halo tile: PSTEP pixels per pass, lane = (pixel, float4 of its channels);
+    //         four passes' loads (clamped addresses, never predicated) are in flight together,
+    //         pixels outside the image are zeroed when the values go to LDS
+    {
+        const int PSTEP = 256 / CV;
+        const int p0 = tid / CV, cv = tid - p0 * CV;
+        const bool lane_on = p0 < PSTEP;
+        for (int r0 = p0; r0 < MP; r0 += 4 * PSTEP) {
+            float4 xv[4];
+            bool okv[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int f = f0 + i * 256;
-            if (f < MP * CV) {
-                const int r = f / CV, cv = f - r * CV;
-                *reinterpret_cast<float4 *>(Xs + r * KS + cv * 4) = okv[i] ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < 4; i++) {
+                const int r = r0 + i * PSTEP;
+                const int iy = r / IWT, ix = r - iy * IWT;
+                const int ih = ih0 + iy, iw = iw0 + ix;
+                okv[i] = r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+                const int ihc = ih < 0 ? 0 : (ih >= d.H ? d.H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= d.W ? d.W - 1 : iw);
+                xv[i] = *reinterpret_cast<const float4 *>(xin + ((int64_t)ihc * d.W + iwc) * d.Cin + (lane_on ? cv * 4 : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = r0 + i * PSTEP;
+                if (lane_on && r < MP) {
+                    *reinterpret_cast<float4 *>(Xs + r * KS + cv * 4) = okv[i] ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cv == 0) {  // ones column + zero K padding of this row
+                        float *xr = Xs + r * KS + d.Cin;
+                        *reinterpret_cast<float4 *>(xr) = make_float4(okv[i] ? 1.f : 0.f, 0.f, 0.f, 0.f);
+                        if ((CV & 1) == 0) *reinterpret_cast<float4 *>(xr + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
             }
         }
     }
-    // zero the K padding columns [Cin, ng*8) once (Cin % 8 == 4 only)
-    if (d.Cin % 8) {
-        for (int r = tid; r < MP; r += 256) *reinterpret_cast<float4 *>(Xs + r * KS + d.Cin) = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < 32) *reinterpret_cast<float4 *>(Ws + tid * KS + d.Cin) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // expand filters of chunk 0 -> registers (32 rows x CV float4 <= 384 float4: <= 2 per thread)
-    float4 wreg0, wreg1;
-    const int wn0 = tid / CV, wc0 = tid - wn0 * CV, wn1 = (tid + 256) / CV, wc1 = (tid + 256) - wn1 * CV;
-    const bool wv0 = tid < 32 * CV, wv1 = tid + 256 < 32 * CV;
-#define MB_FETCH_W(C0)                                                                                                             \
-    do {                                                                                                                         \
-        const int n0_ = (C0) + wn0 < d.C ? (C0) + wn0 : d.C - 1, n1_ = (C0) + wn1 < d.C ? (C0) + wn1 : d.C - 1;                  \
-        wreg0 = *reinterpret_cast<const float4 *>(w1 + (int64_t)(wv0 ? n0_ : 0) * d.Cin + (wv0 ? wc0 * 4 : 0));                  \
-        wreg1 = *reinterpret_cast<const float4 *>(w1 + (int64_t)(wv1 ? n1_ : 0) * d.Cin + (wv1 ? wc1 * 4 : 0));                  \
-    } while (0)
-    MB_FETCH_W(0);
-    const int c = tid & 31, g = tid >> 5;
-    float *ob = out + b * d.out_bs;
-    const int nchunks = (d.C + 31) / 32;
+    // depthwise role: lane = channel, group g8 = PPG consecutive pixels of output row oy
+    const int c = tid & 31, g8 = tid >> 5;
+    const int oy = g8 / SEG, ox0 = (g8 - oy * SEG) * PPG;
+    const float *ebase = Es + ((oy * S) * IWT + ox0 * S) * 32 + c;
+    float *ob = out + b * d.out_bs + ((int64_t)(oh0 + oy) * d.OW + ow0 + ox0) * d.C;
+    const bool row_ok = oh0 + oy < d.OH;
+    const bool seg_full = row_ok && ow0 + ox0 + PPG <= d.OW;
 
     for (int ch = 0; ch < nchunks; ch++) {
         const int c0 = ch * 32;
-        __syncthreads();  // Ws / Es of the previous chunk consumed; first pass: Xs complete
-        if (wv0) *reinterpret_cast<float4 *>(Ws + wn0 * KS + wc0 * 4) = wreg0;
-        if (wv1) *reinterpret_cast<float4 *>(Ws + wn1 * KS + wc1 * 4) = wreg1;
-        __syncthreads();
-        if (ch + 1 < nchunks) MB_FETCH_W(c0 + 32);  // next chunk's filters in flight during this chunk
         // depthwise weights / bias of this chunk (consumed after the expand)
         const int cg = c0 + c;
         const bool cact = cg < d.C;
@@ -910,70 +967,83 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
 #pragma unroll
         for (int q = 0; q < K * K; q++) wd[q] = w2[q * d.C + (cact ? cg : d.C - 1)];
         const float bias2 = d.has_bias2 ? b2[cact ? cg : d.C - 1] : 0.0f;
-        const float bv = d.has_bias1 ? b1[c0 + lr < d.C ? c0 + lr : d.C - 1] : 0.0f;
+        if (ch + 1 < nchunks) fetch_b(bnx, c0 + 32);  // next chunk's filters in flight during this chunk
+        __syncthreads();  // Es of the previous chunk consumed; first pass: Xs complete
 
         // ---- 1+2. expand -> Es
+        const int wrole = (wave - ch) & 3;
 #pragma unroll
         for (int t = 0; t < TPW; t++) {
-            const int mt = wave + 4 * t;
+            const int mt = wrole + 4 * t;
             if (mt < MT) {
                 floatx16 acc[1];
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[0][r] = 0.0f;
-                mfma_ktile_partial<1>(Xs + (mt * 32 + lr) * KS + 4 * lh, Ws + lr * KS + 4 * lh, acc, ng);
+                const float *ap = Xs + (mt * 32 + lr) * KS + 4 * lh;
 #pragma unroll
-                for (int reg = 0; reg < 16; reg++) acc[0][reg] += bv;
+                for (int g = 0; g < MB_MAX_NG; g++)
+                    if (g < ng) {
+                        const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bw[g].x, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bw[g].y, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bw[g].z, acc[0], 0, 0, 0);
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bw[g].w, acc[0], 0, 0, 0);
+                    }
                 act_tile<1>(d.act1, d.p0_1, d.p1_1, acc);
+                float *ep = Es + (mt * 32 + 4 * lh) * 32 + lr;
 #pragma unroll
-                for (int reg = 0; reg < 16; reg++) {
-                    const int r = mt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                    const int iy = r / IWT, ix = r - iy * IWT;
-                    const int ih = ih0 + iy, iw = iw0 + ix;
-                    const bool ok = r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
-                    Es[r * 32 + lr] = ok ? acc[0][reg] : 0.0f;
-                }
+                for (int reg = 0; reg < 16; reg++) ep[((reg & 3) + 8 * (reg >> 2)) * 32] = acc[0][reg];
             }
         }
         __syncthreads();
-        // ---- 3. depthwise from LDS: lane = channel, 8 lane groups share the tile's pixels
-        float sum = 0.0f;
+        // ---- 3. depthwise from LDS, window sliding along the row
         float ov[PPG];
 #pragma unroll
-        for (int q = 0; q < PPG; q++) {
-            const int p = g * PPG + q;  // pixel index inside the tile, row-major
-            const int oy = p / TOW, ox = p - oy * TOW;
-            float a = bias2;
+        for (int q = 0; q < PPG; q++) ov[q] = bias2;
 #pragma unroll
-            for (int ky = 0; ky < K; ky++)
+        for (int ky = 0; ky < K; ky++) {
 #pragma unroll
-                for (int kx = 0; kx < K; kx++) a = fmaf(Es[((oy * S + ky) * IWT + ox * S + kx) * 32 + c], wd[ky * K + kx], a);
-            ov[q] = a;
+            for (int ix = 0; ix < IWS; ix++) {
+                const float v = ebase[(ky * IWT + ix) * 32];
+#pragma unroll
+                for (int kx = 0; kx < K; kx++)
+                    if (ix - kx >= 0 && (ix - kx) % S == 0 && (ix - kx) / S < PPG)
+                        ov[(ix - kx) / S] = fmaf(v, wd[ky * K + kx], ov[(ix - kx) / S]);
+            }
         }
         act_array<PPG>(d.act2, d.p0_2, d.p1_2, ov);
+        float sum = 0.0f;
+        if (seg_full && c0 + 32 <= d.C) {  // block-uniform per lane group: no per-pixel predicates
 #pragma unroll
-        for (int q = 0; q < PPG; q++) {
-            const int p = g * PPG + q;
-            const int oy = p / TOW, ox = p - oy * TOW;
-            const int oh = oh0 + oy, ow = ow0 + ox;
-            if (cact && oh < d.OH && ow < d.OW) {
-                ob[((int64_t)oh * d.OW + ow) * d.C + cg] = ov[q];
+            for (int q = 0; q < PPG; q++) {
+                ob[(int64_t)q * d.C + cg] = ov[q];
                 sum += ov[q];
             }
-        }
-        if (d.has_gap) {
-            red[g * 32 + c] = sum;
-            __syncthreads();
-            if (g == 0 && cact) {
-                float t = red[c];
+        } else {
 #pragma unroll
-                for (int y = 1; y < 8; y++) t += red[y * 32 + c];
-                gap[b * d.gap_bs + (int64_t)blockIdx.x * d.C + cg] = t;
+            for (int q = 0; q < PPG; q++) {
+                if (cact && row_ok && ow0 + ox0 + q < d.OW) {
+                    ob[(int64_t)q * d.C + cg] = ov[q];
+                    sum += ov[q];
+                }
             }
+        }
+        red[(ch * 8 + g8) * 32 + c] = sum;
+#pragma unroll
+        for (int g = 0; g < MB_MAX_NG; g++) bw[g] = bnx[g];
+    }
+    if (d.has_gap) {
+        __syncthreads();
+        for (int cc = tid; cc < d.C; cc += 256) {
+            const float *rp = red + (cc >> 5) * 256 + (cc & 31);
+            float t = rp[0];
+#pragma unroll
+            for (int y = 1; y < 8; y++) t += rp[y * 32];
+            gap[b * d.gap_bs + (int64_t)blockIdx.x * d.C + cc] = t;
         }
     }
 }
 
-#undef MB_FETCH_W
 // ------------------------------------------------------------------ depthwise conv
 // one lane = one output pixel x 4 channels.  grid (ceil(OH*OW*C4/256), batch)
 template <int VEC>
@@ -1351,8 +1421,9 @@ size_t mbconv_lds_bytes(const MbDesc &d) {
     const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
     const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
     const int mp = (hp + 31) / 32 * 32;
-    const int ks = (d.Cin + 7) / 8 * 8 + 4;
-    return (size_t)(mp * ks + 32 * ks + mp * 32 + 8 * 32) * sizeof(float);
+    const int ks = (d.Cin + 8) / 8 * 8 + 4;  // Cin columns + the ones column, padded to 8-wide K groups
+    const int nchunks = (d.C + 31) / 32;
+    return (size_t)(mp * ks + mp * 32 + nchunks * 8 * 32) * sizeof(float);
 }
 
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,

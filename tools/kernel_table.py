@@ -41,7 +41,7 @@ def main():
     total = sum(x[1] for x in acc)
     print(f"{len(acc)} launches, {total:.1f} us per batch of {a.batch}  ({a.batch / total * 1e6:.0f} seg/s serial)")
     for nm, us, macs, byts in sorted(acc, key=lambda x: -x[1])[:a.top]:
-        print(f"{us:9.1f} us  {2 * macs * a.batch / us / 1e6 if us else 0:8.2f} TF/s  {byts * a.batch / us / 1e3 if us else 0:8.1f} GB/s  {nm}")
+        print(f"{us:9.1f} us  {2 * macs / us / 1e6 if us else 0:8.2f} TF/s  {byts / us / 1e3 if us else 0:8.1f} GB/s  {nm}")
     os.unlink(path)
 
 
