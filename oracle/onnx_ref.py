@@ -326,6 +326,25 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
                     r = r.unsqueeze(d)
             elif op == "Concat":
                 r = torch.cat(i, dim=int(a["axis"]))
+            elif op == "Pad":
+                # ONNX Pad, constant mode: pads = [begin_0..begin_{r-1}, end_0..end_{r-1}] (attribute before
+                # opset 11, input after), optional fill value and axes inputs
+                if a.get("mode", "constant") not in ("constant", b"constant"):
+                    raise NotImplementedError("Pad mode " + str(a.get("mode")))
+                if "pads" in a:
+                    pads, value, axes = [int(p) for p in a["pads"]], float(a.get("value", 0.0)), None
+                else:
+                    pads = [int(p) for p in i[1].tolist()]
+                    value = float(i[2].reshape(-1)[0]) if len(i) > 2 and i[2] is not None else 0.0
+                    axes = [int(p) for p in i[3].tolist()] if len(i) > 3 and i[3] is not None else None
+                rank = i[0].dim()
+                axes = axes if axes is not None else list(range(rank))
+                lo, hi = [0] * rank, [0] * rank
+                for k, ax in enumerate(axes):
+                    lo[ax % rank], hi[ax % rank] = pads[k], pads[len(axes) + k]
+                shape = [d + l + h for d, l, h in zip(i[0].shape, lo, hi)]
+                r = torch.full(shape, value, dtype=i[0].dtype)
+                r[tuple(slice(l, l + d) for l, d in zip(lo, i[0].shape))] = i[0]
             elif op == "Slice":
                 if "starts" in a:
                     starts, ends, axes = a["starts"], a["ends"], a.get("axes")

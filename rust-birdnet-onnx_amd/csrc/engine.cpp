@@ -562,6 +562,7 @@ class Builder {
         if (t == "Reshape" || t == "Flatten" || t == "Squeeze" || t == "Unsqueeze") return lower_reshape_like(n);
         if (t == "Slice") return lower_slice(n);
         if (t == "Concat") return lower_concat(n);
+        if (t == "Pad") return lower_pad(n);
         if (t == "Conv") return lower_conv(n);
         if (t == "MatMul" || t == "Gemm") return lower_matmul(n);
         if (t == "BatchNormalization") return lower_batchnorm(n);
@@ -887,6 +888,56 @@ class Builder {
             pos += v.dims[axis];
         }
         define(n.outputs[0], out);
+    }
+
+    // Padded copy of an activation (per-sample dims): the whole result is filled with `value`, then
+    // the interior is overwritten by the input.  Two strided elementwise launches, no new kernel.
+    Val pad_copy(Val v, const Dims &lo, const Dims &hi, float value, const std::string &name) {
+        if (v.is_const) v = upload_as_activation(v);
+        if (v.gate_storage >= 0) v = apply_gate(v, name);
+        Dims od = v.dims;
+        for (size_t i = 0; i < od.size(); i++) od[i] += lo[i] + hi[i];
+        Val out = new_act(od, strides_for_order(od, phys_order(v)));
+        Ref fill{Space::CONSTS, add_const(std::vector<float>{value}), 0};
+        emit_elt("pad.fill:" + name, out, fill, Dims(od.size(), 0), 0, Ref{}, {}, 0, BIN_NONE, ActSpec{});
+        Val slot = out;
+        slot.dims = v.dims;
+        for (size_t i = 0; i < od.size(); i++) slot.offset += lo[i] * out.strides[i];
+        emit_elt("pad.copy:" + name, slot, ref_of(v), v.strides, batch_stride(v), Ref{}, {}, 0, BIN_NONE, ActSpec{});
+        return out;
+    }
+
+    // ONNX Pad, constant mode (pads as attribute for opset < 11, as input otherwise)
+    void lower_pad(const OnnxNode &n) {
+        Val x = get(n, 0);
+        if (n.attr_s("mode", "constant") != "constant") unsupported(n, "only constant-mode Pad is supported");
+        std::vector<int64_t> pads = n.attr_ints("pads");
+        float value = n.attr_f("value", 0.0f);
+        if (pads.empty()) {
+            const Val *pv = opt(n, 1);
+            if (!pv || !pv->is_const) unsupported(n, "Pad needs constant pads");
+            pads = pv->i;
+            const Val *cv = opt(n, 2);
+            if (cv) { if (!const_scalar(*cv, value)) unsupported(n, "Pad needs a constant fill value"); }
+        }
+        const size_t r = x.dims.size() + 1;  // with the batch dimension
+        std::vector<int64_t> axes;
+        if (const Val *av = opt(n, 3)) {
+            if (!av->is_const) unsupported(n, "Pad needs constant axes");
+            axes = av->i;
+        } else {
+            for (size_t i = 0; i < r; i++) axes.push_back((int64_t)i);
+        }
+        if (pads.size() != 2 * axes.size()) unsupported(n, "pads/axes size mismatch");
+        Dims lo(x.dims.size(), 0), hi(x.dims.size(), 0);
+        for (size_t k = 0; k < axes.size(); k++) {
+            int64_t ax = axes[k] < 0 ? axes[k] + (int64_t)r : axes[k];
+            const int64_t p0 = pads[k], p1 = pads[axes.size() + k];
+            if (p0 < 0 || p1 < 0) unsupported(n, "negative pads");
+            if (ax == 0) { if (p0 || p1) unsupported(n, "Pad along the batch dimension"); continue; }
+            lo[ax - 1] = p0; hi[ax - 1] = p1;
+        }
+        define(n.outputs[0], pad_copy(x, lo, hi, value, n.name));
     }
 
     bool unary_spec(const OnnxNode &n, ActSpec &a) {
@@ -1404,6 +1455,17 @@ class Builder {
         if (has_res) op.res = ref_of(res);
 
         bool unit_dil = dil[0] == 1 && dil[1] == 1;
+        // a padded 1-D convolution with a long filter (STFT / learned front ends) is worth a padded copy
+        // of its input: it then runs as the overlapping-rows GEMM on the matrix cores instead of the
+        // direct kernel (Perch-style front end: 14 ms -> GEMM time at batch 128)
+        if (groups == 1 && kh == 1 && H == 1 && unit_dil && pt == 0 && pb == 0 && (pl || pr) && kw * Cin >= 64) {
+            if (gate_storage >= 0) { Val gx = x; gx.gate_storage = gate_storage; x = apply_gate(gx, n.name); gate_storage = -1; }
+            Dims lo(x.dims.size(), 0), hi(x.dims.size(), 0);
+            lo.back() = pl; hi.back() = pr;
+            x = pad_copy(x, lo, hi, 0.0f, n.name);
+            W += pl + pr;
+            pl = pr = 0;
+        }
         bool no_pad = pt == 0 && pl == 0 && pb == 0 && pr == 0;
         const bool gemm_path = groups == 1 && kh == 1 && unit_dil && no_pad && (H == 1 || (kw == 1 && strides[0] == 1 && strides[1] == 1));
         if (gate_storage >= 0 && !(gemm_path && kw == 1)) {  // only the 1x1 GEMM folds the SE gate

@@ -23,13 +23,22 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// Logistic function inside the network (SE gates, SiLU): hardware exp2 and reciprocal
+// (v_exp_f32 / v_rcp_f32, ~1 ulp each; the argument scaling adds |x| * 2^-24 relative), 6
+// instructions instead of ~30 for the IEEE expf + division.  Saturates correctly: x -> -inf gives
+// rcp(inf) = 0, x -> +inf gives rcp(1) = 1.  The CONFIDENCE sigmoid of the post-processing
+// (topk.hip) does not use this: it is bit-exact against the reference's f32 sigmoid.
+__device__ __forceinline__ float net_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+
 __device__ __forceinline__ float act_apply(int act, float x, float p0, float p1) {
     switch (act) {
         case ACT_NONE: return x;
         case ACT_RELU: return fmaxf(x, 0.0f);
         case ACT_CLIP: return fminf(fmaxf(x, p0), p1);
-        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
-        case ACT_SILU: return x / (1.0f + expf(-x));
+        case ACT_SIGMOID: return net_sigmoid(x);
+        case ACT_SILU: return x * net_sigmoid(x);
         case ACT_HSIGMOID: return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f);
         case ACT_HSWISH: return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case ACT_LEAKY: return x >= 0.0f ? x : p0 * x;
@@ -452,8 +461,8 @@ __device__ __forceinline__ void act_array(int act, float p0, float p1, float (&v
     if (act == ACT_NONE) return;
     if (act == ACT_RELU) map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); });
     else if (act == ACT_CLIP) map_array<N>(v, [=](float x) { return fminf(fmaxf(x, p0), p1); });
-    else if (act == ACT_SILU) map_array<N>(v, [](float x) { return x / (1.0f + expf(-x)); });
-    else if (act == ACT_SIGMOID) map_array<N>(v, [](float x) { return 1.0f / (1.0f + expf(-x)); });
+    else if (act == ACT_SILU) map_array<N>(v, [](float x) { return x * net_sigmoid(x); });
+    else if (act == ACT_SIGMOID) map_array<N>(v, [](float x) { return net_sigmoid(x); });
     else if (act == ACT_HSWISH) map_array<N>(v, [](float x) { return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f); });
     else if (act == ACT_HSIGMOID) map_array<N>(v, [=](float x) { return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f); });
     else if (act == ACT_LEAKY) map_array<N>(v, [=](float x) { return x >= 0.0f ? x : p0 * x; });
@@ -465,8 +474,8 @@ __device__ __forceinline__ void act_tile(int act, float p0, float p1, floatx16 (
     if (act == ACT_NONE) return;
     if (act == ACT_RELU) map_tile<NT>(acc, [](float x) { return fmaxf(x, 0.0f); });
     else if (act == ACT_CLIP) map_tile<NT>(acc, [=](float x) { return fminf(fmaxf(x, p0), p1); });
-    else if (act == ACT_SILU) map_tile<NT>(acc, [](float x) { return x / (1.0f + expf(-x)); });
-    else if (act == ACT_SIGMOID) map_tile<NT>(acc, [](float x) { return 1.0f / (1.0f + expf(-x)); });
+    else if (act == ACT_SILU) map_tile<NT>(acc, [](float x) { return x * net_sigmoid(x); });
+    else if (act == ACT_SIGMOID) map_tile<NT>(acc, [](float x) { return net_sigmoid(x); });
     else if (act == ACT_HSWISH) map_tile<NT>(acc, [](float x) { return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f); });
     else if (act == ACT_HSIGMOID) map_tile<NT>(acc, [=](float x) { return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f); });
     else if (act == ACT_LEAKY) map_tile<NT>(acc, [=](float x) { return x >= 0.0f ? x : p0 * x; });

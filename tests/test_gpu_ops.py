@@ -121,6 +121,24 @@ def test_conv1d_with_padding(bn):
     assert_close(got, ref, "padded conv1d")
 
 
+@pytest.mark.parametrize("style", ["input", "attribute", "axes"])
+def test_pad_constant(bn, style):
+    """ONNX Pad (constant mode) on a [B, 6, 40, 600] view: spatial and channel pads, non-zero fill."""
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        if style == "attribute":
+            y = g.node("Pad", [x], pads=[0, 1, 2, 3, 0, 0, 1, 5], value=-1.5)
+        elif style == "input":
+            y = g.node("Pad", [x, i64(0, 1, 2, 3, 0, 0, 1, 5), g.const(np.array(-1.5, dtype=np.float32))])
+        else:
+            y = g.node("Pad", [x, i64(2, 3, 1, 5), g.const(np.array(-1.5, dtype=np.float32)), i64(2, -1)])
+        return g.node("Relu", [g.node("Mul", [y, g.const(np.array(-1.0, dtype=np.float32))])])
+    c = 7 if style != "axes" else 6
+    got, ref = run_both(bn, op_graph(build, [c, 43, 608], in_reshape=[6, 40, 600]), batch=3)
+    assert_close(got, ref, f"pad {style}")
+    assert np.count_nonzero(ref == 1.5) > 0  # the fill value is visible in the result
+
+
 @pytest.mark.parametrize("k,n,style", [(1024, 6522, "gemm"), (96, 10, "matmul"), (130, 33, "matmul_bias"), (7, 5, "gemm_nt")])
 def test_dense_head(bn, k, n, style):
     rng = np.random.default_rng(8)
