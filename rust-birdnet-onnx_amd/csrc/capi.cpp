@@ -747,7 +747,9 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 snprintf(line, sizeof(line), " %dx%dx%d->%dx%dx%d k=%dx%d s=%d g=%d act=%d", op.conv.H, op.conv.W, op.conv.Cin, op.conv.OH, op.conv.OW, op.conv.Cout, op.conv.kh, op.conv.kw, op.conv.sh, op.conv.groups, op.conv.act);
                 extra = line;
             } else if (op.kind == OpKind::ELT) {
-                snprintf(line, sizeof(line), " n=%lld nd=%d stages=%d bin0=%d act0=%d", (long long)op.elt.per_sample, op.elt.nd, op.elt.nstages, op.elt.st[0].bin, op.elt.st[0].act);
+                int w = snprintf(line, sizeof(line), " n=%lld nd=%d stages=%d bin0=%d act0=%d size/so/sa=", (long long)op.elt.per_sample, op.elt.nd, op.elt.nstages, op.elt.st[0].bin, op.elt.st[0].act);
+                for (int q = 0; q < op.elt.nd && w < (int)sizeof(line) - 40; q++)
+                    w += snprintf(line + w, sizeof(line) - w, "%s%lld/%lld/%lld", q ? "," : "", (long long)op.elt.size[q], (long long)op.elt.so[q], (long long)op.elt.sa[q]);
                 extra = line;
             } else if (op.kind == OpKind::MBCONV) {
                 snprintf(line, sizeof(line), " %dx%dx%d->(%d)->%dx%dx%d k=%d s=%d tiles=%dx%d squeeze=%d", op.mb.H, op.mb.W, op.mb.Cin, op.mb.C, op.mb.OH, op.mb.OW, op.mb.C, op.mb.k, op.mb.s, op.mb.tiles_y, op.mb.tiles_x, op.mb.has_gap);

@@ -1735,7 +1735,19 @@ class Builder {
                 bool flat_prod = pe.nd == 1 && pe.so[0] == 1 && pe.sa[0] == 1 && pe.per_sample == ce.per_sample;
                 for (int k = 0; flat_prod && k < pe.nstages; k++)
                     flat_prod = pe.st[k].bin == BIN_NONE || pe.st[k].sb[0] == 0 || pe.st[k].sb[0] == 1;
-                if (!same && !flat_prod) continue;
+                // (C) the consumer is a flat map over the dense intermediate: it adopts the producer's index
+                //     space (its own strides scale by the producer's row-major runs)
+                bool flat_cons = !same && !flat_prod && ce.nd == 1 && ce.sa[0] == 1 && delta == 0 && pe.per_sample == ce.per_sample;
+                int64_t runs[ELT_MAX_DIMS] = {0};
+                if (flat_cons) {
+                    int64_t run = 1;
+                    for (int k = pe.nd - 1; k >= 0; k--) {
+                        if (pe.size[k] != 1 && pe.so[k] != run) flat_cons = false;
+                        runs[k] = run;
+                        run *= pe.size[k];
+                    }
+                }
+                if (!same && !flat_prod && !flat_cons) continue;
                 // the consumer must not also use the intermediate as a stage operand
                 {
                     bool clash = false;
@@ -1753,6 +1765,10 @@ class Builder {
                 if (same) {
                     for (int k = 0; k < pe.nd; k++) fe.sa[k] = pe.sa[k];
                     for (int k = 0; k < pe.nstages; k++) { fe.st[k] = pe.st[k]; fused.eb[k] = prod.eb[k]; }
+                } else if (flat_cons) {
+                    fe.nd = pe.nd;
+                    for (int k = 0; k < pe.nd; k++) { fe.size[k] = pe.size[k]; fe.sa[k] = pe.sa[k]; fe.so[k] = ce.so[0] * runs[k]; }
+                    for (int k = 0; k < pe.nstages; k++) { fe.st[k] = pe.st[k]; fused.eb[k] = prod.eb[k]; }
                 } else {
                     // flat producer: its primary operand and every full-size stage operand are addressed
                     // with the strides the consumer used for the intermediate (fe.sa is already ce.sa)
@@ -1765,11 +1781,48 @@ class Builder {
                         for (int q = 0; q < ELT_MAX_DIMS; q++) fe.st[k].sb[q] = (q < ce.nd && full) ? ce.sa[q] : 0;
                     }
                 }
-                for (int k = 0; k < ce.nstages; k++) { fe.st[pe.nstages + k] = ce.st[k]; fused.eb[pe.nstages + k] = cons.eb[k]; }
+                for (int k = 0; k < ce.nstages; k++) {
+                    fe.st[pe.nstages + k] = ce.st[k];
+                    fused.eb[pe.nstages + k] = cons.eb[k];
+                    if (flat_cons)
+                        for (int q = 0; q < ELT_MAX_DIMS; q++) fe.st[pe.nstages + k].sb[q] = q < pe.nd ? ce.st[k].sb[0] * runs[q] : 0;
+                }
                 fused.bytes = prod.bytes + cons.bytes - 8.0 * (double)pe.per_sample;  // the intermediate never touches memory
                 plan_.ops[j] = fused;
                 plan_.ops.erase(plan_.ops.begin() + u[0]);
                 changed = true;
+            }
+            // (D) a stage operand that is the square x*x of some view, produced only for this stage, is
+            //     read straight from x and squared in the consumer (|z|^2 = re*re + im*im in one launch)
+            for (size_t j = 0; j < plan_.ops.size() && !changed; j++) {
+                PlanOp &cons = plan_.ops[j];
+                if (cons.kind != OpKind::ELT) continue;
+                EltDesc &ce = cons.elt;
+                for (int k = 0; k < ce.nstages && !changed; k++) {
+                    EltStage &cs = ce.st[k];
+                    const Ref &br = cons.eb[k];
+                    if (cs.bin == BIN_NONE || cs.bsq || br.space != Space::ARENA || plan_.storages[br.id].pinned) continue;
+                    const auto &u = users[br.id];
+                    if (u.size() != 2 || u[1] != (int)j) continue;
+                    const PlanOp &prod = plan_.ops[u[0]];
+                    const EltDesc &pe = prod.elt;
+                    if (prod.kind != OpKind::ELT || prod.out.space != Space::ARENA || prod.out.id != br.id || prod.out.offset != br.offset) continue;
+                    if (pe.nstages != 1 || pe.st[0].bin != BIN_MUL || pe.st[0].act != ACT_NONE || pe.st[0].bsq) continue;
+                    if (prod.eb[0].space != prod.a.space || prod.eb[0].id != prod.a.id || prod.eb[0].offset != prod.a.offset || pe.st[0].bb != pe.ba) continue;
+                    if (cons.a.space == Space::ARENA && cons.a.id == br.id) continue;
+                    bool match = pe.nd == ce.nd && pe.bo == cs.bb;
+                    for (int q = 0; match && q < pe.nd; q++)
+                        match = pe.size[q] == ce.size[q] && pe.so[q] == cs.sb[q] && pe.st[0].sb[q] == pe.sa[q];
+                    if (!match) continue;
+                    cons.eb[k] = prod.a;
+                    for (int q = 0; q < ELT_MAX_DIMS; q++) cs.sb[q] = q < pe.nd ? pe.sa[q] : 0;
+                    cs.bb = pe.ba;
+                    cs.bsq = 1;
+                    cons.name += "+sq(" + prod.name + ")";
+                    cons.bytes += prod.bytes - 12.0 * (double)pe.per_sample + 4.0 * (double)pe.per_sample;
+                    plan_.ops.erase(plan_.ops.begin() + u[0]);
+                    changed = true;
+                }
             }
         }
         recompute_liveness();

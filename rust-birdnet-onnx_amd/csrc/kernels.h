@@ -54,6 +54,8 @@ struct EltStage {
     float p0, p1;
     int64_t sb[ELT_MAX_DIMS];
     int64_t bb;   // batch stride of the operand (0 for constants)
+    int32_t bsq;  // 1: the operand is squared before the binary op (|z|^2 = re*re + im*im in one launch)
+    int32_t reserved;
 };
 struct EltDesc {
     int32_t nd;

@@ -31,6 +31,23 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float net_sigmoid(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
 }
+// exp / log / pow of the front end's dynamic-range compression (power spectrum -> x^p, log-mel):
+// hardware exp2 / log2 (v_exp_f32 / v_log_f32, ~1 ulp each).  pow(x, p) = exp2(p * log2 x) for
+// x > 0 has a relative error of about |p * log2 x| * 2^-23 (<= 1e-5 over the 1e-30..1e30 range a
+// spectrogram can span), against ~150 instructions for the correctly rounded powf -- the two Pow
+// chains of the v2.4 front end were VALU-bound on it.  Non-positive bases keep the libm path
+// (signs, zeros, NaN rules).
+__device__ __forceinline__ float net_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float net_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309417f; }
+__device__ __forceinline__ float net_pow(float x, float p) {
+    return x > 0.0f ? __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)) : powf(x, p);
+}
+
+template <int N, class F>
+__device__ __forceinline__ void map_array(float (&v)[N], F f) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = f(v[i]);
+}
 
 __device__ __forceinline__ float act_apply(int act, float x, float p0, float p1) {
     switch (act) {
@@ -43,13 +60,13 @@ __device__ __forceinline__ float act_apply(int act, float x, float p0, float p1)
         case ACT_HSWISH: return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
         case ACT_LEAKY: return x >= 0.0f ? x : p0 * x;
         case ACT_TANH: return tanhf(x);
-        case ACT_EXP: return expf(x);
-        case ACT_LOG: return logf(x);
+        case ACT_EXP: return net_exp(x);
+        case ACT_LOG: return net_log(x);
         case ACT_SQRT: return sqrtf(x);
         case ACT_ABS: return fabsf(x);
         case ACT_NEG: return -x;
         case ACT_RECIP: return 1.0f / x;
-        case ACT_POW: return powf(x, p0);
+        case ACT_POW: return net_pow(x, p0);
         case ACT_AFFINE: return p0 * x + p1;
         case ACT_MAXC: return fmaxf(x, p0);
         case ACT_MINC: return fminf(x, p0);
@@ -64,100 +81,175 @@ __device__ __forceinline__ float act_apply(int act, float x, float p0, float p1)
     }
 }
 
-__device__ __forceinline__ float bin_apply(int bin, float a, float b) {
-    switch (bin) {
-        case BIN_ADD: return a + b;
-        case BIN_SUB: return a - b;
-        case BIN_MUL: return a * b;
-        case BIN_DIV: return a / b;
-        case BIN_POW: return powf(a, b);
-        case BIN_MAX: return fmaxf(a, b);
-        case BIN_MIN: return fminf(a, b);
-        default: return a;
-    }
-}
-
 // ------------------------------------------------------------------ elementwise chains
 struct EltPtrs {
     const float *b[ELT_MAX_STAGES];
 };
 
-// generic strided form.  grid: (ceil(per_sample / 256) capped, batch)
-__global__ __launch_bounds__(256) void elt_strided_kernel(EltDesc d, float *__restrict__ out, const float *__restrict__ a, EltPtrs bp) {
+// Stage ops over a small register array with ONE dispatch on the (launch-uniform) op code: the
+// per-element switch of act_apply / bin_apply costs a branch tree per element per stage.
+template <int N>
+__device__ __forceinline__ void act_array_all(int act, float p0, float p1, float (&v)[N]) {
+    switch (act) {
+        case ACT_NONE: return;
+        case ACT_RELU: map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); }); return;
+        case ACT_CLIP: map_array<N>(v, [=](float x) { return fminf(fmaxf(x, p0), p1); }); return;
+        case ACT_SIGMOID: map_array<N>(v, [](float x) { return net_sigmoid(x); }); return;
+        case ACT_SILU: map_array<N>(v, [](float x) { return x * net_sigmoid(x); }); return;
+        case ACT_HSIGMOID: map_array<N>(v, [=](float x) { return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f); }); return;
+        case ACT_HSWISH: map_array<N>(v, [](float x) { return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f); }); return;
+        case ACT_LEAKY: map_array<N>(v, [=](float x) { return x >= 0.0f ? x : p0 * x; }); return;
+        case ACT_TANH: map_array<N>(v, [](float x) { return tanhf(x); }); return;
+        case ACT_EXP: map_array<N>(v, [](float x) { return net_exp(x); }); return;
+        case ACT_LOG: map_array<N>(v, [](float x) { return net_log(x); }); return;
+        case ACT_SQRT: map_array<N>(v, [](float x) { return sqrtf(x); }); return;
+        case ACT_ABS: map_array<N>(v, [](float x) { return fabsf(x); }); return;
+        case ACT_NEG: map_array<N>(v, [](float x) { return -x; }); return;
+        case ACT_RECIP: map_array<N>(v, [](float x) { return 1.0f / x; }); return;
+        case ACT_POW: map_array<N>(v, [=](float x) { return net_pow(x, p0); }); return;
+        case ACT_AFFINE: map_array<N>(v, [=](float x) { return p0 * x + p1; }); return;
+        case ACT_MAXC: map_array<N>(v, [=](float x) { return fmaxf(x, p0); }); return;
+        case ACT_MINC: map_array<N>(v, [=](float x) { return fminf(x, p0); }); return;
+        case ACT_RSUB: map_array<N>(v, [=](float x) { return p0 - x; }); return;
+        case ACT_RDIV: map_array<N>(v, [=](float x) { return p0 / x; }); return;
+        case ACT_SQUARE: map_array<N>(v, [](float x) { return x * x; }); return;
+        case ACT_FLOOR: map_array<N>(v, [](float x) { return floorf(x); }); return;
+        case ACT_CEIL: map_array<N>(v, [](float x) { return ceilf(x); }); return;
+        case ACT_ERF: map_array<N>(v, [](float x) { return erff(x); }); return;
+        case ACT_SOFTPLUS: map_array<N>(v, [](float x) { return log1pf(expf(x)); }); return;
+        default: return;
+    }
+}
+template <int N, class F>
+__device__ __forceinline__ void zip_array(float (&v)[N], const float (&w)[N], F f) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = f(v[i], w[i]);
+}
+template <int N>
+__device__ __forceinline__ void bin_array(int bin, int bsq, float (&v)[N], float (&w)[N]) {
+    if (bsq) map_array<N>(w, [](float x) { return x * x; });
+    switch (bin) {
+        case BIN_ADD: zip_array<N>(v, w, [](float a, float b) { return a + b; }); return;
+        case BIN_SUB: zip_array<N>(v, w, [](float a, float b) { return a - b; }); return;
+        case BIN_MUL: zip_array<N>(v, w, [](float a, float b) { return a * b; }); return;
+        case BIN_DIV: zip_array<N>(v, w, [](float a, float b) { return a / b; }); return;
+        case BIN_POW: zip_array<N>(v, w, [](float a, float b) { return net_pow(a, b); }); return;
+        case BIN_MAX: zip_array<N>(v, w, [](float a, float b) { return fmaxf(a, b); }); return;
+        case BIN_MIN: zip_array<N>(v, w, [](float a, float b) { return fminf(a, b); }); return;
+        default: return;
+    }
+}
+
+// Unsigned division by a launch-invariant divisor d (1 <= d < 2^31) of n < 2^31:
+//   s = ceil(log2 d), m = ceil(2^(31+s) / d)  ->  n / d == umulhi(n, m) >> (s - 1)      (d >= 2)
+// (m*d - 2^(31+s) < d <= 2^s and n < 2^31, so the error term never reaches the next quotient.)
+struct EltDiv {
+    uint32_t mul[ELT_MAX_DIMS], shift[ELT_MAX_DIMS];  // shift = s - 1; mul == 0 marks d == 1
+};
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t mul, uint32_t shift) {
+    return mul ? (__umulhi(n, mul) >> shift) : n;
+}
+
+// generic strided form: 4 elements per thread, flat index -> multi-index with multiply-shift
+// divisions (no hardware integer division: the per-element div/mod chains made this kernel
+// VALU-bound).  grid: (ceil(per_sample / 1024) capped, batch)
+__global__ __launch_bounds__(256) void elt_strided_kernel(EltDesc d, EltDiv dv, float *__restrict__ out, const float *__restrict__ a, EltPtrs bp) {
     const int64_t bidx = blockIdx.y;
     const uint32_t per = (uint32_t)d.per_sample;
     float *o = out + bidx * d.bo;
     const float *pa = a + bidx * d.ba;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < per; i += gridDim.x * 256u) {
-        uint32_t rem = i;
-        uint32_t idx[ELT_MAX_DIMS];
+    for (uint32_t i0 = blockIdx.x * 1024u + threadIdx.x; i0 < per; i0 += gridDim.x * 1024u) {
+        int64_t oo[4], oa[4], ob[ELT_MAX_STAGES][4];
 #pragma unroll
-        for (int k = ELT_MAX_DIMS - 1; k >= 0; k--) {
-            idx[k] = 0;
-            if (k < d.nd) {
-                const uint32_t sz = (uint32_t)d.size[k];
-                idx[k] = rem % sz;
-                rem /= sz;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + u * 256u;
+            uint32_t rem = i < per ? i : per - 1;
+            oo[u] = 0; oa[u] = 0;
+#pragma unroll
+            for (int s = 0; s < ELT_MAX_STAGES; s++) ob[s][u] = 0;
+#pragma unroll
+            for (int k = ELT_MAX_DIMS - 1; k >= 0; k--) {
+                if (k < d.nd) {
+                    const uint32_t q = fast_div(rem, dv.mul[k], dv.shift[k]);
+                    const uint32_t ix = rem - q * (uint32_t)d.size[k];
+                    rem = q;
+                    oo[u] += (int64_t)ix * d.so[k];
+                    oa[u] += (int64_t)ix * d.sa[k];
+#pragma unroll
+                    for (int s = 0; s < ELT_MAX_STAGES; s++)
+                        if (s < d.nstages) ob[s][u] += (int64_t)ix * d.st[s].sb[k];
+                }
             }
         }
-        int64_t oo = 0, oa = 0;
+        float v[4];
 #pragma unroll
-        for (int k = 0; k < ELT_MAX_DIMS; k++)
-            if (k < d.nd) {
-                oo += (int64_t)idx[k] * d.so[k];
-                oa += (int64_t)idx[k] * d.sa[k];
-            }
-        float v = pa[oa];
+        for (int u = 0; u < 4; u++) v[u] = pa[oa[u]];
 #pragma unroll
         for (int s = 0; s < ELT_MAX_STAGES; s++) {
             if (s < d.nstages) {
                 const EltStage &st = d.st[s];
                 if (st.bin != BIN_NONE) {
-                    int64_t ob = bidx * st.bb;
+                    const float *pb = bp.b[s] + bidx * st.bb;
+                    float w[4];
 #pragma unroll
-                    for (int k = 0; k < ELT_MAX_DIMS; k++)
-                        if (k < d.nd) ob += (int64_t)idx[k] * st.sb[k];
-                    v = bin_apply(st.bin, v, bp.b[s][ob]);
+                    for (int u = 0; u < 4; u++) w[u] = pb[ob[s][u]];
+                    bin_array<4>(st.bin, st.bsq, v, w);
                 }
-                v = act_apply(st.act, v, st.p0, st.p1);
+                act_array_all<4>(st.act, st.p0, st.p1, v);
             }
         }
-        o[oo] = v;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i0 + u * 256u < per) o[oo[u]] = v[u];
     }
 }
 
-// out and a contiguous; every stage operand either contiguous like them or one scalar per sample.
-__global__ __launch_bounds__(256) void elt_flat4_kernel(EltDesc d, float *__restrict__ out, const float *__restrict__ a, EltPtrs bp) {
+// out and a dense over the whole index space (any nd, collapsed to a flat range); every stage
+// operand is dense like them (mode 1), one scalar per sample (mode 0), or periodic (mode 2: it
+// varies only over the trailing dims, e.g. a per-channel vector under a channels-last tensor).
+struct EltFlat {
+    int32_t a_scalar;  // the primary operand is one value per sample (fills)
+    int32_t mode[ELT_MAX_STAGES];
+    uint32_t period[ELT_MAX_STAGES];  // mode 2: elements; 1, 2 or a multiple of 4
+};
+__global__ __launch_bounds__(256) void elt_flat4_kernel(EltDesc d, EltFlat f, float *__restrict__ out, const float *__restrict__ a, EltPtrs bp) {
     const int64_t bidx = blockIdx.y;
     const uint32_t per4 = (uint32_t)(d.per_sample >> 2);
     float4 *o = reinterpret_cast<float4 *>(out + bidx * d.bo);
     const float4 *pa = reinterpret_cast<const float4 *>(a + bidx * d.ba);
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < per4; i += gridDim.x * 256u) {
-        float4 v = pa[i];
+        float v[4];
+        if (f.a_scalar) {
+            v[0] = v[1] = v[2] = v[3] = a[bidx * d.ba];
+        } else {
+            const float4 v4 = pa[i];
+            v[0] = v4.x; v[1] = v4.y; v[2] = v4.z; v[3] = v4.w;
+        }
 #pragma unroll
         for (int s = 0; s < ELT_MAX_STAGES; s++) {
             if (s < d.nstages) {
                 const EltStage &st = d.st[s];
                 if (st.bin != BIN_NONE) {
-                    float4 w;
-                    if (st.sb[0] == 0) {
-                        const float x = bp.b[s][bidx * st.bb];
-                        w = make_float4(x, x, x, x);
+                    const float *pb = bp.b[s] + bidx * st.bb;
+                    float w[4];
+                    if (f.mode[s] == 1) {
+                        const float4 w4 = reinterpret_cast<const float4 *>(pb)[i];
+                        w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+                    } else if (f.mode[s] == 0 || f.period[s] == 1) {
+                        w[0] = w[1] = w[2] = w[3] = pb[0];
+                    } else if (f.period[s] == 2) {
+                        w[0] = w[2] = pb[0];
+                        w[1] = w[3] = pb[1];
                     } else {
-                        w = reinterpret_cast<const float4 *>(bp.b[s] + bidx * st.bb)[i];
+                        const float4 w4 = reinterpret_cast<const float4 *>(pb)[i % (f.period[s] >> 2)];
+                        w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
                     }
-                    v.x = bin_apply(st.bin, v.x, w.x);
-                    v.y = bin_apply(st.bin, v.y, w.y);
-                    v.z = bin_apply(st.bin, v.z, w.z);
-                    v.w = bin_apply(st.bin, v.w, w.w);
+                    bin_array<4>(st.bin, st.bsq, v, w);
                 }
-                v.x = act_apply(st.act, v.x, st.p0, st.p1);
-                v.y = act_apply(st.act, v.y, st.p0, st.p1);
-                v.z = act_apply(st.act, v.z, st.p0, st.p1);
-                v.w = act_apply(st.act, v.w, st.p0, st.p1);
+                act_array_all<4>(st.act, st.p0, st.p1, v);
             }
         }
-        o[i] = v;
+        o[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -449,11 +541,6 @@ __device__ __forceinline__ void map_tile(floatx16 (&acc)[NT], F f) {
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = f(acc[t][r]);
-}
-template <int N, class F>
-__device__ __forceinline__ void map_array(float (&v)[N], F f) {
-#pragma unroll
-    for (int i = 0; i < N; i++) v[i] = f(v[i]);
 }
 // activation over a small register array with ONE dispatch on the (uniform) code
 template <int N>
@@ -1281,19 +1368,59 @@ void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a,
     if (batch <= 0 || d.per_sample <= 0) return;
     EltPtrs bp;
     for (int k = 0; k < ELT_MAX_STAGES; k++) bp.b[k] = b[k];
-    bool vec4 = d.nd == 1 && d.so[0] == 1 && d.sa[0] == 1 && d.per_sample % 4 == 0 && d.bo % 4 == 0 && d.ba % 4 == 0 && aligned16(out) && aligned16(a);
+    // dense (row-major over all dims) out and a -> flat float4 form
+    EltFlat f{};
+    f.a_scalar = 1;
+    for (int k = 0; k < d.nd; k++) f.a_scalar = f.a_scalar && (d.size[k] == 1 || d.sa[k] == 0);
+    bool vec4 = d.per_sample % 4 == 0 && d.bo % 4 == 0 && aligned16(out) && (f.a_scalar || (d.ba % 4 == 0 && aligned16(a)));
+    {
+        int64_t run = 1;
+        for (int k = d.nd - 1; k >= 0 && vec4; k--) {
+            if (d.size[k] != 1 && (d.so[k] != run || (!f.a_scalar && d.sa[k] != run))) vec4 = false;
+            run *= d.size[k];
+        }
+    }
     for (int k = 0; k < d.nstages && vec4; k++) {
         const EltStage &st = d.st[k];
         if (st.bin == BIN_NONE) continue;
-        if (st.sb[0] == 1) vec4 = st.bb % 4 == 0 && aligned16(b[k]);
-        else if (st.sb[0] != 0) vec4 = false;
+        // operand: scalar per sample, or dense (row-major) over the trailing dims t..nd-1 and
+        // broadcast over the outer ones -> period = product of the trailing sizes
+        int t = d.nd;
+        for (int q = 0; q < d.nd; q++)
+            if (d.size[q] != 1 && st.sb[q] != 0) { t = q; break; }
+        if (t == d.nd) { f.mode[k] = 0; continue; }
+        int64_t run = 1;
+        bool ok = true;
+        for (int q = d.nd - 1; q >= t; q--) {
+            if (d.size[q] != 1 && st.sb[q] != run) ok = false;
+            run *= d.size[q];
+        }
+        if (!ok) { vec4 = false; break; }
+        const int64_t period = run;
+        if (period == d.per_sample) {
+            f.mode[k] = 1;
+            vec4 = st.bb % 4 == 0 && aligned16(b[k]);
+        } else {
+            f.mode[k] = 2;
+            f.period[k] = (uint32_t)period;
+            vec4 = (period == 1 || period == 2 || (period % 4 == 0 && st.bb % 4 == 0 && aligned16(b[k])));
+        }
     }
     if (vec4) {
         dim3 grid(cap_blocks((d.per_sample / 4 + 255) / 256, 4096), (unsigned)batch);
-        hipLaunchKernelGGL(elt_flat4_kernel, grid, dim3(256), 0, s, d, out, a, bp);
+        hipLaunchKernelGGL(elt_flat4_kernel, grid, dim3(256), 0, s, d, f, out, a, bp);
     } else {
-        dim3 grid(cap_blocks((d.per_sample + 255) / 256, 4096), (unsigned)batch);
-        hipLaunchKernelGGL(elt_strided_kernel, grid, dim3(256), 0, s, d, out, a, bp);
+        EltDiv dv{};
+        for (int k = 0; k < d.nd; k++) {
+            const uint64_t dd = (uint64_t)d.size[k];
+            if (dd <= 1) { dv.mul[k] = 0; dv.shift[k] = 0; continue; }
+            uint32_t sh = 0;
+            while ((1ull << sh) < dd) sh++;
+            dv.mul[k] = (uint32_t)(((1ull << (31 + sh)) + dd - 1) / dd);
+            dv.shift[k] = sh - 1;
+        }
+        dim3 grid(cap_blocks((d.per_sample + 1023) / 1024, 4096), (unsigned)batch);
+        hipLaunchKernelGGL(elt_strided_kernel, grid, dim3(256), 0, s, d, dv, out, a, bp);
     }
 }
 
