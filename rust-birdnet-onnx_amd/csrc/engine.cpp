@@ -1522,6 +1522,14 @@ class Builder {
                 const int64_t tiles = OH * ((OW + d.tw - 1) / d.tw);
                 d.rpb = (int32_t)std::max<int64_t>(1, std::min<int64_t>(1024 / (Cin / 4), (tiles + 7) / 8));
                 d.nblk = (int32_t)((tiles + d.rpb - 1) / d.rpb);
+                // small feature maps: one block stages the whole map of 32 channels in LDS (one round of
+                // coalesced loads instead of a load-use chain per kernel row) and emits the complete
+                // squeeze sums, so the excite kernel adds nothing up
+                static const bool map_off = getenv("BN_DWMAP") && std::string(getenv("BN_DWMAP")) == "0";
+                if (!map_off && kh == kw && strides[0] == strides[1] && H * W <= 768) {
+                    d.tiled = 2;
+                    d.nblk = 1;
+                }
             }
             std::vector<float> wp(wf.size());  // [C][1][kh][kw] -> [kh][kw][C]
             for (int64_t c = 0; c < Cin; c++)

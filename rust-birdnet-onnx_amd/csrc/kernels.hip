@@ -1271,6 +1271,98 @@ __global__ void dwconv_tiled_kernel(DwDesc d, float *__restrict__ out, const flo
     }
 }
 
+// Depthwise conv of a SMALL feature map (H*W <= 768): one block = (32 channels, one sample).
+//   1. the whole [H*W][32-channel] slab goes to LDS with coalesced float4 loads, 8 in flight
+//   2. lane = channel (conflict-free LDS reads), 8 lane groups take segments of 8 consecutive
+//      pixels of an output row and slide the K x K window along them
+//   3. bias + activation, NHWC store (128 B per pixel), and the COMPLETE per-channel sums of the
+//      activated output for a following squeeze-excite (fixed order; no partials to add up)
+// grid (ceil(C/32), batch), 256 threads, dynamic LDS (H*W*32 + 256 floats).
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_map_kernel(DwDesc d, float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, float *__restrict__ gap) {
+    extern __shared__ __align__(16) float dmsm[];
+    constexpr int PPG = 8, IWS = (PPG - 1) * S + K;
+    const int HW = d.H * d.W;
+    float *In = dmsm;
+    float *red = dmsm + HW * 32;
+    const int c0 = blockIdx.x * 32;
+    const int64_t b = blockIdx.y;
+    const int tid = threadIdx.x;
+    {
+        const int cq = tid & 7, p0 = tid >> 3;
+        const bool qok = c0 + cq * 4 < d.C;
+        const float *ip = in + b * d.in_bs + c0 + (qok ? cq * 4 : 0);
+        for (int pb = p0; pb < HW; pb += 32 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int p = pb + i * 32;
+                v[i] = *reinterpret_cast<const float4 *>(ip + (int64_t)(p < HW ? p : HW - 1) * d.C);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int p = pb + i * 32;
+                if (p < HW) *reinterpret_cast<float4 *>(In + p * 32 + cq * 4) = qok ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    const int c = tid & 31, g8 = tid >> 5;
+    const int cg = c0 + c;
+    const bool cact = cg < d.C;
+    const int cc = cact ? cg : d.C - 1;
+    float wd[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; q++) wd[q] = w[q * d.C + cc];
+    const float bz = d.has_bias ? bias[cc] : 0.0f;
+    __syncthreads();
+    const int nsx = (d.OW + PPG - 1) / PPG;
+    const int nseg = d.OH * nsx;
+    float *ob = out + b * d.out_bs + cg;
+    float sum = 0.0f;
+    for (int seg = g8; seg < nseg; seg += 8) {
+        const int oy = seg / nsx, ox0 = (seg - oy * nsx) * PPG;
+        const int ix0 = ox0 * S - d.pl;
+        float ov[PPG];
+#pragma unroll
+        for (int q = 0; q < PPG; q++) ov[q] = bz;
+#pragma unroll
+        for (int ky = 0; ky < K; ky++) {
+            const int iy = oy * S - d.pt + ky;
+            if (iy >= 0 && iy < d.H) {
+                const float *rp = In + iy * d.W * 32 + c;
+#pragma unroll
+                for (int ix = 0; ix < IWS; ix++) {
+                    const int xg = ix0 + ix;
+                    const float v = (xg >= 0 && xg < d.W) ? rp[xg * 32] : 0.0f;
+#pragma unroll
+                    for (int kx = 0; kx < K; kx++)
+                        if (ix - kx >= 0 && (ix - kx) % S == 0 && (ix - kx) / S < PPG)
+                            ov[(ix - kx) / S] = fmaf(v, wd[ky * K + kx], ov[(ix - kx) / S]);
+                }
+            }
+        }
+        act_array<PPG>(d.act, d.p0, d.p1, ov);
+#pragma unroll
+        for (int q = 0; q < PPG; q++) {
+            if (cact && ox0 + q < d.OW) {
+                ob[((int64_t)oy * d.OW + ox0 + q) * d.C] = ov[q];
+                sum += ov[q];
+            }
+        }
+    }
+    if (d.has_gap) {
+        red[g8 * 32 + c] = sum;
+        __syncthreads();
+        if (g8 == 0 && cact) {
+            float t = red[c];
+#pragma unroll
+            for (int y = 1; y < 8; y++) t += red[y * 32 + c];
+            gap[b * d.gap_bs + cg] = t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ direct conv
 // one lane = one output element (oc fastest).  grid (ceil(OH*OW*Cout/256), batch)
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvDesc d, float *__restrict__ out,
@@ -1586,6 +1678,25 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
 void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w, const float *bias, float *gap,
                    int64_t batch) {
     if (batch <= 0) return;
+    if (d.tiled == 2) {
+        dim3 grid((unsigned)((d.C + 31) / 32), (unsigned)batch);
+        const size_t lds = ((size_t)d.H * d.W * 32 + 256) * sizeof(float);
+#define DWM_LAUNCH(K, S)                                                                                                                           \
+    do {                                                                                                                                         \
+        static size_t attr = 0;                                                                                                                  \
+        if (lds > attr) {                                                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv_map_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr = lds;                                                                                                                          \
+        }                                                                                                                                        \
+        hipLaunchKernelGGL((dwconv_map_kernel<K, S>), grid, dim3(256), lds, s, d, out, in, w, bias, gap);                                        \
+    } while (0)
+        if (d.kw == 3 && d.sw == 1) DWM_LAUNCH(3, 1);
+        else if (d.kw == 3 && d.sw == 2) DWM_LAUNCH(3, 2);
+        else if (d.kw == 5 && d.sw == 1) DWM_LAUNCH(5, 1);
+        else DWM_LAUNCH(5, 2);
+#undef DWM_LAUNCH
+        return;
+    }
     if (d.tiled) {
         const int CV = d.C / 4;
         dim3 grid((unsigned)d.nblk, (unsigned)batch), block((unsigned)(CV * d.rpb));
