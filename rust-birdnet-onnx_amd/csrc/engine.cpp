@@ -1525,7 +1525,7 @@ class Builder {
                 // small feature maps: one block stages the whole map of 32 channels in LDS (one round of
                 // coalesced loads instead of a load-use chain per kernel row) and emits the complete
                 // squeeze sums, so the excite kernel adds nothing up
-                static const bool map_off = getenv("BN_DWMAP") && std::string(getenv("BN_DWMAP")) == "0";
+                const bool map_off = getenv("BN_DWMAP") && std::string(getenv("BN_DWMAP")) == "0";
                 if (!map_off && kh == kw && strides[0] == strides[1] && H * W <= 768) {
                     d.tiled = 2;
                     d.nblk = 1;
@@ -1553,9 +1553,18 @@ class Builder {
                 const bool act_zero = a1 == ACT_NONE || a1 == ACT_RELU || (a1 == ACT_CLIP && pe.gemm.p0 <= 0.f && pe.gemm.p1 >= 0.f) ||
                                       a1 == ACT_SILU || a1 == ACT_HSWISH || a1 == ACT_LEAKY || a1 == ACT_TANH;
                 const double maxhalo = getenv("BN_MBFUSE_HALO") ? atof(getenv("BN_MBFUSE_HALO")) : 3.0;
+                // small feature maps can take the whole-map kernel (one block = 32 mid channels x the whole map:
+                // no halo, any K up to 256, complete squeeze sums).  Opt-in (BN_MBMAP=1): measured on MI355X at
+                // batch 32 it saves 10 launches and ~1% of single-stream latency, but its per-block fixed costs
+                // (filter slab + A rows per 32-channel chunk, half the waves idle on 3x16 maps) make the
+                // marginal cost per extra batch ~30% higher than GEMM + whole-map depthwise, and the three-
+                // context throughput drops from 34.2k to 33.1k seg/s.
+                const bool map_off = !(getenv("BN_MBMAP") && std::string(getenv("BN_MBMAP")) == "1");
+                const int64_t map_maxhw = getenv("BN_MBMAP_MAXHW") ? atoll(getenv("BN_MBMAP_MAXHW")) : 512;
+                const bool whole_map = !map_off && H * W <= map_maxhw;
                 const bool producer = pe.kind == OpKind::GEMM && pe.out.space == Space::ARENA && pe.out.id == x.storage && pe.out.offset == 0 &&
                                       x.offset == 0 && !pe.gemm.has_scale && !pe.gemm.has_res && pe.gemm.rows == H * W && pe.gemm.N == Cin &&
-                                      pe.gemm.lda == pe.gemm.K && pe.gemm.K % 4 == 0 && pe.gemm.K <= maxk && pe.a.offset % 4 == 0 &&
+                                      pe.gemm.lda == pe.gemm.K && pe.gemm.K % 4 == 0 && pe.gemm.K <= (whole_map ? 256 : maxk) && pe.a.offset % 4 == 0 &&
                                       (pe.a.space != Space::ARENA || plan_.storages[pe.a.id].elems % 4 == 0);
                 // halo recompute factor of the expand conv: staged halo pixels / image pixels
                 const int toh0 = strides[1] == 1 ? 8 : 4, tow0 = strides[1] == 1 ? 16 : 8;
@@ -1565,8 +1574,10 @@ class Builder {
                 const bool big_enough = H * W >= 3072 || (strides[1] == 1 && H * W >= 768);
                 MbDesc probe{};
                 probe.k = (int32_t)kw; probe.s = (int32_t)strides[1]; probe.Cin = producer ? pe.gemm.K : 4; probe.C = (int32_t)Cin;
+                probe.H = (int32_t)H; probe.W = (int32_t)W; probe.whole_map = whole_map ? 1 : 0;
                 const bool fits = mbconv_lds_bytes(probe) <= 150 * 1024;
-                if (producer && act_zero && fits && ((halo_factor <= maxhalo && big_enough) || force) && sole_consumer(n.inputs[0]) == cur_) {
+                const bool tiled_ok = act_zero && ((halo_factor <= maxhalo && big_enough) || force);
+                if (producer && fits && (whole_map || tiled_ok) && sole_consumer(n.inputs[0]) == cur_) {
                     PlanOp mb;
                     mb.kind = OpKind::MBCONV;
                     mb.name = "mbconv:" + pe.name.substr(pe.name.find(':') + 1) + "+" + n.name;
@@ -1574,7 +1585,9 @@ class Builder {
                     mb.a = pe.a;
                     // expand filters repacked for the kernel: [C][KW] rows = Cin weights | bias | zeros, KW = 8-wide
                     // K groups covering Cin + 1 columns (the bias rides along as one more K term)
-                    {
+                    if (whole_map) {
+                        mb.w = pe.w;  // [C][Cin] as the GEMM had it
+                    } else {
                         const int64_t Kc = pe.gemm.K, KW = (Kc + 8) / 8 * 8;
                         const std::vector<float> &w0 = plan_.consts[pe.w.id];
                         std::vector<float> wpk((size_t)(Cin * KW), 0.0f);
@@ -1594,7 +1607,12 @@ class Builder {
                     m.in_bs = pe.gemm.a_bs; m.out_bs = d.out_bs;
                     const int toh = m.s == 1 ? 8 : 4, tow = m.s == 1 ? 16 : 8;
                     m.tiles_x = (int32_t)((OW + tow - 1) / tow); m.tiles_y = (int32_t)((OH + toh - 1) / toh);
-                    const double halo = (double)((toh - 1) * m.s + m.k) * ((tow - 1) * m.s + m.k) * m.tiles_x * m.tiles_y;
+                    double halo = (double)((toh - 1) * m.s + m.k) * ((tow - 1) * m.s + m.k) * m.tiles_x * m.tiles_y;
+                    if (whole_map) {
+                        m.whole_map = 1;
+                        m.tiles_x = m.tiles_y = 1;  // one squeeze partial per sample
+                        halo = (double)H * W;
+                    }
                     mb.macs = op.macs;                                   // depthwise part (VALU)
                     mb.weight_bytes = op.weight_bytes + pe.weight_bytes;
                     mb.bytes = 4.0 * ((double)H * W * pe.gemm.K + (double)OH * OW * Cin);

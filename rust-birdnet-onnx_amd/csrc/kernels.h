@@ -130,6 +130,7 @@ struct MbDesc {
     int32_t has_bias1, has_bias2;
     int64_t in_bs, out_bs;
     int32_t tiles_x, tiles_y;  // output tiles of (8x16 at stride 1, 4x8 at stride 2)
+    int32_t whole_map;         // 1: small feature map, one block = (32 mid channels, whole map); w1 is [C][Cin]
     int32_t has_gap;
     int64_t gap_bs;
 };

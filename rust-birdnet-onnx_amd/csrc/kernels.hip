@@ -1271,6 +1271,62 @@ __global__ void dwconv_tiled_kernel(DwDesc d, float *__restrict__ out, const flo
     }
 }
 
+// Depthwise K x K conv of a whole [H*W][32-channel] slab held in LDS (after a barrier): lane =
+// channel, 8 lane groups take segments of 8 consecutive pixels of an output row and slide the
+// window along them; bias + activation, NHWC store, complete per-channel sums (fixed order).
+template <int K, int S>
+__device__ __forceinline__ void dw_map_from_lds(const float *In, float *red, const float (&wd)[K * K], float bz, int H, int W, int OH, int OW,
+                                                int pt, int pl, int C, int act, float p0, float p1, float *__restrict__ ob_sample, int cg,
+                                                bool cact, float *__restrict__ gap_sample) {
+    constexpr int PPG = 8, IWS = (PPG - 1) * S + K;
+    const int c = threadIdx.x & 31, g8 = threadIdx.x >> 5;
+    const int nsx = (OW + PPG - 1) / PPG;
+    const int nseg = OH * nsx;
+    float *ob = ob_sample + cg;
+    float sum = 0.0f;
+    for (int seg = g8; seg < nseg; seg += 8) {
+        const int oy = seg / nsx, ox0 = (seg - oy * nsx) * PPG;
+        const int ix0 = ox0 * S - pl;
+        float ov[PPG];
+#pragma unroll
+        for (int q = 0; q < PPG; q++) ov[q] = bz;
+#pragma unroll
+        for (int ky = 0; ky < K; ky++) {
+            const int iy = oy * S - pt + ky;
+            if (iy >= 0 && iy < H) {
+                const float *rp = In + iy * W * 32 + c;
+#pragma unroll
+                for (int ix = 0; ix < IWS; ix++) {
+                    const int xg = ix0 + ix;
+                    const float v = (xg >= 0 && xg < W) ? rp[xg * 32] : 0.0f;
+#pragma unroll
+                    for (int kx = 0; kx < K; kx++)
+                        if (ix - kx >= 0 && (ix - kx) % S == 0 && (ix - kx) / S < PPG)
+                            ov[(ix - kx) / S] = fmaf(v, wd[ky * K + kx], ov[(ix - kx) / S]);
+                }
+            }
+        }
+        act_array<PPG>(act, p0, p1, ov);
+#pragma unroll
+        for (int q = 0; q < PPG; q++) {
+            if (cact && ox0 + q < OW) {
+                ob[((int64_t)oy * OW + ox0 + q) * C] = ov[q];
+                sum += ov[q];
+            }
+        }
+    }
+    if (gap_sample) {
+        red[g8 * 32 + c] = sum;
+        __syncthreads();
+        if (g8 == 0 && cact) {
+            float t = red[c];
+#pragma unroll
+            for (int y = 1; y < 8; y++) t += red[y * 32 + c];
+            gap_sample[cg] = t;
+        }
+    }
+}
+
 // Depthwise conv of a SMALL feature map (H*W <= 768): one block = (32 channels, one sample).
 //   1. the whole [H*W][32-channel] slab goes to LDS with coalesced float4 loads, 8 in flight
 //   2. lane = channel (conflict-free LDS reads), 8 lane groups take segments of 8 consecutive
@@ -1282,7 +1338,6 @@ template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_map_kernel(DwDesc d, float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w,
                                                          const float *__restrict__ bias, float *__restrict__ gap) {
     extern __shared__ __align__(16) float dmsm[];
-    constexpr int PPG = 8, IWS = (PPG - 1) * S + K;
     const int HW = d.H * d.W;
     float *In = dmsm;
     float *red = dmsm + HW * 32;
@@ -1307,7 +1362,7 @@ __global__ __launch_bounds__(256) void dwconv_map_kernel(DwDesc d, float *__rest
             }
         }
     }
-    const int c = tid & 31, g8 = tid >> 5;
+    const int c = tid & 31;
     const int cg = c0 + c;
     const bool cact = cg < d.C;
     const int cc = cact ? cg : d.C - 1;
@@ -1316,51 +1371,102 @@ __global__ __launch_bounds__(256) void dwconv_map_kernel(DwDesc d, float *__rest
     for (int q = 0; q < K * K; q++) wd[q] = w[q * d.C + cc];
     const float bz = d.has_bias ? bias[cc] : 0.0f;
     __syncthreads();
-    const int nsx = (d.OW + PPG - 1) / PPG;
-    const int nseg = d.OH * nsx;
-    float *ob = out + b * d.out_bs + cg;
-    float sum = 0.0f;
-    for (int seg = g8; seg < nseg; seg += 8) {
-        const int oy = seg / nsx, ox0 = (seg - oy * nsx) * PPG;
-        const int ix0 = ox0 * S - d.pl;
-        float ov[PPG];
+    dw_map_from_lds<K, S>(In, red, wd, bz, d.H, d.W, d.OH, d.OW, d.pt, d.pl, d.C, d.act, d.p0, d.p1, out + b * d.out_bs, cg, cact,
+                          d.has_gap ? gap + b * d.gap_bs : nullptr);
+}
+
+// Fused expand + depthwise for a SMALL feature map (H*W <= 768): one block = (32 mid channels,
+// one sample), no halo, nothing recomputed.
+//   1. the 32 expand filters of the block go to LDS (Ws[32][K+pad], zero K padding)
+//   2. expand on the matrix cores: rows = the map's pixels in m-tiles of 32, A operands straight
+//      from global memory (lane = pixel, one float4 per 8-wide K group, pieces of 8 groups with the
+//      next piece in flight), B from LDS; the m-tiles rotate over the waves with the block index
+//   3. bias + activation -> Es[H*W][32] in LDS
+//   4. depthwise from LDS (dw_map_from_lds) with the complete squeeze sums
+// grid (ceil(C/32), batch), 256 threads, dynamic LDS.
+template <int K, int S>
+__global__ __launch_bounds__(256) void mbconv_map_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
+                                                         const float *__restrict__ w1, const float *__restrict__ b1,
+                                                         const float *__restrict__ w2, const float *__restrict__ b2,
+                                                         float *__restrict__ gap) {
+    extern __shared__ __align__(16) float mmsm[];
+    const int HW = d.H * d.W;
+    const int MT = (HW + 31) / 32;
+    const int ng = (d.Cin + 7) / 8;
+    const int KS = ng * 8 + 4;
+    float *Ws = mmsm;                 // [32][KS]
+    float *Es = Ws + 32 * KS;         // [MT*32][32]
+    float *red = Es + MT * 32 * 32;   // [8][32]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int c0 = blockIdx.x * 32;
+    const int64_t b = blockIdx.y;
+    const float *xin = in + b * d.in_bs;
+    const int CV = d.Cin >> 2;
+    // ---- 1. filters -> LDS (rows past C repeat the last filter: their outputs are never stored)
+    for (int f = tid; f < 32 * (KS >> 2); f += 256) {
+        const int n = f / (KS >> 2), q = f - n * (KS >> 2);
+        const int nn = c0 + n < d.C ? c0 + n : d.C - 1;
+        const float4 v = *reinterpret_cast<const float4 *>(w1 + (int64_t)nn * d.Cin + 4 * (q < CV ? q : 0));
+        *reinterpret_cast<float4 *>(Ws + n * KS + 4 * q) = q < CV ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float bv = d.has_bias1 ? b1[c0 + lr < d.C ? c0 + lr : d.C - 1] : 0.0f;
+    // depthwise weights (consumed after the expand)
+    const int c = tid & 31;
+    const int cg = c0 + c;
+    const bool cact = cg < d.C;
+    const int cc = cact ? cg : d.C - 1;
+    float wd[K * K];
 #pragma unroll
-        for (int q = 0; q < PPG; q++) ov[q] = bz;
+    for (int q = 0; q < K * K; q++) wd[q] = w2[q * d.C + cc];
+    const float bz = d.has_bias2 ? b2[cc] : 0.0f;
+    __syncthreads();
+    // ---- 2+3. expand -> Es
+    const int wrole = (wave + blockIdx.x) & 3;
+    const int npiece = (ng + 7) / 8;
+    for (int mt = wrole; mt < MT; mt += 4) {
+        const int row = mt * 32 + lr;
+        const float *ar = xin + (int64_t)(row < HW ? row : HW - 1) * d.Cin;
+        floatx16 acc;
 #pragma unroll
-        for (int ky = 0; ky < K; ky++) {
-            const int iy = oy * S - d.pt + ky;
-            if (iy >= 0 && iy < d.H) {
-                const float *rp = In + iy * d.W * 32 + c;
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        float4 an[8];
+        auto fetch_a = [&](float4 (&dst)[8], int piece) {
 #pragma unroll
-                for (int ix = 0; ix < IWS; ix++) {
-                    const int xg = ix0 + ix;
-                    const float v = (xg >= 0 && xg < d.W) ? rp[xg * 32] : 0.0f;
+            for (int g = 0; g < 8; g++) {
+                const int slot = 2 * (piece * 8 + g) + lh;  // float4 slot inside the row; the K tail re-reads slot 0 (x 0)
+                dst[g] = *reinterpret_cast<const float4 *>(ar + 4 * (slot < CV ? slot : 0));
+            }
+        };
+        fetch_a(an, 0);
+        for (int piece = 0; piece < npiece; piece++) {
+            float4 ac[8];
 #pragma unroll
-                    for (int kx = 0; kx < K; kx++)
-                        if (ix - kx >= 0 && (ix - kx) % S == 0 && (ix - kx) / S < PPG)
-                            ov[(ix - kx) / S] = fmaf(v, wd[ky * K + kx], ov[(ix - kx) / S]);
+            for (int g = 0; g < 8; g++) ac[g] = an[g];
+            if (piece + 1 < npiece) fetch_a(an, piece + 1);
+            const float *wp = Ws + lr * KS + 4 * lh + 64 * piece;
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                if (piece * 8 + g < ng) {
+                    const float4 b4 = *reinterpret_cast<const float4 *>(wp + 8 * g);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[g].x, b4.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[g].y, b4.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[g].z, b4.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[g].w, b4.w, acc, 0, 0, 0);
                 }
             }
         }
-        act_array<PPG>(d.act, d.p0, d.p1, ov);
+        floatx16 at[1] = {acc};
 #pragma unroll
-        for (int q = 0; q < PPG; q++) {
-            if (cact && ox0 + q < d.OW) {
-                ob[((int64_t)oy * d.OW + ox0 + q) * d.C] = ov[q];
-                sum += ov[q];
-            }
-        }
-    }
-    if (d.has_gap) {
-        red[g8 * 32 + c] = sum;
-        __syncthreads();
-        if (g8 == 0 && cact) {
-            float t = red[c];
+        for (int reg = 0; reg < 16; reg++) at[0][reg] += bv;
+        act_tile<1>(d.act1, d.p0_1, d.p1_1, at);
+        float *ep = Es + (mt * 32 + 4 * lh) * 32 + lr;
 #pragma unroll
-            for (int y = 1; y < 8; y++) t += red[y * 32 + c];
-            gap[b * d.gap_bs + cg] = t;
-        }
+        for (int reg = 0; reg < 16; reg++) ep[((reg & 3) + 8 * (reg >> 2)) * 32] = at[0][reg];
     }
+    __syncthreads();
+    // ---- 4. depthwise + squeeze
+    dw_map_from_lds<K, S>(Es, red, wd, bz, d.H, d.W, d.OH, d.OW, d.pt, d.pl, d.C, d.act2, d.p0_2, d.p1_2, out + b * d.out_bs, cg, cact,
+                          d.has_gap ? gap + b * d.gap_bs : nullptr);
 }
 
 // ------------------------------------------------------------------ direct conv
@@ -1646,6 +1752,10 @@ void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, 
 }
 
 size_t mbconv_lds_bytes(const MbDesc &d) {
+    if (d.whole_map) {
+        const int mt = (d.H * d.W + 31) / 32, ks = (d.Cin + 7) / 8 * 8 + 4;
+        return (size_t)(32 * ks + mt * 32 * 32 + 8 * 32) * sizeof(float);
+    }
     const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
     const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
     const int mp = (hp + 31) / 32 * 32;
@@ -1657,8 +1767,26 @@ size_t mbconv_lds_bytes(const MbDesc &d) {
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
                    const float *b2, float *gap, int64_t batch) {
     if (batch <= 0) return;
-    dim3 grid((unsigned)(d.tiles_x * d.tiles_y), 1, (unsigned)batch);
     const size_t lds = mbconv_lds_bytes(d);
+    if (d.whole_map) {
+        dim3 gridm((unsigned)((d.C + 31) / 32), (unsigned)batch);
+#define MBM_LAUNCH(K, S)                                                                                                                           \
+    do {                                                                                                                                         \
+        static size_t attr = 0;                                                                                                                  \
+        if (lds > attr) {                                                                                                                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mbconv_map_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr = lds;                                                                                                                          \
+        }                                                                                                                                        \
+        hipLaunchKernelGGL((mbconv_map_kernel<K, S>), gridm, dim3(256), lds, s, d, out, in, w1, b1, w2, b2, gap);                                \
+    } while (0)
+        if (d.k == 3 && d.s == 1) MBM_LAUNCH(3, 1);
+        else if (d.k == 3 && d.s == 2) MBM_LAUNCH(3, 2);
+        else if (d.k == 5 && d.s == 1) MBM_LAUNCH(5, 1);
+        else MBM_LAUNCH(5, 2);
+#undef MBM_LAUNCH
+        return;
+    }
+    dim3 grid((unsigned)(d.tiles_x * d.tiles_y), 1, (unsigned)batch);
 #define MB_LAUNCH(K, S)                                                                                                          \
     do {                                                                                                                         \
         static size_t attr = 0;                                                                                                  \

@@ -216,8 +216,10 @@ def test_standalone_batchnorm_and_hard_activations(bn):
 @pytest.mark.parametrize("cin,h,w,cmid,k,stride,act", [(16, 24, 40, 96, 3, 2, "relu"), (24, 12, 40, 144, 3, 1, "relu"),
                                                        (24, 13, 37, 144, 5, 2, "silu"), (40, 9, 19, 240, 3, 2, "relu6"),
                                                        (8, 16, 32, 48, 5, 1, "relu"), (16, 7, 9, 40, 3, 1, None)])
-def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act):
-    """expand 1x1 conv (+BN+act) -> depthwise KxK (+act): one MBCONV launch, expanded tensor only in LDS."""
+@pytest.mark.parametrize("variant", ["tiled", "map"])
+def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
+    """expand 1x1 conv (+BN+act) -> depthwise KxK (+act): one MBCONV launch, expanded tensor only in LDS.
+    Both kernels: output tiles with halo recompute ("tiled") and whole small maps per block ("map")."""
     rng = np.random.default_rng(11)
     assert cin * h * w <= 144000
     pad = k // 2
@@ -247,10 +249,52 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act):
         return activation(g, z)
     data = op_graph(build, [cmid, oh, ow])
     import os
-    os.environ["BN_MBFUSE"] = "force"   # opt-in fusion, also for tiny feature maps (read by the planner at model load)
+    os.environ["BN_MBFUSE"] = "force"   # fuse tiny feature maps with the tiled kernel too (read by the planner at model load)
+    os.environ["BN_MBMAP"] = "0" if variant == "tiled" else "1"
+    os.environ["BN_MBMAP_MAXHW"] = "1024"
     try:
-        assert "MBCONV" in bn.plan_describe(write_model(data))
+        desc = bn.plan_describe(write_model(data))
+        assert "MBCONV" in desc
+        assert ("tiles=1x1" in desc) == (variant == "map" or (oh <= (8 if stride == 1 else 4) and ow <= (16 if stride == 1 else 8)))
         got, ref = run_both(bn, data)
     finally:
-        del os.environ["BN_MBFUSE"]
-    assert_close(got, ref, f"mbconv {cin}->{cmid} k{k} s{stride}")
+        for key in ("BN_MBFUSE", "BN_MBMAP", "BN_MBMAP_MAXHW"):
+            del os.environ[key]
+    assert_close(got, ref, f"mbconv[{variant}] {cin}->{cmid} k{k} s{stride}")
+
+
+@pytest.mark.parametrize("cin,h,w,cmid,k,stride", [(80, 6, 32, 480, 3, 1), (112, 6, 32, 672, 5, 2), (192, 3, 16, 1152, 5, 1),
+                                                  (20, 5, 7, 72, 3, 1), (40, 12, 40, 100, 3, 2)])
+def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride):
+    """The whole-map MBConv kernel at the late-stage shapes (K up to 192, ragged channel counts, K % 8 == 4)
+    followed by a squeeze-excite that consumes its complete channel sums."""
+    rng = np.random.default_rng(12)
+    pad = k // 2
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    cr = max(4, cmid // 24)
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(cin * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, cin, h, w)])
+        w0 = (rng.standard_normal((cin, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+        x = g.node("Conv", [x, g.const(w0)], kernel_shape=[1, 1])
+        we = (rng.standard_normal((cmid, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+        y = g.node("Relu", [g.node("Conv", [x, g.const(we), g.const(rng.standard_normal(cmid).astype(np.float32))], kernel_shape=[1, 1])])
+        wd = (rng.standard_normal((cmid, 1, k, k)) / k).astype(np.float32)
+        z = g.node("Relu", [g.node("Conv", [y, g.const(wd), g.const(rng.standard_normal(cmid).astype(np.float32))], kernel_shape=[k, k],
+                                   strides=[stride, stride], pads=[pad] * 4, group=cmid)])
+        # squeeze-excite + projection
+        s = g.node("GlobalAveragePool", [z])
+        w1 = (rng.standard_normal((cr, cmid, 1, 1)) / np.sqrt(cmid)).astype(np.float32)
+        w2 = (rng.standard_normal((cmid, cr, 1, 1)) / np.sqrt(cr)).astype(np.float32)
+        e = g.node("Relu", [g.node("Conv", [s, g.const(w1), g.const(rng.standard_normal(cr).astype(np.float32))], kernel_shape=[1, 1])])
+        e = g.node("Sigmoid", [g.node("Conv", [e, g.const(w2), g.const(rng.standard_normal(cmid).astype(np.float32))], kernel_shape=[1, 1])])
+        zz = g.node("Mul", [z, e])
+        wp = (rng.standard_normal((24, cmid, 1, 1)) / np.sqrt(cmid)).astype(np.float32)
+        return g.node("Conv", [zz, g.const(wp)], kernel_shape=[1, 1])
+    data = op_graph(build, [24, oh, ow])
+    desc = bn.plan_describe(write_model(data))
+    assert "MBCONV" in desc and "tiles=1x1" in desc, desc
+    got, ref = run_both(bn, data, batch=3)
+    assert_close(got, ref, f"mbconv map {cin}->{cmid} k{k} s{stride}")
