@@ -230,10 +230,29 @@ def main():
             roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(frac_hbm, 4)}
         else:
             roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
-        roof.update({"traffic": None, "kernel": dname, "launches_per_step": d["launches"],
+        # HBM bytes per launch from the committed PMC passes (tools/profile_round.sh + profile_summary.py:
+        # FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes, gfx950 read correction applied)
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
+            if tj.get("batch") == B and dname in tj.get("families", {}):
+                traffic = tj["families"][dname]["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{tj['tag']}_pmc_traffic.json"
+        except (OSError, ValueError, KeyError):
+            pass
+        roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                     "kernel": dname, "launches_per_step": d["launches"],
                      "avg_launch_us": round(d["us"] / d["launches"], 2), "share_of_step": round(d["us"] / total_us, 3),
                      "alt_frac": {"hbm": round(frac_hbm, 4), "mfma_f32": round(frac_mfma, 4)}})
         out["roofline"] = roof
+        # the three longest single launches, each against its own bound (the family number above averages
+        # 33 launches, most of them latency-bound 6x32 / 3x16 feature maps at batch 32)
+        tops = []
+        for (name, us, macs, byts), k in sorted(zip(rows, kind_of), key=lambda t: -t[0][1])[:3]:
+            tfl, gb = 2.0 * macs / (us * 1e-6) / 1e12, byts / (us * 1e-6) / 1e9
+            tops.append({"launch": name, "kind": k, "us": round(us, 1), "TFLOPs": round(tfl, 1), "GBs": round(gb, 1),
+                         "frac_mfma_f32": round(tfl / MFMA_F32_PEAK_TF, 3), "frac_hbm": round(gb / HBM_PEAK_GBS, 3)})
+        out["roofline_top_launches"] = tops
         out["kernel_families"] = {k: {"us_per_step": round(v["us"], 1), "launches": v["launches"],
                                       "TFLOPs": round(2 * v["macs"] / (v["us"] * 1e-6) / 1e12, 2),
                                       "GBs": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1)} for k, v in fam.items()}

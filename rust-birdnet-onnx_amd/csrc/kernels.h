@@ -178,6 +178,7 @@ void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, in
                  int has_min, float min_conf, int64_t k_stride, uint32_t *idx, float *conf,
                  uint32_t *count, uint32_t *flags);
 // LDS bytes the top-K kernel needs for (n, k); 0 if it cannot run (too large).
+void launch_null(hipStream_t s);  // empty kernel (timing calibration)
 size_t topk_lds_bytes(int64_t n, int64_t k);
 size_t mbconv_lds_bytes(const MbDesc &d);  // dynamic LDS of mbconv_expand_dw_kernel for this shape
 

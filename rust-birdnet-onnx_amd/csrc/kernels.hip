@@ -1849,4 +1849,10 @@ void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, 
     }
 }
 
+// empty launch: calibrates the event-to-event overhead of bn_ctx_time_kernels
+namespace {
+__global__ void null_kernel() {}
+}  // namespace
+void launch_null(hipStream_t s) { hipLaunchKernelGGL(null_kernel, dim3(1), dim3(64), 0, s); }
+
 }  // namespace bn

@@ -294,7 +294,16 @@ def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride):
         wp = (rng.standard_normal((24, cmid, 1, 1)) / np.sqrt(cmid)).astype(np.float32)
         return g.node("Conv", [zz, g.const(wp)], kernel_shape=[1, 1])
     data = op_graph(build, [24, oh, ow])
-    desc = bn.plan_describe(write_model(data))
-    assert "MBCONV" in desc and "tiles=1x1" in desc, desc
-    got, ref = run_both(bn, data, batch=3)
+    import os
+    os.environ["BN_MBMAP"] = "1"  # the whole-map fusion is opt-in (read by the planner at model load)
+    try:
+        desc = bn.plan_describe(write_model(data))
+        assert "MBCONV" in desc and "tiles=1x1" in desc, desc
+        got, ref = run_both(bn, data, batch=3)
+    finally:
+        del os.environ["BN_MBMAP"]
     assert_close(got, ref, f"mbconv map {cin}->{cmid} k{k} s{stride}")
+    # and the default plan (GEMM + whole-map depthwise + excite) on the same graph
+    assert "MBCONV" not in bn.plan_describe(write_model(data))
+    got2, _ = run_both(bn, data, batch=3)
+    assert_close(got2, ref, f"gemm + dw map {cin}->{cmid} k{k} s{stride}")

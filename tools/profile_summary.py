@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Condense one tools/profile_round.sh run into the files that are committed under profiles/.
+
+    python tools/profile_summary.py gpurun_out/<tag> <tag>
+
+Writes profiles/<tag>_bench_default.json, _bench_1stream.json, _kernel_stats_default.csv,
+_kernel_stats_1stream.csv (rocprofv3 --kernel-trace --stats), <tag>_pmc_traffic.json and refreshes
+profiles/pmc_traffic.json (what bench.py quotes as `roofline.traffic`).
+
+HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE come from separate --pmc passes, are reported in KiB, and on gfx950 FETCH_SIZE counts
+128-byte requests as 64 bytes for wide coalesced reads, so reads are doubled:
+    traffic = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024        [bytes]
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    n = name.replace("bn::(anonymous namespace)::", "")
+    for key, fam in (("gemm_mfma_kernel", "gemm_mfma_kernel"), ("gemm_splitk_kernel", "gemm_mfma_kernel"), ("mbconv_", "mbconv_expand_dw_kernel"),
+                     ("dwconv_", "dwconv_kernel"), ("conv_small", "conv_direct_kernel"), ("conv_direct", "conv_direct_kernel"),
+                     ("se_fc", "se_fc_kernel"), ("gap_partial", "gap_partial_kernel"), ("elt_", "elt_kernel"), ("reduce_", "reduce_kernel"),
+                     ("topk", "topk_kernel")):
+        if key in n:
+            return fam
+    return "other"
+
+
+def counter_by_family(path, counter):
+    out = defaultdict(lambda: [0.0, 0])
+    seen = set()
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] != counter:
+                    continue
+                fam = family(r["Kernel_Name"])
+                out[fam][0] += float(r["Counter_Value"])
+                if r["Dispatch_Id"] not in seen:
+                    seen.add(r["Dispatch_Id"])
+                    out[fam][1] += 1
+    return out
+
+
+def stats_by_family(path):
+    fams = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(path, "**", "*kernel_stats.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                fam = family(r["Name"])
+                fams[fam][0] += int(r["Calls"])
+                fams[fam][1] += float(r["TotalDurationNs"])
+    return {k: {"calls": v[0], "avg_us": round(v[1] / v[0] / 1000.0, 2), "total_ms": round(v[1] / 1e6, 3)} for k, v in fams.items() if v[0]}
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    os.makedirs("profiles", exist_ok=True)
+    for name in ("bench_default", "bench_1stream"):
+        line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
+        open(f"profiles/{tag}_{name}.json", "w").write(line)
+    for name in ("default", "1stream"):
+        f = glob.glob(os.path.join(src, f"trace_{name}", "**", "*kernel_stats.csv"), recursive=True)[0]
+        shutil.copy(f, f"profiles/{tag}_kernel_stats_{name}.csv")
+    fetch = counter_by_family(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
+    write = counter_by_family(os.path.join(src, "pmc_write"), "WRITE_SIZE")
+    traffic = {}
+    for fam in sorted(set(fetch) | set(write)):
+        fk, n = fetch.get(fam, [0.0, 0])
+        wk, n2 = write.get(fam, [0.0, 0])
+        n = max(n, n2, 1)
+        traffic[fam] = {"launches_profiled": n, "fetch_size_kib_raw_per_launch": round(fk / n, 1), "write_size_kib_per_launch": round(wk / n, 1),
+                        "hbm_bytes_per_launch": round((2.0 * fk + wk) * 1024.0 / n)}
+    doc = {"tag": tag, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/pmc_run.py 32 3",
+           "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
+           "batch": 32, "families": traffic,
+           "kernel_stats_1stream": stats_by_family(os.path.join(src, "trace_1stream")),
+           "kernel_stats_default": stats_by_family(os.path.join(src, "trace_default"))}
+    json.dump(doc, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+    json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
+    print(json.dumps(doc["families"], indent=1))
+    print(json.dumps(doc["kernel_stats_1stream"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
