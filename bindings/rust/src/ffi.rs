@@ -5,6 +5,8 @@ use std::os::raw::c_char;
 #[repr(C)]
 pub struct bn_model { _p: [u8; 0] }
 #[repr(C)]
+pub struct bn_recording { _p: [u8; 0] }
+#[repr(C)]
 pub struct bn_ctx { _p: [u8; 0] }
 
 #[repr(C)]
@@ -40,4 +42,10 @@ extern "C" {
     pub fn bn_topk(c: *mut bn_ctx, batch: usize, top_k: usize, has_min: i32, min_conf: f32, k_stride: usize,
                    idx_out: *mut u32, conf_out: *mut f32, count_out: *mut u32) -> i32;
     pub fn bn_last_error(buf: *mut c_char, cap: usize) -> usize;
+    // recording-level ingest (optional; birdnet-analyze.rs read_wav + chunk_audio on the device)
+    pub fn bn_recording_create(device: i32, pcm: *const core::ffi::c_void, n_samples: usize, format: i32, out: *mut *mut bn_recording) -> i32;
+    pub fn bn_recording_free(r: *mut bn_recording);
+    pub fn bn_chunk_count(n_samples: usize, step_samples: usize) -> usize;
+    pub fn bn_infer_windows(c: *mut bn_ctx, r: *const bn_recording, step_samples: usize, first_window: usize, count: usize,
+                            logits_out: *mut f32, emb_out: *mut f32, cancel: *const i32, timeout_ns: u64) -> i32;
 }

@@ -200,6 +200,40 @@ bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch_size, size_
 bn_status bn_step_results(const bn_ctx *c, const float **logits, const uint32_t **idx,
                           const float **conf, const uint32_t **count, size_t *k_stride);
 
+/*
+ * Recording-level ingest: the caller side of the
+ * hot path.  The reference CLI reads a 16-bit mono WAV, converts every sample
+ * with `f32::from(s) / 32768.0` (src/bin/birdnet-analyze.rs:683-687), cuts it
+ * into fixed-length windows with `chunk_audio` (:707-743: step = S -
+ * floor(overlap * sample_rate), one window for every pos = k*step < len, the
+ * tail zero-padded) and uploads each window as f32.  Here the recording is
+ * uploaded ONCE in its storage format (i16: half the PCIe bytes; with overlap no
+ * sample crosses the bus twice) and the windows of a batch are materialised on
+ * the device, straight into the context's input buffer, by one small kernel in
+ * front of the plan.  The conversion is a division by a power of two, so the
+ * windows are bit-identical to the reference's.
+ */
+typedef struct bn_recording bn_recording;
+#define BN_PCM_I16 0 /* int16_t mono, value / 32768.0 */
+#define BN_PCM_F32 1 /* float mono, used as is */
+bn_status bn_recording_create(int32_t device, const void *pcm, size_t n_samples, int32_t format,
+                              bn_recording **out);
+void bn_recording_free(bn_recording *r);
+size_t bn_recording_samples(const bn_recording *r);
+/* Number of windows chunk_audio produces for n_samples at this step (0 for an
+ * empty recording or step == 0). */
+size_t bn_chunk_count(size_t n_samples, size_t step_samples);
+/* chunk_audio on the device, copied back: windows [first, first+count) as host
+ * f32 [count, segment_samples] (segment_samples % 4 == 0). */
+bn_status bn_recording_windows(const bn_recording *r, size_t segment_samples, size_t step_samples,
+                               size_t first_window, size_t count, float *host_out);
+/* bn_infer over windows [first_window, first_window+count) of the recording
+ * (count <= max_batch; the window length is the model's sample_count).  Same
+ * outputs, cancel and timeout behaviour as bn_infer. */
+bn_status bn_infer_windows(bn_ctx *c, const bn_recording *r, size_t step_samples,
+                           size_t first_window, size_t count, float *logits_out, float *emb_out,
+                           const volatile int32_t *cancel, uint64_t timeout_ns);
+
 /* Diagnostic, needs no device: parse the file, build the launch plan (all graph
  * outputs when all_outputs != 0, else logits + embeddings only) and write a
  * text description (one line per launch, then totals) into buf.  Returns the

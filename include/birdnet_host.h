@@ -155,6 +155,29 @@ class BatchInferenceContext {
 
 struct ClassifierInner;
 
+/* A mono recording uploaded to the device once, in its storage format: the native form of the
+ * reference CLI's read_wav (i16 / 32768.0, src/bin/birdnet-analyze.rs:683-687) + chunk_audio
+ * (:707-743).  Windows are cut on the device (bn_infer_windows). */
+class Recording {
+   public:
+    /* format: BN_PCM_I16 or BN_PCM_F32; throws Error::Inference when the upload fails */
+    Recording(const void *pcm, size_t n_samples, int32_t format, int device = 0);
+    static Recording from_i16(const int16_t *pcm, size_t n_samples, int device = 0) { return Recording(pcm, n_samples, BN_PCM_I16, device); }
+    static Recording from_f32(const float *pcm, size_t n_samples, int device = 0) { return Recording(pcm, n_samples, BN_PCM_F32, device); }
+    size_t n_samples() const { return n_samples_; }
+    const bn_recording *raw() const { return rec_.get(); }
+
+   private:
+    std::shared_ptr<bn_recording> rec_;
+    size_t n_samples_ = 0;
+};
+
+/* One chunk of a recording: start time as chunk_audio reports it + the prediction. */
+struct ChunkResult {
+    float start_time;
+    PredictionResult result;
+};
+
 class Classifier {
    public:
     const ModelConfig &config() const;
@@ -170,6 +193,11 @@ class Classifier {
     /* src/classifier.rs:826-867 */
     std::vector<PredictionResult> predict_batch_with_context(BatchInferenceContext &ctx, const float *const *segments, const size_t *lens,
                                                              size_t n, const InferenceOptions &options = {}) const;
+    /* The CLI's loop body (src/bin/birdnet-analyze.rs:556-600) over chunks [first_chunk, first_chunk+count)
+     * of chunk_audio(recording, overlap): batches of ctx.max_batch_size() windows cut on the device.
+     * count == SIZE_MAX means "to the end".  overlap >= segment duration => Error::Inference. */
+    std::vector<ChunkResult> predict_recording(BatchInferenceContext &ctx, const Recording &rec, float overlap_secs, size_t first_chunk = 0,
+                                               size_t count = (size_t)-1, const InferenceOptions &options = {}) const;
 
    private:
     friend class ClassifierBuilder;
@@ -269,6 +297,11 @@ int32_t bnh_context_model_type(const bnh_context *ctx);
 int32_t bnh_predict_batch_with_context(const bnh_classifier *c, bnh_context *ctx, const float *const *segments, const size_t *lens, size_t n,
                                        int64_t timeout_ns, const volatile int32_t *cancel, bnh_results **out, bnh_error *err);
 
+/* Classifier::predict_recording over a host recording (uploaded once, windows cut on the device);
+ * start_times[i] receives chunk i's start time for i < times_cap. */
+int32_t bnh_predict_recording(const bnh_classifier *c, bnh_context *ctx, const void *pcm, size_t n_samples, int32_t format, float overlap_secs,
+                              size_t first_chunk, size_t count, int64_t timeout_ns, const volatile int32_t *cancel, bnh_results **out,
+                              float *start_times, size_t times_cap, bnh_error *err);
 size_t bnh_results_len(const bnh_results *r);
 int32_t bnh_result_model_type(const bnh_results *r, size_t i);
 size_t bnh_result_n_predictions(const bnh_results *r, size_t i);

@@ -35,14 +35,15 @@ ENGINE_SYMBOLS = [
     "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_device",
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
     "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
-    "bn_last_error",
+    "bn_recording_create", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
+    "bn_infer_windows", "bn_last_error",
 ]
 HOST_SYMBOLS = [
     "bnh_classifier_build", "bnh_classifier_free", "bnh_classifier_config", "bnh_classifier_provider",
     "bnh_classifier_label_count", "bnh_classifier_label", "bnh_predict", "bnh_predict_batch",
     "bnh_create_batch_context", "bnh_context_free", "bnh_context_max_batch_size", "bnh_context_sample_count",
     "bnh_context_input_buffer_capacity", "bnh_context_input_buffer_bytes", "bnh_context_model_type",
-    "bnh_predict_batch_with_context", "bnh_results_len", "bnh_result_model_type", "bnh_result_n_predictions",
+    "bnh_predict_batch_with_context", "bnh_predict_recording", "bnh_results_len", "bnh_result_model_type", "bnh_result_n_predictions",
     "bnh_result_species", "bnh_result_confidence", "bnh_result_index", "bnh_result_raw_scores",
     "bnh_result_embeddings", "bnh_results_free", "bnh_parse_labels", "bnh_chunk_plan",
 ]
@@ -107,6 +108,12 @@ def _load() -> C.CDLL:
         "bn_step_device": (i32, [vp, vp, sz, sz, i32, C.c_float, i32]),
         "bn_step_results": (i32, [vp, C.POINTER(f32p), C.POINTER(u32p), C.POINTER(f32p), C.POINTER(u32p), C.POINTER(sz)]),
         "bn_plan_describe": (sz, [C.c_char_p, i32, i32, C.c_char_p, sz, C.POINTER(i32)]),
+        "bn_recording_create": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
+        "bn_recording_free": (None, [vp]),
+        "bn_recording_samples": (sz, [vp]),
+        "bn_chunk_count": (sz, [sz, sz]),
+        "bn_recording_windows": (i32, [vp, sz, sz, sz, sz, f32p]),
+        "bn_infer_windows": (i32, [vp, vp, sz, sz, sz, f32p, f32p, C.POINTER(C.c_int32), C.c_uint64]),
         "bn_last_error": (sz, [C.c_char_p, sz]),
         # host mirror
         "bnh_classifier_build": (i32, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), sz, i32, C.c_int64, i32,
@@ -128,6 +135,8 @@ def _load() -> C.CDLL:
         "bnh_context_model_type": (i32, [vp]),
         "bnh_predict_batch_with_context": (i32, [vp, vp, C.POINTER(f32p), C.POINTER(sz), sz, C.c_int64,
                                                  C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(BnhError)]),
+        "bnh_predict_recording": (i32, [vp, vp, vp, sz, i32, C.c_float, sz, sz, C.c_int64, C.POINTER(C.c_int32), C.POINTER(vp),
+                                        f32p, sz, C.POINTER(BnhError)]),
         "bnh_results_len": (sz, [vp]),
         "bnh_result_model_type": (i32, [vp, sz]),
         "bnh_result_n_predictions": (sz, [vp, sz]),
@@ -393,6 +402,26 @@ class Classifier:
         return _collect(res)
 
 
+    def predict_recording(self, context: BatchInferenceContext, samples: np.ndarray, overlap_secs: float = 0.0, first_chunk: int = 0,
+                          count: Optional[int] = None, options: Optional[InferenceOptions] = None) -> list:
+        """The reference CLI's read_wav + chunk_audio + batch loop (src/bin/birdnet-analyze.rs:556-600, 683-743) on a mono
+        int16 / float32 recording: uploaded once, windows cut on the device.  Returns [(start_time, PredictionResult)]."""
+        options = options or InferenceOptions()
+        a = np.ascontiguousarray(samples)
+        if a.ndim != 1 or a.dtype not in (np.int16, np.float32):
+            raise ValueError("mono int16 or float32 samples expected")
+        t, c = options._raw()
+        res, err = C.c_void_p(), BnhError()
+        cap = 1 << 20
+        times = np.zeros(cap, dtype=np.float32)
+        if lib.bnh_predict_recording(self._h, context._h, a.ctypes.data_as(C.c_void_p), a.shape[0], 0 if a.dtype == np.int16 else 1,
+                                     C.c_float(overlap_secs), first_chunk, (1 << 64) - 1 if count is None else count, t, c, C.byref(res),
+                                     times.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(err)):
+            raise Error(err)
+        results = _collect(res)
+        return list(zip(times[:len(results)].tolist(), results))
+
+
 class ClassifierBuilder:
     """reference src/classifier.rs:46-383."""
 
@@ -466,7 +495,7 @@ class Model:
         self.device = device
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # lib is gone at interpreter shutdown
             lib.bn_model_free(self._h)
             self._h = None
 
@@ -492,7 +521,7 @@ class Context:
         self._h, self.model, self.max_batch = h, model, max_batch
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib.bn_ctx_destroy(self._h)
             self._h = None
 
@@ -570,6 +599,21 @@ class Context:
             raise EngineError(st)
         return idx, conf, cnt
 
+    def infer_windows(self, rec: "Recording", step_samples: int, first: int, count: int, want_embeddings: bool = True,
+                      timeout_ns: int = 0, cancel=None):
+        """bn_infer_windows: windows [first, first+count) of an uploaded recording -> (logits, embeddings)."""
+        cfg = self.model.config
+        f32p = C.POINTER(C.c_float)
+        logits = np.empty((count, self.output_device(cfg.logits_output)[1]), dtype=np.float32)
+        emb = None
+        if cfg.has_embedding and want_embeddings:
+            emb = np.empty((count, self.output_device(cfg.embedding_output)[1]), dtype=np.float32)
+        st = lib.bn_infer_windows(self._h, rec._h, step_samples, first, count, logits.ctypes.data_as(f32p),
+                                  None if emb is None else emb.ctypes.data_as(f32p), cancel, timeout_ns)
+        if st:
+            raise EngineError(st)
+        return logits, emb
+
     def time_kernels(self, batch: int):
         cap = 1024
         names = C.create_string_buffer(cap * BN_NAME_LEN)
@@ -585,6 +629,37 @@ class Context:
 
     def stream(self) -> int:
         return lib.bn_ctx_stream(self._h) or 0
+
+
+class Recording:
+    """bn_recording: a mono recording uploaded once in its storage format (int16 or float32)."""
+
+    def __init__(self, samples: np.ndarray, device: int = 0):
+        a = np.ascontiguousarray(samples)
+        if a.ndim != 1 or a.dtype not in (np.int16, np.float32):
+            raise ValueError("mono int16 or float32 samples expected")
+        h = C.c_void_p()
+        st = lib.bn_recording_create(device, a.ctypes.data_as(C.c_void_p), a.shape[0], 0 if a.dtype == np.int16 else 1, C.byref(h))
+        if st:
+            raise EngineError(st)
+        self._h = h
+        self.n_samples = int(a.shape[0])
+
+    def __del__(self):
+        if getattr(self, "_h", None) and lib is not None:  # lib is gone at interpreter shutdown
+            lib.bn_recording_free(self._h)
+            self._h = None
+
+    def n_windows(self, step_samples: int) -> int:
+        return int(lib.bn_chunk_count(self.n_samples, step_samples))
+
+    def windows(self, segment_samples: int, step_samples: int, first: int, count: int) -> np.ndarray:
+        """chunk_audio on the device, copied back: f32 [count, segment_samples]."""
+        out = np.zeros((count, segment_samples), dtype=np.float32)
+        st = lib.bn_recording_windows(self._h, segment_samples, step_samples, first, count, out.ctypes.data_as(C.POINTER(C.c_float)))
+        if st:
+            raise EngineError(st)
+        return out
 
 
 def topk_host(logits: np.ndarray, top_k: int, min_confidence: Optional[float] = None, device: int = 0):

@@ -449,29 +449,12 @@ bn_status bn_infer_device(bn_ctx *c, const float *d_pcm, size_t batch, int32_t s
     return BN_OK;
 }
 
-bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch, float *logits_out, float *emb_out, const volatile int32_t *cancel,
-                   uint64_t timeout_ns) {
-    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
-    if (batch == 0) return BN_OK;
-    if (!segs || !logits_out) return fail(BN_ERR_INVALID_ARG, "null argument");
-    if (batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(batch) + " exceeds context max " + std::to_string(c->max_batch));
+// Tail shared by bn_infer / bn_infer_windows once the plan is enqueued on d_input: output copies to
+// pinned staging, wait with cancel / timeout polling, copy out.
+static bn_status finish_infer(bn_ctx *c, size_t batch, float *logits_out, float *emb_out, const volatile int32_t *cancel, uint64_t timeout_ns) {
     const Plan &p = *c->pd->plan;
     const bn_model_config &cfg = c->model->cfg;
-    HIP_TRY(hipSetDevice(c->model->device));
-    bn_status st = drain_if_needed(c);
-    if (st != BN_OK) return st;
-    if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
-    const size_t S = (size_t)p.sample_count;
-    for (size_t b = 0; b < batch; b++) {
-        if (!segs[b]) return fail(BN_ERR_INVALID_ARG, "segment " + std::to_string(b) + " is null");
-        memcpy(c->h_input + b * S, segs[b], S * sizeof(float));
-    }
-    HIP_TRY(hipMemcpyAsync(c->d_input, c->h_input, batch * S * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    st = enqueue_plan(c, c->d_input, batch, cancel);
-    if (st != BN_OK) {
-        c->in_flight = true;
-        return st;
-    }
+    bn_status st = BN_OK;
     c->last_batch = batch;
     const OutputInfo &lo = p.outputs[cfg.logits_output];
     const size_t N = (size_t)lo.row_elems;
@@ -489,6 +472,32 @@ bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch, float *log
     memcpy(logits_out, h_logits, batch * N * sizeof(float));
     if (E) memcpy(emb_out, h_emb, batch * E * sizeof(float));
     return BN_OK;
+}
+
+
+bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch, float *logits_out, float *emb_out, const volatile int32_t *cancel,
+                   uint64_t timeout_ns) {
+    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
+    if (batch == 0) return BN_OK;
+    if (!segs || !logits_out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    if (batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(batch) + " exceeds context max " + std::to_string(c->max_batch));
+    const Plan &p = *c->pd->plan;
+    HIP_TRY(hipSetDevice(c->model->device));
+    bn_status st = drain_if_needed(c);
+    if (st != BN_OK) return st;
+    if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
+    const size_t S = (size_t)p.sample_count;
+    for (size_t b = 0; b < batch; b++) {
+        if (!segs[b]) return fail(BN_ERR_INVALID_ARG, "segment " + std::to_string(b) + " is null");
+        memcpy(c->h_input + b * S, segs[b], S * sizeof(float));
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_input, c->h_input, batch * S * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    st = enqueue_plan(c, c->d_input, batch, cancel);
+    if (st != BN_OK) {
+        c->in_flight = true;
+        return st;
+    }
+    return finish_infer(c, batch, logits_out, emb_out, cancel, timeout_ns);
 }
 
 bn_status bn_ctx_output_device(const bn_ctx *c, int32_t index, const float **d_ptr, size_t *row_elems) {
@@ -735,6 +744,106 @@ bn_status bn_topk_host(int32_t device, const float *logits, size_t rows, size_t 
     bn_status st = bn_topk_device(device, d, rows, n, top_k, has_min, min_conf, k_stride, idx_out, conf_out, count_out);
     (void)hipFree(d);
     return st;
+}
+
+// ---- recording-level ingest (birdnet-analyze.rs:683-687, 707-743) ----
+struct bn_recording {
+    int32_t device = 0;
+    int32_t format = BN_PCM_I16;
+    void *d_pcm = nullptr;
+    size_t n_samples = 0;
+};
+
+bn_status bn_recording_create(int32_t device, const void *pcm, size_t n_samples, int32_t format, bn_recording **out) {
+    if (!out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (format != BN_PCM_I16 && format != BN_PCM_F32) return fail(BN_ERR_INVALID_ARG, "unknown PCM format");
+    if (n_samples && !pcm) return fail(BN_ERR_INVALID_ARG, "null PCM buffer");
+    if (bn_device_count() <= 0) return fail(BN_ERR_NO_DEVICE, "no gfx950 device visible");
+    HIP_TRY(hipSetDevice(device));
+    auto r = std::make_unique<bn_recording>();
+    r->device = device;
+    r->format = format;
+    r->n_samples = n_samples;
+    const size_t bytes = n_samples * (format == BN_PCM_I16 ? sizeof(int16_t) : sizeof(float));
+    HIP_TRY(hipMalloc(&r->d_pcm, std::max<size_t>(bytes, 16)));
+    if (bytes) {
+        hipError_t e = hipMemcpy(r->d_pcm, pcm, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(r->d_pcm);
+            return fail(BN_ERR_BACKEND, std::string("recording upload failed: ") + hipGetErrorString(e));
+        }
+    }
+    *out = r.release();
+    return BN_OK;
+}
+
+void bn_recording_free(bn_recording *r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->d_pcm) (void)hipFree(r->d_pcm);
+    delete r;
+}
+
+size_t bn_recording_samples(const bn_recording *r) { return r ? r->n_samples : 0; }
+
+size_t bn_chunk_count(size_t n_samples, size_t step_samples) {
+    if (n_samples == 0 || step_samples == 0) return 0;
+    return (n_samples + step_samples - 1) / step_samples;  // one window for every pos = k*step < n_samples
+}
+
+static bn_status check_windows(const bn_recording *r, size_t S, size_t step, size_t first, size_t count) {
+    if (!r) return fail(BN_ERR_INVALID_ARG, "null recording");
+    if (S == 0 || S % 4 != 0 || S > 0xffffffffull) return fail(BN_ERR_INVALID_ARG, "segment_samples must be a positive multiple of 4");
+    if (step == 0) return fail(BN_ERR_INVALID_ARG, "step_samples must be positive (overlap shorter than the segment)");
+    const size_t total = bn_chunk_count(r->n_samples, step);
+    if (first > total || count > total - first) return fail(BN_ERR_INVALID_ARG, "window range [" + std::to_string(first) + ", " + std::to_string(first + count) + ") exceeds the " + std::to_string(total) + " windows of the recording");
+    return BN_OK;
+}
+
+bn_status bn_recording_windows(const bn_recording *r, size_t segment_samples, size_t step_samples, size_t first_window, size_t count, float *host_out) {
+    bn_status st = check_windows(r, segment_samples, step_samples, first_window, count);
+    if (st != BN_OK) return st;
+    if (count == 0) return BN_OK;
+    if (!host_out) return fail(BN_ERR_INVALID_ARG, "null host buffer");
+    HIP_TRY(hipSetDevice(r->device));
+    float *d = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), count * segment_samples * sizeof(float)));
+    (void)hipGetLastError();
+    launch_windows(nullptr, d, r->d_pcm, r->format == BN_PCM_I16, r->n_samples, (uint64_t)first_window * step_samples, step_samples, (uint32_t)segment_samples,
+                   (uint32_t)count);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(host_out, d, count * segment_samples * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("window kernel failed: ") + hipGetErrorString(e));
+    return BN_OK;
+}
+
+bn_status bn_infer_windows(bn_ctx *c, const bn_recording *r, size_t step_samples, size_t first_window, size_t count, float *logits_out, float *emb_out,
+                           const volatile int32_t *cancel, uint64_t timeout_ns) {
+    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
+    const size_t S = (size_t)c->pd->plan->sample_count;
+    bn_status st = check_windows(r, S, step_samples, first_window, count);
+    if (st != BN_OK) return st;
+    if (count == 0) return BN_OK;
+    if (!logits_out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    if (count > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(count) + " exceeds context max " + std::to_string(c->max_batch));
+    if (r->device != c->model->device) return fail(BN_ERR_INVALID_ARG, "recording and context live on different devices");
+    HIP_TRY(hipSetDevice(c->model->device));
+    st = drain_if_needed(c);
+    if (st != BN_OK) return st;
+    if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
+    (void)hipGetLastError();
+    launch_windows(c->stream, c->d_input, r->d_pcm, r->format == BN_PCM_I16, r->n_samples, (uint64_t)first_window * step_samples, step_samples, (uint32_t)S,
+                   (uint32_t)count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("window kernel launch failed: ") + hipGetErrorString(e));
+    st = enqueue_plan(c, c->d_input, count, cancel);
+    if (st != BN_OK) {
+        c->in_flight = true;
+        return st;
+    }
+    return finish_infer(c, count, logits_out, emb_out, cancel, timeout_ns);
 }
 
 size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int32_t all_outputs, char *buf, size_t cap, bn_status *status) {

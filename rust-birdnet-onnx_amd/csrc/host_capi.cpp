@@ -154,6 +154,23 @@ int32_t bnh_predict_batch_with_context(const bnh_classifier *c, bnh_context *ctx
     });
 }
 
+int32_t bnh_predict_recording(const bnh_classifier *c, bnh_context *ctx, const void *pcm, size_t n_samples, int32_t format, float overlap_secs,
+                              size_t first_chunk, size_t count, int64_t timeout_ns, const volatile int32_t *cancel, bnh_results **out, float *start_times,
+                              size_t times_cap, bnh_error *err) {
+    if (out) *out = nullptr;
+    return guarded(err, [&] {
+        InferenceOptions o = make_opts(timeout_ns, cancel);
+        Recording rec(pcm, n_samples, format, 0);
+        auto chunks = c->cl.predict_recording(*ctx->ctx, rec, overlap_secs, first_chunk, count, o);
+        auto r = std::make_unique<bnh_results>();
+        for (size_t i = 0; i < chunks.size(); i++) {
+            if (start_times && i < times_cap) start_times[i] = chunks[i].start_time;
+            r->v.push_back(std::move(chunks[i].result));
+        }
+        *out = r.release();
+    });
+}
+
 size_t bnh_results_len(const bnh_results *r) { return r ? r->v.size() : 0; }
 int32_t bnh_result_model_type(const bnh_results *r, size_t i) { return (int32_t)r->v[i].model_type; }
 size_t bnh_result_n_predictions(const bnh_results *r, size_t i) { return r->v[i].predictions.size(); }

@@ -102,7 +102,8 @@ namespace {
 constexpr size_t kDefaultCtxCap = 1024;
 
 // process_batch_outputs_from_flat (classifier.rs:872-911): slice rows, top-K, copy raw scores.
-std::vector<PredictionResult> run_on_ctx(ClassifierInner &in, bn_ctx *ctx, const float *const *segs, size_t n, const InferenceOptions &opt) {
+template <class InferFn>
+std::vector<PredictionResult> run_on_ctx_with(ClassifierInner &in, bn_ctx *ctx, size_t n, const InferenceOptions &opt, InferFn infer) {
     // row lengths as planned (equal to num_species / embedding_dim for every 2-D output)
     size_t N = in.config.num_species, E = in.config.embedding_dim.value_or(0);
     {
@@ -114,7 +115,7 @@ std::vector<PredictionResult> run_on_ctx(ClassifierInner &in, bn_ctx *ctx, const
     std::vector<float> logits(n * N), emb(n * E);
     const volatile int32_t *cancel = opt.cancellation_token ? opt.cancellation_token->raw() : nullptr;
     const uint64_t timeout_ns = opt.timeout ? std::max<uint64_t>((uint64_t)opt.timeout->count(), 1) : 0;
-    bn_status st = bn_infer(ctx, segs, n, logits.data(), E ? emb.data() : nullptr, cancel, timeout_ns);
+    bn_status st = infer(logits.data(), E ? emb.data() : nullptr, cancel, timeout_ns);
     if (st != BN_OK) throw from_status(st, opt);
     const size_t k = std::min(in.top_k, N);
     std::vector<uint32_t> idx(n * std::max<size_t>(k, 1)), cnt(n);
@@ -134,6 +135,12 @@ std::vector<PredictionResult> run_on_ctx(ClassifierInner &in, bn_ctx *ctx, const
         }
     }
     return out;
+}
+
+std::vector<PredictionResult> run_on_ctx(ClassifierInner &in, bn_ctx *ctx, const float *const *segs, size_t n, const InferenceOptions &opt) {
+    return run_on_ctx_with(in, ctx, n, opt, [&](float *logits, float *emb, const volatile int32_t *cancel, uint64_t timeout_ns) {
+        return bn_infer(ctx, segs, n, logits, emb, cancel, timeout_ns);
+    });
 }
 
 bn_ctx *ensure_default_ctx(ClassifierInner &in, size_t n) {
@@ -198,6 +205,40 @@ std::vector<PredictionResult> Classifier::predict_batch_with_context(BatchInfere
     for (size_t i = 0; i < n; i++)
         if (lens[i] != ctx.sample_count_) throw batch_input_size(i, ctx.sample_count_, lens[i]);
     return run_on_ctx(*inner_, ctx.ctx_, segments, n, options);
+}
+
+// ---- recording-level path (birdnet-analyze.rs:556-600, 683-687, 707-743) ----
+Recording::Recording(const void *pcm, size_t n_samples, int32_t format, int device) : n_samples_(n_samples) {
+    bn_recording *r = nullptr;
+    if (bn_recording_create(device, pcm, n_samples, format, &r) != BN_OK) throw inference("failed to upload recording: " + last_backend_error());
+    rec_ = std::shared_ptr<bn_recording>(r, [](bn_recording *p) { bn_recording_free(p); });
+}
+
+std::vector<ChunkResult> Classifier::predict_recording(BatchInferenceContext &ctx, const Recording &rec, float overlap_secs, size_t first_chunk, size_t count,
+                                                       const InferenceOptions &options) const {
+    const ModelConfig &cfg = inner_->config;
+    // chunk_audio: overlap_samples = (overlap * sample_rate) as usize; step = segment - overlap_samples
+    const size_t overlap_samples = (size_t)(overlap_secs * (float)cfg.sample_rate);
+    if (overlap_secs < 0.0f || overlap_samples >= cfg.sample_count) throw inference("overlap must be shorter than the segment duration");
+    const size_t step = cfg.sample_count - overlap_samples;
+    const size_t total = bn_chunk_count(rec.n_samples(), step);
+    if (first_chunk > total) throw inference("first chunk " + std::to_string(first_chunk) + " is past the " + std::to_string(total) + " chunks of the recording");
+    const size_t n = std::min(count, total - first_chunk);
+    std::vector<ChunkResult> out;
+    out.reserve(n);
+    for (size_t off = 0; off < n; off += ctx.max_batch_size_) {
+        const size_t m = std::min(ctx.max_batch_size_, n - off);
+        const size_t first = first_chunk + off;
+        auto part = run_on_ctx_with(*inner_, ctx.ctx_, m, options, [&](float *logits, float *emb, const volatile int32_t *cancel, uint64_t timeout_ns) {
+            return bn_infer_windows(ctx.ctx_, rec.raw(), step, first, m, logits, emb, cancel, timeout_ns);
+        });
+        for (size_t i = 0; i < m; i++) {
+            // start_time = pos as f32 / sample_rate as f32 (birdnet-analyze.rs:736)
+            const float t = (float)((first + i) * step) / (float)cfg.sample_rate;
+            out.push_back(ChunkResult{t, std::move(part[i])});
+        }
+    }
+    return out;
 }
 
 Classifier ClassifierBuilder::build() {

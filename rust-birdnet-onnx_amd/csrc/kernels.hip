@@ -1849,6 +1849,41 @@ void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, 
     }
 }
 
+// ------------------------------------------------------------------ recording -> windows
+// chunk_audio on the device (reference src/bin/birdnet-analyze.rs:707-743) fused with the WAV
+// sample conversion (:683-687, f32::from(s) / 32768.0 -- a division by a power of two, exact):
+// window w of the launch starts at sample (first + w) * step; samples past the end of the recording
+// are 0.  One lane = 4 consecutive samples of a window (float4 store; S % 4 == 0 checked by the
+// caller), reads are 2- or 4-byte loads at arbitrary alignment.  grid (ceil(S/1024), count)
+namespace {
+template <class T>
+__global__ __launch_bounds__(256) void windows_kernel(float *__restrict__ dst, const T *__restrict__ src, uint64_t n_samples, uint64_t first_start,
+                                                     uint64_t step, uint32_t S) {
+    const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (i >= S) return;
+    const uint64_t pos = first_start + (uint64_t)blockIdx.y * step + i;
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint64_t q = pos + u;
+        if (q < n_samples) {
+            if constexpr (sizeof(T) == 2) v[u] = (float)src[q] * (1.0f / 32768.0f);
+            else v[u] = (float)src[q];
+        } else {
+            v[u] = 0.0f;
+        }
+    }
+    *reinterpret_cast<float4 *>(dst + (uint64_t)blockIdx.y * S + i) = make_float4(v[0], v[1], v[2], v[3]);
+}
+}  // namespace
+void launch_windows(hipStream_t s, float *dst, const void *src, int32_t is_i16, uint64_t n_samples, uint64_t first_start, uint64_t step, uint32_t S,
+                    uint32_t count) {
+    if (count == 0 || S == 0) return;
+    dim3 grid((S / 4 + 255) / 256, count);
+    if (is_i16) hipLaunchKernelGGL(windows_kernel<int16_t>, grid, dim3(256), 0, s, dst, static_cast<const int16_t *>(src), n_samples, first_start, step, S);
+    else hipLaunchKernelGGL(windows_kernel<float>, grid, dim3(256), 0, s, dst, static_cast<const float *>(src), n_samples, first_start, step, S);
+}
+
 // empty launch: calibrates the event-to-event overhead of bn_ctx_time_kernels
 namespace {
 __global__ void null_kernel() {}

@@ -1,0 +1,106 @@
+"""Recording-level ingest on the device: i16 -> f32 conversion and chunk_audio
+windows materialised by a kernel, against the oracle's restatement of the reference CLI
+(src/bin/birdnet-analyze.rs:683-687 read_wav, :707-743 chunk_audio).  Bit-exact: integer / index work
+plus a division by a power of two."""
+import numpy as np
+import pytest
+
+import oracle
+from gpu_helpers import synth, write_model
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_windows(pcm_i16: np.ndarray, S: int, overlap: float, sr: int):
+    f32 = (pcm_i16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)  # f32::from(s) / 32768.0
+    starts, times = oracle.chunk_plan(len(f32), S, overlap, sr)
+    return np.stack([oracle.chunk_fill(f32, S, int(st)) for st in starts]) if len(starts) else np.zeros((0, S), np.float32), starts
+
+
+@pytest.mark.parametrize("n,S,overlap,sr", [(144000 * 3 + 777, 144000, 0.0, 48000), (500000, 144000, 1.5, 48000), (1000, 144000, 0.0, 48000),
+                                            (160000 * 2, 160000, 2.5, 32000), (144000, 144000, 0.0, 48000), (144001, 144000, 2.9, 48000)])
+def test_device_windows_match_chunk_audio(bn, n, S, overlap, sr):
+    rng = np.random.default_rng(n)
+    pcm = rng.integers(-32768, 32768, size=n, dtype=np.int16)
+    pcm[:4] = [-32768, 32767, 0, -1]  # extremes of the conversion
+    want, starts = reference_windows(pcm, S, overlap, sr)
+    step = S - int(np.floor(np.float32(overlap) * np.float32(sr)))
+    rec = bn.Recording(pcm)
+    assert rec.n_windows(step) == len(starts)
+    got = rec.windows(S, step, 0, len(starts))
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # a sub-range, and float input passed through untouched
+    if len(starts) > 2:
+        assert np.array_equal(rec.windows(S, step, 1, 2), want[1:3])
+    recf = bn.Recording((pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32))
+    assert np.array_equal(recf.windows(S, step, 0, len(starts)).view(np.uint32), want.view(np.uint32))
+
+
+def test_empty_recording_and_bad_ranges(bn):
+    rec = bn.Recording(np.zeros(0, dtype=np.int16))
+    assert rec.n_windows(144000) == 0
+    assert rec.windows(144000, 144000, 0, 0).shape == (0, 144000)
+    rec = bn.Recording(np.zeros(1000, dtype=np.int16))
+    with pytest.raises(bn.EngineError):
+        rec.windows(144000, 144000, 0, 2)       # only one window exists
+    with pytest.raises(bn.EngineError):
+        rec.windows(144000, 0, 0, 1)            # overlap >= segment
+    with pytest.raises(bn.EngineError):
+        rec.windows(144002, 144002, 0, 1)       # not a multiple of 4
+
+
+def test_infer_windows_equals_infer_on_host_windows(bn):
+    """The whole path fed from an uploaded i16 recording gives the same BITS as bn_infer on host-made windows."""
+    S, sr, overlap = 144000, 48000, 1.0
+    rng = np.random.default_rng(5)
+    t = np.arange(S * 4 + 12345) / sr
+    pcm = np.clip(8000 * np.sin(2 * np.pi * 1800 * t) + rng.normal(0, 500, t.shape), -32768, 32767).astype(np.int16)
+    want_windows, starts = reference_windows(pcm, S, overlap, sr)
+    step = S - int(overlap * sr)
+    path = write_model(synth.birdnet_v24(num_species=300, width=0.5))
+    model = bn.Model(path)
+    ctx = bn.Context(model, 4)
+    rec = bn.Recording(pcm)
+    G = len(starts)
+    assert G == rec.n_windows(step) and G > 4
+    got = []
+    for first in range(0, G, 4):
+        cnt = min(4, G - first)
+        lg, _ = ctx.infer_windows(rec, step, first, cnt)
+        got.append(lg.copy())
+    got = np.concatenate(got)
+    ref = np.concatenate([ctx.infer(want_windows[f:f + 4])[0].copy() for f in range(0, G, 4)])
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    with pytest.raises(bn.EngineError):
+        ctx.infer_windows(rec, step, 0, 5)  # exceeds the context's max batch
+
+
+def test_predict_recording_through_the_host_mirror(bn, tmp_path):
+    """Classifier::predict_recording == predict_batch over chunk_audio windows made on the host (same bits, same
+    top-K, start times as chunk_audio reports them)."""
+    S, sr, overlap = 144000, 48000, 0.5
+    rng = np.random.default_rng(9)
+    t = np.arange(S * 5 + 999) / sr
+    pcm = np.clip(6000 * np.sin(2 * np.pi * 3100 * t) + rng.normal(0, 900, t.shape), -32768, 32767).astype(np.int16)
+    windows, starts = reference_windows(pcm, S, overlap, sr)
+    _, times = oracle.chunk_plan(len(pcm), S, overlap, sr)
+    path = write_model(synth.birdnet_v24(num_species=300, width=0.5))
+    labels = [f"Genus species{i}_Common {i}" for i in range(300)]
+    cl = bn.ClassifierBuilder().model_path(path).labels(labels).top_k(5).with_rocm(0).build()
+    ctx = cl.create_batch_context(4)
+    got = cl.predict_recording(ctx, pcm, overlap)
+    assert len(got) == len(starts)
+    ref = []
+    for f in range(0, len(starts), 4):
+        ref += cl.predict_batch_with_context(ctx, [w for w in windows[f:f + 4]])
+    for (tm, g), r, t_ref in zip(got, ref, times):
+        assert np.float32(tm) == np.float32(t_ref)
+        assert np.array_equal(np.asarray(g.raw_scores, dtype=np.float32).view(np.uint32), np.asarray(r.raw_scores, dtype=np.float32).view(np.uint32))
+        assert [(p.index, p.species, np.float32(p.confidence)) for p in g.predictions] == [(p.index, p.species, np.float32(p.confidence)) for p in r.predictions]
+    # a sub-range and the overlap validation
+    part = cl.predict_recording(ctx, pcm, overlap, first_chunk=2, count=3)
+    assert [np.float32(a) for a, _ in part] == [np.float32(x) for x in times[2:5]]
+    with pytest.raises(bn.Error) as e:
+        cl.predict_recording(ctx, pcm, 3.0)
+    assert e.value.kind == bn.ErrorKind.Inference

@@ -164,3 +164,17 @@ def test_model_type_constants(bn):  # types.rs:14-44, tests :194-235
     assert (M.BirdNetV30.sample_rate(), M.BirdNetV30.segment_duration(), M.BirdNetV30.sample_count()) == (32000, 5.0, 160000)
     assert (M.PerchV2.sample_rate(), M.PerchV2.sample_count()) == (32000, 160000)
     assert not M.BirdNetV24.has_embeddings() and M.BirdNetV30.has_embeddings() and M.PerchV2.has_embeddings()
+
+
+def test_engine_chunk_count_matches_chunk_audio(bn):
+    """bn_chunk_count (pure host arithmetic) == number of chunks of the reference's chunk_audio
+    (src/bin/birdnet-analyze.rs:707-743) as restated by the oracle and by the host mirror."""
+    import oracle
+    for n in (0, 1, 999, 144000, 144001, 300000, 144000 * 7 + 3):
+        for S, sr in ((144000, 48000), (160000, 32000)):
+            for overlap in (0.0, 0.5, 1.5, 2.9):
+                step = S - int(np.floor(np.float32(overlap) * np.float32(sr)))
+                starts, _ = oracle.chunk_plan(n, S, overlap, sr)
+                assert bn.lib.bn_chunk_count(n, step) == len(starts)
+                assert len(bn.chunk_plan(n, S, overlap, sr)[0]) == len(starts)
+    assert bn.lib.bn_chunk_count(1000, 0) == 0
