@@ -1547,7 +1547,7 @@ class Builder {
             const bool mb_off = mbenv && std::string(mbenv) == "0";
             if (d.tiled && kh == kw && strides[0] == strides[1] && !mb_off && !plan_.ops.empty()) {
                 PlanOp &pe = plan_.ops.back();
-                const int maxk = std::min(44, getenv("BN_MBFUSE_MAXK") ? atoi(getenv("BN_MBFUSE_MAXK")) : 44);  // kernel: Cin + 1 columns in <= 6 K groups
+                const int maxk = std::min(48, getenv("BN_MBFUSE_MAXK") ? atoi(getenv("BN_MBFUSE_MAXK")) : 48);  // kernel: <= 6 K groups in registers
                 // the kernel relies on act(0) == 0 for the expand activation (pixels outside the image)
                 const int a1 = pe.gemm.act;
                 const bool act_zero = a1 == ACT_NONE || a1 == ACT_RELU || (a1 == ACT_CLIP && pe.gemm.p0 <= 0.f && pe.gemm.p1 >= 0.f) ||
@@ -1583,18 +1583,16 @@ class Builder {
                     mb.name = "mbconv:" + pe.name.substr(pe.name.find(':') + 1) + "+" + n.name;
                     mb.out = op.out;
                     mb.a = pe.a;
-                    // expand filters repacked for the kernel: [C][KW] rows = Cin weights | bias | zeros, KW = 8-wide
-                    // K groups covering Cin + 1 columns (the bias rides along as one more K term)
+                    // expand filters repacked for the kernel: [C][KW] rows = Cin weights | zeros, KW = Cin rounded up to
+                    // 8-wide K groups (the bias starts the accumulators)
                     if (whole_map) {
                         mb.w = pe.w;  // [C][Cin] as the GEMM had it
                     } else {
-                        const int64_t Kc = pe.gemm.K, KW = (Kc + 8) / 8 * 8;
+                        const int64_t Kc = pe.gemm.K, KW = (Kc + 7) / 8 * 8;
                         const std::vector<float> &w0 = plan_.consts[pe.w.id];
                         std::vector<float> wpk((size_t)(Cin * KW), 0.0f);
-                        for (int64_t nn = 0; nn < Cin; nn++) {
+                        for (int64_t nn = 0; nn < Cin; nn++)
                             for (int64_t k = 0; k < Kc; k++) wpk[nn * KW + k] = w0[pe.w.offset + nn * Kc + k];
-                            if (pe.gemm.has_bias) wpk[nn * KW + Kc] = plan_.consts[pe.bias.id][pe.bias.offset + nn];
-                        }
                         mb.w = Ref{Space::CONSTS, add_const(wpk), 0};
                     }
                     mb.bias = pe.bias;

@@ -954,16 +954,17 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
 // ------------------------------------------------------------------ fused expand + depthwise
 // One block = one output tile (TOH x TOW pixels), ALL mid channels in chunks of 32:
 //   0. the input halo tile ((TOH-1)*S+K) x ((TOW-1)*S+K) pixels x Cin is staged in LDS ONCE
-//      (Cin <= 44: the whole K extent fits).  Pixels outside the image are zero rows.  Column Cin
-//      of a row holds 1 for pixels inside the image and 0 outside: the expand bias rides along as
-//      one more K term, so a pixel outside the image expands to exactly act(0) = 0 -- which is what
-//      the depthwise conv's zero padding of the EXPANDED tensor needs -- with no per-element mask
-//      or bias add in the epilogue (the planner only fuses activations with act(0) == 0)
+//      (Cin <= 48: the whole K extent fits).  Pixels outside the image are zero rows and carry a
+//      validity flag Vs[pixel] = 0 (1 inside).
 //   per chunk of 32 mid channels:
 //   1. expand on the matrix cores: rows = halo pixels (A from LDS), cols = 32 filters whose
 //      B operands come STRAIGHT from global memory into registers (lane = filter, one float4 per
-//      8-wide K group, bias in the slot of column Cin), prefetched one chunk ahead; the m-tiles
-//      rotate over the waves from chunk to chunk so the odd tile does not always load one SIMD
+//      8-wide K group), prefetched one chunk ahead; the accumulators START at bias * Vs[pixel], so
+//      a pixel outside the image expands to exactly act(0) = 0 -- which is what the depthwise
+//      conv's zero padding of the EXPANDED tensor needs -- with no mask or bias add in the
+//      epilogue and no extra K group (the planner only fuses activations with act(0) == 0);
+//      interior tiles skip the flag look-ups; the m-tiles rotate over the waves from chunk to
+//      chunk so the odd tile does not always load one SIMD
 //   2. activation, written to LDS [pixel][32]
 //   3. depthwise K x K from LDS: lane = channel (conflict free), each lane slides the window
 //      along PPG consecutive pixels of one output row, so every LDS value is read once per row
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
 //   after the loop: per-tile channel sums for a following squeeze-excite (fixed order)
 // The expanded tensor never exists in HBM.  grid (tiles, 1, batch), 256 threads, dynamic LDS;
 // two barriers per chunk.
-constexpr int MB_MAX_NG = 6;  // Cin + 1 <= 48
+constexpr int MB_MAX_NG = 6;  // Cin <= 48
 template <int K, int S>
 __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                                const float *__restrict__ w1, const float *__restrict__ b1,
@@ -986,11 +987,12 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
     constexpr int IWS = (PPG - 1) * S + K;  // input columns one lane group touches
     static_assert(TOW % PPG == 0, "a lane group must stay inside one output row");
     extern __shared__ __align__(16) float msm[];
-    const int ng = (d.Cin + 8) / 8;  // 8-wide K groups holding data (Cin columns + the ones column)
+    const int ng = (d.Cin + 7) / 8;  // 8-wide K groups holding data
     const int KS = ng * 8 + 4;       // LDS row stride (floats): (KS/4) is odd -> conflict-free b128 reads
     float *Xs = msm;             // [MP][KS]
     float *Es = Xs + MP * KS;    // [MP][32]
-    float *red = Es + MP * 32;   // [nchunks][8][32]
+    float *Vs = Es + MP * 32;    // [MP] 1.0 for halo pixels inside the image, else 0.0
+    float *red = Vs + MP;        // [nchunks][8][32]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
     const int oh0 = ty * TOH, ow0 = tx * TOW;
@@ -999,10 +1001,12 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
     const float *xin = in + b * d.in_bs;
     const int CV = d.Cin >> 2;  // float4 per pixel (Cin % 4 == 0)
     const int nchunks = (d.C + 31) / 32;
+    // the whole halo lies inside the image (interior tiles): no validity look-ups in the expand
+    const bool all_valid = ih0 >= 0 && ih0 + IHT <= d.H && iw0 >= 0 && iw0 + IWT <= d.W;
 
     // expand filters of a chunk: lane (lr, lh) holds columns 8g + 4lh .. +3 of filter c0 + lr for
-    // every K group g.  w1 is the planner's padded repack [C][ng*8] = weights | bias | zeros, so
-    // these are plain loads with nothing depending on them until the matrix instructions.
+    // every K group g.  w1 is the planner's padded repack [C][ng*8] = weights | zeros, so these are
+    // plain loads with nothing depending on them until the matrix instructions.
     float4 bw[MB_MAX_NG], bnx[MB_MAX_NG];
     auto fetch_b = [&](float4 (&dst)[MB_MAX_NG], int c0) {
         const int n = c0 + lr < d.C ? c0 + lr : d.C - 1;
@@ -1037,10 +1041,9 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
                 const int r = r0 + i * PSTEP;
                 if (lane_on && r < MP) {
                     *reinterpret_cast<float4 *>(Xs + r * KS + cv * 4) = okv[i] ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (cv == 0) {  // ones column + zero K padding of this row
-                        float *xr = Xs + r * KS + d.Cin;
-                        *reinterpret_cast<float4 *>(xr) = make_float4(okv[i] ? 1.f : 0.f, 0.f, 0.f, 0.f);
-                        if ((CV & 1) == 0) *reinterpret_cast<float4 *>(xr + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cv == 0) {  // validity flag + zero K padding of this row
+                        Vs[r] = okv[i] ? 1.0f : 0.0f;
+                        if (CV & 1) *reinterpret_cast<float4 *>(Xs + r * KS + d.Cin) = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
             }
@@ -1063,6 +1066,7 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
 #pragma unroll
         for (int q = 0; q < K * K; q++) wd[q] = w2[q * d.C + (cact ? cg : d.C - 1)];
         const float bias2 = d.has_bias2 ? b2[cact ? cg : d.C - 1] : 0.0f;
+        const float bv = d.has_bias1 ? b1[c0 + lr < d.C ? c0 + lr : d.C - 1] : 0.0f;
         if (ch + 1 < nchunks) fetch_b(bnx, c0 + 32);  // next chunk's filters in flight during this chunk
         __syncthreads();  // Es of the previous chunk consumed; first pass: Xs complete
 
@@ -1072,9 +1076,18 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
         for (int t = 0; t < TPW; t++) {
             const int mt = wrole + 4 * t;
             if (mt < MT) {
+                // the accumulators start at the bias for pixels inside the image and at 0 outside: a pixel
+                // outside the image then expands to act(0) = 0, which is what the depthwise conv's zero
+                // padding of the EXPANDED tensor needs, with no mask in the epilogue and no extra K group
                 floatx16 acc[1];
+                if (all_valid) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[0][r] = 0.0f;
+                    for (int r = 0; r < 16; r++) acc[0][r] = bv;
+                } else {
+                    const float *vp = Vs + mt * 32 + 4 * lh;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[0][r] = bv * vp[(r & 3) + 8 * (r >> 2)];
+                }
                 const float *ap = Xs + (mt * 32 + lr) * KS + 4 * lh;
 #pragma unroll
                 for (int g = 0; g < MB_MAX_NG; g++)
@@ -1759,9 +1772,9 @@ size_t mbconv_lds_bytes(const MbDesc &d) {
     const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
     const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
     const int mp = (hp + 31) / 32 * 32;
-    const int ks = (d.Cin + 8) / 8 * 8 + 4;  // Cin columns + the ones column, padded to 8-wide K groups
+    const int ks = (d.Cin + 7) / 8 * 8 + 4;
     const int nchunks = (d.C + 31) / 32;
-    return (size_t)(mp * ks + mp * 32 + nchunks * 8 * 32) * sizeof(float);
+    return (size_t)(mp * ks + mp * 32 + mp + nchunks * 8 * 32) * sizeof(float);
 }
 
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
