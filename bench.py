@@ -84,7 +84,9 @@ def main():
     os.unlink(path)
     cfg = model.config
     N = cfg.num_species
-    ctxs = [bn.Context(model, B) for _ in range(max(1, args.streams))]
+    # N > 1: one context more than batches in flight, so that `streams` batches keep computing while the
+    # oldest one's logits are being all-gathered (its context is idle until the collective has read them)
+    ctxs = [bn.Context(model, B) for _ in range(max(1, args.streams) + (1 if world > 1 else 0))]
 
     # synthetic inputs, resident in HBM before the timed region: this rank's contiguous shard of
     # NBUF global batches (global segment index = (buffer * world + rank) * B + i)
@@ -193,7 +195,7 @@ def main():
             "workload": "BirdNET v2.4 (synthetic-weights hypothesised topology), batch=32 synthetic 48 kHz 3 s segments per GPU, inputs resident in HBM, logits+top-10 copied to host",
             "global_batch": B * world,
             "segments_per_gpu_per_step": B,
-            "streams_per_gpu": len(ctxs),
+            "streams_per_gpu": max(1, args.streams),
             "num_species": int(N),
             "x_realtime": round(value * 3.0, 1),
             "parallelism": f"segment-sharded x{world}" + (" + RCCL all-gather of logits" if world > 1 else ""),

@@ -1718,6 +1718,10 @@ static void launch_gemm_splitk(hipStream_t s, const GemmDesc &d, float *C, const
     {
         // few output tiles and a deep K: 32-row tiles with the 4 waves of a block splitting K
         const int64_t m32 = (total_rows + 31) / 32;
+        static const int force_bn = getenv("BN_FORCE_SPLITK_BN") ? atoi(getenv("BN_FORCE_SPLITK_BN")) : 0;  // experiments only
+        if (force_bn == 96 && d.N > 64) return launch_gemm_bn<96, true>(s, d, C, A, W, bias, res, scale, total_rows);
+        if (force_bn >= 64 && d.N > 32) return launch_gemm_bn<64, true>(s, d, C, A, W, bias, res, scale, total_rows);
+        if (force_bn == 32) return launch_gemm_bn<32, true>(s, d, C, A, W, bias, res, scale, total_rows);
         if (d.N > 32 && m32 * ((d.N + 63) / 64) >= 512) launch_gemm_bn<64, true>(s, d, C, A, W, bias, res, scale, total_rows);
         else launch_gemm_bn<32, true>(s, d, C, A, W, bias, res, scale, total_rows);
     }
