@@ -234,6 +234,13 @@ bn_status bn_infer_windows(bn_ctx *c, const bn_recording *r, size_t step_samples
                            size_t first_window, size_t count, float *logits_out, float *emb_out,
                            const volatile int32_t *cancel, uint64_t timeout_ns);
 
+/* bn_step_device over windows of an uploaded recording: window kernel + plan + top-K + D2H of
+ * logits and top-K into the context's pinned buffers, asynchronous unless sync != 0; read with
+ * bn_step_results after bn_ctx_synchronize.  This is the loop body of a recording analysis
+ * (src/bin/birdnet-analyze.rs:556-600) with several contexts in flight. */
+bn_status bn_step_windows(bn_ctx *c, const bn_recording *r, size_t step_samples, size_t first_window,
+                          size_t count, size_t top_k, int32_t has_min, float min_conf, int32_t sync);
+
 /* Diagnostic, needs no device: parse the file, build the launch plan (all graph
  * outputs when all_outputs != 0, else logits + embeddings only) and write a
  * text description (one line per launch, then totals) into buf.  Returns the

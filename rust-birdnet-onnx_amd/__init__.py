@@ -36,7 +36,7 @@ ENGINE_SYMBOLS = [
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
     "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
     "bn_recording_create", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
-    "bn_infer_windows", "bn_last_error",
+    "bn_infer_windows", "bn_step_windows", "bn_last_error",
 ]
 HOST_SYMBOLS = [
     "bnh_classifier_build", "bnh_classifier_free", "bnh_classifier_config", "bnh_classifier_provider",
@@ -114,6 +114,7 @@ def _load() -> C.CDLL:
         "bn_chunk_count": (sz, [sz, sz]),
         "bn_recording_windows": (i32, [vp, sz, sz, sz, sz, f32p]),
         "bn_infer_windows": (i32, [vp, vp, sz, sz, sz, f32p, f32p, C.POINTER(C.c_int32), C.c_uint64]),
+        "bn_step_windows": (i32, [vp, vp, sz, sz, sz, sz, i32, C.c_float, i32]),
         "bn_last_error": (sz, [C.c_char_p, sz]),
         # host mirror
         "bnh_classifier_build": (i32, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), sz, i32, C.c_int64, i32,
@@ -613,6 +614,14 @@ class Context:
         if st:
             raise EngineError(st)
         return logits, emb
+
+    def step_windows(self, rec: "Recording", step_samples: int, first: int, count: int, top_k: int = 10,
+                     min_confidence: Optional[float] = None, sync: bool = False):
+        """bn_step_windows: one asynchronous hot-path pass over windows of an uploaded recording."""
+        st = lib.bn_step_windows(self._h, rec._h, step_samples, first, count, top_k, 0 if min_confidence is None else 1,
+                                 C.c_float(min_confidence or 0.0), 1 if sync else 0)
+        if st:
+            raise EngineError(st)
 
     def time_kernels(self, batch: int):
         cap = 1024

@@ -846,6 +846,25 @@ bn_status bn_infer_windows(bn_ctx *c, const bn_recording *r, size_t step_samples
     return finish_infer(c, count, logits_out, emb_out, cancel, timeout_ns);
 }
 
+bn_status bn_step_windows(bn_ctx *c, const bn_recording *r, size_t step_samples, size_t first_window, size_t count, size_t top_k, int32_t has_min,
+                          float min_conf, int32_t sync) {
+    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
+    const size_t S = (size_t)c->pd->plan->sample_count;
+    bn_status st = check_windows(r, S, step_samples, first_window, count);
+    if (st != BN_OK) return st;
+    if (count == 0) return BN_OK;
+    if (count > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(count) + " exceeds context max " + std::to_string(c->max_batch));
+    if (r->device != c->model->device) return fail(BN_ERR_INVALID_ARG, "recording and context live on different devices");
+    HIP_TRY(hipSetDevice(c->model->device));
+    (void)hipGetLastError();
+    // stream order keeps this behind whatever the context still has in flight
+    launch_windows(c->stream, c->d_input, r->d_pcm, r->format == BN_PCM_I16, r->n_samples, (uint64_t)first_window * step_samples, step_samples, (uint32_t)S,
+                   (uint32_t)count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("window kernel launch failed: ") + hipGetErrorString(e));
+    return bn_step_device(c, c->d_input, count, top_k, has_min, min_conf, sync);
+}
+
 size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int32_t all_outputs, char *buf, size_t cap, bn_status *status) {
     bn_status dummy;
     if (!status) status = &dummy;

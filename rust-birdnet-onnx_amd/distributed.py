@@ -96,3 +96,75 @@ def analyze_sharded(windows_for: Callable[[int, int], np.ndarray], n_windows: in
     else:
         local = torch.zeros((0, n_cols), dtype=torch.float32, device=device or "cpu")
     return gather_rows(local, n_windows, dist)
+
+
+def shard_sample_range(n_samples: int, segment_samples: int, step_samples: int, lo: int, hi: int) -> Tuple[int, int]:
+    """Samples [a, b) of the recording that windows [lo, hi) touch: a = lo*step, b = min(n, (hi-1)*step + S).
+    A rank uploads only this slice; window g of the recording is window g - lo of the slice, and the
+    zero padding of the recording's last window is reproduced by the slice ending at n."""
+    if hi <= lo:
+        return 0, 0
+    return lo * step_samples, min(n_samples, (hi - 1) * step_samples + segment_samples)
+
+
+def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: float, batch: int = 32, streams: int = 3, top_k: int = 10,
+                              min_confidence: Optional[float] = None, dist=None, gather: str = "logits", ctxs=None):
+    """BASELINE.json configs[4]: a long mono recording (int16 or float32), sharded by window across the
+    ranks of one node.  Every rank uploads its slice once (bn_recording_create), cuts windows on the
+    device and keeps `streams` contexts in flight (bn_step_windows); ONE collective at the end
+    assembles the [G, N] logits (gather="logits") or only the [G, k] top-K rows (gather="topk").
+
+    Returns (logits or None, topk_idx, topk_conf, topk_count) for all G windows, in time order."""
+    import torch
+
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    cfg = model.config
+    S, sr = int(cfg.sample_count), int(cfg.sample_rate)
+    step = S - int(np.float32(overlap_secs) * np.float32(sr))
+    if step <= 0:
+        raise ValueError("overlap must be shorter than the segment duration")
+    n = int(samples.shape[0])
+    G = (n + step - 1) // step if n > 0 else 0
+    lo, hi = shard_range(G, rank, world)
+    a, b = shard_sample_range(n, S, step, lo, hi)
+    rec = bn.Recording(np.ascontiguousarray(samples[a:b]), device=model.device)
+    if ctxs is None:  # callers analysing many recordings keep their contexts (arena + captured graphs)
+        ctxs = [bn.Context(model, batch) for _ in range(max(1, streams))]
+    N = ctxs[0].output_device(cfg.logits_output)[1]
+    k = min(top_k, N)
+    n_local = hi - lo
+    logits = np.empty((n_local, N), dtype=np.float32) if gather == "logits" else None
+    idx = np.zeros((n_local, k), dtype=np.uint32)
+    conf = np.zeros((n_local, k), dtype=np.float32)
+    cnt = np.zeros(n_local, dtype=np.uint32)
+    jobs = [(f, min(batch, n_local - f)) for f in range(0, n_local, batch)]
+
+    def collect(j):
+        f, m = jobs[j]
+        c = ctxs[j % len(ctxs)]
+        c.synchronize()
+        lg, ix, cf, ct = c.step_results(m)
+        if logits is not None:
+            logits[f:f + m] = lg[:m]
+        idx[f:f + m], conf[f:f + m], cnt[f:f + m] = ix[:m, :k], cf[:m, :k], ct[:m]
+
+    for j, (f, m) in enumerate(jobs):
+        if j >= len(ctxs):
+            collect(j - len(ctxs))
+        ctxs[j % len(ctxs)].step_windows(rec, step, f, m, top_k, min_confidence)
+    for j in range(max(0, len(jobs) - len(ctxs)), len(jobs)):
+        collect(j)
+
+    if world == 1:
+        return logits, idx, conf, cnt
+    dev = torch.device("cuda", model.device) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+    def gather_np(arr, dtype):
+        t = torch.from_numpy(arr.astype(dtype, copy=False).reshape(n_local, -1)).to(dev)
+        return gather_rows(t, G, dist).cpu().numpy()
+    g_idx = gather_np(idx.view(np.int32), np.int32).view(np.uint32)
+    g_conf = gather_np(conf, np.float32)
+    g_cnt = gather_np(cnt.view(np.int32).reshape(-1, 1), np.int32).view(np.uint32).reshape(-1)
+    g_logits = gather_np(logits, np.float32) if logits is not None else None
+    return g_logits, g_idx, g_conf, g_cnt

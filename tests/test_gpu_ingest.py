@@ -104,3 +104,65 @@ def test_predict_recording_through_the_host_mirror(bn, tmp_path):
     with pytest.raises(bn.Error) as e:
         cl.predict_recording(ctx, pcm, 3.0)
     assert e.value.kind == bn.ErrorKind.Inference
+
+
+def _sharded_worker(rank, world, port, model_path, pcm_path, out_dir, overlap):
+    import importlib as _il
+    import os as _os
+    import sys as _sys
+
+    import torch  # noqa: F401  (first: one HIP runtime per process)
+    import torch.distributed as dist
+
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    _os.environ["MASTER_ADDR"] = "127.0.0.1"
+    _os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bn_ = _il.import_module("rust-birdnet-onnx_amd")
+    d = _il.import_module("rust-birdnet-onnx_amd.distributed")
+    model = bn_.Model(model_path, device=0)
+    pcm = np.load(pcm_path)
+    logits, idx, conf, cnt = d.analyze_recording_sharded(bn_, model, pcm, overlap, batch=4, streams=2, top_k=5, dist=dist)
+    np.savez(_os.path.join(out_dir, f"rank{rank}.npz"), logits=logits, idx=idx, conf=conf, cnt=cnt)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [0.0, 1.0])
+def test_sharded_recording_ingest_two_ranks_equal_single_pass(bn, tmp_path, overlap):
+    """SURVEY 8(e) + 8(f)1: two ranks (gloo, both on this GPU) each upload their slice of an i16 recording, cut
+    windows on the device, and all-gather; every rank holds exactly the single-process result, which itself equals
+    bn_infer over chunk_audio windows made on the host."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    dmod = __import__("importlib").import_module("rust-birdnet-onnx_amd.distributed")
+    S, sr = 144000, 48000
+    rng = np.random.default_rng(21)
+    t = np.arange(S * 9 + 4321) / sr
+    pcm = np.clip(7000 * np.sin(2 * np.pi * 2200 * t) + rng.normal(0, 700, t.shape), -32768, 32767).astype(np.int16)
+    path = write_model(synth.birdnet_v24(num_species=300, width=0.5))
+    model = bn.Model(path)
+    want_logits, want_idx, want_conf, want_cnt = dmod.analyze_recording_sharded(bn, model, pcm, overlap, batch=4, streams=2, top_k=5)
+    windows, starts = reference_windows(pcm, S, overlap, sr)
+    ctx = bn.Context(model, 4)
+    ref = np.concatenate([ctx.infer(windows[f:f + 4])[0].copy() for f in range(0, len(starts), 4)])
+    assert want_logits.shape == ref.shape and np.array_equal(want_logits.view(np.uint32), ref.view(np.uint32))
+    assert (want_cnt <= 5).all() and (want_idx[want_cnt > 0, 0] == np.argmax(ref, axis=1)[want_cnt > 0]).all()
+    # slices: what each rank uploads covers exactly its windows
+    step = S - int(overlap * sr)
+    G = len(starts)
+    for r in range(2):
+        lo, hi = dmod.shard_range(G, r, 2)
+        a, b = dmod.shard_sample_range(len(pcm), S, step, lo, hi)
+        assert a == lo * step and b == min(len(pcm), (hi - 1) * step + S)
+    np.save(tmp_path / "pcm.npy", pcm)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sharded_worker, args=(2, port, path, str(tmp_path / "pcm.npy"), str(tmp_path), overlap), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert np.array_equal(got["logits"].view(np.uint32), want_logits.view(np.uint32))
+        assert np.array_equal(got["idx"], want_idx) and np.array_equal(got["cnt"], want_cnt)
+        assert np.array_equal(got["conf"].view(np.uint32), want_conf.view(np.uint32))
