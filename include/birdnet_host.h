@@ -144,6 +144,10 @@ class BatchInferenceContext {
     size_t input_buffer_capacity() const { return max_batch_size_ * sample_count_; }
     size_t input_buffer_bytes() const { return input_buffer_capacity() * sizeof(float); }
     ModelType model_type() const { return model_type_; }
+    /* Native extension: graph output `index` of the last batch, row-major
+     * [batch, row_elems] -- e.g. Perch's spatial embedding (1) and spectrogram (2), which the reference
+     * discards.  Only for contexts made by create_native_batch_context(.., all_outputs = true). */
+    std::vector<float> read_output(int index, size_t batch, size_t *row_elems = nullptr) const;
 
    private:
     friend class Classifier;
@@ -190,6 +194,10 @@ class Classifier {
                                                 const InferenceOptions &options = {}) const;
     /* src/classifier.rs:777-792 (PerchV2 => Error::Inference, batch_context.rs:107-114) */
     std::unique_ptr<BatchInferenceContext> create_batch_context(size_t max_batch_size) const;
+    /* Native extension: the same context for EVERY model family (the reference refuses PerchV2,
+     * batch_context.rs:107-114; the native context has no such limit), optionally computing all graph
+     * outputs so that read_output() can return the ones the reference drops. */
+    std::unique_ptr<BatchInferenceContext> create_native_batch_context(size_t max_batch_size, bool all_outputs = false) const;
     /* src/classifier.rs:826-867 */
     std::vector<PredictionResult> predict_batch_with_context(BatchInferenceContext &ctx, const float *const *segments, const size_t *lens,
                                                              size_t n, const InferenceOptions &options = {}) const;
@@ -299,6 +307,9 @@ int32_t bnh_predict_batch_with_context(const bnh_classifier *c, bnh_context *ctx
 
 /* Classifier::predict_recording over a host recording (uploaded once, windows cut on the device);
  * start_times[i] receives chunk i's start time for i < times_cap. */
+int32_t bnh_create_native_batch_context(const bnh_classifier *c, size_t max_batch, int32_t all_outputs, bnh_context **out, bnh_error *err);
+/* returns the number of floats needed (batch * row_elems); writes up to cap of them */
+size_t bnh_context_read_output(const bnh_context *ctx, int32_t index, size_t batch, float *out, size_t cap, size_t *row_elems, bnh_error *err);
 int32_t bnh_predict_recording(const bnh_classifier *c, bnh_context *ctx, const void *pcm, size_t n_samples, int32_t format, float overlap_secs,
                               size_t first_chunk, size_t count, int64_t timeout_ns, const volatile int32_t *cancel, bnh_results **out,
                               float *start_times, size_t times_cap, bnh_error *err);

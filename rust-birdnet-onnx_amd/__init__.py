@@ -41,7 +41,7 @@ ENGINE_SYMBOLS = [
 HOST_SYMBOLS = [
     "bnh_classifier_build", "bnh_classifier_free", "bnh_classifier_config", "bnh_classifier_provider",
     "bnh_classifier_label_count", "bnh_classifier_label", "bnh_predict", "bnh_predict_batch",
-    "bnh_create_batch_context", "bnh_context_free", "bnh_context_max_batch_size", "bnh_context_sample_count",
+    "bnh_create_batch_context", "bnh_create_native_batch_context", "bnh_context_read_output", "bnh_context_free", "bnh_context_max_batch_size", "bnh_context_sample_count",
     "bnh_context_input_buffer_capacity", "bnh_context_input_buffer_bytes", "bnh_context_model_type",
     "bnh_predict_batch_with_context", "bnh_predict_recording", "bnh_results_len", "bnh_result_model_type", "bnh_result_n_predictions",
     "bnh_result_species", "bnh_result_confidence", "bnh_result_index", "bnh_result_raw_scores",
@@ -128,6 +128,8 @@ def _load() -> C.CDLL:
         "bnh_predict_batch": (i32, [vp, C.POINTER(f32p), C.POINTER(sz), sz, C.c_int64, C.POINTER(C.c_int32),
                                     C.POINTER(vp), C.POINTER(BnhError)]),
         "bnh_create_batch_context": (i32, [vp, sz, C.POINTER(vp), C.POINTER(BnhError)]),
+        "bnh_create_native_batch_context": (i32, [vp, sz, i32, C.POINTER(vp), C.POINTER(BnhError)]),
+        "bnh_context_read_output": (sz, [vp, i32, sz, f32p, sz, C.POINTER(sz), C.POINTER(BnhError)]),
         "bnh_context_free": (None, [vp]),
         "bnh_context_max_batch_size": (sz, [vp]),
         "bnh_context_sample_count": (sz, [vp]),
@@ -340,6 +342,19 @@ class BatchInferenceContext:
     def model_type(self) -> ModelType:
         return ModelType(lib.bnh_context_model_type(self._h))
 
+    def read_output(self, index: int, batch: int) -> np.ndarray:
+        """Native extension: graph output `index` of the last batch as [batch, row_elems] (contexts made with
+        create_native_batch_context(all_outputs=True) also hold the outputs the reference discards)."""
+        err, row = BnhError(), C.c_size_t()
+        need = lib.bnh_context_read_output(self._h, index, batch, None, 0, C.byref(row), C.byref(err))
+        if err.kind:
+            raise Error(err)
+        out = np.zeros(need, dtype=np.float32)
+        lib.bnh_context_read_output(self._h, index, batch, out.ctypes.data_as(C.POINTER(C.c_float)), need, C.byref(row), C.byref(err))
+        if err.kind:
+            raise Error(err)
+        return out.reshape(batch, row.value)
+
 
 class Classifier:
     """reference src/classifier.rs:436-867, backed by the compiled C++ mirror."""
@@ -389,6 +404,13 @@ class Classifier:
     def create_batch_context(self, max_batch_size: int) -> BatchInferenceContext:
         h, err = C.c_void_p(), BnhError()
         if lib.bnh_create_batch_context(self._h, max_batch_size, C.byref(h), C.byref(err)):
+            raise Error(err)
+        return BatchInferenceContext(h)
+
+    def create_native_batch_context(self, max_batch_size: int, all_outputs: bool = False) -> BatchInferenceContext:
+        """Native extension: a batch context for every model family, Perch included (the reference refuses it)."""
+        h, err = C.c_void_p(), BnhError()
+        if lib.bnh_create_native_batch_context(self._h, max_batch_size, 1 if all_outputs else 0, C.byref(h), C.byref(err)):
             raise Error(err)
         return BatchInferenceContext(h)
 

@@ -136,6 +136,27 @@ int32_t bnh_create_batch_context(const bnh_classifier *c, size_t max_batch, bnh_
     });
 }
 
+int32_t bnh_create_native_batch_context(const bnh_classifier *c, size_t max_batch, int32_t all_outputs, bnh_context **out, bnh_error *err) {
+    if (out) *out = nullptr;
+    return guarded(err, [&] {
+        auto x = std::make_unique<bnh_context>();
+        x->ctx = c->cl.create_native_batch_context(max_batch, all_outputs != 0);
+        *out = x.release();
+    });
+}
+
+size_t bnh_context_read_output(const bnh_context *ctx, int32_t index, size_t batch, float *out, size_t cap, size_t *row_elems, bnh_error *err) {
+    size_t need = 0;
+    guarded(err, [&] {
+        size_t row = 0;
+        std::vector<float> v = ctx->ctx->read_output(index, batch, &row);
+        if (row_elems) *row_elems = row;
+        need = v.size();
+        if (out) memcpy(out, v.data(), std::min(cap, need) * sizeof(float));
+    });
+    return need;
+}
+
 void bnh_context_free(bnh_context *ctx) { delete ctx; }
 size_t bnh_context_max_batch_size(const bnh_context *ctx) { return ctx->ctx->max_batch_size(); }
 size_t bnh_context_sample_count(const bnh_context *ctx) { return ctx->ctx->sample_count(); }

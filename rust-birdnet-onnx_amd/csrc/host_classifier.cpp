@@ -197,6 +197,26 @@ std::unique_ptr<BatchInferenceContext> Classifier::create_batch_context(size_t m
     return c;
 }
 
+std::unique_ptr<BatchInferenceContext> Classifier::create_native_batch_context(size_t max_batch_size, bool all_outputs) const {
+    std::unique_ptr<BatchInferenceContext> c(new BatchInferenceContext());
+    if (bn_ctx_create(inner_->model, std::max<size_t>(max_batch_size, 1), all_outputs ? BN_CTX_ALL_OUTPUTS : BN_CTX_DEFAULT, &c->ctx_) != BN_OK)
+        throw inference("failed to create IoBinding: " + last_backend_error());
+    c->max_batch_size_ = max_batch_size;
+    c->sample_count_ = inner_->config.sample_count;
+    c->model_type_ = inner_->config.model_type;
+    return c;
+}
+
+std::vector<float> BatchInferenceContext::read_output(int index, size_t batch, size_t *row_elems) const {
+    const float *dp = nullptr;
+    size_t row = 0;
+    if (bn_ctx_output_device(ctx_, index, &dp, &row) != BN_OK) throw inference(last_backend_error());
+    if (row_elems) *row_elems = row;
+    std::vector<float> out(batch * row);
+    if (batch && bn_ctx_read_output(ctx_, index, batch, out.data()) != BN_OK) throw inference(last_backend_error());
+    return out;
+}
+
 std::vector<PredictionResult> Classifier::predict_batch_with_context(BatchInferenceContext &ctx, const float *const *segments, const size_t *lens, size_t n,
                                                                      const InferenceOptions &options) const {
     if (n == 0) return {};

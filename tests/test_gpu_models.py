@@ -143,6 +143,32 @@ def test_perch_outputs_and_context_refusal(bn, perch_small):
         bn.Context(m, 2).read_output(1, 1)   # not computed by a default context
 
 
+def test_perch_in_the_native_batch_context(bn, perch_small):
+    """the native context serves Perch too (same results as predict_batch, bit for bit) and can
+    hand out the spectrogram / spatial embedding the reference discards."""
+    data, path = perch_small
+    clf = bn.Classifier.builder().model_path(path).labels(labels(700)).top_k(4).with_rocm().build()
+    x = synth.synthetic_segments(3, 160000, 32000)
+    out = onnx_ref.run_model(data, x)
+    ctx = clf.create_native_batch_context(4, all_outputs=True)
+    assert (ctx.model_type(), ctx.max_batch_size(), ctx.sample_count()) == (bn.ModelType.PerchV2, 4, 160000)
+    got = clf.predict_batch_with_context(ctx, list(x))
+    check_results(got, out["label"], out["embedding"], 4, None)
+    ref = clf.predict_batch(list(x))
+    for g, r in zip(got, ref):
+        assert np.array_equal(np.asarray(g.raw_scores, np.float32).view(np.uint32), np.asarray(r.raw_scores, np.float32).view(np.uint32))
+        assert [(p.index, np.float32(p.confidence)) for p in g.predictions] == [(p.index, np.float32(p.confidence)) for p in r.predictions]
+    assert_close(ctx.read_output(2, 3).reshape(out["spectrogram"].shape), out["spectrogram"], "spectrogram")
+    assert_close(ctx.read_output(1, 3).reshape(out["spatial_embedding"].shape), out["spatial_embedding"], "spatial")
+    # the usual context checks still apply (batch_context.rs:188-211)
+    with pytest.raises(bn.Error) as e:
+        clf.predict_batch_with_context(ctx, list(synth.synthetic_segments(5, 160000, 32000)))
+    assert "batch size 5 exceeds context max 4" in str(e.value)
+    plain = clf.create_native_batch_context(2)
+    with pytest.raises(bn.Error):
+        plain.read_output(1, 1)  # not computed without all_outputs
+
+
 def test_model_type_override(bn, perch_small, v24_small):
     _, ppath = perch_small
     clf = bn.Classifier.builder().model_path(ppath).labels(labels(700)).model_type(bn.ModelType.PerchV2).build()
