@@ -51,7 +51,11 @@ typedef enum bn_status {
 typedef enum bn_model_type {
     BN_MODEL_BIRDNET_V24 = 0,
     BN_MODEL_BIRDNET_V30 = 1,
-    BN_MODEL_PERCH_V2 = 2
+    BN_MODEL_PERCH_V2 = 2,
+    /* Not an audio model: no detection rules, output 0 is the result.  Used for the range filter's
+     * meta model ((lat, lon, week) -> per-species prior, src/rangefilter.rs:451-496); only valid as
+     * model_type_override.  sample_count = elements per input row, num_species = last dim of output 0. */
+    BN_MODEL_GENERIC = 100
 } bn_model_type;
 
 /* Tensor metadata: what session.inputs()/outputs() + dtype().tensor_shape()

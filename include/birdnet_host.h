@@ -86,12 +86,17 @@ class Error : public std::runtime_error {
         Inference,
         Timeout,         /* duration_ns */
         Cancelled,
+        InvalidCoordinates,   /* latitude, longitude */
+        InvalidDate,          /* month, day */
+        RangeFilterInference,
     };
     Error(Kind k, const std::string &msg, size_t index = 0, size_t expected = 0, size_t got = 0, uint64_t duration_ns = 0)
         : std::runtime_error(msg), kind(k), index(index), expected(expected), got(got), duration_ns(duration_ns) {}
     Kind kind;
     size_t index, expected, got;
     uint64_t duration_ns;
+    float latitude = 0.0f, longitude = 0.0f;  /* InvalidCoordinates */
+    uint32_t month = 0, day = 0;              /* InvalidDate */
 };
 
 class CancellationToken {
@@ -239,6 +244,60 @@ std::vector<std::string> load_labels_from_file(const std::string &path, ModelTyp
 std::vector<std::string> parse_text_labels(const std::string &content);
 std::vector<std::string> parse_csv_labels(const std::string &content);
 
+/* ---- range filter (src/rangefilter.rs): location / date prior over species from a small meta model ---- */
+struct LocationScore {  /* src/types.rs:111-120 */
+    std::string species;
+    float score;
+    size_t index;
+};
+/* rangefilter.rs:77-81: 48-week year, week = (month-1)*4 + (day-1)/7 + 1 */
+float calculate_week(uint32_t month, uint32_t day);
+/* rangefilter.rs:91-133: throw Error::InvalidCoordinates / Error::InvalidDate */
+void validate_coordinates(float latitude, float longitude);
+void validate_date(uint32_t month, uint32_t day);
+/* rangefilter.rs:333-386: species in the meta model with score >= threshold are kept (confidence *= score when
+ * reranking), those below are dropped, species unknown to the meta model are kept unchanged; descending re-sort
+ * when reranking (equal confidences keep their order; the reference's sort_unstable leaves that open). */
+std::vector<Prediction> filter_predictions(const std::vector<Prediction> &predictions, const std::vector<LocationScore> &location_scores,
+                                           float threshold, bool rerank);
+
+struct RangeFilterInner;
+class RangeFilterBuilder;
+class RangeFilter {
+   public:
+    static RangeFilterBuilder builder();
+    /* rangefilter.rs:435-502: validate, week, run the meta model on [lat, lon, week], keep scores >= threshold,
+     * sort descending.  The model runs on the MI355X through the same engine (BN_MODEL_GENERIC). */
+    std::vector<LocationScore> predict(float latitude, float longitude, uint32_t month, uint32_t day) const;
+    std::vector<Prediction> filter_predictions(const std::vector<Prediction> &predictions, const std::vector<LocationScore> &location_scores,
+                                               bool rerank) const;
+    std::vector<std::vector<Prediction>> filter_batch_predictions(const std::vector<std::vector<Prediction>> &predictions_batch,
+                                                                  const std::vector<LocationScore> &location_scores, bool rerank) const;
+    size_t labels_count() const;
+    float threshold() const;
+
+   private:
+    friend class RangeFilterBuilder;
+    std::shared_ptr<RangeFilterInner> inner_;
+};
+
+class RangeFilterBuilder {  /* rangefilter.rs:142-277 */
+   public:
+    RangeFilterBuilder &model_path(std::string p) { model_path_ = std::move(p); return *this; }
+    RangeFilterBuilder &labels_path(std::string p) { labels_path_ = std::move(p); labels_.reset(); return *this; }
+    RangeFilterBuilder &labels(std::vector<std::string> l) { labels_ = std::move(l); labels_path_.reset(); return *this; }
+    RangeFilterBuilder &from_classifier_labels(const std::vector<std::string> &l) { return labels(l); }
+    RangeFilterBuilder &threshold(float t) { threshold_ = t; return *this; }
+    RangeFilterBuilder &with_rocm(int device = 0) { device_ = device; return *this; }
+    RangeFilter build();
+
+   private:
+    std::optional<std::string> model_path_, labels_path_;
+    std::optional<std::vector<std::string>> labels_;
+    float threshold_ = 0.01f;  /* rangefilter.rs:165 */
+    int device_ = 0;
+};
+
 /* chunk_audio (src/bin/birdnet-analyze.rs:707-743): start sample + start time of every chunk. */
 struct Chunk {
     size_t start;
@@ -271,12 +330,17 @@ enum {
     BNH_ERR_INFERENCE = 10,
     BNH_ERR_TIMEOUT = 11,
     BNH_ERR_CANCELLED = 12,
-    BNH_ERR_OTHER = 13
+    BNH_ERR_INVALID_COORDINATES = 13,
+    BNH_ERR_INVALID_DATE = 14,
+    BNH_ERR_RANGE_FILTER_INFERENCE = 15,
+    BNH_ERR_OTHER = 16
 };
 typedef struct bnh_error {
     int32_t kind;
     uint64_t index, expected, got, duration_ns;
     char message[512];
+    float latitude, longitude; /* InvalidCoordinates */
+    uint32_t month, day;       /* InvalidDate */
 } bnh_error;
 
 /* Builder in one call.  labels: NULL => labels_path is used (either may be NULL => LabelsRequired).
@@ -323,6 +387,24 @@ size_t bnh_result_raw_scores(const bnh_results *r, size_t i, const float **data)
 /* returns 0 and leaves *data NULL when embeddings is None */
 size_t bnh_result_embeddings(const bnh_results *r, size_t i, const float **data);
 void bnh_results_free(bnh_results *r);
+
+/* ---- range filter ---- */
+typedef struct bnh_range_filter bnh_range_filter;
+float bnh_calculate_week(uint32_t month, uint32_t day);
+int32_t bnh_validate_coordinates(float latitude, float longitude, bnh_error *err);
+int32_t bnh_validate_date(uint32_t month, uint32_t day, bnh_error *err);
+/* labels: NULL => labels_path (either may be NULL => LabelsRequired); threshold < 0 => default 0.01 */
+int32_t bnh_range_filter_build(const char *model_path, const char *labels_path, const char *const *labels, size_t n_labels, float threshold,
+                               int32_t device, bnh_range_filter **out, bnh_error *err);
+void bnh_range_filter_free(bnh_range_filter *f);
+/* RangeFilter::predict: writes up to cap (index, score) pairs, sorted descending; *n_out = number of scores */
+int32_t bnh_range_filter_predict(const bnh_range_filter *f, float latitude, float longitude, uint32_t month, uint32_t day, uint32_t *idx_out,
+                                 float *score_out, size_t cap, size_t *n_out, bnh_error *err);
+const char *bnh_range_filter_label(const bnh_range_filter *f, size_t i);
+/* filter_predictions_impl on parallel arrays (species by name): returns the number of survivors, their positions
+ * in the input in keep_pos and their confidences in conf_out */
+size_t bnh_filter_predictions(const char *const *pred_species, const float *pred_conf, size_t n_pred, const char *const *loc_species,
+                              const float *loc_score, size_t n_loc, float threshold, int32_t rerank, uint32_t *keep_pos, float *conf_out);
 
 /* labels.rs parsers and chunk_audio, for host-logic tests */
 size_t bnh_parse_labels(const char *content, int32_t csv, char *out, size_t cap); /* '\n'-joined; returns needed bytes */

@@ -41,7 +41,7 @@ class OracleConfig(ctypes.Structure):
 def build() -> str:
     """Compile liboracle.so with gcc (idempotent)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("postprocess.c", "detection.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("postprocess.c", "detection.c", "rangefilter.c")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -53,6 +53,16 @@ def lib() -> ctypes.CDLL:
         L = ctypes.CDLL(build())
         f32p = ctypes.POINTER(ctypes.c_float)
         u32p = ctypes.POINTER(ctypes.c_uint32)
+        L.oracle_calculate_week.restype = ctypes.c_float
+        L.oracle_calculate_week.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        L.oracle_validate_coordinates.restype = ctypes.c_int
+        L.oracle_validate_coordinates.argtypes = [ctypes.c_float, ctypes.c_float]
+        L.oracle_validate_date.restype = ctypes.c_int
+        L.oracle_validate_date.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+        L.oracle_location_scores.restype = ctypes.c_size_t
+        L.oracle_location_scores.argtypes = [f32p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_float, u32p, f32p]
+        L.oracle_filter_predictions.restype = ctypes.c_size_t
+        L.oracle_filter_predictions.argtypes = [u32p, f32p, ctypes.c_size_t, u32p, f32p, ctypes.c_size_t, ctypes.c_float, ctypes.c_int, u32p, f32p]
         L.oracle_sigmoid.restype = ctypes.c_float
         L.oracle_sigmoid.argtypes = [ctypes.c_float]
         L.oracle_top_k.restype = ctypes.c_size_t
@@ -170,3 +180,42 @@ def chunk_fill(samples: np.ndarray, segment_samples: int, start: int) -> np.ndar
     lib().oracle_chunk_fill(_f32p(s), s.shape[0], segment_samples, ctypes.c_uint64(start),
                             _f32p(out))
     return out
+
+
+# ---- range filter host logic (rangefilter.rs) ----
+def calculate_week(month: int, day: int) -> float:
+    return float(lib().oracle_calculate_week(month, day))
+
+
+def validate_coordinates(latitude: float, longitude: float) -> int:
+    """0 ok, 1 latitude, 2 longitude (rangefilter.rs:91-107)."""
+    return int(lib().oracle_validate_coordinates(ctypes.c_float(latitude), ctypes.c_float(longitude)))
+
+
+def validate_date(month: int, day: int) -> int:
+    """0 ok, 1 month, 2 day (rangefilter.rs:118-133)."""
+    return int(lib().oracle_validate_date(month, day))
+
+
+def location_scores(scores: np.ndarray, n_labels: int, threshold: float):
+    """rangefilter.rs:477-496 -> (indices, scores) sorted descending."""
+    s = np.ascontiguousarray(scores, dtype=np.float32).reshape(-1)
+    idx = np.zeros(max(len(s), 1), dtype=np.uint32)
+    sc = np.zeros(max(len(s), 1), dtype=np.float32)
+    m = lib().oracle_location_scores(_f32p(s), len(s), n_labels, ctypes.c_float(threshold),
+                                     idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), _f32p(sc))
+    return idx[:m], sc[:m]
+
+
+def filter_predictions(pred_species, pred_conf, loc_species, loc_score, threshold: float, rerank: bool):
+    """rangefilter.rs:333-386 on integer species ids -> (positions of the survivors in the input, confidences)."""
+    ps = np.ascontiguousarray(pred_species, dtype=np.uint32)
+    pc = np.ascontiguousarray(pred_conf, dtype=np.float32)
+    ls = np.ascontiguousarray(loc_species, dtype=np.uint32)
+    lc = np.ascontiguousarray(loc_score, dtype=np.float32)
+    pos = np.zeros(max(len(ps), 1), dtype=np.uint32)
+    conf = np.zeros(max(len(ps), 1), dtype=np.float32)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    m = lib().oracle_filter_predictions(ps.ctypes.data_as(u32p), _f32p(pc), len(ps), ls.ctypes.data_as(u32p), _f32p(lc), len(ls),
+                                        ctypes.c_float(threshold), 1 if rerank else 0, pos.ctypes.data_as(u32p), _f32p(conf))
+    return pos[:m], conf[:m]

@@ -46,6 +46,8 @@ HOST_SYMBOLS = [
     "bnh_predict_batch_with_context", "bnh_predict_recording", "bnh_results_len", "bnh_result_model_type", "bnh_result_n_predictions",
     "bnh_result_species", "bnh_result_confidence", "bnh_result_index", "bnh_result_raw_scores",
     "bnh_result_embeddings", "bnh_results_free", "bnh_parse_labels", "bnh_chunk_plan",
+    "bnh_calculate_week", "bnh_validate_coordinates", "bnh_validate_date", "bnh_range_filter_build", "bnh_range_filter_free",
+    "bnh_range_filter_predict", "bnh_range_filter_label", "bnh_filter_predictions",
 ]
 
 
@@ -70,7 +72,8 @@ class BnModelCost(C.Structure):
 
 class BnhError(C.Structure):
     _fields_ = [("kind", C.c_int32), ("index", C.c_uint64), ("expected", C.c_uint64), ("got", C.c_uint64),
-                ("duration_ns", C.c_uint64), ("message", C.c_char * 512)]
+                ("duration_ns", C.c_uint64), ("message", C.c_char * 512), ("latitude", C.c_float), ("longitude", C.c_float),
+                ("month", C.c_uint32), ("day", C.c_uint32)]
 
 
 def _load() -> C.CDLL:
@@ -140,6 +143,14 @@ def _load() -> C.CDLL:
                                                  C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(BnhError)]),
         "bnh_predict_recording": (i32, [vp, vp, vp, sz, i32, C.c_float, sz, sz, C.c_int64, C.POINTER(C.c_int32), C.POINTER(vp),
                                         f32p, sz, C.POINTER(BnhError)]),
+        "bnh_calculate_week": (C.c_float, [C.c_uint32, C.c_uint32]),
+        "bnh_validate_coordinates": (i32, [C.c_float, C.c_float, C.POINTER(BnhError)]),
+        "bnh_validate_date": (i32, [C.c_uint32, C.c_uint32, C.POINTER(BnhError)]),
+        "bnh_range_filter_build": (i32, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), sz, C.c_float, i32, C.POINTER(vp), C.POINTER(BnhError)]),
+        "bnh_range_filter_free": (None, [vp]),
+        "bnh_range_filter_predict": (i32, [vp, C.c_float, C.c_float, C.c_uint32, C.c_uint32, u32p, f32p, sz, C.POINTER(sz), C.POINTER(BnhError)]),
+        "bnh_range_filter_label": (C.c_char_p, [vp, sz]),
+        "bnh_filter_predictions": (sz, [C.POINTER(C.c_char_p), f32p, sz, C.POINTER(C.c_char_p), f32p, sz, C.c_float, i32, u32p, f32p]),
         "bnh_results_len": (sz, [vp]),
         "bnh_result_model_type": (i32, [vp, sz]),
         "bnh_result_n_predictions": (sz, [vp, sz]),
@@ -230,7 +241,10 @@ class ErrorKind(enum.IntEnum):
     Inference = 10
     Timeout = 11
     Cancelled = 12
-    Other = 13
+    InvalidCoordinates = 13
+    InvalidDate = 14
+    RangeFilterInference = 15
+    Other = 16
 
 
 class Error(Exception):
@@ -240,6 +254,7 @@ class Error(Exception):
         super().__init__(e.message.decode("utf-8", "replace"))
         self.kind = ErrorKind(e.kind)
         self.index, self.expected, self.got, self.duration_ns = e.index, e.expected, e.got, e.duration_ns
+        self.latitude, self.longitude, self.month, self.day = e.latitude, e.longitude, e.month, e.day
 
 
 class EngineError(RuntimeError):
@@ -691,6 +706,122 @@ class Recording:
         if st:
             raise EngineError(st)
         return out
+
+
+# ---- range filter (reference src/rangefilter.rs) ----
+@dataclass
+class LocationScore:
+    species: str
+    score: float
+    index: int
+
+
+def calculate_week(month: int, day: int) -> float:
+    return float(lib.bnh_calculate_week(month, day))
+
+
+def validate_coordinates(latitude: float, longitude: float) -> None:
+    err = BnhError()
+    if lib.bnh_validate_coordinates(C.c_float(latitude), C.c_float(longitude), C.byref(err)):
+        raise Error(err)
+
+
+def validate_date(month: int, day: int) -> None:
+    err = BnhError()
+    if lib.bnh_validate_date(month, day, C.byref(err)):
+        raise Error(err)
+
+
+def filter_predictions(predictions: list, location_scores: list, threshold: float, rerank: bool) -> list:
+    """filter_predictions_impl (rangefilter.rs:333-386) through the compiled C++ mirror."""
+    n, m = len(predictions), len(location_scores)
+    ps = (C.c_char_p * max(n, 1))(*[p.species.encode() for p in predictions])
+    pc = (C.c_float * max(n, 1))(*[p.confidence for p in predictions])
+    ls = (C.c_char_p * max(m, 1))(*[s.species.encode() for s in location_scores])
+    lc = (C.c_float * max(m, 1))(*[s.score for s in location_scores])
+    pos = (C.c_uint32 * max(n, 1))()
+    conf = (C.c_float * max(n, 1))()
+    k = lib.bnh_filter_predictions(ps, pc, n, ls, lc, m, C.c_float(threshold), 1 if rerank else 0, pos, conf)
+    return [Prediction(predictions[pos[i]].species, float(conf[i]), predictions[pos[i]].index) for i in range(k)]
+
+
+class RangeFilter:
+    """reference src/rangefilter.rs:395-580; the meta model runs on the MI355X (BN_MODEL_GENERIC)."""
+
+    def __init__(self, handle, threshold: float):
+        self._h = handle
+        self.threshold = threshold
+
+    def __del__(self):
+        if getattr(self, "_h", None) and lib is not None:
+            lib.bnh_range_filter_free(self._h)
+            self._h = None
+
+    @staticmethod
+    def builder() -> "RangeFilterBuilder":
+        return RangeFilterBuilder()
+
+    def predict(self, latitude: float, longitude: float, month: int, day: int) -> list:
+        err, n = BnhError(), C.c_size_t()
+        cap = 1 << 16
+        idx = (C.c_uint32 * cap)()
+        sc = (C.c_float * cap)()
+        if lib.bnh_range_filter_predict(self._h, C.c_float(latitude), C.c_float(longitude), month, day, idx, sc, cap, C.byref(n), C.byref(err)):
+            raise Error(err)
+        return [LocationScore(lib.bnh_range_filter_label(self._h, idx[i]).decode(), float(sc[i]), int(idx[i])) for i in range(min(n.value, cap))]
+
+    def filter_predictions(self, predictions: list, location_scores: list, rerank: bool) -> list:
+        return filter_predictions(predictions, location_scores, self.threshold, rerank)
+
+    def filter_batch_predictions(self, predictions_batch: list, location_scores: list, rerank: bool) -> list:
+        return [filter_predictions(p, location_scores, self.threshold, rerank) for p in predictions_batch]
+
+
+class RangeFilterBuilder:
+    """reference src/rangefilter.rs:142-277."""
+
+    def __init__(self):
+        self._model_path = None
+        self._labels_path = None
+        self._labels = None
+        self._threshold = 0.01
+        self._device = 0
+
+    def model_path(self, p: str):
+        self._model_path = p
+        return self
+
+    def labels_path(self, p: str):
+        self._labels_path, self._labels = p, None
+        return self
+
+    def labels(self, l: list):
+        self._labels, self._labels_path = list(l), None
+        return self
+
+    def from_classifier_labels(self, l: list):
+        return self.labels(l)
+
+    def threshold(self, t: float):
+        self._threshold = t
+        return self
+
+    def with_rocm(self, device: int = 0):
+        self._device = device
+        return self
+
+    def build(self) -> RangeFilter:
+        h, err = C.c_void_p(), BnhError()
+        labels = None
+        if self._labels is not None:
+            labels = (C.c_char_p * max(len(self._labels), 1))(*[x.encode() for x in self._labels])
+        st = lib.bnh_range_filter_build(self._model_path.encode() if self._model_path else None,
+                                        self._labels_path.encode() if self._labels_path else None, labels,
+                                        len(self._labels) if self._labels is not None else 0, C.c_float(self._threshold), self._device,
+                                        C.byref(h), C.byref(err))
+        if st:
+            raise Error(err)
+        return RangeFilter(h, self._threshold)
 
 
 def topk_host(logits: np.ndarray, top_k: int, min_confidence: Optional[float] = None, device: int = 0):

@@ -265,7 +265,24 @@ bn_status finish_load(std::unique_ptr<bn_model> m, int32_t device, int32_t model
         }
     }
     std::string reason;
-    if (!detect_model_type(m->io.input_shape, m->io.output_shapes, model_type_override, m->cfg, reason)) return fail(BN_ERR_MODEL_DETECTION, reason);
+    if (model_type_override == BN_MODEL_GENERIC) {
+        // the range filter's meta model (rangefilter.rs:250-262): any single-input graph; output 0 is the result
+        if (m->io.output_shapes.empty() || m->io.output_shapes[0].empty() || m->io.output_shapes[0].back() <= 0)
+            return fail(BN_ERR_MODEL_DETECTION, "empty output shape");
+        bn_model_config &c = m->cfg;
+        memset(&c, 0, sizeof(c));
+        c.model_type = BN_MODEL_GENERIC;
+        c.sample_count = 1;
+        for (size_t k = 1; k < m->io.input_shape.size(); k++) {
+            if (m->io.input_shape[k] <= 0) return fail(BN_ERR_MODEL_DETECTION, "generic model needs a static per-row input shape");
+            c.sample_count *= (uint64_t)m->io.input_shape[k];
+        }
+        c.num_species = (uint64_t)m->io.output_shapes[0].back();
+        c.logits_output = 0;
+        c.embedding_output = -1;
+    } else if (!detect_model_type(m->io.input_shape, m->io.output_shapes, model_type_override, m->cfg, reason)) {
+        return fail(BN_ERR_MODEL_DETECTION, reason);
+    }
     std::vector<int> wanted{m->cfg.logits_output};
     if (m->cfg.embedding_output >= 0) wanted.push_back(m->cfg.embedding_output);
     bn_status st = make_plan(m.get(), wanted, m->main_plan);

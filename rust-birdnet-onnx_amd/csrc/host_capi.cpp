@@ -26,6 +26,10 @@ int32_t set_err(bnh_error *err, const Error &e) {
         err->expected = e.expected;
         err->got = e.got;
         err->duration_ns = e.duration_ns;
+        err->latitude = e.latitude;
+        err->longitude = e.longitude;
+        err->month = e.month;
+        err->day = e.day;
         snprintf(err->message, sizeof(err->message), "%s", e.what());
     }
     return kind;
@@ -209,6 +213,71 @@ size_t bnh_result_embeddings(const bnh_results *r, size_t i, const float **data)
     return r->v[i].embeddings->size();
 }
 void bnh_results_free(bnh_results *r) { delete r; }
+
+// ---- range filter ----
+struct bnh_range_filter {
+    RangeFilter f;
+    std::vector<std::string> labels;
+};
+
+float bnh_calculate_week(uint32_t month, uint32_t day) { return calculate_week(month, day); }
+int32_t bnh_validate_coordinates(float latitude, float longitude, bnh_error *err) {
+    return guarded(err, [&] { validate_coordinates(latitude, longitude); });
+}
+int32_t bnh_validate_date(uint32_t month, uint32_t day, bnh_error *err) {
+    return guarded(err, [&] { validate_date(month, day); });
+}
+
+int32_t bnh_range_filter_build(const char *model_path, const char *labels_path, const char *const *labels, size_t n_labels, float threshold, int32_t device,
+                               bnh_range_filter **out, bnh_error *err) {
+    if (out) *out = nullptr;
+    return guarded(err, [&] {
+        RangeFilterBuilder b = RangeFilter::builder();
+        std::vector<std::string> l;
+        if (model_path) b.model_path(model_path);
+        if (labels) {
+            for (size_t i = 0; i < n_labels; i++) l.emplace_back(labels[i]);
+            b.labels(l);
+        } else if (labels_path) b.labels_path(labels_path);
+        if (threshold >= 0.0f) b.threshold(threshold);
+        b.with_rocm(device);
+        auto r = std::make_unique<bnh_range_filter>();
+        r->f = b.build();
+        if (labels) r->labels = std::move(l);
+        else if (labels_path) r->labels = load_labels_from_file(labels_path, ModelType::BirdNetV24);
+        *out = r.release();
+    });
+}
+
+void bnh_range_filter_free(bnh_range_filter *f) { delete f; }
+const char *bnh_range_filter_label(const bnh_range_filter *f, size_t i) { return i < f->labels.size() ? f->labels[i].c_str() : nullptr; }
+
+int32_t bnh_range_filter_predict(const bnh_range_filter *f, float latitude, float longitude, uint32_t month, uint32_t day, uint32_t *idx_out, float *score_out,
+                                 size_t cap, size_t *n_out, bnh_error *err) {
+    if (n_out) *n_out = 0;
+    return guarded(err, [&] {
+        auto v = f->f.predict(latitude, longitude, month, day);
+        if (n_out) *n_out = v.size();
+        for (size_t i = 0; i < v.size() && i < cap; i++) {
+            if (idx_out) idx_out[i] = (uint32_t)v[i].index;
+            if (score_out) score_out[i] = v[i].score;
+        }
+    });
+}
+
+size_t bnh_filter_predictions(const char *const *pred_species, const float *pred_conf, size_t n_pred, const char *const *loc_species, const float *loc_score,
+                              size_t n_loc, float threshold, int32_t rerank, uint32_t *keep_pos, float *conf_out) {
+    std::vector<Prediction> preds;
+    for (size_t i = 0; i < n_pred; i++) preds.push_back(Prediction{pred_species[i], pred_conf[i], i});  // index carries the input position
+    std::vector<LocationScore> loc;
+    for (size_t i = 0; i < n_loc; i++) loc.push_back(LocationScore{loc_species[i], loc_score[i], i});
+    auto out = filter_predictions(preds, loc, threshold, rerank != 0);
+    for (size_t i = 0; i < out.size(); i++) {
+        keep_pos[i] = (uint32_t)out[i].index;
+        conf_out[i] = out[i].confidence;
+    }
+    return out.size();
+}
 
 size_t bnh_parse_labels(const char *content, int32_t csv, char *out, size_t cap) {
     std::vector<std::string> l;

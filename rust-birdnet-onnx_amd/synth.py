@@ -320,3 +320,24 @@ def synthetic_segments(n: int, sample_count: int, sample_rate: int, first_index:
         noise = bits * (2.0 / 65535.0) - 1.0
         out[k] = (0.5 * np.sin(2.0 * np.pi * freqs[gi % 4] * t) + 0.05 * noise).astype(np.float32)
     return out
+
+
+def meta_model(num_species: int = 6522, hidden: int = 64, seed: int = 7) -> bytes:
+    """Synthetic range-filter meta model with the I/O contract of reference src/rangefilter.rs:451-496:
+    input f32 [1, 3] = (latitude, longitude, week), ONE output f32 [1, num_species] of probabilities (the Rust
+    side applies no sigmoid).  Topology is a guess (the real file is not available offline): scaled inputs ->
+    dense + ReLU -> dense + ReLU -> dense + Sigmoid."""
+    rng = np.random.RandomState(seed)
+    g = GraphBuilder("birdnet_meta_synth")
+    g.add_input("input", [1, 3])
+    scale = g.const(np.array([1.0 / 90.0, 1.0 / 180.0, 1.0 / 48.0], dtype=np.float32))
+    x = g.node("Mul", ["input", scale])
+    w1 = g.const((rng.randn(3, hidden) * 1.5).astype(np.float32))
+    x = g.node("Relu", [g.node("Add", [g.node("MatMul", [x, w1]), g.const((rng.randn(hidden) * 0.3).astype(np.float32))])])
+    w2 = g.const((rng.randn(hidden, hidden) / np.sqrt(hidden)).astype(np.float32))
+    x = g.node("Relu", [g.node("Add", [g.node("MatMul", [x, w2]), g.const((rng.randn(hidden) * 0.3).astype(np.float32))])])
+    w3 = g.const((rng.randn(hidden, num_species) * (3.0 / np.sqrt(hidden))).astype(np.float32))
+    y = g.node("Sigmoid", [g.node("Add", [g.node("MatMul", [x, w3]), g.const((rng.randn(num_species) * 1.5 - 2.0).astype(np.float32))])])
+    g.node("Identity", [y], outputs=["output"])
+    g.add_output("output", [1, num_species])
+    return g.serialize()

@@ -178,3 +178,80 @@ def test_engine_chunk_count_matches_chunk_audio(bn):
                 assert bn.lib.bn_chunk_count(n, step) == len(starts)
                 assert len(bn.chunk_plan(n, S, overlap, sr)[0]) == len(starts)
     assert bn.lib.bn_chunk_count(1000, 0) == 0
+
+
+# ---- range filter host logic (reference src/rangefilter.rs): the compiled C++ mirror against the oracle ----
+def test_range_filter_week_and_validation(bn):
+    import oracle
+    for m in range(1, 13):
+        for d in range(1, 32):
+            assert bn.calculate_week(m, d) == oracle.calculate_week(m, d)
+    for lat, lon in ((45.0, -122.0), (-90.0, -180.0), (90.0, 180.0), (91.0, 0.0), (0.0, 181.0), (-90.5, 10.0), (float("nan"), 0.0), (95.0, 200.0)):
+        code = oracle.validate_coordinates(lat, lon)
+        if code == 0:
+            bn.validate_coordinates(lat, lon)
+            continue
+        with pytest.raises(bn.Error) as e:
+            bn.validate_coordinates(lat, lon)
+        assert e.value.kind == bn.ErrorKind.InvalidCoordinates
+        assert ("latitude must be in range [-90, 90]" in str(e.value)) == (code == 1)
+        assert ("longitude must be in range [-180, 180]" in str(e.value)) == (code == 2)
+    with pytest.raises(bn.Error) as e:          # Display text of src/error.rs:72-73 with Rust's f32 formatting
+        bn.validate_coordinates(95.0, 200.0)
+    assert str(e.value) == "invalid coordinates: latitude: 95, longitude: 200, reason: latitude must be in range [-90, 90], got 95"
+    assert (e.value.latitude, e.value.longitude) == (95.0, 200.0)
+    with pytest.raises(bn.Error) as e:
+        bn.validate_coordinates(-90.5, 0.25)
+    assert "latitude: -90.5, longitude: 0.25" in str(e.value)
+    for m, d in ((1, 1), (6, 15), (12, 31), (0, 1), (13, 1), (1, 0), (1, 32)):
+        code = oracle.validate_date(m, d)
+        if code == 0:
+            bn.validate_date(m, d)
+            continue
+        with pytest.raises(bn.Error) as e:
+            bn.validate_date(m, d)
+        assert e.value.kind == bn.ErrorKind.InvalidDate and (e.value.month, e.value.day) == (m, d)
+        assert (f"month must be in range [1, 12], got {m}" in str(e.value)) == (code == 1)
+        assert (f"day must be in range [1, 31], got {d}" in str(e.value)) == (code == 2)
+    with pytest.raises(bn.Error) as e:
+        bn.validate_date(13, 32)
+    assert str(e.value) == "invalid date: month: 13, day: 32, reason: month must be in range [1, 12], got 13"
+
+
+def test_range_filter_filter_predictions_against_oracle(bn):
+    import oracle
+    rng = np.random.default_rng(3)
+    names = [f"Species {i}" for i in range(12)]
+    for trial in range(200):
+        n_pred, n_loc = int(rng.integers(0, 9)), int(rng.integers(0, 10))
+        ps = rng.integers(0, 12, n_pred)
+        pc = rng.choice([0.05, 0.3, 0.5, 0.5, 0.8, 0.9], n_pred).astype(np.float32)
+        ls = rng.integers(0, 12, n_loc)          # duplicates on purpose: the last entry wins
+        lc = rng.choice([0.001, 0.02, 0.03, 0.5, 0.9, 1.0], n_loc).astype(np.float32)
+        thr, rerank = float(rng.choice([0.01, 0.03, 0.1])), bool(rng.integers(0, 2))
+        pos, conf = oracle.filter_predictions(ps, pc, ls, lc, thr, rerank)
+        preds = [bn.Prediction(names[s], float(c), int(s)) for s, c in zip(ps, pc)]
+        locs = [bn.LocationScore(names[s], float(c), int(s)) for s, c in zip(ls, lc)]
+        got = bn.filter_predictions(preds, locs, thr, rerank)
+        assert [(g.species, np.float32(g.confidence)) for g in got] == [(names[ps[p]], np.float32(c)) for p, c in zip(pos, conf)], trial
+    # the reference's own KATs (rangefilter.rs:707-889) through the product
+    P, L = bn.Prediction, bn.LocationScore
+    out = bn.filter_predictions([P("Species A", 0.8, 0), P("Species B", 0.3, 1), P("Species C", 0.05, 2)],
+                                [L("Species A", 0.9, 0), L("Species B", 0.02, 1), L("Species C", 0.5, 2)], 0.03, False)
+    assert [p.species for p in out] == ["Species A", "Species C"]
+    out = bn.filter_predictions([P("Species A", 0.8, 0), P("Species B", 0.7, 1), P("Species D", 0.9, 3)],
+                                [L("Species A", 0.9, 0), L("Species C", 0.8, 2)], 0.03, False)
+    assert [(p.species, np.float32(p.confidence), p.index) for p in out] == [("Species A", np.float32(0.8), 0), ("Species B", np.float32(0.7), 1),
+                                                                            ("Species D", np.float32(0.9), 3)]
+
+
+def test_range_filter_builder_errors_without_a_device(bn, tmp_path):
+    with pytest.raises(bn.Error) as e:                                   # rangefilter.rs:692-697
+        bn.RangeFilter.builder().build()
+    assert e.value.kind == bn.ErrorKind.ModelPathRequired
+    with pytest.raises(bn.Error) as e:                                   # rangefilter.rs:699-704
+        bn.RangeFilter.builder().model_path("/tmp/model.onnx").build()
+    assert e.value.kind == bn.ErrorKind.LabelsRequired
+    with pytest.raises(bn.Error) as e:
+        bn.RangeFilter.builder().model_path("/tmp/model.onnx").labels_path(str(tmp_path / "missing.txt")).build()
+    assert e.value.kind == bn.ErrorKind.LabelLoad
