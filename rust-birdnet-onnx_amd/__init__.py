@@ -22,6 +22,12 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+try:  # PyTorch, when present, must load ITS bundled HIP runtime first: the wheel's libamdhip64 and the
+    # system one this library links against do not coexist in one process (torch.cuda then sees no GPU)
+    import torch  # noqa: F401
+except ImportError:  # the package itself needs no PyTorch
+    pass
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbirdnet_hip.so")
 
