@@ -222,6 +222,22 @@ typedef struct bn_recording bn_recording;
 #define BN_PCM_F32 1 /* float mono, used as is */
 bn_status bn_recording_create(int32_t device, const void *pcm, size_t n_samples, int32_t format,
                               bn_recording **out);
+/* Sample-rate conversion front end (the reference CLI refuses a WAV whose rate differs
+ * from the model's, src/bin/birdnet-analyze.rs:447-455).  The recording is uploaded in its storage format and
+ * converted ON THE DEVICE to f32 at dst_rate by a polyphase windowed-sinc FIR: L/M = dst/src reduced, cutoff
+ * 0.5*min(1, L/M) of the source Nyquist band, `zero_crossings` sinc lobes per side (0 => 16) under a Kaiser
+ * window (beta 8.6, ~ -90 dB), every phase normalised to unit DC gain.  The result holds
+ * ceil(n_samples * L / M) samples and is used like any other recording.  src_rate == dst_rate is a plain upload.
+ * There is no reference behaviour to match; the filter design above is the contract (oracle/resample.py). */
+bn_status bn_recording_create_resampled(int32_t device, const void *pcm, size_t n_samples, int32_t format,
+                                        uint32_t src_rate, uint32_t dst_rate, uint32_t zero_crossings,
+                                        bn_recording **out);
+/* The polyphase table the resampler uses, for inspection / tests: writes up to cap floats of [L][T] and
+ * returns L*T; *L_out, *M_out, *T_out receive the factors.  Needs no device. */
+size_t bn_resample_table(uint32_t src_rate, uint32_t dst_rate, uint32_t zero_crossings, float *table, size_t cap,
+                         uint32_t *L_out, uint32_t *M_out, uint32_t *T_out);
+/* Copy samples [first, first+count) of an f32 recording back to the host (tests, diagnostics). */
+bn_status bn_recording_read_f32(const bn_recording *r, size_t first, size_t count, float *host_out);
 void bn_recording_free(bn_recording *r);
 size_t bn_recording_samples(const bn_recording *r);
 /* Number of windows chunk_audio produces for n_samples at this step (0 for an

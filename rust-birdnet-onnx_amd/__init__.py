@@ -42,7 +42,7 @@ ENGINE_SYMBOLS = [
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
     "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
     "bn_recording_create", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
-    "bn_infer_windows", "bn_step_windows", "bn_last_error",
+    "bn_infer_windows", "bn_step_windows", "bn_recording_create_resampled", "bn_resample_table", "bn_recording_read_f32", "bn_last_error",
 ]
 HOST_SYMBOLS = [
     "bnh_classifier_build", "bnh_classifier_free", "bnh_classifier_config", "bnh_classifier_provider",
@@ -124,6 +124,9 @@ def _load() -> C.CDLL:
         "bn_recording_windows": (i32, [vp, sz, sz, sz, sz, f32p]),
         "bn_infer_windows": (i32, [vp, vp, sz, sz, sz, f32p, f32p, C.POINTER(C.c_int32), C.c_uint64]),
         "bn_step_windows": (i32, [vp, vp, sz, sz, sz, sz, i32, C.c_float, i32]),
+        "bn_recording_create_resampled": (i32, [i32, vp, sz, i32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp)]),
+        "bn_resample_table": (sz, [C.c_uint32, C.c_uint32, C.c_uint32, f32p, sz, u32p, u32p, u32p]),
+        "bn_recording_read_f32": (i32, [vp, sz, sz, f32p]),
         "bn_last_error": (sz, [C.c_char_p, sz]),
         # host mirror
         "bnh_classifier_build": (i32, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), sz, i32, C.c_int64, i32,
@@ -686,16 +689,31 @@ class Context:
 class Recording:
     """bn_recording: a mono recording uploaded once in its storage format (int16 or float32)."""
 
-    def __init__(self, samples: np.ndarray, device: int = 0):
+    def __init__(self, samples: np.ndarray, device: int = 0, src_rate: Optional[int] = None, dst_rate: Optional[int] = None,
+                 zero_crossings: int = 0):
+        """src_rate / dst_rate given and different: converted on the device by the polyphase resampler
+        (bn_recording_create_resampled); the recording then holds f32 samples at dst_rate."""
         a = np.ascontiguousarray(samples)
         if a.ndim != 1 or a.dtype not in (np.int16, np.float32):
             raise ValueError("mono int16 or float32 samples expected")
         h = C.c_void_p()
-        st = lib.bn_recording_create(device, a.ctypes.data_as(C.c_void_p), a.shape[0], 0 if a.dtype == np.int16 else 1, C.byref(h))
+        fmt = 0 if a.dtype == np.int16 else 1
+        if src_rate and dst_rate:
+            st = lib.bn_recording_create_resampled(device, a.ctypes.data_as(C.c_void_p), a.shape[0], fmt, src_rate, dst_rate, zero_crossings, C.byref(h))
+        else:
+            st = lib.bn_recording_create(device, a.ctypes.data_as(C.c_void_p), a.shape[0], fmt, C.byref(h))
         if st:
             raise EngineError(st)
         self._h = h
-        self.n_samples = int(a.shape[0])
+        self.n_samples = int(lib.bn_recording_samples(h))
+
+    def read_f32(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        count = self.n_samples - first if count is None else count
+        out = np.zeros(max(count, 0), dtype=np.float32)
+        st = lib.bn_recording_read_f32(self._h, first, count, out.ctypes.data_as(C.POINTER(C.c_float)))
+        if st:
+            raise EngineError(st)
+        return out
 
     def __del__(self):
         if getattr(self, "_h", None) and lib is not None:  # lib is gone at interpreter shutdown
@@ -828,6 +846,15 @@ class RangeFilterBuilder:
         if st:
             raise Error(err)
         return RangeFilter(h, self._threshold)
+
+
+def resample_table(src_rate: int, dst_rate: int, zero_crossings: int = 0):
+    """The resampler's polyphase table [L, T] and (L, M, T) -- host arithmetic, needs no device."""
+    L, M, T = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    n = lib.bn_resample_table(src_rate, dst_rate, zero_crossings, None, 0, C.byref(L), C.byref(M), C.byref(T))
+    tab = np.zeros(n, dtype=np.float32)
+    lib.bn_resample_table(src_rate, dst_rate, zero_crossings, tab.ctypes.data_as(C.POINTER(C.c_float)), n, C.byref(L), C.byref(M), C.byref(T))
+    return tab.reshape(L.value, T.value), L.value, M.value, T.value
 
 
 def topk_host(logits: np.ndarray, top_k: int, min_confidence: Optional[float] = None, device: int = 0):

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -792,6 +793,111 @@ bn_status bn_recording_create(int32_t device, const void *pcm, size_t n_samples,
         }
     }
     *out = r.release();
+    return BN_OK;
+}
+
+// ---- polyphase resampler (no reference counterpart; design documented in include/birdnet_hip.h) ----
+namespace {
+double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 500; k++) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+struct ResampleTable {
+    uint32_t L = 1, M = 1, T = 0;
+    std::vector<float> coef;  // [L][T]
+};
+ResampleTable make_resample_table(uint32_t src_rate, uint32_t dst_rate, uint32_t zc) {
+    ResampleTable t;
+    if (zc == 0) zc = 16;
+    uint32_t a = dst_rate, b = src_rate;
+    while (b) { const uint32_t r = a % b; a = b; b = r; }
+    t.L = dst_rate / a;
+    t.M = src_rate / a;
+    const double ratio = (double)t.L / (double)t.M;
+    const double fc = 0.5 * std::min(1.0, ratio);        // cutoff in cycles per SOURCE sample
+    const double half = (double)zc / (2.0 * fc);          // support half-width in source samples
+    t.T = 2u * (uint32_t)std::ceil(half);                 // taps per phase (even)
+    const double beta = 8.6, i0b = bessel_i0(beta), pi = 3.14159265358979323846;
+    t.coef.assign((size_t)t.L * t.T, 0.0f);
+    for (uint32_t p = 0; p < t.L; p++) {
+        // output sample sits at source position base + p/L; tap j reads source index base + j - (T/2 - 1)
+        std::vector<double> h(t.T);
+        double sum = 0.0;
+        for (uint32_t j = 0; j < t.T; j++) {
+            const double tau = (double)p / (double)t.L - ((double)j - (double)(t.T / 2 - 1));  // output time - tap time
+            const double u = tau / half;
+            double w = 0.0;
+            if (std::fabs(u) < 1.0) w = bessel_i0(beta * std::sqrt(1.0 - u * u)) / i0b;
+            const double xarg = 2.0 * fc * tau;
+            const double sinc = std::fabs(xarg) < 1e-12 ? 1.0 : std::sin(pi * xarg) / (pi * xarg);
+            h[j] = 2.0 * fc * sinc * w;
+            sum += h[j];
+        }
+        for (uint32_t j = 0; j < t.T; j++) t.coef[(size_t)p * t.T + j] = (float)(h[j] / sum);
+    }
+    return t;
+}
+}  // namespace
+
+size_t bn_resample_table(uint32_t src_rate, uint32_t dst_rate, uint32_t zero_crossings, float *table, size_t cap, uint32_t *L_out, uint32_t *M_out,
+                         uint32_t *T_out) {
+    if (src_rate == 0 || dst_rate == 0) return 0;
+    const ResampleTable t = make_resample_table(src_rate, dst_rate, zero_crossings);
+    if (L_out) *L_out = t.L;
+    if (M_out) *M_out = t.M;
+    if (T_out) *T_out = t.T;
+    if (table) memcpy(table, t.coef.data(), std::min(cap, t.coef.size()) * sizeof(float));
+    return t.coef.size();
+}
+
+bn_status bn_recording_create_resampled(int32_t device, const void *pcm, size_t n_samples, int32_t format, uint32_t src_rate, uint32_t dst_rate,
+                                        uint32_t zero_crossings, bn_recording **out) {
+    if (!out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (src_rate == 0 || dst_rate == 0) return fail(BN_ERR_INVALID_ARG, "sample rates must be positive");
+    if (src_rate == dst_rate) return bn_recording_create(device, pcm, n_samples, format, out);
+    bn_recording *src = nullptr;
+    bn_status st = bn_recording_create(device, pcm, n_samples, format, &src);
+    if (st != BN_OK) return st;
+    const ResampleTable t = make_resample_table(src_rate, dst_rate, zero_crossings);
+    const size_t n_dst = (size_t)(((unsigned __int128)n_samples * t.L + t.M - 1) / t.M);
+    auto r = std::make_unique<bn_recording>();
+    r->device = device;
+    r->format = BN_PCM_F32;
+    r->n_samples = n_dst;
+    float *d_table = nullptr;
+    hipError_t e = hipMalloc(&r->d_pcm, std::max<size_t>(n_dst * sizeof(float), 16));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_table), t.coef.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_table, t.coef.data(), t.coef.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        (void)hipGetLastError();
+        launch_resample(nullptr, static_cast<float *>(r->d_pcm), src->d_pcm, format == BN_PCM_I16, d_table, n_samples, n_dst, t.L, t.M, t.T);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (d_table) (void)hipFree(d_table);
+    bn_recording_free(src);
+    if (e != hipSuccess) {
+        if (r->d_pcm) (void)hipFree(r->d_pcm);
+        return fail(BN_ERR_BACKEND, std::string("resampling failed: ") + hipGetErrorString(e));
+    }
+    *out = r.release();
+    return BN_OK;
+}
+
+bn_status bn_recording_read_f32(const bn_recording *r, size_t first, size_t count, float *host_out) {
+    if (!r || (count && !host_out)) return fail(BN_ERR_INVALID_ARG, "null argument");
+    if (r->format != BN_PCM_F32) return fail(BN_ERR_INVALID_ARG, "recording is not f32");
+    if (first > r->n_samples || count > r->n_samples - first) return fail(BN_ERR_INVALID_ARG, "sample range exceeds the recording");
+    if (count == 0) return BN_OK;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipMemcpy(host_out, static_cast<const float *>(r->d_pcm) + first, count * sizeof(float), hipMemcpyDeviceToHost));
     return BN_OK;
 }
 

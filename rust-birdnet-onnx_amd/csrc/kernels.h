@@ -181,6 +181,9 @@ void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, in
 // recording -> f32 windows (chunk_audio + i16/32768 conversion); S % 4 == 0
 void launch_windows(hipStream_t s, float *dst, const void *src, int32_t is_i16, uint64_t n_samples, uint64_t first_start, uint64_t step, uint32_t S,
                     uint32_t count);
+// polyphase FIR resampler: table [L][T], output n reads phase (n*M)%L at source position (n*M)/L
+void launch_resample(hipStream_t s, float *dst, const void *src, int32_t is_i16, const float *table, uint64_t n_src, uint64_t n_dst, uint32_t L, uint32_t M,
+                     uint32_t T);
 void launch_null(hipStream_t s);  // empty kernel (timing calibration)
 size_t topk_lds_bytes(int64_t n, int64_t k);
 size_t mbconv_lds_bytes(const MbDesc &d);  // dynamic LDS of mbconv_expand_dw_kernel for this shape

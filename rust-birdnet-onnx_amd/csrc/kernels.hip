@@ -1901,6 +1901,43 @@ void launch_windows(hipStream_t s, float *dst, const void *src, int32_t is_i16, 
     else hipLaunchKernelGGL(windows_kernel<float>, grid, dim3(256), 0, s, dst, static_cast<const float *>(src), n_samples, first_start, step, S);
 }
 
+// ------------------------------------------------------------------ polyphase resampler
+// y[n] = sum_j table[(n*M) % L][j] * x[(n*M) / L + j - (T/2 - 1)]   (zero outside the recording)
+// with a host-built windowed-sinc table (L phases x T taps, each phase normalised to unit DC gain).
+// One lane = one output sample; the phase rows are tiny and cache-resident, the input reads of a
+// wave overlap almost entirely.  The source is int16 (/32768, exact) or f32.
+namespace {
+template <class T_>
+__global__ __launch_bounds__(256) void resample_kernel(float *__restrict__ dst, const T_ *__restrict__ src, const float *__restrict__ table,
+                                                      uint64_t n_src, uint64_t n_dst, uint32_t L, uint32_t M, uint32_t T) {
+    const uint64_t n = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (n >= n_dst) return;
+    const uint64_t pos = n * M;
+    const uint64_t base = pos / L;
+    const uint32_t phase = (uint32_t)(pos - base * L);
+    const float *row = table + (uint64_t)phase * T;
+    const int64_t first = (int64_t)base - (int64_t)(T / 2 - 1);
+    float acc = 0.0f;
+    for (uint32_t j = 0; j < T; j++) {
+        const int64_t q = first + j;
+        float x = 0.0f;
+        if (q >= 0 && (uint64_t)q < n_src) {
+            if constexpr (sizeof(T_) == 2) x = (float)src[q] * (1.0f / 32768.0f);
+            else x = (float)src[q];
+        }
+        acc = fmaf(row[j], x, acc);
+    }
+    dst[n] = acc;
+}
+}  // namespace
+void launch_resample(hipStream_t s, float *dst, const void *src, int32_t is_i16, const float *table, uint64_t n_src, uint64_t n_dst, uint32_t L, uint32_t M,
+                     uint32_t T) {
+    if (n_dst == 0) return;
+    dim3 grid((unsigned)((n_dst + 255) / 256));
+    if (is_i16) hipLaunchKernelGGL(resample_kernel<int16_t>, grid, dim3(256), 0, s, dst, static_cast<const int16_t *>(src), table, n_src, n_dst, L, M, T);
+    else hipLaunchKernelGGL(resample_kernel<float>, grid, dim3(256), 0, s, dst, static_cast<const float *>(src), table, n_src, n_dst, L, M, T);
+}
+
 // empty launch: calibrates the event-to-event overhead of bn_ctx_time_kernels
 namespace {
 __global__ void null_kernel() {}

@@ -166,3 +166,49 @@ def test_sharded_recording_ingest_two_ranks_equal_single_pass(bn, tmp_path, over
         assert np.array_equal(got["logits"].view(np.uint32), want_logits.view(np.uint32))
         assert np.array_equal(got["idx"], want_idx) and np.array_equal(got["cnt"], want_cnt)
         assert np.array_equal(got["conf"].view(np.uint32), want_conf.view(np.uint32))
+
+
+@pytest.mark.parametrize("src,dst,dtype", [(44100, 48000, np.int16), (48000, 32000, np.int16), (22050, 48000, np.float32), (96000, 48000, np.int16),
+                                           (44100, 32000, np.float32)])
+def test_device_resampler_matches_the_oracle(bn, src, dst, dtype):
+    """polyphase resampling on the device == oracle/resample.py (fp32 tolerance: the kernel
+    accumulates in f32 with fmaf, the oracle in f64)."""
+    from oracle import resample as R
+    rng = np.random.default_rng(src + dst)
+    n = src * 2 + 137
+    t = np.arange(n) / src
+    x = 0.5 * np.sin(2 * np.pi * 1500.0 * t) + 0.2 * np.sin(2 * np.pi * 5200.0 * t) + 0.05 * rng.standard_normal(n)
+    pcm = np.clip(np.round(x * 32767), -32768, 32767).astype(np.int16) if dtype == np.int16 else x.astype(np.float32)
+    want = R.resample(pcm, src, dst)
+    rec = bn.Recording(pcm, src_rate=src, dst_rate=dst)
+    assert rec.n_samples == len(want) == -(-n * dst // src)
+    got = rec.read_f32()
+    assert np.abs(got - want).max() <= 3e-6, float(np.abs(got - want).max())
+    # same rate: a plain upload, windows bit-identical to chunk_audio
+    if dtype == np.int16:
+        same = bn.Recording(pcm, src_rate=dst, dst_rate=dst)
+        w, _ = reference_windows(pcm, 144000, 0.0, 48000)
+        assert np.array_equal(same.windows(144000, 144000, 0, len(w)), w)
+
+
+def test_resampled_recording_through_the_network(bn):
+    """A 44.1 kHz int16 recording analysed by the 48 kHz model: device resampling + windows + plan == the same
+    windows made on the host from the oracle's resampled signal, within the network tolerance."""
+    from gpu_helpers import ATOL, RTOL
+    from oracle import resample as R
+    src, dst, S = 44100, 48000, 144000
+    rng = np.random.default_rng(77)
+    t = np.arange(src * 7) / src
+    pcm = np.clip(9000 * np.sin(2 * np.pi * 2100 * t) + rng.normal(0, 600, t.shape), -32768, 32767).astype(np.int16)
+    model = bn.Model(write_model(synth.birdnet_v24(num_species=300, width=0.5)))
+    ctx = bn.Context(model, 4)
+    rec = bn.Recording(pcm, src_rate=src, dst_rate=dst)
+    G = rec.n_windows(S)
+    got = np.concatenate([ctx.infer_windows(rec, S, f, min(4, G - f))[0].copy() for f in range(0, G, 4)])
+    y = R.resample(pcm, src, dst)
+    starts, _ = oracle.chunk_plan(len(y), S, 0.0, dst)
+    win = np.stack([oracle.chunk_fill(y, S, int(s)) for s in starts])
+    ref = np.concatenate([ctx.infer(win[f:f + 4])[0].copy() for f in range(0, G, 4)])
+    assert got.shape == ref.shape
+    assert np.all(np.abs(got - ref) <= ATOL + RTOL * np.abs(ref))
+    assert (np.argmax(got, axis=1) == np.argmax(ref, axis=1)).all()

@@ -255,3 +255,38 @@ def test_range_filter_builder_errors_without_a_device(bn, tmp_path):
     with pytest.raises(bn.Error) as e:
         bn.RangeFilter.builder().model_path("/tmp/model.onnx").labels_path(str(tmp_path / "missing.txt")).build()
     assert e.value.kind == bn.ErrorKind.LabelLoad
+
+
+def test_resampler_table_matches_the_oracle_design(bn):
+    """Polyphase table of bn_recording_create_resampled (host arithmetic) == oracle/resample.py, bit for bit."""
+    from oracle import resample as R
+    for src, dst, zc in ((44100, 48000, 0), (48000, 32000, 0), (22050, 48000, 16), (16000, 32000, 8), (96000, 48000, 0), (44100, 32000, 12), (8000, 48000, 0)):
+        tab, L, M, T = bn.resample_table(src, dst, zc)
+        want, oL, oM, oT = R.make_table(src, dst, zc)
+        assert (L, M, T) == (oL, oM, oT) and tab.shape == want.shape
+        assert np.array_equal(tab.view(np.uint32), want.view(np.uint32))
+        assert np.allclose(tab.sum(axis=1), 1.0, atol=2e-7)            # every phase has unit DC gain
+
+
+def test_resampler_oracle_against_scipy_on_band_limited_signals():
+    """The oracle's design is a sane resampler: a tone well inside both Nyquist bands comes out as the same tone
+    (scipy's resample_poly as an independent implementation; loose tolerance, interior samples only)."""
+    from scipy import signal
+
+    from oracle import resample as R
+    for src, dst in ((44100, 48000), (48000, 32000), (22050, 48000)):
+        t = np.arange(src) / src
+        x = (0.6 * np.sin(2 * np.pi * 1000.0 * t) + 0.3 * np.sin(2 * np.pi * 3300.0 * t + 0.4)).astype(np.float32)
+        y = R.resample(x, src, dst)
+        assert len(y) == -(-len(x) * dst // src)
+        td = np.arange(len(y)) / dst
+        ideal = 0.6 * np.sin(2 * np.pi * 1000.0 * td) + 0.3 * np.sin(2 * np.pi * 3300.0 * td + 0.4)
+        mid = slice(2000, len(y) - 2000)
+        assert np.abs(y[mid] - ideal[mid]).max() < 2e-4
+        g = np.gcd(src, dst)
+        ys = signal.resample_poly(x.astype(np.float64), dst // g, src // g, window=("kaiser", 8.6))
+        assert np.abs(y[mid] - ys[mid]).max() < 5e-3
+    # a tone above the new Nyquist is removed when down-sampling
+    t = np.arange(48000) / 48000
+    y = R.resample((0.8 * np.sin(2 * np.pi * 20000.0 * t)).astype(np.float32), 48000, 32000)
+    assert np.abs(y[2000:-2000]).max() < 1e-3
