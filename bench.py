@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
+    ap.add_argument("--model", choices=["v24", "v30", "perch"], default="v24",
+                    help="v24 = the benchmark (BASELINE configs[1]); v30 / perch = configs[2] / [3], informational (use --batch 64 / 128)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -75,8 +77,12 @@ def main():
     bn = importlib.import_module("rust-birdnet-onnx_amd")
     synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
 
-    S, SR, B = 144000, 48000, args.batch
-    model_bytes = synth.birdnet_v24()  # full-size hypothesised topology, seeded synthetic weights
+    MODELS = {"v24": (144000, 48000, 3.0, synth.birdnet_v24, "BirdNET v2.4", "3s@48kHz"),
+              "v30": (160000, 32000, 5.0, synth.birdnet_v30, "BirdNET v3.0", "5s@32kHz"),
+              "perch": (160000, 32000, 5.0, synth.perch_v2, "Perch v2", "5s@32kHz")}
+    S, SR, SEC, make_model, model_name, seg_name = MODELS[args.model]
+    B = args.batch
+    model_bytes = make_model()  # full-size hypothesised topology, seeded synthetic weights
     with tempfile.NamedTemporaryFile(suffix=".onnx", delete=False) as f:
         f.write(model_bytes)
         path = f.name
@@ -179,7 +185,7 @@ def main():
     value = total_segments / dt
 
     out = {
-        "metric": "audio-segments/sec (batch) BirdNET v2.4 3s@48kHz",
+        "metric": f"audio-segments/sec (batch) {model_name} {seg_name}",
         "value": round(value, 2),
         "unit": "segments/s",
         "n_gpus": world,
@@ -192,12 +198,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "BirdNET v2.4 (synthetic-weights hypothesised topology), batch=32 synthetic 48 kHz 3 s segments per GPU, inputs resident in HBM, logits+top-10 copied to host",
+            "workload": f"{model_name} (synthetic-weights hypothesised topology), batch={B} synthetic {SR // 1000} kHz {SEC:g} s segments per GPU, inputs resident in HBM, logits+top-10 copied to host",
             "global_batch": B * world,
             "segments_per_gpu_per_step": B,
             "streams_per_gpu": max(1, args.streams),
             "num_species": int(N),
-            "x_realtime": round(value * 3.0, 1),
+            "x_realtime": round(value * SEC, 1),
             "parallelism": f"segment-sharded x{world}" + (" + RCCL all-gather of logits" if world > 1 else ""),
         },
     }
