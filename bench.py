@@ -39,13 +39,15 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="segments per GPU per step (BASELINE configs[1]: 32)")
-    ap.add_argument("--streams", type=int, default=3, help="contexts (HIP streams) in flight per GPU")
+    ap.add_argument("--streams", type=int, default=4, help="contexts (HIP streams) in flight per GPU")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="segments the CPU oracle is timed on")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: run the N > 1 code path (process group, staging copy, all-gather) with a single rank")
     ap.add_argument("--model", choices=["v24", "v30", "perch"], default="v24",
                     help="v24 = the benchmark (BASELINE configs[1]); v30 / perch = configs[2] / [3], informational (use --batch 64 / 128)")
     args = ap.parse_args()
@@ -55,12 +57,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    use_dist = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
 
+    # Four contexts need four hardware queues of their own: the ROCm runtime multiplexes streams onto
+    # GPU_MAX_HW_QUEUES (default 4) queues per process and the null stream takes one, so with the default a
+    # fourth context shares a queue with another and serialises behind it (measured: 30.4 k seg/s with 4
+    # contexts on 4 queues, 37.3 k on 8).  Must be set before the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
 
     dist = None
     dev = local_rank if args.device is None else args.device
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist_mod
 
         dist = dist_mod
@@ -90,9 +101,7 @@ def main():
     os.unlink(path)
     cfg = model.config
     N = cfg.num_species
-    # N > 1: one context more than batches in flight, so that `streams` batches keep computing while the
-    # oldest one's logits are being all-gathered (its context is idle until the collective has read them)
-    ctxs = [bn.Context(model, B) for _ in range(max(1, args.streams) + (1 if world > 1 else 0))]
+    ctxs = [bn.Context(model, B) for _ in range(max(1, args.streams))]
 
     # synthetic inputs, resident in HBM before the timed region: this rank's contiguous shard of
     # NBUF global batches (global segment index = (buffer * world + rank) * B + i)
@@ -104,7 +113,7 @@ def main():
     torch.cuda.synchronize()
 
     gathered = None
-    if world > 1:
+    if use_dist:
         gathered = torch.empty((world * B, N), dtype=torch.float32, device="cuda")
 
     class _DevView:  # zero-copy torch view of the context's device logits
@@ -114,49 +123,44 @@ def main():
     logit_views = []
     for c in ctxs:
         ptr, n = c.output_device(cfg.logits_output)
-        logit_views.append(torch.as_tensor(_DevView(ptr, (B, n)), device="cuda") if world > 1 else None)
+        logit_views.append(torch.as_tensor(_DevView(ptr, (B, n)), device="cuda") if use_dist else None)
 
     S_ = len(ctxs)
-    LAG = S_ - 1 if world > 1 else S_  # N > 1: consume one step early so the collective overlaps compute
-    gather_done = [None] * S_  # per context: event after the collective that read its logits
+    # N > 1: a context's logits are copied to a small staging buffer and all-gathered from there, so the
+    # context is free for its next batch as soon as the copy is done (same number of contexts in flight as N = 1)
+    stage = [torch.empty((B, N), dtype=torch.float32, device="cuda") for _ in range(2)] if (use_dist and args.backend == "nccl") else None
 
     def finish(j):
         """Results of step j are complete on the host side; with N > 1 all-gather its logits."""
         c = ctxs[j % S_]
         c.synchronize()
-        if world > 1:
+        if use_dist:
             if args.backend == "nccl":
-                dist.all_gather_into_tensor(gathered, logit_views[j % S_])
+                st = stage[j % 2]  # its previous collective was enqueued earlier on this same stream
+                st.copy_(logit_views[j % S_], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-                gather_done[j % S_] = ev
+                dist.all_gather_into_tensor(gathered, st)
+                ev.synchronize()  # the copy has read the context's logits: the context may run again
             else:  # rehearsal backends gather on the host
                 parts = [torch.empty((B, N), dtype=torch.float32) for _ in range(world)]
                 dist.all_gather(parts, logit_views[j % S_].cpu())
 
     def step(i):
-        # contexts are used round-robin; a context's previous results are consumed one step before
-        # it is reused so that the collective overlaps the next step's kernels
-        if S_ > 1 and i >= LAG:
-            finish(i - LAG)
-        c = ctxs[i % S_]
-        if gather_done[i % S_] is not None:
-            gather_done[i % S_].synchronize()  # the collective no longer reads this context's logits
-            gather_done[i % S_] = None
-        c.step_device(bufs[i % NBUF].data_ptr(), B, args.top_k, 0.1, sync=False)
-        if S_ == 1:
-            finish(i)
+        # contexts are used round-robin; a context's previous results are consumed just before it is reused
+        if i >= S_:
+            finish(i - S_)
+        ctxs[i % S_].step_device(bufs[i % NBUF].data_ptr(), B, args.top_k, 0.1, sync=False)
 
     def drain(total):
-        if S_ > 1:
-            for j in range(max(0, total - LAG), total):
-                finish(j)
+        for j in range(max(0, total - S_), total):
+            finish(j)
 
     def fence():
         for c in ctxs:
             c.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for i in range(args.warmup):
@@ -169,7 +173,7 @@ def main():
     drain(args.steps)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -289,7 +293,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
