@@ -22,6 +22,10 @@ from typing import Optional, Sequence
 
 import numpy as np
 
+# Several contexts in flight need hardware queues of their own: the ROCm runtime multiplexes streams onto
+# GPU_MAX_HW_QUEUES (default 4) queues and the null stream takes one.  Read when the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 try:  # PyTorch, when present, must load ITS bundled HIP runtime first: the wheel's libamdhip64 and the
     # system one this library links against do not coexist in one process (torch.cuda then sees no GPU)
     import torch  # noqa: F401

@@ -107,7 +107,7 @@ def shard_sample_range(n_samples: int, segment_samples: int, step_samples: int, 
     return lo * step_samples, min(n_samples, (hi - 1) * step_samples + segment_samples)
 
 
-def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: float, batch: int = 32, streams: int = 3, top_k: int = 10,
+def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: float, batch: int = 32, streams: int = 4, top_k: int = 10,
                               min_confidence: Optional[float] = None, dist=None, gather: str = "logits", ctxs=None):
     """BASELINE.json configs[4]: a long mono recording (int16 or float32), sharded by window across the
     ranks of one node.  Every rank uploads its slice once (bn_recording_create), cuts windows on the

@@ -18,7 +18,9 @@ import tempfile
 import time
 
 import numpy as np
-import torch
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # four contexts, four hardware queues of their own (see bench.py)
+import torch  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -41,7 +43,7 @@ def main():
     ap.add_argument("--hours", type=float, default=1.0)
     ap.add_argument("--overlap", type=float, default=0.0)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=4)
     ap.add_argument("--gather", choices=["logits", "topk"], default="logits")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--device", type=int, default=None)
