@@ -1545,6 +1545,61 @@ class Builder {
             // BN_MBFUSE=0 disables, BN_MBFUSE=force fuses every eligible pair (tests).
             const char *mbenv = getenv("BN_MBFUSE");
             const bool mb_off = mbenv && std::string(mbenv) == "0";
+            // Stem variant: the producer is a dense k1 x k1 convolution with few input channels (k1*k1*Cin1 <= 48,
+            // e.g. the 3x3 stride-2 conv over the 2-channel spectrogram image).  Its output tile is rebuilt from im2col
+            // rows staged in LDS and never written to HBM either (same kernel, different staging).  BN_STEMFUSE=0 disables.
+            if (d.tiled && kh == kw && strides[0] == strides[1] && !mb_off && !plan_.ops.empty() &&
+                !(getenv("BN_STEMFUSE") && std::string(getenv("BN_STEMFUSE")) == "0")) {
+                PlanOp &pe = plan_.ops.back();
+                const ConvDesc &cd = pe.conv;
+                const int a1 = cd.act;
+                const bool act_zero = a1 == ACT_NONE || a1 == ACT_RELU || (a1 == ACT_CLIP && cd.p0 <= 0.f && cd.p1 >= 0.f) || a1 == ACT_SILU ||
+                                      a1 == ACT_HSWISH || a1 == ACT_LEAKY || a1 == ACT_TANH;
+                const bool stem = pe.kind == OpKind::CONV && pe.out.space == Space::ARENA && pe.out.id == x.storage && pe.out.offset == 0 && x.offset == 0 &&
+                                  cd.groups == 1 && cd.kh == cd.kw && cd.sh == cd.sw && cd.dh == 1 && cd.dw == 1 && !cd.has_res && cd.Cin <= 4 &&
+                                  cd.kh * cd.kw * cd.Cin <= 48 && cd.OH == H && cd.OW == W && cd.Cout == Cin && act_zero &&
+                                  (H * W >= 3072 || (mbenv && std::string(mbenv) == "force"));
+                MbDesc probe{};
+                probe.k = (int32_t)kw; probe.s = (int32_t)strides[1]; probe.Cin = stem ? cd.kh * cd.kw * cd.Cin : 4; probe.C = (int32_t)Cin;
+                if (stem && mbconv_lds_bytes(probe) <= 150 * 1024 && sole_consumer(n.inputs[0]) == cur_) {
+                    PlanOp mb;
+                    mb.kind = OpKind::MBCONV;
+                    mb.name = "stem:" + pe.name.substr(pe.name.find(':') + 1) + "+" + n.name;
+                    mb.out = op.out;
+                    mb.a = pe.a;
+                    // first-conv filters [kh][kw][Cin1][Cout] (as lowered for the direct kernel) -> [Cout][KW]: im2col column
+                    // order (ky, kx, c), zero padded to 8-wide K groups
+                    const int64_t K1 = (int64_t)cd.kh * cd.kw * cd.Cin, KW = (K1 + 7) / 8 * 8;
+                    {
+                        const std::vector<float> &w0 = plan_.consts[pe.w.id];
+                        std::vector<float> wpk((size_t)(Cin * KW), 0.0f);
+                        for (int64_t nn = 0; nn < Cin; nn++)
+                            for (int64_t k = 0; k < K1; k++) wpk[nn * KW + k] = w0[pe.w.offset + k * Cin + nn];
+                        mb.w = Ref{Space::CONSTS, add_const(wpk), 0};
+                    }
+                    mb.bias = pe.bias;
+                    mb.w2 = op.w; mb.bias2 = op.bias;
+                    MbDesc &m = mb.mb;
+                    m.H = (int32_t)H; m.W = (int32_t)W; m.Cin = (int32_t)K1; m.C = (int32_t)Cin; m.OH = (int32_t)OH; m.OW = (int32_t)OW;
+                    m.k = (int32_t)kw; m.s = (int32_t)strides[1]; m.pt = (int32_t)pt; m.pl = (int32_t)pl;
+                    m.act1 = cd.act; m.p0_1 = cd.p0; m.p1_1 = cd.p1; m.has_bias1 = cd.has_bias;
+                    m.act2 = act.act; m.p0_2 = act.p0; m.p1_2 = act.p1; m.has_bias2 = has_bias;
+                    m.in_bs = cd.in_bs; m.out_bs = d.out_bs;
+                    m.k1 = cd.kh; m.s1 = cd.sh; m.pt1 = cd.pt; m.pl1 = cd.pl; m.H1 = cd.H; m.W1 = cd.W; m.Cin1 = cd.Cin;
+                    const int toh = m.s == 1 ? 8 : 4, tow = m.s == 1 ? 16 : 8;
+                    m.tiles_x = (int32_t)((OW + tow - 1) / tow); m.tiles_y = (int32_t)((OH + toh - 1) / toh);
+                    const double halo = (double)((toh - 1) * m.s + m.k) * ((tow - 1) * m.s + m.k) * m.tiles_x * m.tiles_y;
+                    mb.macs = op.macs;
+                    mb.weight_bytes = op.weight_bytes + pe.weight_bytes;
+                    mb.bytes = 4.0 * ((double)cd.H * cd.W * cd.Cin + (double)OH * OW * Cin);
+                    mb.mfma = false;
+                    mb.macs_mfma_extra = halo * (double)K1 * Cin;
+                    plan_.ops.pop_back();
+                    push_op(std::move(mb));
+                    define(cur, out);
+                    return;
+                }
+            }
             if (d.tiled && kh == kw && strides[0] == strides[1] && !mb_off && !plan_.ops.empty()) {
                 PlanOp &pe = plan_.ops.back();
                 const int maxk = std::min(48, getenv("BN_MBFUSE_MAXK") ? atoi(getenv("BN_MBFUSE_MAXK")) : 48);  // kernel: <= 6 K groups in registers

@@ -131,6 +131,10 @@ struct MbDesc {
     int64_t in_bs, out_bs;
     int32_t tiles_x, tiles_y;  // output tiles of (8x16 at stride 1, 4x8 at stride 2)
     int32_t whole_map;         // 1: small feature map, one block = (32 mid channels, whole map); w1 is [C][Cin]
+    // first conv is a k1 x k1 convolution with few input channels (stem) instead of a 1x1 expand: the halo tile is
+    // staged as im2col rows, Cin = k1*k1*Cin1 (column order (ky, kx, c)); H, W are its OUTPUT map (what the
+    // depthwise conv reads), H1 x W1 x Cin1 the image it reads with stride s1 and padding (pt1, pl1).  k1 == 0: 1x1.
+    int32_t k1, s1, pt1, pl1, H1, W1, Cin1;
     int32_t has_gap;
     int64_t gap_bs;
 };

@@ -973,7 +973,7 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
 // The expanded tensor never exists in HBM.  grid (tiles, 1, batch), 256 threads, dynamic LDS;
 // two barriers per chunk.
 constexpr int MB_MAX_NG = 6;  // Cin <= 48
-template <int K, int S>
+template <int K, int S, bool IM2COL>
 __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                                const float *__restrict__ w1, const float *__restrict__ b1,
                                                                const float *__restrict__ w2, const float *__restrict__ b2,
@@ -1017,10 +1017,51 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
     };
     fetch_b(bw, 0);
 
-    // ---- 0. stage the halo tile: PSTEP pixels per pass, lane = (pixel, float4 of its channels);
-    //         four passes' loads (clamped addresses, never predicated) are in flight together,
-    //         pixels outside the image are zeroed when the values go to LDS
-    {
+    // ---- 0. stage the halo tile
+    if constexpr (IM2COL) {
+        // stem: every halo pixel of the first conv's OUTPUT map becomes one im2col row of k1*k1*Cin1 input values
+        // (column = (ky*k1 + kx)*Cin1 + c); taps outside the input image are the conv's own zero padding, pixels
+        // outside the output map are zero rows with Vs = 0.  Clamped loads, selection at LDS-store time.
+        const int KK = d.k1 * d.k1;
+        for (int r = tid; r < MP; r += 256) {
+            const int iy = r / IWT, ix = r - iy * IWT;
+            const int ih = ih0 + iy, iw = iw0 + ix;
+            const bool ok = r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+            Vs[r] = ok ? 1.0f : 0.0f;
+            for (int k = d.Cin; k < ng * 8; k++) Xs[r * KS + k] = 0.0f;  // K padding
+        }
+        for (int it0 = tid; it0 < MP * KK; it0 += 256 * 4) {
+            float v[4][4];
+            bool okv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int it = it0 + i * 256;
+                const int r = it / KK, t = it - r * KK;
+                const int ky = t / d.k1, kx = t - ky * d.k1;
+                const int iy = r / IWT, ix = r - iy * IWT;
+                const int ih = ih0 + iy, iw = iw0 + ix;
+                const int y = ih * d.s1 + ky - d.pt1, x = iw * d.s1 + kx - d.pl1;
+                okv[i] = it < MP * KK && r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W && y >= 0 && y < d.H1 && x >= 0 && x < d.W1;
+                const int yc = y < 0 ? 0 : (y >= d.H1 ? d.H1 - 1 : y), xc = x < 0 ? 0 : (x >= d.W1 ? d.W1 - 1 : x);
+                const float *px = xin + ((int64_t)yc * d.W1 + xc) * d.Cin1;
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) v[i][cc] = px[cc < d.Cin1 ? cc : 0];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int it = it0 + i * 256;
+                if (it < MP * KK) {
+                    const int r = it / KK, t = it - r * KK;
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++)
+                        if (cc < d.Cin1) Xs[r * KS + t * d.Cin1 + cc] = okv[i] ? v[i][cc] : 0.0f;
+                }
+            }
+        }
+    } else {
+        // 1x1 expand: PSTEP pixels per pass, lane = (pixel, float4 of its channels);
+        // four passes' loads (clamped addresses, never predicated) are in flight together,
+        // pixels outside the image are zeroed when the values go to LDS
         const int PSTEP = 256 / CV;
         const int p0 = tid / CV, cv = tid - p0 * CV;
         const bool lane_on = p0 < PSTEP;
@@ -1804,19 +1845,25 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
         return;
     }
     dim3 grid((unsigned)(d.tiles_x * d.tiles_y), 1, (unsigned)batch);
-#define MB_LAUNCH(K, S)                                                                                                          \
+#define MB_LAUNCH2(K, S, IM)                                                                                                     \
     do {                                                                                                                         \
         static size_t attr = 0;                                                                                                  \
         if (lds > attr) {                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mbconv_expand_dw_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mbconv_expand_dw_kernel<K, S, IM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr = lds;                                                                                                          \
         }                                                                                                                        \
-        hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S>), grid, dim3(256), lds, s, d, out, in, w1, b1, w2, b2, gap);           \
+        hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, IM>), grid, dim3(256), lds, s, d, out, in, w1, b1, w2, b2, gap);       \
+    } while (0)
+#define MB_LAUNCH(K, S)                  \
+    do {                                 \
+        if (d.k1 > 0) MB_LAUNCH2(K, S, true); \
+        else MB_LAUNCH2(K, S, false);    \
     } while (0)
     if (d.k == 3 && d.s == 1) MB_LAUNCH(3, 1);
     else if (d.k == 3 && d.s == 2) MB_LAUNCH(3, 2);
     else if (d.k == 5 && d.s == 1) MB_LAUNCH(5, 1);
     else MB_LAUNCH(5, 2);
+#undef MB_LAUNCH2
 #undef MB_LAUNCH
 }
 

@@ -263,6 +263,57 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
     assert_close(got, ref, f"mbconv[{variant}] {cin}->{cmid} k{k} s{stride}")
 
 
+@pytest.mark.parametrize("cin,h,w,cout,k1,s1,k,stride,act", [(2, 96, 511, 32, 3, 2, 3, 1, "relu"), (1, 64, 129, 24, 5, 2, 3, 2, "relu6"),
+                                                            (3, 70, 90, 40, 3, 1, 5, 1, "silu"), (2, 65, 131, 16, 3, 2, 5, 2, None)])
+def test_fused_stem_conv_depthwise(bn, cin, h, w, cout, k1, s1, k, stride, act):
+    """dense k1 x k1 conv with few input channels (+BN+act) -> depthwise KxK (+act): one launch (im2col rows in LDS),
+    against the oracle; the unfused plan (BN_STEMFUSE=0) must agree too."""
+    rng = np.random.default_rng(13)
+    assert cin * h * w <= 144000
+    p1, p2 = k1 // 2, k // 2
+    h1, w1 = (h + 2 * p1 - k1) // s1 + 1, (w + 2 * p1 - k1) // s1 + 1
+    oh, ow = (h1 + 2 * p2 - k) // stride + 1, (w1 + 2 * p2 - k) // stride + 1
+
+    def activation(g, y):
+        if act == "relu":
+            return g.node("Relu", [y])
+        if act == "silu":
+            return g.node("Mul", [y, g.node("Sigmoid", [y])])
+        if act == "relu6":
+            return g.node("Clip", [y, g.const(np.float32(0)), g.const(np.float32(6))])
+        return y
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(cin * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, h, w, cin)])
+        x = g.node("Transpose", [x], perm=[0, 3, 1, 2])                       # channels-last image, as the front end leaves it
+        w0 = (rng.standard_normal((cout, cin, k1, k1)) / np.sqrt(cin * k1 * k1)).astype(np.float32)
+        y = g.node("Conv", [x, g.const(w0), g.const(rng.standard_normal(cout).astype(np.float32))], kernel_shape=[k1, k1], strides=[s1, s1], pads=[p1] * 4)
+        y = activation(g, y)
+        wd = (rng.standard_normal((cout, 1, k, k)) / k).astype(np.float32)
+        z = g.node("Conv", [y, g.const(wd), g.const(rng.standard_normal(cout).astype(np.float32))], kernel_shape=[k, k],
+                   strides=[stride, stride], pads=[p2] * 4, group=cout)
+        return activation(g, z)
+    data = op_graph(build, [cout, oh, ow])
+    import os
+    os.environ["BN_MBFUSE"] = "force"   # fuse small feature maps too (the planner keeps those unfused by default)
+    try:
+        desc = bn.plan_describe(write_model(data))
+        assert "stem:" in desc, desc
+        got, ref = run_both(bn, data)
+    finally:
+        del os.environ["BN_MBFUSE"]
+    assert_close(got, ref, f"stem {cin}->{cout} k1={k1} s1={s1} dw k{k} s{stride}")
+    os.environ["BN_STEMFUSE"] = "0"
+    try:
+        assert "stem:" not in bn.plan_describe(write_model(data))
+        got2, _ = run_both(bn, data)
+    finally:
+        del os.environ["BN_STEMFUSE"]
+    assert_close(got2, ref, "unfused stem")
+
+
 @pytest.mark.parametrize("cin,h,w,cmid,k,stride", [(80, 6, 32, 480, 3, 1), (112, 6, 32, 672, 5, 2), (192, 3, 16, 1152, 5, 1),
                                                   (20, 5, 7, 72, 3, 1), (40, 12, 40, 100, 3, 2)])
 def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride):
