@@ -1735,6 +1735,14 @@ static void launch_gemm_tiled(hipStream_t s, const GemmDesc &d, float *C, const 
     // Measured on MI355X (tools/gemm_bench): 32-wide N tiles win or tie almost everywhere -- more,
     // smaller blocks hide the load latency better than wider tiles save operand re-reads.  Wider
     // tiles only pay once the grid is several thousand blocks deep (high-resolution expand convs).
+    static const int deep_bn = getenv("BN_DEEPK_BN") ? atoi(getenv("BN_DEEPK_BN")) : 0;  // experiments: N tile for K >= 1024
+    if (deep_bn && d.K >= 1024) {
+        if (deep_bn == 128) return launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
+        if (deep_bn == 96) return launch_gemm_bn<96, false>(s, d, C, A, W, bias, res, scale, total_rows);
+        if (deep_bn == 64) return launch_gemm_bn<64, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    }
+    // (deep K, the DFT framing convs: 64-wide N tiles give +1% with four contexts in flight but cost 8% of the
+    // kernel's own time -- 98 -> 110 us, 105 -> 94 TF/s -- so the 32-wide tiles stay; BN_DEEPK_BN=64 to compare)
     const int64_t blocks32 = mblocks * ((d.N + 31) / 32);
     if (blocks32 > 6000 && d.N > 64 && waste(96) < waste(128) && waste(96) <= waste(64)) launch_gemm_bn<96, false>(s, d, C, A, W, bias, res, scale, total_rows);
     else if (blocks32 > 6000 && d.N > 64 && waste(128) <= waste(64)) launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
