@@ -163,7 +163,8 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
             e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
             (void)hipGraphDestroy(g);
             if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-            if (c->graphs.size() >= 16) {  // bounded cache
+            if (c->graphs.size() >= 16) {  // bounded cache; nothing of this context may still be replaying one of them
+                (void)hipStreamSynchronize(c->stream);
                 for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
                 c->graphs.clear();
             }
