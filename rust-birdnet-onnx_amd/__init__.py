@@ -33,7 +33,7 @@ except ImportError:  # the package itself needs no PyTorch
     pass
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbirdnet_hip.so")
+LIB_PATH = os.environ.get("BN_LIB") or os.path.join(_HERE, "libbirdnet_hip.so")  # BN_LIB: A/B builds of the same ABI
 
 BN_MAX_OUTPUTS, BN_MAX_RANK, BN_NAME_LEN = 8, 6, 64
 BN_CTX_DEFAULT, BN_CTX_ALL_OUTPUTS, BN_CTX_NO_GRAPH = 0, 1, 2

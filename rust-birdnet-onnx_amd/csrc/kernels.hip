@@ -719,6 +719,9 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
 // interleaved), each wave staging its own operand slices through a private LDS region with no
 // block barrier in the main loop; the four partial accumulators are then summed through LDS in a
 // fixed order (deterministic) and the epilogue is shared between the waves.
+#ifndef SPLITK_PF
+#define SPLITK_PF 1  // k-slices per wave in flight (register prefetch depth of the split-K kernel)
+#endif
 template <int BN, int AVEC, int WVEC, bool GATED>
 __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__restrict__ C,
                                                           const float *__restrict__ A,
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_kernel(GemmDesc d, float *__r
     int64_t aoff[A_IT], soff[A_IT];
     a_offsets<AVEC, A_RPP, A_IT>(d, total_rows, row0, a_row, aoff, soff);
     const int ksteps = (d.K + GEMM_BK - 1) / GEMM_BK;
-    constexpr int PF = GEMM_PF;
+    constexpr int PF = SPLITK_PF;
     float ra[PF][A_IT * AVEC];
     float rg[PF][GATED ? A_IT * AVEC : 1];
     float rw[PF][W_IT * WVEC];
