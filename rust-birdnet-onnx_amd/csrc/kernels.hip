@@ -938,19 +938,25 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
         }
     }
     __syncthreads();
-    // excite: 256 channels per block, 4 thread groups split the Cr terms (fixed-order combine)
+    // excite: 256-channel slices, 4 thread groups split the Cr terms (fixed-order combine).  A block takes the
+    // slices blockIdx.x, blockIdx.x + gridDim.x, ...: the launcher caps the blocks per sample so that a large
+    // batch does not redo the first half once per slice (the result does not depend on that split)
     const int cl = threadIdx.x & 255, q = threadIdx.x >> 8;
-    const int c = blockIdx.x * 256 + cl;
-    float acc = 0.f;
-    if (c < d.C) {
+    const int nslices = (d.C + 255) / 256;
+    for (int slice = blockIdx.x; slice < nslices; slice += gridDim.x) {
+        const int c = slice * 256 + cl;
+        float acc = 0.f;
+        if (c < d.C) {
 #pragma unroll 4
-        for (int j = q; j < d.Cr; j += 4) acc = fmaf(hid[j], w2t[(int64_t)j * d.C + c], acc);
-    }
-    red[q * 256 + cl] = acc;
-    __syncthreads();
-    if (q == 0 && c < d.C) {
-        const float v = ((red[cl] + red[256 + cl]) + red[512 + cl]) + red[768 + cl] + (b2 ? b2[c] : 0.f);
-        gate[b * d.out_bs + c] = act_apply(d.act2, v, d.p0_2, d.p1_2);
+            for (int j = q; j < d.Cr; j += 4) acc = fmaf(hid[j], w2t[(int64_t)j * d.C + c], acc);
+        }
+        red[q * 256 + cl] = acc;
+        __syncthreads();
+        if (q == 0 && c < d.C) {
+            const float v = ((red[cl] + red[256 + cl]) + red[512 + cl]) + red[768 + cl] + (b2 ? b2[c] : 0.f);
+            gate[b * d.out_bs + c] = act_apply(d.act2, v, d.p0_2, d.p1_2);
+        }
+        __syncthreads();  // red is reused by the next slice
     }
 }
 
@@ -1800,7 +1806,10 @@ void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, 
                   const float *b1, const float *w2, const float *b2, int64_t batch) {
     (void)hidden;
     if (batch <= 0) return;
-    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)((d.C + 255) / 256), (unsigned)batch), dim3(1024),
+    // blocks per sample: one per 256-channel slice, capped so that the whole launch stays near two blocks per CU
+    const int64_t nslices = (d.C + 255) / 256;
+    const int64_t per_sample = std::max<int64_t>(1, std::min<int64_t>(nslices, 512 / std::max<int64_t>(batch, 1)));
+    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)per_sample, (unsigned)batch), dim3(1024),
                        (size_t)(d.C + d.Cr + 1024) * sizeof(float), s, d, gate, partial, w1, b1, w2, b2);
 }
 
