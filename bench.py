@@ -224,7 +224,7 @@ def main():
         desc = bn.plan_describe(path_for_describe(model_bytes))
         kind_of = [l.split()[1] for l in desc.splitlines() if l[:3].strip().isdigit()]
         fam_name = {"GEMM": "gemm_mfma_kernel", "DWCONV": "dwconv_kernel", "CONV": "conv_direct_kernel", "MBCONV": "mbconv_expand_dw_kernel",
-                    "REDUCE": "reduce_kernel", "ELT": "elt_kernel", "GAP": "gap_partial_kernel", "SEFC": "se_fc_kernel"}
+                    "REDUCE": "reduce_kernel", "ELT": "elt_kernel", "GAP": "gap_partial_kernel", "SEFC": "se_fc_kernel", "POOL": "pool_kernel"}
         fam = {}
         for (name, us, macs, byts), k in zip(rows, kind_of):
             f_ = fam.setdefault(fam_name[k], {"us": 0.0, "macs": 0.0, "bytes": 0.0, "launches": 0})

@@ -390,6 +390,49 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
                     r = (xx * xx).sum(dim=ax, keepdim=keep).sqrt()
                 else:
                     r = (xx * xx).sum(dim=ax, keepdim=keep)
+            elif op in ("Softmax", "LogSoftmax"):
+                # ONNX >= 13: along `axis` (default -1); older opsets flatten from `axis`, identical for the last axis
+                ax = int(a.get("axis", -1))
+                r = torch.softmax(i[0], dim=ax) if op == "Softmax" else torch.log_softmax(i[0], dim=ax)
+            elif op == "Split":
+                ax = int(a.get("axis", 0))
+                if "split" in a:
+                    sizes = [int(v) for v in a["split"]]
+                elif len(i) > 1 and i[1] is not None:
+                    sizes = [int(v) for v in i[1].tolist()]
+                else:
+                    k = len(n.outputs)
+                    each = -(-i[0].shape[ax] // k)
+                    sizes = [min(each, i[0].shape[ax] - j * each) for j in range(k)]
+                parts = torch.split(i[0], sizes, dim=ax)
+                for nm, part in zip(n.outputs, parts):
+                    if nm:
+                        env[nm] = part
+                continue
+            elif op in ("MaxPool", "AveragePool"):
+                # floor mode, no dilation; pads [begin..., end...]; AveragePool divides by the in-image tap count
+                # unless count_include_pad (ONNX default 0)
+                ks = [int(v) for v in a["kernel_shape"]]
+                st = [int(v) for v in a.get("strides", [1] * len(ks))]
+                pads = [int(v) for v in a.get("pads", [0] * (2 * len(ks)))]
+                xx = i[0]
+                sp = len(ks)
+                pad_arg = []
+                for d_ in reversed(range(sp)):
+                    pad_arg += [pads[d_], pads[sp + d_]]
+                if op == "MaxPool":
+                    xp = torch.nn.functional.pad(xx, pad_arg, value=float("-inf"))
+                    r = torch.nn.functional.max_pool2d(xp, ks, st) if sp == 2 else torch.nn.functional.max_pool1d(xp, ks[0], st[0])
+                else:
+                    xp = torch.nn.functional.pad(xx, pad_arg, value=0.0)
+                    ones = torch.nn.functional.pad(torch.ones_like(xx), pad_arg, value=0.0)
+                    if sp == 2:
+                        ssum = torch.nn.functional.avg_pool2d(xp, ks, st, divisor_override=1)
+                        cnt = torch.nn.functional.avg_pool2d(ones, ks, st, divisor_override=1)
+                    else:
+                        ssum = torch.nn.functional.avg_pool1d(xp, ks[0], st[0]) * ks[0]
+                        cnt = torch.nn.functional.avg_pool1d(ones, ks[0], st[0]) * ks[0]
+                    r = ssum / (float(np.prod(ks)) if int(a.get("count_include_pad", 0)) else cnt.clamp(min=1.0))
             elif op == "GlobalAveragePool":
                 r = i[0].mean(dim=list(range(2, i[0].dim())), keepdim=True)
             elif op == "GlobalMaxPool":

@@ -125,6 +125,7 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
             break;
         case OpKind::DWCONV: launch_dwconv(c->stream, op.dw, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.b, d_in), batch); break;
         case OpKind::GAP: launch_gap_partial(c->stream, op.gap, out, a, batch); break;
+        case OpKind::POOL: launch_pool(c->stream, op.pool, out, a, batch); break;
         case OpKind::MBCONV:
             launch_mbconv(c->stream, op.mb, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
                           resolve(c, op.bias2, d_in), resolve(c, op.b, d_in), batch);
@@ -1012,7 +1013,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
             if (cfg.embedding_output >= 0) wanted.push_back(cfg.embedding_output);
         }
         auto p = build_plan(om, wanted);
-        static const char *kinds[] = {"ELT", "REDUCE", "GEMM", "CONV", "DWCONV", "GAP", "SEFC", "MBCONV"};
+        static const char *kinds[] = {"ELT", "REDUCE", "GEMM", "CONV", "DWCONV", "GAP", "SEFC", "MBCONV", "POOL"};
         char line[512];
         for (size_t k = 0; k < p->ops.size(); k++) {
             const PlanOp &op = p->ops[k];
@@ -1033,6 +1034,10 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 extra = line;
             } else if (op.kind == OpKind::MBCONV) {
                 snprintf(line, sizeof(line), " %dx%dx%d->(%d)->%dx%dx%d k=%d s=%d tiles=%dx%d squeeze=%d", op.mb.H, op.mb.W, op.mb.Cin, op.mb.C, op.mb.OH, op.mb.OW, op.mb.C, op.mb.k, op.mb.s, op.mb.tiles_y, op.mb.tiles_x, op.mb.has_gap);
+                extra = line;
+            } else if (op.kind == OpKind::POOL) {
+                snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%dx%d max=%d", op.pool.H, op.pool.W, op.pool.C, op.pool.OH, op.pool.OW, op.pool.kh, op.pool.kw,
+                         op.pool.sh, op.pool.sw, op.pool.is_max);
                 extra = line;
             } else if (op.kind == OpKind::GAP) {
                 snprintf(line, sizeof(line), " HW=%lld C=%d splits=%d", (long long)op.gap.HW, op.gap.C, op.gap.splits);

@@ -563,6 +563,9 @@ class Builder {
         if (t == "Slice") return lower_slice(n);
         if (t == "Concat") return lower_concat(n);
         if (t == "Pad") return lower_pad(n);
+        if (t == "Softmax" || t == "LogSoftmax") return lower_softmax(n);
+        if (t == "Split") return lower_split(n);
+        if (t == "MaxPool" || t == "AveragePool") return lower_pool(n);
         if (t == "Conv") return lower_conv(n);
         if (t == "MatMul" || t == "Gemm") return lower_matmul(n);
         if (t == "BatchNormalization") return lower_batchnorm(n);
@@ -938,6 +941,131 @@ class Builder {
             lo[ax - 1] = p0; hi[ax - 1] = p1;
         }
         define(n.outputs[0], pad_copy(x, lo, hi, value, n.name));
+    }
+
+    // MaxPool / AveragePool (1-D or 2-D, no dilation, floor mode) on a channels-last tensor.
+    void lower_pool(const OnnxNode &n) {
+        Val x = get(n, 0);
+        if (x.is_const) unsupported(n, "pooling of a constant");
+        if (x.gate_storage >= 0) x = apply_gate(x, n.name);
+        const size_t sp = x.dims.size() - 1;
+        if (sp != 1 && sp != 2) unsupported(n, "only 1-D and 2-D pooling is supported");
+        if (n.attr_i("ceil_mode", 0) != 0) unsupported(n, "ceil_mode pooling");
+        for (auto dd : n.attr_ints("dilations")) if (dd != 1) unsupported(n, "dilated pooling");
+        if (n.outputs.size() > 1 && !n.outputs[1].empty()) unsupported(n, "MaxPool indices output");
+        auto ks = n.attr_ints("kernel_shape");
+        if (ks.size() != sp) unsupported(n, "kernel_shape rank mismatch");
+        auto st = n.attr_ints("strides");
+        if (st.empty()) st.assign(sp, 1);
+        auto pads = n.attr_ints("pads");
+        if (pads.empty()) pads.assign(2 * sp, 0);
+        const int64_t C = x.dims[0], H = sp == 2 ? x.dims[1] : 1, W = sp == 2 ? x.dims[2] : x.dims[1];
+        const int64_t kh = sp == 2 ? ks[0] : 1, kw = sp == 2 ? ks[1] : ks[0];
+        const int64_t sh = sp == 2 ? st[0] : 1, sw = sp == 2 ? st[1] : st[0];
+        int64_t pt = sp == 2 ? pads[0] : 0, pl = sp == 2 ? pads[1] : pads[0], pb = sp == 2 ? pads[2] : 0, pr = sp == 2 ? pads[3] : pads[1];
+        const std::string auto_pad = n.attr_s("auto_pad", "NOTSET");
+        auto out_dim = [&](int64_t in, int64_t k, int64_t s_, int64_t &p0, int64_t &p1) {
+            if (auto_pad == "SAME_UPPER" || auto_pad == "SAME_LOWER") {
+                const int64_t o = (in + s_ - 1) / s_;
+                const int64_t tot = std::max<int64_t>((o - 1) * s_ + k - in, 0);
+                p0 = auto_pad == "SAME_UPPER" ? tot / 2 : tot - tot / 2;
+                p1 = tot - p0;
+                return o;
+            }
+            if (auto_pad == "VALID") p0 = p1 = 0;
+            return (in + p0 + p1 - k) / s_ + 1;
+        };
+        const int64_t OH = out_dim(H, kh, sh, pt, pb), OW = out_dim(W, kw, sw, pl, pr);
+        if (OH <= 0 || OW <= 0) unsupported(n, "empty pooling output");
+        x = to_channels_last(x, n.name);
+        Dims od = sp == 2 ? Dims{C, OH, OW} : Dims{C, OW};
+        Dims ostr = sp == 2 ? Dims{1, OW * C, C} : Dims{1, C};
+        Val out = new_act(od, ostr);
+        PlanOp op;
+        op.kind = OpKind::POOL;
+        op.name = n.op_type + ":" + n.name;
+        op.out = ref_of(out);
+        op.a = ref_of(x);
+        PoolDesc &d = op.pool;
+        d.H = (int32_t)H; d.W = (int32_t)W; d.C = (int32_t)C; d.OH = (int32_t)OH; d.OW = (int32_t)OW;
+        d.kh = (int32_t)kh; d.kw = (int32_t)kw; d.sh = (int32_t)sh; d.sw = (int32_t)sw; d.pt = (int32_t)pt; d.pl = (int32_t)pl;
+        d.is_max = n.op_type == "MaxPool" ? 1 : 0;
+        d.count_include_pad = (int32_t)n.attr_i("count_include_pad", 0);
+        d.in_bs = batch_stride(x); d.out_bs = plan_.storages[out.storage].elems;
+        op.macs = 0;
+        op.bytes = 4.0 * ((double)C * H * W + (double)C * OH * OW);
+        push_op(std::move(op));
+        define(n.outputs[0], out);
+    }
+
+    // Softmax / LogSoftmax over one non-batch axis, expanded into the launches the engine already has
+    // (max -> x - max -> exp -> sum -> divide, or ... -> log(sum) -> subtract); the elementwise-chain pass fuses
+    // the neighbours.  Opset < 13 semantics (flatten from `axis`) coincide with this when `axis` is the last one.
+    void lower_softmax(const OnnxNode &n) {
+        const Val &x = get(n, 0);
+        if (x.is_const) unsupported(n, "Softmax of a constant");
+        const int64_t r = (int64_t)x.dims.size() + 1;
+        int64_t axis = n.attr_i("axis", -1);
+        if (axis < 0) axis += r;
+        if (axis <= 0 || axis >= r) unsupported(n, "Softmax over the batch dimension");
+        auto mk = [&](const char *op, const std::string &suffix, std::vector<std::string> ins, const std::string &out) {
+            OnnxNode q;
+            q.op_type = op;
+            q.name = n.name + "/" + suffix;
+            q.inputs = std::move(ins);
+            q.outputs = {out};
+            return q;
+        };
+        auto with_axes = [&](OnnxNode q) {
+            OnnxAttr a;
+            a.name = "axes"; a.type = 7; a.ints = {axis};
+            q.attrs["axes"] = a;
+            OnnxAttr k;
+            k.name = "keepdims"; k.type = 2; k.i = 1;
+            q.attrs["keepdims"] = k;
+            return q;
+        };
+        const std::string b = n.outputs[0] + "/sm.";
+        lower_reduce(with_axes(mk("ReduceMax", "max", {n.inputs[0]}, b + "max")));
+        lower_binary(mk("Sub", "shift", {n.inputs[0], b + "max"}, b + "shift"));
+        ActSpec e; e.act = ACT_EXP;
+        lower_unary(mk("Exp", "exp", {b + "shift"}, b + "exp"), e);
+        lower_reduce(with_axes(mk("ReduceSum", "sum", {b + "exp"}, b + "sum")));
+        if (n.op_type == "Softmax") {
+            lower_binary(mk("Div", "div", {b + "exp", b + "sum"}, n.outputs[0]));
+        } else {
+            ActSpec l; l.act = ACT_LOG;
+            lower_unary(mk("Log", "log", {b + "sum"}, b + "lse"), l);
+            lower_binary(mk("Sub", "sub", {b + "shift", b + "lse"}, n.outputs[0]));
+        }
+    }
+
+    // Split along a non-batch axis: every output is a view (no launch).
+    void lower_split(const OnnxNode &n) {
+        const Val &v = get(n, 0);
+        const int64_t r = (int64_t)v.dims.size() + 1;
+        int64_t axis = n.attr_i("axis", 0);
+        if (axis < 0) axis += r;
+        if (axis <= 0 || axis >= r) unsupported(n, "Split along the batch dimension");
+        axis -= 1;
+        std::vector<int64_t> sizes = n.attr_ints("split");
+        if (sizes.empty() && has_input(n, 1)) sizes = const_ints(n, get(n, 1));
+        const int64_t nout = (int64_t)n.outputs.size();
+        if (sizes.empty()) {
+            const int64_t each = (v.dims[axis] + nout - 1) / nout;
+            for (int64_t k = 0; k < nout; k++) sizes.push_back(std::min(each, v.dims[axis] - k * each));
+        }
+        if ((int64_t)sizes.size() != nout) unsupported(n, "split sizes do not match the outputs");
+        int64_t pos = 0;
+        for (int64_t k = 0; k < nout; k++) {
+            if (sizes[k] < 0 || pos + sizes[k] > v.dims[axis]) unsupported(n, "split sizes exceed the dimension");
+            if (v.is_const) unsupported(n, "Split of a constant");
+            Val o = v;
+            o.dims[axis] = sizes[k];
+            o.offset = v.offset + pos * v.strides[axis];
+            if (!n.outputs[k].empty()) define(n.outputs[k], o);
+            pos += sizes[k];
+        }
     }
 
     bool unary_spec(const OnnxNode &n, ActSpec &a) {

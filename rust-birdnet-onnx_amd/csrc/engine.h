@@ -28,7 +28,7 @@ struct Ref {
     int64_t offset = 0;  // elements (per sample for INPUT/ARENA)
 };
 
-enum class OpKind : int32_t { ELT, REDUCE, GEMM, CONV, DWCONV, GAP, SEFC, MBCONV };
+enum class OpKind : int32_t { ELT, REDUCE, GEMM, CONV, DWCONV, GAP, SEFC, MBCONV, POOL };
 
 struct PlanOp {
     OpKind kind;
@@ -43,6 +43,7 @@ struct PlanOp {
     GapDesc gap{};
     SeFcDesc se{};
     MbDesc mb{};
+    PoolDesc pool{};
     double macs = 0;        // per sample
     double macs_mfma_extra = 0;  // MBCONV: the expand part runs on the matrix cores
     double bytes = 0;       // algorithmic bytes read+written per sample (weights excluded)

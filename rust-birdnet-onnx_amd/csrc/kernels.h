@@ -138,6 +138,16 @@ struct MbDesc {
     int32_t has_gap;
     int64_t gap_bs;
 };
+// MaxPool / AveragePool over an NHWC tensor (1-D pooling = H == 1).
+struct PoolDesc {
+    int32_t H, W, C, OH, OW;
+    int32_t kh, kw, sh, sw, pt, pl;
+    int32_t is_max;             // 1 = MaxPool, 0 = AveragePool
+    int32_t count_include_pad;  // AveragePool: divide by kh*kw instead of the number of in-image taps
+    int64_t in_bs, out_bs;
+};
+void launch_pool(hipStream_t s, const PoolDesc &d, float *out, const float *in, int64_t batch);
+
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1,
                    const float *b1, const float *w2, const float *b2, float *gap, int64_t batch);
 

@@ -1933,6 +1933,55 @@ void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, 
     }
 }
 
+// ------------------------------------------------------------------ pooling
+// MaxPool / AveragePool, NHWC: one lane = one output pixel x VEC channels.  Max ignores padding taps;
+// average divides by the in-image tap count unless count_include_pad.  grid (ceil(total/256) capped, batch)
+namespace {
+template <int VEC>
+__global__ __launch_bounds__(256) void pool_kernel(PoolDesc d, float *__restrict__ out, const float *__restrict__ in) {
+    const int64_t b = blockIdx.y;
+    const int CV = d.C / VEC;
+    const uint32_t total = (uint32_t)d.OH * d.OW * CV;
+    const float *ip = in + b * d.in_bs;
+    float *op = out + b * d.out_bs;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int cv = i % CV;
+        const uint32_t pix = i / CV;
+        const int ow = pix % d.OW, oh = pix / d.OW;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[v] = d.is_max ? -INFINITY : 0.0f;
+        int taps = 0;
+        for (int ky = 0; ky < d.kh; ky++) {
+            const int ih = oh * d.sh - d.pt + ky;
+            if (ih < 0 || ih >= d.H) continue;
+            for (int kx = 0; kx < d.kw; kx++) {
+                const int iw = ow * d.sw - d.pl + kx;
+                if (iw < 0 || iw >= d.W) continue;
+                const float *px = ip + ((int64_t)ih * d.W + iw) * d.C + cv * VEC;
+#pragma unroll
+                for (int v = 0; v < VEC; v++) acc[v] = d.is_max ? fmaxf(acc[v], px[v]) : acc[v] + px[v];
+                taps++;
+            }
+        }
+        const float div = d.is_max ? 1.0f : (float)(d.count_include_pad ? d.kh * d.kw : (taps > 0 ? taps : 1));
+        float *po = op + (int64_t)pix * d.C + cv * VEC;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) po[v] = d.is_max ? acc[v] : acc[v] / div;
+    }
+}
+}  // namespace
+void launch_pool(hipStream_t s, const PoolDesc &d, float *out, const float *in, int64_t batch) {
+    if (batch <= 0) return;
+    if (d.C % 4 == 0) {
+        dim3 grid(cap_blocks(((int64_t)d.OH * d.OW * (d.C / 4) + 255) / 256, 8192), (unsigned)batch);
+        hipLaunchKernelGGL(pool_kernel<4>, grid, dim3(256), 0, s, d, out, in);
+    } else {
+        dim3 grid(cap_blocks(((int64_t)d.OH * d.OW * d.C + 255) / 256, 8192), (unsigned)batch);
+        hipLaunchKernelGGL(pool_kernel<1>, grid, dim3(256), 0, s, d, out, in);
+    }
+}
+
 // ------------------------------------------------------------------ recording -> windows
 // chunk_audio on the device (reference src/bin/birdnet-analyze.rs:707-743) fused with the WAV
 // sample conversion (:683-687, f32::from(s) / 32768.0 -- a division by a power of two, exact):

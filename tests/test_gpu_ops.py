@@ -121,6 +121,60 @@ def test_conv1d_with_padding(bn):
     assert_close(got, ref, "padded conv1d")
 
 
+@pytest.mark.parametrize("op,axis_last", [("Softmax", True), ("LogSoftmax", True), ("Softmax", False)])
+def test_softmax(bn, op, axis_last):
+    """Softmax / LogSoftmax along a non-batch axis (expanded into reduce + elementwise launches)."""
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        y = g.node("Mul", [x, g.const(np.float32(4.0))])
+        if axis_last:
+            return g.node(op, [y], axis=-1)
+        return g.node(op, [y], axis=1)
+    shape = [600, 240] if axis_last else [600, 240]
+    got, ref = run_both(bn, op_graph(build, shape, in_reshape=shape), batch=3)
+    assert_close(got, ref, f"{op} axis_last={axis_last}", atol=1e-5, rtol=2e-4)
+    if op == "Softmax":
+        assert np.allclose(ref.sum(axis=-1 if axis_last else 1), 1.0, atol=1e-4)
+
+
+def test_split_views(bn):
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        a, b_, c = g.node("Split", [x, i64(5, 7, 12)], n_out=3, axis=1)
+        y = g.node("Concat", [c, g.node("Relu", [a]), g.node("Neg", [b_])], axis=1)
+        e, f = g.node("Split", [y], n_out=2, axis=2)        # equal halves
+        return g.node("Sub", [e, f])
+    got, ref = run_both(bn, op_graph(build, [24, 3000], in_reshape=[24, 6000]), batch=2)
+    assert_close(got, ref, "split")
+
+
+@pytest.mark.parametrize("op,c,h,w,k,stride,pad,cip", [("MaxPool", 32, 24, 40, 3, 2, 1, 0), ("MaxPool", 6, 17, 23, 2, 2, 0, 0),
+                                                      ("AveragePool", 32, 24, 40, 3, 2, 1, 0), ("AveragePool", 16, 15, 31, 3, 1, 1, 1),
+                                                      ("AveragePool", 5, 9, 9, 5, 3, 2, 0)])
+def test_pooling(bn, op, c, h, w, k, stride, pad, cip):
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(c * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, c, h, w)])
+        kw = dict(kernel_shape=[k, k], strides=[stride, stride], pads=[pad] * 4)
+        if op == "AveragePool" and cip:
+            kw["count_include_pad"] = 1
+        return g.node(op, [x], **kw)
+    got, ref = run_both(bn, op_graph(build, [c, oh, ow]), batch=2)
+    assert_close(got, ref, f"{op} {c}x{h}x{w} k{k} s{stride} p{pad}")
+
+
+def test_pooling_1d(bn):
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Reshape", [x, i64(-1, 12, 12000)])
+        return g.node("MaxPool", [g.node("AveragePool", [x], kernel_shape=[4], strides=[4])], kernel_shape=[3], strides=[2], pads=[1, 1])
+    got, ref = run_both(bn, op_graph(build, [12, 1500]), batch=2)
+    assert_close(got, ref, "pool1d")
+
+
 @pytest.mark.parametrize("style", ["input", "attribute", "axes"])
 def test_pad_constant(bn, style):
     """ONNX Pad (constant mode) on a [B, 6, 40, 600] view: spatial and channel pads, non-zero fill."""
