@@ -507,11 +507,34 @@ bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch, float *log
     if (st != BN_OK) return st;
     if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
     const size_t S = (size_t)p.sample_count;
-    for (size_t b = 0; b < batch; b++) {
+    for (size_t b = 0; b < batch; b++)
         if (!segs[b]) return fail(BN_ERR_INVALID_ARG, "segment " + std::to_string(b) + " is null");
-        memcpy(c->h_input + b * S, segs[b], S * sizeof(float));
+    // Stage the caller's slices into pinned memory and upload in up to 4 chunks: a helper thread per chunk copies
+    // while the previous chunk's H2D transfer is already on the wire (a single-threaded 18 MB memcpy alone costs
+    // more than the whole plan at batch 32).
+    {
+        const size_t bytes_total = batch * S * sizeof(float);
+        const size_t nchunk = bytes_total >= (4u << 20) ? std::min<size_t>(4, batch) : 1;
+        if (nchunk == 1) {
+            for (size_t b = 0; b < batch; b++) memcpy(c->h_input + b * S, segs[b], S * sizeof(float));
+            HIP_TRY(hipMemcpyAsync(c->d_input, c->h_input, bytes_total, hipMemcpyHostToDevice, c->stream));
+        } else {
+            std::vector<std::thread> workers;
+            std::vector<size_t> lo(nchunk + 1);
+            for (size_t k = 0; k <= nchunk; k++) lo[k] = batch * k / nchunk;
+            for (size_t k = 0; k < nchunk; k++)
+                workers.emplace_back([&, k] {
+                    for (size_t b = lo[k]; b < lo[k + 1]; b++) memcpy(c->h_input + b * S, segs[b], S * sizeof(float));
+                });
+            hipError_t e = hipSuccess;
+            for (size_t k = 0; k < nchunk; k++) {
+                workers[k].join();
+                if (e == hipSuccess && lo[k + 1] > lo[k])
+                    e = hipMemcpyAsync(c->d_input + lo[k] * S, c->h_input + lo[k] * S, (lo[k + 1] - lo[k]) * S * sizeof(float), hipMemcpyHostToDevice, c->stream);
+            }
+            if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("input upload failed: ") + hipGetErrorString(e));
+        }
     }
-    HIP_TRY(hipMemcpyAsync(c->d_input, c->h_input, batch * S * sizeof(float), hipMemcpyHostToDevice, c->stream));
     st = enqueue_plan(c, c->d_input, batch, cancel);
     if (st != BN_OK) {
         c->in_flight = true;
