@@ -270,6 +270,32 @@ def test_size_independent_properties_at_bench_size(bn, v24_full):
         assert idx[r, :cnt[r]].tolist() == [w[0] for w in want]
 
 
+@pytest.mark.parametrize("family,batch", [("v30", 64), ("perch", 128)])
+def test_size_independent_properties_other_configs(bn, family, batch):
+    """BASELINE.json configs[2] (BirdNET v3.0, batch 64, embeddings) and configs[3] (Perch v2, batch 128) at full
+    model size: permutation equivariance and duplicate-row equality of logits AND embeddings, bit for bit; device
+    top-K equals the oracle's top_k on the device logits."""
+    data = synth.birdnet_v30() if family == "v30" else synth.perch_v2()
+    m = bn.Model(write_model(data))
+    assert m.config.sample_count == 160000 and m.config.has_embedding
+    ctx = bn.Context(m, batch)
+    x = synth.synthetic_segments(batch, 160000, 32000)
+    x[5] = x[batch - 3]
+    la, ea = ctx.infer(x)
+    la, ea = la.copy(), ea.copy()
+    perm = np.random.default_rng(1).permutation(batch)
+    lb, eb = ctx.infer(x[perm])
+    assert np.isfinite(la).all() and np.isfinite(ea).all()
+    assert la[perm].tobytes() == lb.tobytes() and ea[perm].tobytes() == eb.tobytes()
+    assert la[5].tobytes() == la[batch - 3].tobytes() and ea[5].tobytes() == ea[batch - 3].tobytes()
+    assert ea.shape[1] == (1024 if family == "v30" else 1536)
+    idx, conf, cnt = ctx.topk(batch, 5, None)
+    for r in range(0, batch, 7):
+        want = oracle.top_k(lb[r], 5)
+        assert idx[r, :cnt[r]].tolist() == [w[0] for w in want]
+        assert [np.float32(c).tobytes() for c in conf[r, :cnt[r]]] == [np.float32(w[1]).tobytes() for w in want]
+
+
 def test_sharded_recording_equals_single_pass(bn, v24_small):
     """BASELINE.json configs[4] at reduced length: a continuous recording cut by chunk_audio rules,
     processed as R contiguous shards with a different batch size per shard, concatenated, must be
