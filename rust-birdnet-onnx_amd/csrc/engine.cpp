@@ -141,6 +141,20 @@ class Builder {
         wanted_names_ = want;
         absorbed_.assign(nodes_.size(), false);
 
+        // Arity of every node up front: the lowering (and its look-ahead fusion) indexes inputs / outputs directly,
+        // so a malformed file must be refused here, not found by an out-of-range read later.
+        for (const auto &nd : nodes_) {
+            static const std::map<std::string, size_t> min_inputs = {
+                {"Add", 2}, {"Sub", 2}, {"Mul", 2}, {"Div", 2}, {"Pow", 2}, {"Max", 2}, {"Min", 2}, {"Conv", 2}, {"MatMul", 2}, {"Gemm", 2},
+                {"BatchNormalization", 5}, {"Reshape", 2}, {"Gather", 2}, {"Concat", 1}};
+            if (nd.outputs.empty() || nd.outputs[0].empty()) throw UnsupportedModel("node '" + nd.name + "' (" + nd.op_type + ") has no output");
+            auto it = min_inputs.find(nd.op_type);
+            const size_t need = it != min_inputs.end() ? it->second : (nd.op_type == "Constant" || nd.op_type == "ConstantOfShape" || nd.op_type == "Range" ? 0 : 1);
+            if (nd.inputs.size() < need) throw UnsupportedModel("node '" + nd.name + "' (" + nd.op_type + ") has " + std::to_string(nd.inputs.size()) + " inputs, needs " + std::to_string(need));
+            for (size_t k = 0; k < need; k++)
+                if (nd.inputs[k].empty()) throw UnsupportedModel("node '" + nd.name + "' (" + nd.op_type + "): required input " + std::to_string(k) + " is missing");
+        }
+
         prune_zero_rows();
 
         for (size_t k = 0; k < nodes_.size(); k++) {
@@ -959,6 +973,10 @@ class Builder {
         if (st.empty()) st.assign(sp, 1);
         auto pads = n.attr_ints("pads");
         if (pads.empty()) pads.assign(2 * sp, 0);
+        if (st.size() != sp || pads.size() != 2 * sp) unsupported(n, "strides / pads do not match the spatial rank");
+        for (auto e : ks) if (e <= 0) unsupported(n, "kernel_shape must be positive");
+        for (auto e : st) if (e <= 0) unsupported(n, "strides must be positive");
+        for (auto e : pads) if (e < 0) unsupported(n, "negative pads");
         const int64_t C = x.dims[0], H = sp == 2 ? x.dims[1] : 1, W = sp == 2 ? x.dims[2] : x.dims[1];
         const int64_t kh = sp == 2 ? ks[0] : 1, kw = sp == 2 ? ks[1] : ks[0];
         const int64_t sh = sp == 2 ? st[0] : 1, sw = sp == 2 ? st[1] : st[0];
@@ -1497,6 +1515,8 @@ class Builder {
         auto get2 = [&](const char *key, int64_t dflt) {
             auto v = n.attr_ints(key);
             if (v.empty()) v.assign(sp, dflt);
+            if (v.size() != sp) unsupported(n, std::string(key) + " does not match the spatial rank");
+            for (auto e : v) if (e <= 0) unsupported(n, std::string(key) + " must be positive");
             if (sp == 1) v.insert(v.begin(), dflt == 0 ? 0 : 1);
             return v;
         };
@@ -1505,6 +1525,8 @@ class Builder {
         auto strides = get2("strides", 1), dil = get2("dilations", 1);
         std::vector<int64_t> pads = n.attr_ints("pads");
         if (pads.empty()) pads.assign(2 * sp, 0);
+        if (pads.size() != 2 * sp) unsupported(n, "pads does not match the spatial rank");
+        for (auto e : pads) if (e < 0) unsupported(n, "negative pads");
         int64_t pt, pl, pb, pr;
         if (sp == 2) { pt = pads[0]; pl = pads[1]; pb = pads[2]; pr = pads[3]; }
         else { pt = pb = 0; pl = pads[0]; pr = pads[1]; }

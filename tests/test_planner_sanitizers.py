@@ -1,0 +1,43 @@
+"""Sanitizers run on the CPU build only (GPU ASan is not available on the pool): the ONNX reader and the planner,
+compiled with -fsanitize=address,undefined, plan the synthetic model families and a few hundred truncated /
+bit-flipped copies of each file.  Every malformed file must be planned or refused -- never read out of bounds."""
+import importlib
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+
+
+@pytest.fixture(scope="module")
+def asan_binary(tmp_path_factory):
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    out = tmp_path_factory.mktemp("asan") / "asan_plan"
+    src = os.path.join(ROOT, "rust-birdnet-onnx_amd", "csrc")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-D__HIP_PLATFORM_AMD__",
+           "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), "-I" + src, os.path.join(ROOT, "tools", "asan_plan.cpp"),
+           os.path.join(src, "onnx_proto.cpp"), os.path.join(src, "engine.cpp"), os.path.join(src, "detect.cpp"), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("sanitizer build unavailable: " + r.stderr[-400:])
+    return str(out)
+
+
+def test_reader_and_planner_under_asan_ubsan(asan_binary, tmp_path):
+    files = []
+    for name, data in (("v24", synth.birdnet_v24(num_species=50, width=0.25, depth=0.25, head=64)),
+                       ("v30", synth.birdnet_v30(num_species=40, width=0.25, depth=0.25)),
+                       ("perch", synth.perch_v2(num_species=60, width=0.25, depth=0.25, emb=96)),
+                       ("meta", synth.meta_model(num_species=30, hidden=8))):
+        p = tmp_path / f"{name}.onnx"
+        p.write_bytes(data)
+        files.append(str(p))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", ASAN_PLAN_MUTATIONS=os.environ.get("ASAN_PLAN_MUTATIONS", "300"))
+    r = subprocess.run([asan_binary] + files, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.stdout.count("none crashed") == 4 and r.stdout.count("  ok:") == 4, r.stdout
