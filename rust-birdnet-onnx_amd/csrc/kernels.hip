@@ -1334,6 +1334,251 @@ __global__ void dwconv_tiled_kernel(DwDesc d, float *__restrict__ out, const flo
     }
 }
 
+// Pipelined variant of the kernel above (512 threads): waves 0-3 only expand, waves 4-7 only run the depthwise
+// conv, one chunk behind, from the other half of a double-buffered Es -- the matrix-core phase of chunk c+1 and the
+// vector-ALU phase of chunk c overlap inside the block, with ONE barrier per chunk.  Same arithmetic, same order of
+// every sum, so the results are bit-identical to mbconv_expand_dw_kernel.
+template <int K, int S, bool IM2COL>
+__global__ __launch_bounds__(512) void mbconv_pipe_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
+                                                               const float *__restrict__ w1, const float *__restrict__ b1,
+                                                               const float *__restrict__ w2, const float *__restrict__ b2,
+                                                               float *__restrict__ gap) {
+    constexpr int TOH = S == 1 ? 8 : 4, TOW = S == 1 ? 16 : 8;
+    constexpr int IHT = (TOH - 1) * S + K, IWT = (TOW - 1) * S + K, HP = IHT * IWT;
+    constexpr int MT = (HP + 31) / 32, MP = MT * 32;
+    constexpr int TPW = (MT + 3) / 4;   // m-tiles per wave
+    constexpr int PPG = TOH * TOW / 8;  // consecutive output pixels (of one row) per lane group
+    constexpr int SEG = TOW / PPG;      // lane groups per output row
+    constexpr int IWS = (PPG - 1) * S + K;  // input columns one lane group touches
+    static_assert(TOW % PPG == 0, "a lane group must stay inside one output row");
+    extern __shared__ __align__(16) float msm[];
+    const int ng = (d.Cin + 7) / 8;  // 8-wide K groups holding data
+    const int KS = ng * 8 + 4;       // LDS row stride (floats): (KS/4) is odd -> conflict-free b128 reads
+    float *Xs = msm;             // [MP][KS]
+    float *Esb = Xs + MP * KS;   // [2][MP][32]: the expand waves fill one buffer while the depthwise waves read the other
+    float *Vs = Esb + 2 * MP * 32;  // [MP] 1.0 for halo pixels inside the image, else 0.0
+    float *red = Vs + MP;        // [nchunks][8][32]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const bool is_exp = wave < 4;  // waves 0-3: expand (matrix cores); waves 4-7: depthwise (vector ALU)
+    const int ew = wave & 3;
+    const int ty = blockIdx.x / d.tiles_x, tx = blockIdx.x - ty * d.tiles_x;
+    const int oh0 = ty * TOH, ow0 = tx * TOW;
+    const int ih0 = oh0 * S - d.pt, iw0 = ow0 * S - d.pl;
+    const int64_t b = blockIdx.z;
+    const float *xin = in + b * d.in_bs;
+    const int CV = d.Cin >> 2;  // float4 per pixel (Cin % 4 == 0)
+    const int nchunks = (d.C + 31) / 32;
+    // the whole halo lies inside the image (interior tiles): no validity look-ups in the expand
+    const bool all_valid = ih0 >= 0 && ih0 + IHT <= d.H && iw0 >= 0 && iw0 + IWT <= d.W;
+
+    // expand filters of a chunk: lane (lr, lh) holds columns 8g + 4lh .. +3 of filter c0 + lr for
+    // every K group g.  w1 is the planner's padded repack [C][ng*8] = weights | zeros, so these are
+    // plain loads with nothing depending on them until the matrix instructions.
+    float4 bw[MB_MAX_NG], bnx[MB_MAX_NG];
+    auto fetch_b = [&](float4 (&dst)[MB_MAX_NG], int c0) {
+        const int n = c0 + lr < d.C ? c0 + lr : d.C - 1;
+        const float *wr = w1 + (int64_t)n * (ng * 8) + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < MB_MAX_NG; g++)
+            if (g < ng) dst[g] = *reinterpret_cast<const float4 *>(wr + 8 * g);
+    };
+    if (is_exp) fetch_b(bw, 0);
+
+    // ---- 0. stage the halo tile
+    if constexpr (IM2COL) {
+        // stem: every halo pixel of the first conv's OUTPUT map becomes one im2col row of k1*k1*Cin1 input values
+        // (column = (ky*k1 + kx)*Cin1 + c); taps outside the input image are the conv's own zero padding, pixels
+        // outside the output map are zero rows with Vs = 0.  Clamped loads, selection at LDS-store time.
+        const int KK = d.k1 * d.k1;
+        for (int r = tid; r < MP; r += 512) {
+            const int iy = r / IWT, ix = r - iy * IWT;
+            const int ih = ih0 + iy, iw = iw0 + ix;
+            const bool ok = r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+            Vs[r] = ok ? 1.0f : 0.0f;
+            for (int k = d.Cin; k < ng * 8; k++) Xs[r * KS + k] = 0.0f;  // K padding
+        }
+        for (int it0 = tid; it0 < MP * KK; it0 += 512 * 4) {
+            float v[4][4];
+            bool okv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int it = it0 + i * 512;
+                const int r = it / KK, t = it - r * KK;
+                const int ky = t / d.k1, kx = t - ky * d.k1;
+                const int iy = r / IWT, ix = r - iy * IWT;
+                const int ih = ih0 + iy, iw = iw0 + ix;
+                const int y = ih * d.s1 + ky - d.pt1, x = iw * d.s1 + kx - d.pl1;
+                okv[i] = it < MP * KK && r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W && y >= 0 && y < d.H1 && x >= 0 && x < d.W1;
+                const int yc = y < 0 ? 0 : (y >= d.H1 ? d.H1 - 1 : y), xc = x < 0 ? 0 : (x >= d.W1 ? d.W1 - 1 : x);
+                const float *px = xin + ((int64_t)yc * d.W1 + xc) * d.Cin1;
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) v[i][cc] = px[cc < d.Cin1 ? cc : 0];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int it = it0 + i * 512;
+                if (it < MP * KK) {
+                    const int r = it / KK, t = it - r * KK;
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++)
+                        if (cc < d.Cin1) Xs[r * KS + t * d.Cin1 + cc] = okv[i] ? v[i][cc] : 0.0f;
+                }
+            }
+        }
+    } else {
+        // 1x1 expand: PSTEP pixels per pass, lane = (pixel, float4 of its channels);
+        // four passes' loads (clamped addresses, never predicated) are in flight together,
+        // pixels outside the image are zeroed when the values go to LDS
+        const int PSTEP = 512 / CV;
+        const int p0 = tid / CV, cv = tid - p0 * CV;
+        const bool lane_on = p0 < PSTEP;
+        for (int r0 = p0; r0 < MP; r0 += 4 * PSTEP) {
+            float4 xv[4];
+            bool okv[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = r0 + i * PSTEP;
+                const int iy = r / IWT, ix = r - iy * IWT;
+                const int ih = ih0 + iy, iw = iw0 + ix;
+                okv[i] = r < HP && ih >= 0 && ih < d.H && iw >= 0 && iw < d.W;
+                const int ihc = ih < 0 ? 0 : (ih >= d.H ? d.H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= d.W ? d.W - 1 : iw);
+                xv[i] = *reinterpret_cast<const float4 *>(xin + ((int64_t)ihc * d.W + iwc) * d.Cin + (lane_on ? cv * 4 : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = r0 + i * PSTEP;
+                if (lane_on && r < MP) {
+                    *reinterpret_cast<float4 *>(Xs + r * KS + cv * 4) = okv[i] ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (cv == 0) {  // validity flag + zero K padding of this row
+                        Vs[r] = okv[i] ? 1.0f : 0.0f;
+                        if (CV & 1) *reinterpret_cast<float4 *>(Xs + r * KS + d.Cin) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+            }
+        }
+    }
+    // depthwise role: lane = channel, group g8 = PPG consecutive pixels of output row oy
+    const int c = tid & 31, g8 = (tid & 255) >> 5;
+    const int oy = g8 / SEG, ox0 = (g8 - oy * SEG) * PPG;
+    const int eoff = ((oy * S) * IWT + ox0 * S) * 32 + c;
+    float *ob = out + b * d.out_bs + ((int64_t)(oh0 + oy) * d.OW + ow0 + ox0) * d.C;
+    const bool row_ok = oh0 + oy < d.OH;
+    const bool seg_full = row_ok && ow0 + ox0 + PPG <= d.OW;
+
+    // operands of a chunk are fetched one iteration ahead by the group that consumes them
+    float wd[K * K], wdn[K * K], bias2 = 0.f, bias2n = 0.f, bv = 0.f, bvn = 0.f;
+    auto fetch_dw = [&](int c0) {
+        const int cgn = c0 + c < d.C ? c0 + c : d.C - 1;
+#pragma unroll
+        for (int q = 0; q < K * K; q++) wdn[q] = w2[q * d.C + cgn];
+        bias2n = d.has_bias2 ? b2[cgn] : 0.0f;
+    };
+    if (is_exp) bvn = d.has_bias1 ? b1[lr < d.C ? lr : d.C - 1] : 0.0f;
+    else fetch_dw(0);
+    __syncthreads();  // Xs / Vs complete
+
+    // software pipeline, one barrier per iteration: iteration `it` expands chunk `it` into buffer it & 1 (waves 0-3)
+    // while the depthwise conv of chunk it - 1 runs from the other buffer (waves 4-7)
+    for (int it = 0; it <= nchunks; it++) {
+        if (is_exp) {
+            if (it < nchunks) {
+                const int c0 = it * 32;
+                bv = bvn;
+                if (it + 1 < nchunks) {
+                    fetch_b(bnx, c0 + 32);
+                    bvn = d.has_bias1 ? b1[c0 + 32 + lr < d.C ? c0 + 32 + lr : d.C - 1] : 0.0f;
+                }
+                float *Es = Esb + (it & 1) * MP * 32;
+                const int wrole = (ew - it) & 3;
+#pragma unroll
+                for (int t = 0; t < TPW; t++) {
+                    const int mt = wrole + 4 * t;
+                    if (mt < MT) {
+                        floatx16 acc[1];
+                        if (all_valid) {
+#pragma unroll
+                            for (int r = 0; r < 16; r++) acc[0][r] = bv;
+                        } else {
+                            const float *vp = Vs + mt * 32 + 4 * lh;
+#pragma unroll
+                            for (int r = 0; r < 16; r++) acc[0][r] = bv * vp[(r & 3) + 8 * (r >> 2)];
+                        }
+                        const float *ap = Xs + (mt * 32 + lr) * KS + 4 * lh;
+#pragma unroll
+                        for (int g = 0; g < MB_MAX_NG; g++)
+                            if (g < ng) {
+                                const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
+                                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bw[g].x, acc[0], 0, 0, 0);
+                                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bw[g].y, acc[0], 0, 0, 0);
+                                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bw[g].z, acc[0], 0, 0, 0);
+                                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bw[g].w, acc[0], 0, 0, 0);
+                            }
+                        act_tile<1>(d.act1, d.p0_1, d.p1_1, acc);
+                        float *ep = Es + (mt * 32 + 4 * lh) * 32 + lr;
+#pragma unroll
+                        for (int reg = 0; reg < 16; reg++) ep[((reg & 3) + 8 * (reg >> 2)) * 32] = acc[0][reg];
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < MB_MAX_NG; g++) bw[g] = bnx[g];
+            }
+        } else if (it >= 1) {
+            const int ch = it - 1;
+            const int c0 = ch * 32;
+            const int cg = c0 + c;
+            const bool cact = cg < d.C;
+#pragma unroll
+            for (int q = 0; q < K * K; q++) wd[q] = wdn[q];
+            bias2 = bias2n;
+            if (ch + 1 < nchunks) fetch_dw(c0 + 32);
+            const float *ebase = Esb + (ch & 1) * MP * 32 + eoff;
+            float ov[PPG];
+#pragma unroll
+            for (int q = 0; q < PPG; q++) ov[q] = bias2;
+#pragma unroll
+            for (int ky = 0; ky < K; ky++) {
+#pragma unroll
+                for (int ix = 0; ix < IWS; ix++) {
+                    const float v = ebase[(ky * IWT + ix) * 32];
+#pragma unroll
+                    for (int kx = 0; kx < K; kx++)
+                        if (ix - kx >= 0 && (ix - kx) % S == 0 && (ix - kx) / S < PPG)
+                            ov[(ix - kx) / S] = fmaf(v, wd[ky * K + kx], ov[(ix - kx) / S]);
+                }
+            }
+            act_array<PPG>(d.act2, d.p0_2, d.p1_2, ov);
+            float sum = 0.0f;
+            if (seg_full && c0 + 32 <= d.C) {
+#pragma unroll
+                for (int q = 0; q < PPG; q++) {
+                    ob[(int64_t)q * d.C + cg] = ov[q];
+                    sum += ov[q];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < PPG; q++) {
+                    if (cact && row_ok && ow0 + ox0 + q < d.OW) {
+                        ob[(int64_t)q * d.C + cg] = ov[q];
+                        sum += ov[q];
+                    }
+                }
+            }
+            red[(ch * 8 + g8) * 32 + c] = sum;
+        }
+        __syncthreads();
+    }
+    if (d.has_gap) {
+        for (int cc = tid; cc < d.C; cc += 512) {
+            const float *rp = red + (cc >> 5) * 256 + (cc & 31);
+            float t = rp[0];
+#pragma unroll
+            for (int y = 1; y < 8; y++) t += rp[y * 32];
+            gap[b * d.gap_bs + (int64_t)blockIdx.x * d.C + cc] = t;
+        }
+    }
+}
+
+
 // Depthwise K x K conv of a whole [H*W][32-channel] slab held in LDS (after a barrier): lane =
 // channel, 8 lane groups take segments of 8 consecutive pixels of an output row and slide the
 // window along them; bias + activation, NHWC store, complete per-channel sums (fixed order).
@@ -1842,6 +2087,16 @@ size_t mbconv_lds_bytes(const MbDesc &d) {
     return (size_t)(mp * ks + mp * 32 + mp + nchunks * 8 * 32) * sizeof(float);
 }
 
+// dynamic LDS of the pipelined variant (Es double-buffered)
+size_t mbconv_pipe_lds_bytes(const MbDesc &d) {
+    const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
+    const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
+    const int mp = (hp + 31) / 32 * 32;
+    const int ks = (d.Cin + 7) / 8 * 8 + 4;
+    const int nchunks = (d.C + 31) / 32;
+    return (size_t)(mp * ks + 2 * mp * 32 + mp + nchunks * 8 * 32) * sizeof(float);
+}
+
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
                    const float *b2, float *gap, int64_t batch) {
     if (batch <= 0) return;
@@ -1865,6 +2120,36 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
         return;
     }
     dim3 grid((unsigned)(d.tiles_x * d.tiles_y), 1, (unsigned)batch);
+    // The pipelined variant pays when the plain kernel fits only ONE block per CU (5x5 stride-1 tiles: 83 KB of LDS,
+    // four waves per CU): its eight waves overlap the matrix-core and vector phases inside the block (47 -> 40 us).
+    // Where two or more plain blocks fit, those already overlap each other and the plain kernel is faster.
+    // BN_MBPIPE=0 never, =1 always (results are bit-identical either way).
+    const int pipe_mode = getenv("BN_MBPIPE") ? atoi(getenv("BN_MBPIPE")) : -1;  // read per launch (launches are captured once per graph)
+    const size_t plds = mbconv_pipe_lds_bytes(d);
+    const bool pipe = pipe_mode == 1 || (pipe_mode == -1 && lds > 80 * 1024);
+    if (pipe && d.C > 32 && plds <= 160 * 1024) {
+#define MBP_LAUNCH2(K, S, IM)                                                                                                    \
+    do {                                                                                                                         \
+        static size_t attr = 0;                                                                                                  \
+        if (plds > attr) {                                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mbconv_pipe_kernel<K, S, IM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds); \
+            attr = plds;                                                                                                         \
+        }                                                                                                                        \
+        hipLaunchKernelGGL((mbconv_pipe_kernel<K, S, IM>), grid, dim3(512), plds, s, d, out, in, w1, b1, w2, b2, gap);           \
+    } while (0)
+#define MBP_LAUNCH(K, S)                       \
+    do {                                       \
+        if (d.k1 > 0) MBP_LAUNCH2(K, S, true); \
+        else MBP_LAUNCH2(K, S, false);         \
+    } while (0)
+        if (d.k == 3 && d.s == 1) MBP_LAUNCH(3, 1);
+        else if (d.k == 3 && d.s == 2) MBP_LAUNCH(3, 2);
+        else if (d.k == 5 && d.s == 1) MBP_LAUNCH(5, 1);
+        else MBP_LAUNCH(5, 2);
+#undef MBP_LAUNCH
+#undef MBP_LAUNCH2
+        return;
+    }
 #define MB_LAUNCH2(K, S, IM)                                                                                                     \
     do {                                                                                                                         \
         static size_t attr = 0;                                                                                                  \

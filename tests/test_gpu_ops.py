@@ -270,7 +270,7 @@ def test_standalone_batchnorm_and_hard_activations(bn):
 @pytest.mark.parametrize("cin,h,w,cmid,k,stride,act", [(16, 24, 40, 96, 3, 2, "relu"), (24, 12, 40, 144, 3, 1, "relu"),
                                                        (24, 13, 37, 144, 5, 2, "silu"), (40, 9, 19, 240, 3, 2, "relu6"),
                                                        (8, 16, 32, 48, 5, 1, "relu"), (16, 7, 9, 40, 3, 1, None)])
-@pytest.mark.parametrize("variant", ["tiled", "map"])
+@pytest.mark.parametrize("variant", ["tiled", "pipe", "map"])
 def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
     """expand 1x1 conv (+BN+act) -> depthwise KxK (+act): one MBCONV launch, expanded tensor only in LDS.
     Both kernels: output tiles with halo recompute ("tiled") and whole small maps per block ("map")."""
@@ -304,15 +304,16 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
     data = op_graph(build, [cmid, oh, ow])
     import os
     os.environ["BN_MBFUSE"] = "force"   # fuse tiny feature maps with the tiled kernel too (read by the planner at model load)
-    os.environ["BN_MBMAP"] = "0" if variant == "tiled" else "1"
+    os.environ["BN_MBMAP"] = "1" if variant == "map" else "0"
     os.environ["BN_MBMAP_MAXHW"] = "1024"
+    os.environ["BN_MBPIPE"] = "1" if variant == "pipe" else "0"   # pipelined 512-thread variant of the tiled kernel
     try:
         desc = bn.plan_describe(write_model(data))
         assert "MBCONV" in desc
         assert ("tiles=1x1" in desc) == (variant == "map" or (oh <= (8 if stride == 1 else 4) and ow <= (16 if stride == 1 else 8)))
         got, ref = run_both(bn, data)
     finally:
-        for key in ("BN_MBFUSE", "BN_MBMAP", "BN_MBMAP_MAXHW"):
+        for key in ("BN_MBFUSE", "BN_MBMAP", "BN_MBMAP_MAXHW", "BN_MBPIPE"):
             del os.environ[key]
     assert_close(got, ref, f"mbconv[{variant}] {cin}->{cmid} k{k} s{stride}")
 
@@ -366,6 +367,34 @@ def test_fused_stem_conv_depthwise(bn, cin, h, w, cout, k1, s1, k, stride, act):
     finally:
         del os.environ["BN_STEMFUSE"]
     assert_close(got2, ref, "unfused stem")
+
+
+def test_pipelined_mbconv_is_bit_identical_to_the_plain_kernel(bn):
+    """The planner / launcher may pick either MBConv variant per shape; results must not depend on that choice."""
+    import os
+    rng = np.random.default_rng(5)
+    cin, h, w, cmid, k = 40, 12, 64, 240, 5
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(cin * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, cin, h, w)])
+        x = g.node("Conv", [x, g.const((rng.standard_normal((cin, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32))], kernel_shape=[1, 1])
+        y = g.node("Relu", [g.node("Conv", [x, g.const((rng.standard_normal((cmid, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)),
+                                            g.const(rng.standard_normal(cmid).astype(np.float32))], kernel_shape=[1, 1])])
+        return g.node("Relu", [g.node("Conv", [y, g.const((rng.standard_normal((cmid, 1, k, k)) / k).astype(np.float32))], kernel_shape=[k, k],
+                                      pads=[k // 2] * 4, group=cmid)])
+    data = op_graph(build, [cmid, h, w])
+    outs = []
+    for mode in ("0", "1"):
+        os.environ["BN_MBPIPE"] = mode
+        os.environ["BN_MBFUSE"] = "force"
+        try:
+            assert "MBCONV" in bn.plan_describe(write_model(data))
+            outs.append(run_both(bn, data, batch=3)[0].copy())
+        finally:
+            del os.environ["BN_MBPIPE"], os.environ["BN_MBFUSE"]
+    assert outs[0].tobytes() == outs[1].tobytes()
 
 
 @pytest.mark.parametrize("cin,h,w,cmid,k,stride", [(80, 6, 32, 480, 3, 1), (112, 6, 32, 672, 5, 2), (192, 3, 16, 1152, 5, 1),
