@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="contexts (HIP streams) in flight per GPU")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="segments the CPU oracle is timed on")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="segments the CPU oracle is timed on (about 15-30 s of host work)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
