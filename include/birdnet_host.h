@@ -243,6 +243,11 @@ class ClassifierBuilder {
 std::vector<std::string> load_labels_from_file(const std::string &path, ModelType t);
 std::vector<std::string> parse_text_labels(const std::string &content);
 std::vector<std::string> parse_csv_labels(const std::string &content);
+/* labels.rs:95-121: ["a","b"]  |  {"labels": ["a","b"]}  |  [{"name"|"label"|"species": "a"}, ...]; anything else
+ * => Error::LabelParse("unrecognized JSON format: ...") */
+std::vector<std::string> parse_json_labels(const std::string &content);
+enum class LabelFormat { Text = 0, Csv = 1, Json = 2 };  /* src/types.rs LabelFormat */
+std::vector<std::string> parse_labels(const std::string &content, LabelFormat format);  /* labels.rs:33-39 */
 
 /* ---- range filter (src/rangefilter.rs): location / date prior over species from a small meta model ---- */
 struct LocationScore {  /* src/types.rs:111-120 */
@@ -408,6 +413,9 @@ size_t bnh_filter_predictions(const char *const *pred_species, const float *pred
 
 /* labels.rs parsers and chunk_audio, for host-logic tests */
 size_t bnh_parse_labels(const char *content, int32_t csv, char *out, size_t cap); /* '\n'-joined; returns needed bytes */
+/* parse_labels with a LabelFormat (0 text, 1 csv, 2 json): labels joined by '\x1f' (labels may contain newlines in
+ * JSON); returns the needed bytes, or 0 with *err filled on Error::LabelParse */
+size_t bnh_parse_labels_format(const char *content, int32_t format, char *out, size_t cap, bnh_error *err);
 size_t bnh_chunk_plan(size_t n_samples, size_t segment_samples, float overlap_secs, uint32_t sample_rate, uint64_t *starts,
                       float *start_times, size_t cap);
 

@@ -55,7 +55,7 @@ HOST_SYMBOLS = [
     "bnh_context_input_buffer_capacity", "bnh_context_input_buffer_bytes", "bnh_context_model_type",
     "bnh_predict_batch_with_context", "bnh_predict_recording", "bnh_results_len", "bnh_result_model_type", "bnh_result_n_predictions",
     "bnh_result_species", "bnh_result_confidence", "bnh_result_index", "bnh_result_raw_scores",
-    "bnh_result_embeddings", "bnh_results_free", "bnh_parse_labels", "bnh_chunk_plan",
+    "bnh_result_embeddings", "bnh_results_free", "bnh_parse_labels", "bnh_parse_labels_format", "bnh_chunk_plan",
     "bnh_calculate_week", "bnh_validate_coordinates", "bnh_validate_date", "bnh_range_filter_build", "bnh_range_filter_free",
     "bnh_range_filter_predict", "bnh_range_filter_label", "bnh_filter_predictions",
 ]
@@ -156,6 +156,7 @@ def _load() -> C.CDLL:
                                                  C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(BnhError)]),
         "bnh_predict_recording": (i32, [vp, vp, vp, sz, i32, C.c_float, sz, sz, C.c_int64, C.POINTER(C.c_int32), C.POINTER(vp),
                                         f32p, sz, C.POINTER(BnhError)]),
+        "bnh_parse_labels_format": (sz, [C.c_char_p, i32, C.c_char_p, sz, C.POINTER(BnhError)]),
         "bnh_calculate_week": (C.c_float, [C.c_uint32, C.c_uint32]),
         "bnh_validate_coordinates": (i32, [C.c_float, C.c_float, C.POINTER(BnhError)]),
         "bnh_validate_date": (i32, [C.c_uint32, C.c_uint32, C.POINTER(BnhError)]),
@@ -896,6 +897,26 @@ def parse_labels(content: str, csv: bool) -> list:
     lib.bnh_parse_labels(content.encode("utf-8"), 1 if csv else 0, buf, max(n, 1))
     s = buf.value.decode("utf-8")
     return s.split("\n") if s else []
+
+
+class LabelFormat(enum.IntEnum):
+    """reference src/types.rs LabelFormat."""
+    Text = 0
+    Csv = 1
+    Json = 2
+
+
+def parse_labels_format(content: str, fmt: "LabelFormat") -> list:
+    """parse_labels (reference src/labels.rs:33-39) through the compiled C++ mirror; raises Error(LabelParse)."""
+    err = BnhError()
+    raw = content.encode("utf-8")
+    n = lib.bnh_parse_labels_format(raw, int(fmt), None, 0, C.byref(err))
+    if n == 0:
+        raise Error(err)
+    buf = C.create_string_buffer(n)
+    lib.bnh_parse_labels_format(raw, int(fmt), buf, n, C.byref(err))
+    s = buf.raw[:n - 1].decode("utf-8")
+    return s.split("\x1f") if s else []
 
 
 def chunk_plan(n_samples: int, segment_samples: int, overlap_secs: float, sample_rate: int):

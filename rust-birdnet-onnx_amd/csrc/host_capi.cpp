@@ -292,6 +292,21 @@ size_t bnh_parse_labels(const char *content, int32_t csv, char *out, size_t cap)
     return joined.size() + 1;
 }
 
+size_t bnh_parse_labels_format(const char *content, int32_t format, char *out, size_t cap, bnh_error *err) {
+    std::string joined;
+    const int32_t rc = guarded(err, [&] {
+        const auto l = parse_labels(content ? content : "", (LabelFormat)format);
+        for (size_t i = 0; i < l.size(); i++) joined += (i ? "\x1f" : "") + l[i];
+    });
+    if (rc != BNH_OK) return 0;
+    if (out && cap) {
+        const size_t n = std::min(cap - 1, joined.size());
+        memcpy(out, joined.data(), n);
+        out[n] = 0;
+    }
+    return joined.size() + 1;
+}
+
 size_t bnh_chunk_plan(size_t n_samples, size_t segment_samples, float overlap_secs, uint32_t sample_rate, uint64_t *starts, float *start_times,
                       size_t cap) {
     auto v = chunk_plan(n_samples, segment_samples, overlap_secs, sample_rate);

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <stdexcept>
 
 namespace birdnet {
 
@@ -353,6 +354,199 @@ std::vector<std::string> parse_csv_labels(const std::string &content) {
         if (!label.empty()) out.push_back(label);
     }
     return out;
+}
+
+// ---- JSON labels (labels.rs:95-121), with serde_json's acceptance rules for the three shapes ----
+namespace {
+struct JsonValue {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    std::string str;
+    std::vector<JsonValue> items;                             // Array
+    std::vector<std::pair<std::string, JsonValue>> members;   // Object (duplicates: the last one wins, as in serde)
+};
+struct JsonParser {
+    const std::string &s;
+    size_t p = 0;
+    int depth = 0;
+    explicit JsonParser(const std::string &src) : s(src) {}
+    void ws() { while (p < s.size() && (s[p] == ' ' || s[p] == '\t' || s[p] == '\n' || s[p] == '\r')) p++; }
+    [[noreturn]] void bad() { throw std::runtime_error("invalid JSON"); }
+    static void utf8(std::string &o, uint32_t cp) {
+        if (cp < 0x80) o += (char)cp;
+        else if (cp < 0x800) { o += (char)(0xC0 | (cp >> 6)); o += (char)(0x80 | (cp & 0x3F)); }
+        else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+        else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+    }
+    uint32_t hex4() {
+        if (p + 4 > s.size()) bad();
+        uint32_t v = 0;
+        for (int k = 0; k < 4; k++) {
+            const char ch = s[p++];
+            v <<= 4;
+            if (ch >= '0' && ch <= '9') v |= (uint32_t)(ch - '0');
+            else if (ch >= 'a' && ch <= 'f') v |= (uint32_t)(ch - 'a' + 10);
+            else if (ch >= 'A' && ch <= 'F') v |= (uint32_t)(ch - 'A' + 10);
+            else bad();
+        }
+        return v;
+    }
+    std::string string() {
+        if (p >= s.size() || s[p] != '"') bad();
+        p++;
+        std::string o;
+        while (true) {
+            if (p >= s.size()) bad();
+            const unsigned char ch = (unsigned char)s[p++];
+            if (ch == '"') break;
+            if (ch < 0x20) bad();
+            if (ch != '\\') { o += (char)ch; continue; }
+            if (p >= s.size()) bad();
+            const char e = s[p++];
+            switch (e) {
+                case '"': o += '"'; break;
+                case '\\': o += '\\'; break;
+                case '/': o += '/'; break;
+                case 'b': o += '\b'; break;
+                case 'f': o += '\f'; break;
+                case 'n': o += '\n'; break;
+                case 'r': o += '\r'; break;
+                case 't': o += '\t'; break;
+                case 'u': {
+                    uint32_t cp = hex4();
+                    if (cp >= 0xD800 && cp <= 0xDBFF) {  // surrogate pair
+                        if (p + 2 > s.size() || s[p] != '\\' || s[p + 1] != 'u') bad();
+                        p += 2;
+                        const uint32_t lo = hex4();
+                        if (lo < 0xDC00 || lo > 0xDFFF) bad();
+                        cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                    } else if (cp >= 0xDC00 && cp <= 0xDFFF) bad();
+                    utf8(o, cp);
+                    break;
+                }
+                default: bad();
+            }
+        }
+        return o;
+    }
+    JsonValue value() {
+        if (++depth > 128) bad();
+        ws();
+        if (p >= s.size()) bad();
+        JsonValue v;
+        const char ch = s[p];
+        if (ch == '"') { v.kind = JsonValue::String; v.str = string(); }
+        else if (ch == '[') {
+            v.kind = JsonValue::Array;
+            p++;
+            ws();
+            if (p < s.size() && s[p] == ']') p++;
+            else
+                while (true) {
+                    v.items.push_back(value());
+                    ws();
+                    if (p < s.size() && s[p] == ',') { p++; continue; }
+                    if (p < s.size() && s[p] == ']') { p++; break; }
+                    bad();
+                }
+        } else if (ch == '{') {
+            v.kind = JsonValue::Object;
+            p++;
+            ws();
+            if (p < s.size() && s[p] == '}') p++;
+            else
+                while (true) {
+                    ws();
+                    std::string key = string();
+                    ws();
+                    if (p >= s.size() || s[p] != ':') bad();
+                    p++;
+                    v.members.emplace_back(std::move(key), value());
+                    ws();
+                    if (p < s.size() && s[p] == ',') { p++; continue; }
+                    if (p < s.size() && s[p] == '}') { p++; break; }
+                    bad();
+                }
+        } else if (s.compare(p, 4, "true") == 0) { v.kind = JsonValue::Bool; p += 4; }
+        else if (s.compare(p, 5, "false") == 0) { v.kind = JsonValue::Bool; p += 5; }
+        else if (s.compare(p, 4, "null") == 0) { v.kind = JsonValue::Null; p += 4; }
+        else if (ch == '-' || (ch >= '0' && ch <= '9')) {
+            v.kind = JsonValue::Number;
+            const size_t st = p;
+            if (s[p] == '-') p++;
+            while (p < s.size() && ((s[p] >= '0' && s[p] <= '9') || s[p] == '.' || s[p] == 'e' || s[p] == 'E' || s[p] == '+' || s[p] == '-')) p++;
+            if (p == st || (s[st] == '-' && p == st + 1)) bad();
+        } else bad();
+        depth--;
+        return v;
+    }
+    JsonValue document() {
+        JsonValue v = value();
+        ws();
+        if (p != s.size()) bad();  // trailing characters
+        return v;
+    }
+};
+// Vec<String>: every element a string
+bool as_string_array(const JsonValue &v, std::vector<std::string> &out) {
+    if (v.kind != JsonValue::Array) return false;
+    out.clear();
+    for (const auto &e : v.items) {
+        if (e.kind != JsonValue::String) return false;
+        out.push_back(e.str);
+    }
+    return true;
+}
+const JsonValue *member(const JsonValue &o, const char *key) {
+    const JsonValue *hit = nullptr;
+    for (const auto &kv : o.members)
+        if (kv.first == key) hit = &kv.second;
+    return hit;
+}
+}  // namespace
+
+std::vector<std::string> parse_json_labels(const std::string &content) {
+    JsonValue doc;
+    bool ok = true;
+    try {
+        doc = JsonParser(content).document();
+    } catch (const std::exception &) {
+        ok = false;
+    }
+    std::vector<std::string> labels;
+    if (ok) {
+        if (as_string_array(doc, labels)) return labels;                       // ["a", "b"]
+        if (doc.kind == JsonValue::Object) {                                    // {"labels": [...]} (other keys ignored)
+            const JsonValue *l = member(doc, "labels");
+            if (l && as_string_array(*l, labels)) return labels;
+        }
+        if (doc.kind == JsonValue::Array) {                                     // [{"name"|"label"|"species": ...}, ...]
+            bool shape = true;
+            labels.clear();
+            for (const auto &e : doc.items) {
+                if (e.kind != JsonValue::Object) { shape = false; break; }
+                const JsonValue *pick = nullptr;
+                for (const char *key : {"name", "label", "species"}) {
+                    const JsonValue *m = member(e, key);
+                    if (!m || m->kind == JsonValue::Null) continue;            // Option<String>: missing or null => None
+                    if (m->kind != JsonValue::String) { shape = false; break; }  // wrong type: the whole document fails
+                    if (!pick) pick = m;
+                }
+                if (!shape) break;
+                if (pick) labels.push_back(pick->str);
+            }
+            if (shape && !labels.empty()) return labels;
+        }
+    }
+    throw Error(Error::LabelParse,
+                "failed to parse labels: unrecognized JSON format: expected array of strings, {labels: [...]}, or [{name: ...}]");
+}
+
+std::vector<std::string> parse_labels(const std::string &content, LabelFormat format) {
+    switch (format) {
+        case LabelFormat::Text: return parse_text_labels(content);
+        case LabelFormat::Csv: return parse_csv_labels(content);
+        default: return parse_json_labels(content);
+    }
 }
 
 std::vector<std::string> load_labels_from_file(const std::string &path, ModelType t) {
