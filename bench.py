@@ -255,7 +255,9 @@ def main():
         roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                      "kernel": dname, "launches_per_step": d["launches"],
                      "avg_launch_us": round(d["us"] / d["launches"], 2), "share_of_step": round(d["us"] / total_us, 3),
-                     "alt_frac": {"hbm": round(frac_hbm, 4), "mfma_f32": round(frac_mfma, 4)}})
+                     "alt_frac": {"hbm": round(frac_hbm, 4), "mfma_f32": round(frac_mfma, 4)},
+                     "flops_counted": "multiply-adds the launches perform (planner's walk after its rewrites: mel-dead DFT bins pruned, "
+                                      "mirror-symmetric DFT bases folded to half their taps) -- not the exporter graph's nominal count"})
         out["roofline"] = roof
         # the three longest single launches, each against its own bound (the family number above averages
         # 33 launches, most of them latency-bound 6x32 / 3x16 feature maps at batch 32)

@@ -560,6 +560,75 @@ class Builder {
         }
     }
 
+    // ------------------------------------------------------------- folded framing convolutions
+    // A long single-channel 1-D filter bank whose rows are symmetric (w[n] == w[L-n], windowed cosine bases) or
+    // antisymmetric (w[n] == -w[L-n], windowed sine bases) about the frame centre, with w[0] == 0 (Hann-type
+    // windows), needs only half the multiplications:
+    //     sum_n w[n] x[n] = sum_{n=1}^{L/2-1} w[n] (x[n] +- x[L-n]) + w[L/2] x[L/2]
+    // The GEMM stages the folded frame rows (kernels.h, GemmDesc::fold) and K drops from L to L/2.  Rows count as
+    // (anti)symmetric when the two halves agree within BN_CONVFOLD_TOL x max|w| (default 2^-23: one unit in the
+    // last place of the largest tap -- f32-rounded DFT bases differ from their mirror image by that much in
+    // ~1 % of the taps); the first-half taps are the ones kept.  Maximal runs of equal symmetry become one launch
+    // each (cos block, sin block), writing column slices of the same output.  BN_CONVFOLD=0 disables.
+    bool fold_framing_conv(const OnnxNode &n, const PlanOp &base, const std::vector<float> &wf, int64_t Cout, int64_t L, int64_t OW,
+                           bool has_bias) {
+        const char *env = getenv("BN_CONVFOLD");
+        if (env && std::string(env) == "0") return false;
+        if (L < 128 || L % 64 != 0) return false;  // K = L/2 must be a whole number of 32-wide K steps
+        const double tol = getenv("BN_CONVFOLD_TOL") ? atof(getenv("BN_CONVFOLD_TOL")) : 1.1920929e-7;
+        float maxabs = 0.0f;
+        for (float v : wf) maxabs = std::max(maxabs, std::fabs(v));
+        if (!(maxabs > 0.0f) || !std::isfinite(maxabs)) return false;
+        const float eps = (float)(tol * maxabs);
+        std::vector<int> cls((size_t)Cout);
+        for (int64_t o = 0; o < Cout; o++) {
+            const float *w = &wf[(size_t)(o * L)];
+            if (!(std::fabs(w[0]) <= eps)) return false;
+            bool sym = true, anti = std::fabs(w[L / 2]) <= eps;
+            for (int64_t k = 1; k < L / 2 && (sym || anti); k++) {
+                if (!(std::fabs(w[k] - w[L - k]) <= eps)) sym = false;
+                if (!(std::fabs(w[k] + w[L - k]) <= eps)) anti = false;
+            }
+            if (!sym && !anti) return false;
+            cls[(size_t)o] = (sym && anti) ? 0 : (sym ? 1 : -1);  // 0: an all-zero row joins either neighbour
+        }
+        struct Run { int64_t n0, n1; int sign; };
+        std::vector<Run> runs;
+        for (int64_t o = 0; o < Cout; o++) {
+            const int c = cls[(size_t)o];
+            if (!runs.empty() && (c == 0 || runs.back().sign == 0 || c == runs.back().sign)) {
+                runs.back().n1 = o + 1;
+                if (runs.back().sign == 0) runs.back().sign = c;
+            } else runs.push_back(Run{o, o + 1, c});
+        }
+        if (runs.size() > 4) return false;
+        const int64_t K = L / 2;
+        for (const Run &r : runs) {
+            const int sign = r.sign == 0 ? 1 : r.sign;
+            const int64_t nn = r.n1 - r.n0;
+            std::vector<float> wk((size_t)(nn * K));
+            for (int64_t o = 0; o < nn; o++) {
+                const float *w = &wf[(size_t)((r.n0 + o) * L)];
+                for (int64_t c = 0; c + 1 < K; c++) wk[(size_t)(o * K + c)] = w[c + 1];
+                wk[(size_t)(o * K + K - 1)] = sign > 0 ? 0.5f * w[K] : 0.0f;  // centre tap: its "pair" is itself
+            }
+            PlanOp f = base;
+            f.name = "Conv:" + n.name + (sign > 0 ? "~sym" : "~anti");
+            f.out.offset += r.n0;
+            if (has_bias) f.bias.offset += r.n0;
+            f.w = Ref{Space::CONSTS, add_const(wk), 0};
+            f.gemm.N = (int32_t)nn;
+            f.gemm.K = (int32_t)K;
+            f.gemm.fold = sign;
+            f.gemm.fold_n = (int32_t)L;
+            f.macs = (double)OW * nn * K;  // multiplications actually performed
+            f.weight_bytes = 4.0 * (wk.size() + (has_bias ? nn : 0));
+            f.bytes = base.bytes * (double)nn / (double)Cout;
+            push_op(std::move(f));
+        }
+        return true;
+    }
+
     // ------------------------------------------------------------- lowering
     void lower(const OnnxNode &n) {
         const std::string &t = n.op_type;
@@ -1649,8 +1718,12 @@ class Builder {
             for (int64_t o = 0; o < Cout; o++)
                 for (int64_t c = 0; c < Cin; c++)
                     for (int64_t k = 0; k < kw; k++) wp[(o * kw + k) * Cin + c] = wf[(o * Cin + c) * kw + k];
-            op.w = Ref{Space::CONSTS, add_const(wp), 0};
             op.a = ref_of(x);
+            if (H == 1 && Cin == 1 && !has_res && gate_storage < 0 && fold_framing_conv(n, op, wf, Cout, kw, OW, has_bias)) {
+                define(cur, out);
+                return;
+            }
+            op.w = Ref{Space::CONSTS, add_const(wp), 0};
         } else if (groups == Cin && cpg == 1 && Cout == Cin) {
             x = to_channels_last(x, n.name);
             if (has_res) {  // depthwise kernel has no residual input: undo that fusion

@@ -90,6 +90,10 @@ struct GemmDesc {
     int32_t has_bias, has_res;
     int32_t has_scale;    // A is multiplied by scale[b, k] on load (squeeze-excite gate)
     int64_t s_bs;         // batch stride of scale
+    // Folded framing rows (filters that are symmetric / antisymmetric about their centre, e.g. windowed DFT
+    // bases): fold = +1 / -1, fold_n = the filter length.  Column c < K = fold_n / 2 of the operand is then
+    // x[1 + c] + fold * x[fold_n - 1 - c] of the frame, and W holds the first-half taps 1 .. fold_n/2.
+    int32_t fold, fold_n;
 };
 
 // Direct NHWC convolution, weights [kh][kw][cin/groups][cout].

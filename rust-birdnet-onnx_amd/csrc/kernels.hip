@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 
 #include "kernels.h"
 
@@ -465,6 +466,23 @@ __device__ __forceinline__ void load_a_regs(const GemmDesc &d, const float *__re
     }
 }
 
+// Folded framing rows (GemmDesc::fold): column c of the folded operand is x[1 + c] + sign * x[fold_n - 1 - c] of
+// the frame.  One of the two pairs always starts at an odd element: both are loaded as 4-byte aligned dwordx2
+// (the hardware's unaligned mode handles it) and combined when the tile is written to LDS.
+typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
+template <int ITERS>
+__device__ __forceinline__ void load_a_fold_regs(const GemmDesc &d, const float *__restrict__ A, const int64_t (&aoff)[ITERS], int k,
+                                                 float (&fwd)[ITERS * 2], float (&rev)[ITERS * 2]) {
+#pragma unroll
+    for (int i = 0; i < ITERS; i++) {
+        const float *p = A + aoff[i];
+        const float2u f = *reinterpret_cast<const float2u *>(p + 1 + k);
+        const float2u r = *reinterpret_cast<const float2u *>(p + (d.fold_n - 2 - k));
+        fwd[i * 2] = f.x; fwd[i * 2 + 1] = f.y;
+        rev[i * 2] = r.y; rev[i * 2 + 1] = r.x;  // mirrored order
+    }
+}
+
 template <int WVEC, int ROWS_PER_PASS, int ITERS>
 __device__ __forceinline__ void load_w_regs(const GemmDesc &d, const float *__restrict__ W, int n_first, int k, float (&regs)[ITERS * WVEC]) {
     const int kc = k < d.K ? k : 0;
@@ -621,7 +639,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc &d, float *__restri
     }
 }
 
-template <int BN, int AVEC, int WVEC, bool GATED>
+template <int BN, int AVEC, int WVEC, bool GATED, bool FOLD = false>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__restrict__ C,
                                                         const float *__restrict__ A,
                                                         const float *__restrict__ W,
@@ -653,14 +671,18 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
     // PF K tiles are kept in flight in registers: a load round trip costs ~2 us on this part while
     // the MFMAs of one K step take 0.2-0.9 us, so a one-deep prefetch leaves the waves waiting
     constexpr int PF = GEMM_PF;
+    static_assert(!FOLD || (AVEC == 2 && !GATED), "folded rows are staged as float pairs, ungated");
     float ra[PF][A_IT * AVEC];
+    float rm[PF][FOLD ? A_IT * AVEC : 1];  // mirrored half of a folded row
     float rg[PF][GATED ? A_IT * AVEC : 1];
+    const float fold_sign = (float)d.fold;
     float rw[PF][W_IT * WVEC];
     const int ksteps = (d.K + GEMM_BK - 1) / GEMM_BK;
 #pragma unroll
     for (int p = 0; p < PF; p++)
         if (p < ksteps) {
-            load_a_regs<AVEC, A_IT>(d, A, aoff, p * GEMM_BK + a_col, ra[p]);
+            if constexpr (FOLD) load_a_fold_regs<A_IT>(d, A, aoff, p * GEMM_BK + a_col, ra[p], rm[p]);
+            else load_a_regs<AVEC, A_IT>(d, A, aoff, p * GEMM_BK + a_col, ra[p]);
             if constexpr (GATED) load_gate_regs<AVEC, A_IT>(d, scale, soff, p * GEMM_BK + a_col, rg[p]);
             load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, p * GEMM_BK + w_col, rw[p]);
         }
@@ -677,11 +699,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
 #pragma unroll
                     for (int i = 0; i < A_IT * AVEC; i++) ra[p][i] *= rg[p][i];
                 }
+                if constexpr (FOLD) {
+#pragma unroll
+                    for (int i = 0; i < A_IT * AVEC; i++) ra[p][i] = fmaf(fold_sign, rm[p][i], ra[p][i]);
+                }
                 store_tile_regs<AVEC, A_RPP, A_IT>(As, a_row, a_col, ra[p]);
                 store_tile_regs<WVEC, W_RPP, W_IT>(Ws, w_row, w_col, rw[p]);
                 __syncthreads();
                 if (ks + PF < ksteps) {  // refill this slot with the tile PF steps ahead
-                    load_a_regs<AVEC, A_IT>(d, A, aoff, (ks + PF) * GEMM_BK + a_col, ra[p]);
+                    if constexpr (FOLD) load_a_fold_regs<A_IT>(d, A, aoff, (ks + PF) * GEMM_BK + a_col, ra[p], rm[p]);
+                    else load_a_regs<AVEC, A_IT>(d, A, aoff, (ks + PF) * GEMM_BK + a_col, ra[p]);
                     if constexpr (GATED) load_gate_regs<AVEC, A_IT>(d, scale, soff, (ks + PF) * GEMM_BK + a_col, rg[p]);
                     load_w_regs<WVEC, W_RPP, W_IT>(d, W, n0 + w_row, (ks + PF) * GEMM_BK + w_col, rw[p]);
                 }
@@ -1950,6 +1977,16 @@ static void launch_gemm_bn(hipStream_t s, const GemmDesc &d, float *C, const flo
     const bool w4 = (d.K % 4 == 0) && aligned16(W);
     int avec = 1;
     const bool s4 = !d.has_scale || (d.s_bs % 4 == 0 && aligned16(scale));
+    if constexpr (!SPLITK) {
+        if (d.fold) {  // planner guarantees: K % 32 == 0 (no K tail), 16-byte aligned W, no gate
+            if (d.K % GEMM_BK || d.fold_n != 2 * d.K || !w4 || d.has_scale) {
+                fprintf(stderr, "birdnet_hip: folded GEMM launched with an unsupported layout\n");
+                abort();
+            }
+            hipLaunchKernelGGL((gemm_mfma_kernel<BN, 2, 4, false, true>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows);
+            return;
+        }
+    }
     if (d.K % 4 == 0 && d.lda % 4 == 0 && d.a_bs % 4 == 0 && aligned16(A) && s4) avec = 4;
     else if (d.K % 2 == 0 && d.lda % 2 == 0 && d.a_bs % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 7u) == 0) avec = 2;
 #define BN_LAUNCH2(AV, WV, G)                                                                                                  \
@@ -1989,6 +2026,19 @@ static void launch_gemm_tiled(hipStream_t s, const GemmDesc &d, float *C, const 
     // Measured on MI355X (tools/gemm_bench): 32-wide N tiles win or tie almost everywhere -- more,
     // smaller blocks hide the load latency better than wider tiles save operand re-reads.  Wider
     // tiles only pay once the grid is several thousand blocks deep (high-resolution expand convs).
+    if (d.fold) {
+        static const int fold_bn_wide = getenv("BN_FOLD_BN") ? atoi(getenv("BN_FOLD_BN")) : 0;  // experiments only
+        static const int fold_bn_narrow = getenv("BN_FOLD_BN_NARROW") ? atoi(getenv("BN_FOLD_BN_NARROW")) : fold_bn_wide;
+        const int fold_bn = d.N > 200 ? fold_bn_wide : fold_bn_narrow;
+        if (fold_bn == 128) return launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
+        if (fold_bn == 96) return launch_gemm_bn<96, false>(s, d, C, A, W, bias, res, scale, total_rows);
+        if (fold_bn == 64) return launch_gemm_bn<64, false>(s, d, C, A, W, bias, res, scale, total_rows);
+        if (fold_bn == 32) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
+        // folded rows cost two loads per staged element, so the wider tile (operand rows shared by two N tiles) wins
+        // with several contexts in flight: 64 / 64 41.35 k seg/s, 32 / 32 40.0 k, 96 / 64 41.1 k, 64 / 128 41.2 k
+        if (d.N > 32) return launch_gemm_bn<64, false>(s, d, C, A, W, bias, res, scale, total_rows);
+        return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    }
     static const int deep_bn = getenv("BN_DEEPK_BN") ? atoi(getenv("BN_DEEPK_BN")) : 0;  // experiments: N tile for K >= 1024
     if (deep_bn && d.K >= 1024) {
         if (deep_bn == 128) return launch_gemm_bn<128, false>(s, d, C, A, W, bias, res, scale, total_rows);
@@ -2034,7 +2084,7 @@ void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, con
                  const float *res, const float *scale, int64_t batch) {
     if (batch <= 0) return;
     const int64_t total_rows = batch * d.rows;
-    if (gemm_use_splitk(d)) launch_gemm_splitk(s, d, C, A, W, bias, res, scale, total_rows);
+    if (!d.fold && gemm_use_splitk(d)) launch_gemm_splitk(s, d, C, A, W, bias, res, scale, total_rows);
     else launch_gemm_tiled(s, d, C, A, W, bias, res, scale, total_rows);
 }
 

@@ -110,6 +110,60 @@ def test_conv1d_framing_as_gemm(bn, n_fft, hop, bins):
     assert_close(got, ref, f"conv1d n_fft={n_fft} hop={hop}")
 
 
+@pytest.mark.parametrize("n_fft,hop,kind,bias", [(2048, 278, "real", False), (1024, 280, "complex", True),
+                                                 (640, 320, "complex", False), (256, 37, "sin-first", True)])
+def test_conv1d_folded_dft_framing(bn, n_fft, hop, kind, bias, monkeypatch):
+    """Windowed DFT filter banks (cos rows symmetric, sin rows antisymmetric about the frame centre, w[0] == 0) run
+    as folded GEMMs with half the K; the result matches the plain convolution of the oracle and of the unfolded plan."""
+    import importlib
+    synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+    rng = np.random.default_rng(8)
+    w = synth.dft_basis(n_fft, "complex")
+    half = w.shape[0] // 2
+    if kind == "real":
+        w = w[5:half - 3]
+    elif kind == "sin-first":
+        w = np.concatenate([w[half:half + 7], w[3:12], np.zeros((2, 1, n_fft), np.float32)], axis=0)
+    w = np.ascontiguousarray(w * rng.uniform(0.5, 2.0, (w.shape[0], 1, 1)).astype(np.float32))
+    b = rng.standard_normal(w.shape[0]).astype(np.float32)
+    frames = (144000 - n_fft) // hop + 1
+
+    def build(g, x):
+        u = g.node("Unsqueeze", [x, g.const(np.array([1], dtype=np.int64))])
+        return g.node("Conv", [u, g.const(w)] + ([g.const(b)] if bias else []), kernel_shape=[n_fft], strides=[hop])
+    data = op_graph(build, [w.shape[0], frames])
+    text = bn.plan_describe(write_model(data))
+    assert "~sym" in text or "~anti" in text, text
+    assert text.count("~") == (1 if kind == "real" else 2), text
+    got, ref = run_both(bn, data, batch=2)
+    assert_close(got, ref, f"folded conv1d n_fft={n_fft} {kind}")
+    monkeypatch.setenv("BN_CONVFOLD", "0")
+    assert "~" not in bn.plan_describe(write_model(data))
+    plain, _ = run_both(bn, data, batch=2)
+    assert_close(got, plain, "folded vs unfolded plan", atol=2e-5 * float(np.abs(plain).max()), rtol=0)
+
+
+def test_conv1d_not_folded_when_not_symmetric(bn):
+    """A filter bank that is symmetric except for one tap, or whose tap 0 is not zero, keeps the full-length GEMM."""
+    import importlib
+    synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+    for breaker in ("tap", "w0"):
+        w = synth.dft_basis(512, "real")[:9].copy()
+        if breaker == "tap":
+            w[4, 0, 100] += 1e-3
+        else:
+            w[:, 0, 0] = 0.01
+        frames = (144000 - 512) // 256 + 1
+
+        def build(g, x):
+            u = g.node("Unsqueeze", [x, g.const(np.array([1], dtype=np.int64))])
+            return g.node("Conv", [u, g.const(w)], kernel_shape=[512], strides=[256])
+        data = op_graph(build, [9, frames])
+        assert "~" not in bn.plan_describe(write_model(data))
+        got, ref = run_both(bn, data, batch=2)
+        assert_close(got, ref, f"unfolded conv1d ({breaker})")
+
+
 def test_conv1d_with_padding(bn):
     rng = np.random.default_rng(7)
     w = (rng.standard_normal((9, 1, 640)) / 25.0).astype(np.float32)

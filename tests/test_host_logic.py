@@ -107,8 +107,23 @@ def test_plan_of_v24_model(bn, tmp_path):
     assert kinds.count("CONV") + sum("stem:" in l for l in lines) == 1
     assert "OUTPUT 0 output computed=1 row_elems=100" in text
     # mel filterbank zero rows pruned the DFT conv: 1025 -> <200 bins and 513 -> <400
+    # ... and the Hann-windowed cosine bases are symmetric about the frame centre: folded GEMMs with half the taps
+    gemm_n = [int(l.split("N=")[1].split()[0]) for l in lines if "~sym" in l and ((" K=1024 " in l and "lda=278" in l) or (" K=512 " in l and "lda=280" in l))]
+    assert len(gemm_n) == 2 and max(gemm_n) < 400, gemm_n
+
+
+def test_plan_without_folding(bn, tmp_path, monkeypatch):
+    monkeypatch.setenv("BN_CONVFOLD", "0")
+    p = tmp_path / "m.onnx"
+    p.write_bytes(synth.birdnet_v24(num_species=100, width=0.5, depth=0.5, head=128))
+    lines = bn.plan_describe(str(p)).splitlines()
+    assert not any("~" in l for l in lines)
     gemm_n = [int(l.split("N=")[1].split()[0]) for l in lines if " K=2048 " in l or " K=1024 " in l and "lda=28" in l]
-    assert gemm_n and max(gemm_n) < 400, gemm_n
+    assert len(gemm_n) == 2 and max(gemm_n) < 400, gemm_n
+    # a looser tolerance than the bases' rounding noise is never needed; a zero tolerance only folds exact mirror images
+    monkeypatch.delenv("BN_CONVFOLD")
+    monkeypatch.setenv("BN_CONVFOLD_TOL", "0")
+    assert not any("~" in l for l in bn.plan_describe(str(p)).splitlines())
 
 
 def test_dead_outputs_are_not_planned(bn, tmp_path):
