@@ -1554,6 +1554,34 @@ class Builder {
         op_.out = ref_of(out);
         op_.a = ref_of(v);
         op_.bytes = 4.0 * (double)(d.kept * d.red + d.kept);
+        // A whole-segment min / max (144 000 samples -> one number) as ONE block per sample leaves the chip idle
+        // (32 blocks at batch 32, 26 us).  Min and max do not depend on the order of evaluation, so the range is cut
+        // into c chunks reduced by c blocks per sample and a second tiny launch reduces the c partials: bit-identical
+        // result, ~4x less time.  Sums keep their single fixed-order pass.  BN_REDUCE_SPLIT=0 disables.
+        if ((op == RED_MAX || op == RED_MIN) && d.nk == 0 && d.nr == 1 && d.rin[0] == 1 && d.red >= 32768 &&
+            !(getenv("BN_REDUCE_SPLIT") && std::string(getenv("BN_REDUCE_SPLIT")) == "0")) {
+            int64_t c = 0;
+            for (int64_t q = 64; q >= 4 && !c; q--)
+                if (d.red % q == 0 && (d.red / q) % 4 == 0 && d.red / q >= 8192) c = q;
+            if (c) {
+                Val part = new_act(Dims{c}, Dims{1});
+                PlanOp s1 = op_, s2 = op_;
+                s1.name += "/chunks";
+                s1.out = ref_of(part);
+                s1.red.nk = 1; s1.red.ksize[0] = c; s1.red.kin[0] = d.red / c; s1.red.kout[0] = 1; s1.red.kept = c;
+                s1.red.rsize[0] = d.red / c; s1.red.red = d.red / c;
+                s1.red.bo = plan_.storages[part.storage].elems;
+                s1.bytes = 4.0 * (double)(d.red + c);
+                s2.a = ref_of(part);
+                s2.red.rsize[0] = c; s2.red.red = c;
+                s2.red.bi = plan_.storages[part.storage].elems;
+                s2.bytes = 4.0 * (double)(c + 1);
+                push_op(std::move(s1));
+                push_op(std::move(s2));
+                define(n.outputs[0], out);
+                return;
+            }
+        }
         push_op(std::move(op_));
         define(n.outputs[0], out);
     }

@@ -1964,7 +1964,9 @@ void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *
         hipLaunchKernelGGL(reduce_inner_kept_kernel, grid, dim3(64, 16), 0, s, d, out, in);
     } else {
         dim3 grid((unsigned)d.kept, (unsigned)batch);
-        const int vec4 = d.nr == 1 && d.rin[0] == 1 && d.bi % 4 == 0 && aligned16(in) && d.nk == 0;
+        bool kept_aligned = true;
+        for (int k = 0; k < d.nk; k++) kept_aligned = kept_aligned && d.kin[k] % 4 == 0;
+        const int vec4 = d.nr == 1 && d.rin[0] == 1 && d.bi % 4 == 0 && aligned16(in) && kept_aligned;
         hipLaunchKernelGGL(reduce_row_kernel, grid, dim3(d.red >= 8192 ? 1024 : 256), 0, s, d, out, in, vec4);
     }
 }

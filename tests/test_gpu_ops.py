@@ -164,6 +164,37 @@ def test_conv1d_not_folded_when_not_symmetric(bn):
         assert_close(got, ref, f"unfolded conv1d ({breaker})")
 
 
+@pytest.mark.parametrize("length", [144000, 65536, 40000])
+def test_whole_segment_min_max_bit_exact(bn, length, monkeypatch):
+    """Min / max over a whole segment: long ranges are cut into chunks reduced by several blocks per sample plus a
+    tiny second launch -- same bits as numpy (min / max do not depend on evaluation order) and as the one-pass plan."""
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        if length != 144000:
+            x = g.node("Slice", [x, i64(0), i64(length), i64(1), i64(1)])
+        mn = g.node("ReduceMin", [x], axes=[1], keepdims=1)
+        mx = g.node("ReduceMax", [g.node("Sub", [x, mn])], axes=[1], keepdims=1)
+        return g.node("Concat", [mn, mx], axis=1)
+    data = op_graph(build, [2])
+    text = bn.plan_describe(write_model(data))
+    assert ("/chunks" in text) == (length >= 65536), text
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((5, 144000)).astype(np.float32)
+    x[1, 143999] = -9.0
+    x[2, 0] = 11.0
+    x[3, length - 1] = 7.5
+    path = write_model(data)
+    got, _ = bn.Context(bn.Model(path), 8).infer(x)
+    xs = x[:, :length]
+    mn = xs.min(axis=1, keepdims=True)
+    want = np.concatenate([mn, (xs - mn).max(axis=1, keepdims=True)], axis=1)
+    assert np.array_equal(got.reshape(5, 2).view(np.uint32), want.view(np.uint32))
+    monkeypatch.setenv("BN_REDUCE_SPLIT", "0")
+    assert "/chunks" not in bn.plan_describe(path)
+    one_pass, _ = bn.Context(bn.Model(path), 8).infer(x)
+    assert np.array_equal(one_pass.view(np.uint32), got.view(np.uint32))
+
+
 def test_conv1d_with_padding(bn):
     rng = np.random.default_rng(7)
     w = (rng.standard_normal((9, 1, 640)) / 25.0).astype(np.float32)
