@@ -1044,6 +1044,11 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
             if (op.kind == OpKind::GEMM) {
                 snprintf(line, sizeof(line), " rows=%lld K=%d N=%d lda=%lld act=%d bias=%d res=%d gate=%d", (long long)op.gemm.rows, op.gemm.K, op.gemm.N, (long long)op.gemm.lda, op.gemm.act, op.gemm.has_bias, op.gemm.has_res, op.gemm.has_scale);
                 extra = line;
+                if (op.gemm.fold) { snprintf(line, sizeof(line), " fold=%d/%d", op.gemm.fold, op.gemm.fold_n); extra += line; }
+                if (op.gemm.npost || op.gemm.out_strided) {
+                    snprintf(line, sizeof(line), " post=%d out_rs=%lld out_cs=%lld", op.gemm.npost, (long long)op.gemm.out_rs, (long long)op.gemm.out_cs);
+                    extra += line;
+                }
             } else if (op.kind == OpKind::DWCONV) {
                 snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%d act=%d tiled=%d squeeze=%d nblk=%d", op.dw.H, op.dw.W, op.dw.C, op.dw.OH, op.dw.OW, op.dw.kh, op.dw.kw, op.dw.sh, op.dw.act, op.dw.tiled, op.dw.has_gap, op.dw.nblk);
                 extra = line;

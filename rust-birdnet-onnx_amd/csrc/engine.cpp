@@ -2155,7 +2155,79 @@ class Builder {
                 }
             }
         }
+        absorb_chains_into_gemms();
         recompute_liveness();
+    }
+
+    // (E) An elementwise chain of unary stages (power-law compression, affine maps, layout copies) whose primary
+    // operand is the dense result of the GEMM launched just for it moves into that GEMM's epilogue: the stages run
+    // on the accumulators and the store goes through the chain's output view (kernels.h, GemmDesc::npost /
+    // out_strided).  v2.4 front end: mel MatMul -> x^2 -> x^p -> flip / transpose into the 2-channel image, per
+    // branch one launch instead of two and no dense [frames, mels] round trip.  BN_GEMMPOST=0 disables.
+    void absorb_chains_into_gemms() {
+        if (getenv("BN_GEMMPOST") && std::string(getenv("BN_GEMMPOST")) == "0") return;
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            std::vector<std::vector<int>> users(plan_.storages.size());
+            std::vector<Ref *> refs;
+            for (size_t k = 0; k < plan_.ops.size(); k++) {
+                all_refs(plan_.ops[k], refs);
+                for (Ref *r : refs)
+                    if (r->space == Space::ARENA && (users[r->id].empty() || users[r->id].back() != (int)k)) users[r->id].push_back((int)k);
+            }
+            for (size_t j = 0; j < plan_.ops.size() && !changed; j++) {
+                PlanOp &cons = plan_.ops[j];
+                if (cons.kind != OpKind::ELT || cons.a.space != Space::ARENA || cons.out.space != Space::ARENA) continue;
+                const auto &u = users[cons.a.id];
+                if (u.size() != 2 || u[1] != (int)j || plan_.storages[cons.a.id].pinned) continue;
+                PlanOp &prod = plan_.ops[u[0]];
+                if (prod.kind != OpKind::GEMM || prod.out.space != Space::ARENA || prod.out.id != cons.a.id) continue;
+                GemmDesc g = prod.gemm;
+                const EltDesc &ce = cons.elt;
+                if (g.npost || g.out_strided || !gemm_accepts_post(g) || g.ldc != g.N || g.c_bs != g.rows * g.N || ce.ba != g.c_bs) continue;
+                bool unary = true;
+                int npost = 0;
+                for (int k = 0; k < ce.nstages; k++) {
+                    unary = unary && ce.st[k].bin == BIN_NONE;
+                    if (ce.st[k].act != ACT_NONE) npost++;
+                }
+                if (!unary || npost > 4 || ce.per_sample != g.rows * g.N) continue;
+                // the chain's index space must be (a signed permutation of) rows x N
+                int64_t rs = 0, cs = 0, base = cons.out.offset, want_delta = 0;
+                bool ok = true, have_row = g.rows == 1, have_col = g.N == 1;
+                for (int k = 0; k < ce.nd && ok; k++) {
+                    if (ce.size[k] == 1) continue;
+                    const int64_t sa = ce.sa[k], mag = sa < 0 ? -sa : sa;
+                    int64_t *dst = nullptr;
+                    if (!have_col && !have_row && sa == 1 && ce.size[k] == g.rows * g.N) {  // flat map over the dense result
+                        rs = g.N * ce.so[k]; cs = ce.so[k]; have_row = have_col = true;
+                        continue;
+                    }
+                    if (!have_col && mag == 1 && ce.size[k] == g.N) { dst = &cs; have_col = true; }
+                    else if (!have_row && mag == g.N && ce.size[k] == g.rows) { dst = &rs; have_row = true; }
+                    else { ok = false; break; }
+                    if (sa > 0) *dst = ce.so[k];
+                    else { *dst = -ce.so[k]; base += (ce.size[k] - 1) * ce.so[k]; want_delta += (ce.size[k] - 1) * mag; }
+                }
+                if (!ok || !have_row || !have_col || cons.a.offset - prod.out.offset != want_delta) continue;
+                g.out_strided = 1;
+                g.out_rs = rs; g.out_cs = cs;
+                g.c_bs = ce.bo;
+                g.npost = 0;
+                for (int k = 0; k < ce.nstages; k++)
+                    if (ce.st[k].act != ACT_NONE) {
+                        g.post_act[g.npost] = ce.st[k].act; g.post_p0[g.npost] = ce.st[k].p0; g.post_p1[g.npost] = ce.st[k].p1;
+                        g.npost++;
+                    }
+                prod.gemm = g;
+                prod.out = Ref{cons.out.space, cons.out.id, base};
+                prod.name += "+" + cons.name;
+                prod.bytes += cons.bytes - 8.0 * (double)ce.per_sample;  // the dense intermediate never touches memory
+                plan_.ops.erase(plan_.ops.begin() + j);
+                changed = true;
+            }
+        }
     }
 
     // --------------------------------------------------------- memory plan

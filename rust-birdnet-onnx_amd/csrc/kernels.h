@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace bn {
 
@@ -94,6 +95,11 @@ struct GemmDesc {
     // bases): fold = +1 / -1, fold_n = the filter length.  Column c < K = fold_n / 2 of the operand is then
     // x[1 + c] + fold * x[fold_n - 1 - c] of the frame, and W holds the first-half taps 1 .. fold_n/2.
     int32_t fold, fold_n;
+    // Absorbed elementwise chain (planner rule E): unary stages applied after act, and the consumer's output view.
+    int32_t npost, out_strided;
+    int32_t post_act[4];
+    float post_p0[4], post_p1[4];
+    int64_t out_rs, out_cs;  // element (m, n) of sample b is stored at C + b*c_bs + m*out_rs + n*out_cs
 };
 
 // Direct NHWC convolution, weights [kh][kw][cin/groups][cout].
@@ -181,6 +187,20 @@ void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, 
 void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a,
                     const float *const (&b)[ELT_MAX_STAGES], int64_t batch);
 void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *in, int64_t batch);
+// Which of the two GEMM kernels runs is decided from per-sample quantities only, so that the
+// summation order of every output element -- and with it the result bits -- does not depend on
+// how many segments share a batch (a shard's last, shorter batch matches the single-GPU run).
+// (host logic shared by the launcher and the planner)
+inline bool gemm_use_splitk(const GemmDesc &d) {
+    static const int min_k = getenv("BN_SPLITK_MINK") ? atoi(getenv("BN_SPLITK_MINK")) : 256;
+    static const int max_rows = getenv("BN_SPLITK_MAXROWS") ? atoi(getenv("BN_SPLITK_MAXROWS")) : 256;
+    // deep K, few output tiles per sample (measured: pays below ~8 tiles of 128x32 per sample);
+    // the split-K kernel has no K-tail step
+    const double tiles = (double)d.rows / 128 * ((d.N + 31) / 32);
+    return !d.fold && d.K >= min_k && d.rows <= max_rows && d.K % 32 == 0 && tiles < 8.0;
+}
+// true when the launch would run a kernel variant that supports npost / out_strided
+inline bool gemm_accepts_post(const GemmDesc &d) { return !d.fold && !d.has_scale && !d.has_res && !gemm_use_splitk(d); }
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W,
                  const float *bias, const float *res, const float *scale, int64_t batch);
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w,

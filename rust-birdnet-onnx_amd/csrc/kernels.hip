@@ -394,6 +394,7 @@ __global__ __launch_bounds__(1024) void reduce_row_kernel(ReduceDesc d, float *_
 #define GEMM_BK_VALUE 32
 #endif
 constexpr int GEMM_BM = 128, GEMM_BK = GEMM_BK_VALUE, GEMM_LD = GEMM_BK + 4;
+static_assert(GEMM_BM == 128 && GEMM_BK == 32, "gemm_use_splitk (kernels.h) restates the tile sizes");
 #ifndef GEMM_PF
 #define GEMM_PF 1
 #endif
@@ -587,12 +588,42 @@ __device__ __forceinline__ void act_tile(int act, float p0, float p1, floatx16 (
     else if (act == ACT_TANH) map_tile<NT>(acc, [](float x) { return tanhf(x); });
 }
 
+// every unary stage code (the elementwise kernels' set) over an accumulator tile: absorbed elementwise chains
+template <int NT>
+__device__ __forceinline__ void act_tile_all(int act, float p0, float p1, floatx16 (&acc)[NT]) {
+    switch (act) {
+        case ACT_EXP: map_tile<NT>(acc, [](float x) { return net_exp(x); }); return;
+        case ACT_LOG: map_tile<NT>(acc, [](float x) { return net_log(x); }); return;
+        case ACT_SQRT: map_tile<NT>(acc, [](float x) { return sqrtf(x); }); return;
+        case ACT_ABS: map_tile<NT>(acc, [](float x) { return fabsf(x); }); return;
+        case ACT_NEG: map_tile<NT>(acc, [](float x) { return -x; }); return;
+        case ACT_RECIP: map_tile<NT>(acc, [](float x) { return 1.0f / x; }); return;
+        case ACT_POW: map_tile<NT>(acc, [=](float x) { return net_pow(x, p0); }); return;
+        case ACT_AFFINE: map_tile<NT>(acc, [=](float x) { return p0 * x + p1; }); return;
+        case ACT_MAXC: map_tile<NT>(acc, [=](float x) { return fmaxf(x, p0); }); return;
+        case ACT_MINC: map_tile<NT>(acc, [=](float x) { return fminf(x, p0); }); return;
+        case ACT_RSUB: map_tile<NT>(acc, [=](float x) { return p0 - x; }); return;
+        case ACT_RDIV: map_tile<NT>(acc, [=](float x) { return p0 / x; }); return;
+        case ACT_SQUARE: map_tile<NT>(acc, [](float x) { return x * x; }); return;
+        case ACT_FLOOR: map_tile<NT>(acc, [](float x) { return floorf(x); }); return;
+        case ACT_CEIL: map_tile<NT>(acc, [](float x) { return ceilf(x); }); return;
+        case ACT_ERF: map_tile<NT>(acc, [](float x) { return erff(x); }); return;
+        case ACT_SOFTPLUS: map_tile<NT>(acc, [](float x) { return log1pf(expf(x)); }); return;
+        default: act_tile<NT>(act, p0, p1, acc); return;
+    }
+}
+
 // Shared epilogue: bias, activation, residual, store.  Lane (lr, lh) of a wave holds, in
 // acc[t][reg], C[rbase + (reg&3) + 8*(reg>>2) + 4*lh][n0 + 32*t + lr].  Output (and residual) rows
 // of one launch are contiguous across samples (ldc == N-stride of a dense [rows*batch, ldc]
 // array) whenever c_bs == rows*ldc, which the planner guarantees for its own allocations; then no
 // per-row division is needed.
-template <int NT>
+//
+// POST (GemmDesc::npost / out_strided): an elementwise chain of unary stages that followed the GEMM in the plan is
+// applied to the accumulators, and the result is stored through that chain's output view (element (m, n) of sample
+// b at C + b*c_bs + m*out_rs + n*out_cs: transposed / flipped / channel-interleaved targets such as the
+// spectrogram image), so the dense GEMM result and the separate strided copy never touch memory.
+template <int NT, bool POST = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmDesc &d, float *__restrict__ C, const float *__restrict__ bias,
                                               const float *__restrict__ res, floatx16 (&acc)[NT], int64_t rbase, int64_t total_rows,
                                               int n0, int lr, int lh, int reg_lo, int reg_hi) {
@@ -609,6 +640,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc &d, float *__restri
             for (int r = 0; r < 16; r++) acc[t][r] += bv[t];
     }
     act_tile<NT>(d.act, d.p0, d.p1, acc);
+    if constexpr (POST) {
+        for (int sidx = 0; sidx < d.npost; sidx++) act_tile_all<NT>(d.post_act[sidx], d.post_p0[sidx], d.post_p1[sidx], acc);
+        if (d.out_strided) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int64_t r = rbase + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (reg >= reg_lo && reg < reg_hi && r < total_rows) {
+                    int64_t b, m;
+                    row_split(d, r, b, m);
+                    float *crow = C + b * d.c_bs + m * d.out_rs;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        const int n = n0 + t * 32 + lr;
+                        if (n < d.N) crow[(int64_t)n * d.out_cs] = acc[t][reg];
+                    }
+                }
+            }
+            return;
+        }
+    }
     const bool flat_c = d.c_bs == d.rows * d.ldc;
     const bool flat_r = !d.has_res || d.r_bs == d.rows * d.ldr;
 #pragma unroll
@@ -639,7 +690,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc &d, float *__restri
     }
 }
 
-template <int BN, int AVEC, int WVEC, bool GATED, bool FOLD = false>
+template <int BN, int AVEC, int WVEC, bool GATED, bool FOLD = false, bool POST = false>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__restrict__ C,
                                                         const float *__restrict__ A,
                                                         const float *__restrict__ W,
@@ -737,7 +788,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
         mfma_ktile_partial<NT>(ap, wp, acc, (d.K - kfull * GEMM_BK + 7) / 8);
     }
     if (!wave_active) return;
-    gemm_epilogue<NT>(d, C, bias, res, acc, row0 + wave * 32, total_rows, n0, lr, lh, 0, 16);
+    gemm_epilogue<NT, POST>(d, C, bias, res, acc, row0 + wave * 32, total_rows, n0, lr, lh, 0, 16);
 }
 
 // ------------------------------------------------------------------ small-M GEMM: intra-block split-K
@@ -1991,6 +2042,26 @@ static void launch_gemm_bn(hipStream_t s, const GemmDesc &d, float *C, const flo
     }
     if (d.K % 4 == 0 && d.lda % 4 == 0 && d.a_bs % 4 == 0 && aligned16(A) && s4) avec = 4;
     else if (d.K % 2 == 0 && d.lda % 2 == 0 && d.a_bs % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 7u) == 0) avec = 2;
+    if constexpr (!SPLITK && BN == 32) {
+        if (d.npost || d.out_strided) {  // absorbed elementwise chain: ungated 32-wide tiles only (gemm_accepts_post)
+            if (d.has_scale || d.has_res || d.fold) {
+                fprintf(stderr, "birdnet_hip: GEMM post stages launched with an unsupported layout\n");
+                abort();
+            }
+#define BN_LAUNCH_POST(AV, WV) hipLaunchKernelGGL((gemm_mfma_kernel<32, AV, WV, false, false, true>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows)
+            if (w4) {
+                if (avec == 4) BN_LAUNCH_POST(4, 4);
+                else if (avec == 2) BN_LAUNCH_POST(2, 4);
+                else BN_LAUNCH_POST(1, 4);
+            } else {
+                if (avec == 4) BN_LAUNCH_POST(4, 1);
+                else if (avec == 2) BN_LAUNCH_POST(2, 1);
+                else BN_LAUNCH_POST(1, 1);
+            }
+#undef BN_LAUNCH_POST
+            return;
+        }
+    }
 #define BN_LAUNCH2(AV, WV, G)                                                                                                  \
     do {                                                                                                                       \
         if constexpr (SPLITK) hipLaunchKernelGGL((gemm_splitk_kernel<BN, AV, WV, G>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows); \
@@ -2056,18 +2127,6 @@ static void launch_gemm_tiled(hipStream_t s, const GemmDesc &d, float *C, const 
     else launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
 }
 
-// Which of the two GEMM kernels runs is decided from per-sample quantities only, so that the
-// summation order of every output element -- and with it the result bits -- does not depend on
-// how many segments share a batch (a shard's last, shorter batch matches the single-GPU run).
-static bool gemm_use_splitk(const GemmDesc &d) {
-    static const int min_k = getenv("BN_SPLITK_MINK") ? atoi(getenv("BN_SPLITK_MINK")) : 256;
-    static const int max_rows = getenv("BN_SPLITK_MAXROWS") ? atoi(getenv("BN_SPLITK_MAXROWS")) : 256;
-    // deep K, few output tiles per sample (measured: pays below ~8 tiles of 128x32 per sample);
-    // the split-K kernel has no K-tail step
-    const double tiles = (double)d.rows / GEMM_BM * ((d.N + 31) / 32);
-    return d.K >= min_k && d.rows <= max_rows && d.K % GEMM_BK == 0 && tiles < 8.0;
-}
-
 static void launch_gemm_splitk(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
                                const float *res, const float *scale, int64_t total_rows) {
     {
@@ -2086,7 +2145,8 @@ void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, con
                  const float *res, const float *scale, int64_t batch) {
     if (batch <= 0) return;
     const int64_t total_rows = batch * d.rows;
-    if (!d.fold && gemm_use_splitk(d)) launch_gemm_splitk(s, d, C, A, W, bias, res, scale, total_rows);
+    if (d.npost || d.out_strided) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    if (gemm_use_splitk(d)) launch_gemm_splitk(s, d, C, A, W, bias, res, scale, total_rows);
     else launch_gemm_tiled(s, d, C, A, W, bias, res, scale, total_rows);
 }
 

@@ -195,6 +195,49 @@ def test_whole_segment_min_max_bit_exact(bn, length, monkeypatch):
     assert np.array_equal(one_pass.view(np.uint32), got.view(np.uint32))
 
 
+@pytest.mark.parametrize("variant", ["pow-flip-transpose", "affine-transpose", "exp-dense", "interleave"])
+def test_matmul_with_absorbed_elementwise_chain(bn, variant, monkeypatch):
+    """A chain of unary stages after a MatMul (and the layout copy behind it) runs in the GEMM epilogue: stages on
+    the accumulators, store through the chain's output view.  Checked against the oracle and the unfused plan."""
+    rng = np.random.default_rng(12)
+    rows, k, n = 300, 77, 96
+    w = (rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float32)
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(rows * k), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, rows, k)])
+        y = g.node("MatMul", [x, g.const(w)])                                   # [B, rows, n]
+        if variant == "pow-flip-transpose":
+            y = g.node("Pow", [g.node("Pow", [y, g.const(np.float32(2.0))]), g.const(np.float32(0.3))])
+            y = g.node("Slice", [y, i64(-1), i64(-(2 ** 62)), i64(2), i64(-1)])  # reverse the n axis
+            return g.node("Transpose", [y], perm=[0, 2, 1])                      # [B, n, rows]
+        if variant == "affine-transpose":
+            y = g.node("Add", [g.node("Mul", [y, g.const(np.float32(1.5))]), g.const(np.float32(-0.25))])
+            return g.node("Transpose", [g.node("Relu", [y])], perm=[0, 2, 1])
+        if variant == "exp-dense":
+            return g.node("Exp", [g.node("Mul", [y, g.const(np.float32(0.5))])])
+        # two MatMul branches written into alternating channels of one image (the v2.4 spectrogram layout)
+        y2 = g.node("Abs", [g.node("MatMul", [x, g.const(np.ascontiguousarray(w[:, ::-1]))])])
+        a = g.node("Unsqueeze", [g.node("Transpose", [g.node("Sqrt", [g.node("Abs", [y])])], perm=[0, 2, 1]), i64(1)])
+        b = g.node("Unsqueeze", [g.node("Transpose", [y2], perm=[0, 2, 1]), i64(1)])
+        img = g.node("Concat", [a, b], axis=1)                                   # [B, 2, n, rows]
+        wc = (rng.standard_normal((4, 2, 3, 3)) / 4).astype(np.float32)
+        return g.node("Conv", [img, g.const(wc)], kernel_shape=[3, 3], pads=[1, 1, 1, 1])
+    shape = {"pow-flip-transpose": [n, rows], "affine-transpose": [n, rows], "exp-dense": [rows, n], "interleave": [4, n, rows]}[variant]
+    data = op_graph(build, shape)
+    text = bn.plan_describe(write_model(data))
+    assert text.count(" post=") == (2 if variant == "interleave" else 1), text
+    # nothing elementwise is left but the NHWC -> NCHW copy of the convolution result in the last variant
+    assert sum(l.split()[1] == "ELT" for l in text.splitlines() if l[:3].strip().isdigit()) == (1 if variant == "interleave" else 0), text
+    got, ref = run_both(bn, data, batch=3)
+    assert_close(got, ref, f"absorbed chain {variant}")
+    monkeypatch.setenv("BN_GEMMPOST", "0")
+    assert " post=" not in bn.plan_describe(write_model(data))
+    plain, _ = run_both(bn, data, batch=3)
+    assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)), "same arithmetic either way"
+
+
 def test_conv1d_with_padding(bn):
     rng = np.random.default_rng(7)
     w = (rng.standard_normal((9, 1, 640)) / 25.0).astype(np.float32)
