@@ -965,15 +965,44 @@ class Builder {
         if (to_conv && od.size() == 3) ostr = Dims{1, od[2] * od[0], od[0]};
         else if (to_conv && od.size() == 2) ostr = Dims{1, od[0]};
         Val out = new_act(od, ostr);
+        // Concat of single-channel planes along the channel axis followed by BatchNormalization (the v2.4 spectrogram
+        // image): every plane sees ONE scale and shift, so the normalisation rides on the copy of each plane (and, with
+        // rule E, ends up in the epilogue of the GEMM that produced it) instead of one more pass over the image.
+        std::vector<float> plane_s, plane_t;
+        std::string result = n.outputs[0];
+        if (axis == 0 && od[0] == (int64_t)ins.size()) {
+            int c = sole_consumer(n.outputs[0]);
+            if (c >= 0 && nodes_[c].op_type == "BatchNormalization" && nodes_[c].inputs.size() >= 5 && nodes_[c].inputs[0] == n.outputs[0]) {
+                const OnnxNode &bn_ = nodes_[c];
+                const Val &sc = get(bn_, 1), &bi = get(bn_, 2), &mu = get(bn_, 3), &var = get(bn_, 4);
+                if (sc.is_const && bi.is_const && mu.is_const && var.is_const && sc.numel() == od[0] && bi.numel() == od[0] &&
+                    mu.numel() == od[0] && var.numel() == od[0] && bn_.outputs.size() == 1) {
+                    const float eps = bn_.attr_f("epsilon", 1e-5f);
+                    for (int64_t k = 0; k < od[0]; k++) {
+                        const float sk = sc.f[k] / std::sqrt(var.f[k] + eps);
+                        plane_s.push_back(sk);
+                        plane_t.push_back(bi.f[k] - mu.f[k] * sk);
+                    }
+                    absorbed_[c] = true;
+                    result = bn_.outputs[0];
+                }
+            }
+        }
         int64_t pos = 0;
         for (auto &v : ins) {
             Val slot = out;
             slot.dims = v.dims;
             slot.offset = out.offset + pos * out.strides[axis];
-            emit_elt("concat:" + n.name, slot, ref_of(v), v.strides, batch_stride(v), Ref{}, {}, 0, BIN_NONE, ActSpec{});
+            ActSpec plane_act;
+            std::string what = "concat:" + n.name;
+            if (!plane_s.empty()) {
+                plane_act.act = ACT_AFFINE; plane_act.p0 = plane_s[(size_t)pos]; plane_act.p1 = plane_t[(size_t)pos];
+                what += "+bn";
+            }
+            emit_elt(what, slot, ref_of(v), v.strides, batch_stride(v), Ref{}, {}, 0, BIN_NONE, plane_act);
             pos += v.dims[axis];
         }
-        define(n.outputs[0], out);
+        define(result, out);
     }
 
     // Padded copy of an activation (per-sample dims): the whole result is filled with `value`, then

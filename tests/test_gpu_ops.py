@@ -222,6 +222,9 @@ def test_matmul_with_absorbed_elementwise_chain(bn, variant, monkeypatch):
         a = g.node("Unsqueeze", [g.node("Transpose", [g.node("Sqrt", [g.node("Abs", [y])])], perm=[0, 2, 1]), i64(1)])
         b = g.node("Unsqueeze", [g.node("Transpose", [y2], perm=[0, 2, 1]), i64(1)])
         img = g.node("Concat", [a, b], axis=1)                                   # [B, 2, n, rows]
+        # per-plane normalisation: rides on each plane's copy, i.e. ends up in the two GEMM epilogues as well
+        img = g.node("BatchNormalization", [img, g.const(np.array([0.7, 1.3], np.float32)), g.const(np.array([0.1, -0.2], np.float32)),
+                                            g.const(np.array([0.3, 0.5], np.float32)), g.const(np.array([1.5, 0.8], np.float32))], epsilon=1e-3)
         wc = (rng.standard_normal((4, 2, 3, 3)) / 4).astype(np.float32)
         return g.node("Conv", [img, g.const(wc)], kernel_shape=[3, 3], pads=[1, 1, 1, 1])
     shape = {"pow-flip-transpose": [n, rows], "affine-transpose": [n, rows], "exp-dense": [rows, n], "interleave": [4, n, rows]}[variant]
