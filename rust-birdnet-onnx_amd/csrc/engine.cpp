@@ -1513,6 +1513,35 @@ class Builder {
         const std::string &t = n.op_type;
         if (v.is_const) unsupported(n, "reduction of a constant");
         if (try_squeeze_excite(n, v)) return;
+        // max(x - s) == max(x) - s exactly when s is one number per reduced range (rounding is monotone), same for min:
+        // the reduction reads x itself and the shifted signal is no longer needed for it -- in the min-max normalisation
+        // of the v2.4 front end the Sub then has a single consumer left and fuses into the scaling chain (one pass less).
+        if ((t == "ReduceMax" || t == "ReduceMin") && !(getenv("BN_REDUCE_SHIFT") && std::string(getenv("BN_REDUCE_SHIFT")) == "0")) {
+            int prod = -1;
+            for (size_t k = 0; k < nodes_.size() && prod < 0; k++)
+                if (live_[k] && !absorbed_[k] && nodes_[k].op_type == "Sub" && nodes_[k].outputs.size() == 1 && nodes_[k].outputs[0] == n.inputs[0]) prod = (int)k;
+            if (prod >= 0 && nodes_[prod].inputs.size() == 2 && n.attr_i("keepdims", 1) != 0) {
+                const OnnxNode &sub = nodes_[prod];
+                auto xi = vals_.find(sub.inputs[0]), si = vals_.find(sub.inputs[1]);
+                if (xi != vals_.end() && si != vals_.end() && !xi->second.is_const && xi->second.dims == v.dims && live_consumers(n.inputs[0]).size() > 1) {
+                    // s must be constant along every reduced axis: here, one element per sample
+                    if (si->second.numel() == 1) {
+                        OnnxNode r2 = n;
+                        r2.name = n.name + "/unshifted";
+                        r2.inputs[0] = sub.inputs[0];
+                        r2.outputs = {n.outputs[0] + "/unshifted"};
+                        lower_reduce(r2);
+                        OnnxNode s2;
+                        s2.op_type = "Sub";
+                        s2.name = n.name + "/shift";
+                        s2.inputs = {r2.outputs[0], sub.inputs[1]};
+                        s2.outputs = {n.outputs[0]};
+                        lower_binary(s2);
+                        return;
+                    }
+                }
+            }
+        }
         int op;
         std::vector<int64_t> axes;
         bool keep = n.attr_i("keepdims", 1) != 0;
@@ -2090,7 +2119,7 @@ class Builder {
                 const EltDesc &pe = prod.elt, &ce = cons.elt;
                 if (pe.bo != ce.ba) continue;
                 bool same = pe.nd == ce.nd && delta == 0;
-                for (int k = 0; same && k < pe.nd; k++) same = pe.size[k] == ce.size[k] && pe.so[k] == ce.sa[k];
+                for (int k = 0; same && k < pe.nd; k++) same = pe.size[k] == ce.size[k] && (pe.size[k] == 1 || pe.so[k] == ce.sa[k]);
                 bool flat_prod = pe.nd == 1 && pe.so[0] == 1 && pe.sa[0] == 1 && pe.per_sample == ce.per_sample;
                 for (int k = 0; flat_prod && k < pe.nstages; k++)
                     flat_prod = pe.st[k].bin == BIN_NONE || pe.st[k].sb[0] == 0 || pe.st[k].sb[0] == 1;

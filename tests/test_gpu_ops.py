@@ -241,6 +241,26 @@ def test_matmul_with_absorbed_elementwise_chain(bn, variant, monkeypatch):
     assert np.array_equal(got.view(np.uint32), plain.view(np.uint32)), "same arithmetic either way"
 
 
+def test_minmax_normalisation_reads_the_signal_once_less(bn, monkeypatch):
+    """max(x - min) is taken as max(x) - min (exact: rounding is monotone), so x - min has one consumer left and
+    fuses into the scaling chain; same bits as the plan without the rewrite."""
+    def build(g, x):
+        mn = g.node("ReduceMin", [x], axes=[1], keepdims=1)
+        x1 = g.node("Sub", [x, mn])
+        mx = g.node("ReduceMax", [x1], axes=[1], keepdims=1)
+        return g.node("Div", [x1, g.node("Add", [mx, g.const(np.float32(1e-6))])])
+    data = op_graph(build, [144000])
+    path = write_model(data)
+    text = bn.plan_describe(path)
+    assert "/unshifted" in text and sum(l.split()[1] == "ELT" and "n=144000" in l for l in text.splitlines() if l[:3].strip().isdigit()) == 1, text
+    got, ref = run_both(bn, data, batch=3, scale=0.3)
+    assert_close(got, ref, "min-max normalisation", atol=1e-6, rtol=1e-6)
+    monkeypatch.setenv("BN_REDUCE_SHIFT", "0")
+    assert "/unshifted" not in bn.plan_describe(path)
+    plain, _ = run_both(bn, data, batch=3, scale=0.3)
+    assert np.array_equal(got.view(np.uint32), plain.view(np.uint32))
+
+
 def test_conv1d_with_padding(bn):
     rng = np.random.default_rng(7)
     w = (rng.standard_normal((9, 1, 640)) / 25.0).astype(np.float32)
