@@ -791,6 +791,119 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmDesc d, float *__res
     gemm_epilogue<NT, POST>(d, C, bias, res, acc, row0 + wave * 32, total_rows, n0, lr, lh, 0, 16);
 }
 
+// ------------------------------------------------------------------ folded framing GEMM, signal resident in LDS
+// The folded framing GEMM above re-reads every frame row from L2 once per K step and N tile: 530 MB of L2 -> L1
+// traffic per launch at batch 32 (6.8 TB/s; matrix pipe 40 % busy, PMC).  Frames overlap (hop 278 of 2048 taps), so
+// the 64 frames of a block span only 63*hop + L samples (<= 80 KB): this kernel loads that span into LDS ONCE and
+// builds each folded 64 x 32 operand tile from it (LDS -> LDS, double buffered), while the filter tile streams
+// through registers as before.  2*WN waves: wave w owns rows 32*(w&1).. and columns 32*(w>>1)..; one barrier per K
+// step.  Same K order, fragment layout and fold expression as gemm_mfma_kernel<.., FOLD>: bit-identical results.
+struct FrameDesc {
+    int32_t rows, N, K, L, hop;   // per-sample frames, outputs, folded taps (L/2), filter length, frame hop
+    int32_t tiles;                // 64-row tiles per sample
+    int32_t span;                 // floats of signal one block keeps: 63*hop + L
+    int32_t vec4;                 // span loads as float4 (16-byte aligned sample rows)
+    int64_t a_bs, ldc, c_bs;
+    float sign;
+    int32_t has_bias;
+};
+constexpr int FRAME_BM = 64;
+__global__ __launch_bounds__(640) void frame_fold_kernel(FrameDesc d, float *__restrict__ C, const float *__restrict__ A,
+                                                         const float *__restrict__ W, const float *__restrict__ bias) {
+    extern __shared__ __align__(16) float frame_lds[];
+    const int T = blockDim.x, tid = threadIdx.x;
+    const int BN = (T >> 7) * 32;  // WN wave columns of 32 outputs
+    float *sig = frame_lds;
+    float *As = sig + ((d.span + 3) & ~3);
+    float *Ws = As + 2 * FRAME_BM * GEMM_LD;
+    const int b = blockIdx.x / d.tiles, rt = blockIdx.x - b * d.tiles;
+    const int row0 = rt * FRAME_BM;
+    const int rows_here = min(FRAME_BM, d.rows - row0);
+    const int n0 = blockIdx.y * BN;
+    const float *src = A + (int64_t)b * d.a_bs + (int64_t)row0 * d.hop;
+    const int count = (rows_here - 1) * d.hop + d.L;
+    if (d.vec4) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(sig);
+        const int n4 = count >> 2;
+        for (int i = tid; i < n4; i += T) d4[i] = s4[i];
+        for (int i = (n4 << 2) + tid; i < count; i += T) sig[i] = src[i];
+    } else {
+        for (int i = tid; i < count; i += T) sig[i] = src[i];
+    }
+    // filter tile staging: BN rows x 32 taps = BN * 8 float4, up to 2 per thread (BN <= 160, T = 4 * BN)
+    const int wq = tid & 7, wr = tid >> 3;  // float4 column, row of this thread's first filter vector
+    const int wrows_per_pass = T >> 3;      // = BN / 2
+    auto w_ptr = [&](int pass, int k0) {
+        int n = n0 + wr + pass * wrows_per_pass;
+        n = n < d.N ? n : d.N - 1;
+        return reinterpret_cast<const float4 *>(W + (int64_t)n * d.K + k0 + 4 * wq);
+    };
+    float4 rw0 = *w_ptr(0, 0), rw1 = *w_ptr(1, 0);
+    const int ksteps = d.K / GEMM_BK;
+    // operand staging: a thread owns up to 4 (row, column pair) slots of the 64 x 32 tile, fixed over the K loop, so the
+    // row offsets are resolved once; per K step it reads the forward and mirrored pairs and writes one float2
+    // (measured: pairs beat the conflict-free one-element-per-lane mapping, 49 vs 54 us -- instruction count, not banks)
+    constexpr int SLOTS = 4;
+    int fwd_off[SLOTS], rev_off[SLOTS], dst_off[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; i++) {
+        const int p = tid + i * T;
+        const int r = (p >> 4) & (FRAME_BM - 1), cp = (p & 15) * 2;
+        const int re = r < rows_here ? r : rows_here - 1;
+        fwd_off[i] = re * d.hop + 1 + cp;
+        rev_off[i] = re * d.hop + d.L - 2 - cp;
+        dst_off[i] = p < FRAME_BM * 16 ? r * GEMM_LD + cp : -1;
+    }
+    auto stage_a = [&](int ks, float *dst) {
+        const int k0 = ks * GEMM_BK;
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) {
+            if (dst_off[i] >= 0) {
+                const float *f = sig + fwd_off[i] + k0, *m = sig + rev_off[i] - k0;
+                *reinterpret_cast<float2 *>(dst + dst_off[i]) = make_float2(fmaf(d.sign, m[1], f[0]), fmaf(d.sign, m[0], f[1]));
+            }
+        }
+    };
+    auto store_w = [&](float *dst) {
+        *reinterpret_cast<float4 *>(dst + wr * GEMM_LD + 4 * wq) = rw0;
+        *reinterpret_cast<float4 *>(dst + (wr + wrows_per_pass) * GEMM_LD + 4 * wq) = rw1;
+    };
+    __syncthreads();  // signal span complete
+    stage_a(0, As);
+    store_w(Ws);
+    if (ksteps > 1) { rw0 = *w_ptr(0, GEMM_BK); rw1 = *w_ptr(1, GEMM_BK); }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    floatx16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[0][r] = 0.0f;
+    for (int ks = 0; ks < ksteps; ks++) {
+        const int cur = ks & 1;
+        float *An = As + (cur ^ 1) * FRAME_BM * GEMM_LD, *Wn = Ws + (cur ^ 1) * BN * GEMM_LD;
+        if (ks + 1 < ksteps) {
+            stage_a(ks + 1, An);
+            store_w(Wn);
+            if (ks + 2 < ksteps) { rw0 = *w_ptr(0, (ks + 2) * GEMM_BK); rw1 = *w_ptr(1, (ks + 2) * GEMM_BK); }
+        }
+        const float *ap = As + cur * FRAME_BM * GEMM_LD + (wm * 32 + lr) * GEMM_LD + 4 * lh;
+        const float *wp = Ws + cur * BN * GEMM_LD + (wn * 32 + lr) * GEMM_LD + 4 * lh;
+        mfma_ktile_full<1>(ap, wp, acc);
+        __syncthreads();
+    }
+    const int n = n0 + wn * 32 + lr;
+    if (n >= d.N) return;
+    const float bv = d.has_bias ? bias[n] : 0.0f;
+    float *cb = C + (int64_t)b * d.c_bs + (int64_t)row0 * d.ldc + n;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        if (r < rows_here) cb[(int64_t)r * d.ldc] = acc[0][reg] + bv;
+    }
+}
+
 // ------------------------------------------------------------------ small-M GEMM: intra-block split-K
 // When the output has few 128-row tiles (late CNN stages, FC head) the kernel above leaves most
 // CUs idle.  Here a block owns one 32 x BN tile and its 4 waves split K between them (k-steps
@@ -2141,11 +2254,44 @@ static void launch_gemm_splitk(hipStream_t s, const GemmDesc &d, float *C, const
     }
 }
 
+// Folded framing GEMM from an LDS-resident signal span; false when the shape does not fit (the caller then runs the
+// generic folded GEMM).  Decided from per-sample quantities and pointer alignment only.  BN_FRAMELDS=0 disables.
+static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, int64_t batch) {
+    if (getenv("BN_FRAMELDS") && atoi(getenv("BN_FRAMELDS")) == 0) return false;
+    if (d.has_res || d.has_scale || d.act != ACT_NONE || d.K % GEMM_BK || d.fold_n != 2 * d.K || d.K % 4 || !aligned16(W)) return false;
+    if (d.lda <= 0 || d.lda > 4096 || d.rows < 32 || d.c_bs < 0) return false;
+    FrameDesc f{};
+    f.rows = (int32_t)d.rows; f.N = d.N; f.K = d.K; f.L = d.fold_n; f.hop = (int32_t)d.lda;
+    f.tiles = (int32_t)((d.rows + FRAME_BM - 1) / FRAME_BM);
+    f.span = (FRAME_BM - 1) * f.hop + f.L;
+    f.vec4 = d.a_bs % 4 == 0 && (FRAME_BM * (int64_t)f.hop) % 4 == 0 && aligned16(A);
+    f.a_bs = d.a_bs; f.ldc = d.ldc; f.c_bs = d.c_bs;
+    f.sign = (float)d.fold; f.has_bias = d.has_bias;
+    // wave columns: the N tile (32 * WN) with the least padding among 128 and 160 (fewer, wider tiles on a tie)
+    static const int force_wn = getenv("BN_FRAME_WN") ? atoi(getenv("BN_FRAME_WN")) : 0;  // experiments only
+    auto padded = [&](int bn) { return (d.N + bn - 1) / bn * bn; };
+    int wn = padded(160) <= padded(128) ? 5 : 4;
+    if (d.N <= 96) wn = (d.N + 31) / 32 < 2 ? 2 : (d.N + 31) / 32;
+    if (force_wn >= 2 && force_wn <= 5) wn = force_wn;
+    const int bn = 32 * wn;
+    const size_t lds = (size_t)(((f.span + 3) & ~3) + 2 * FRAME_BM * GEMM_LD + 2 * bn * GEMM_LD) * sizeof(float);
+    if (lds > 160 * 1024) return false;
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(frame_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        configured = lds;
+    }
+    dim3 grid((unsigned)(f.tiles * batch), (unsigned)((d.N + bn - 1) / bn));
+    hipLaunchKernelGGL(frame_fold_kernel, grid, dim3(128 * wn), lds, s, f, C, A, W, bias);
+    return true;
+}
+
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
                  const float *res, const float *scale, int64_t batch) {
     if (batch <= 0) return;
     const int64_t total_rows = batch * d.rows;
     if (d.npost || d.out_strided) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
+    if (d.fold && launch_frame_fold(s, d, C, A, W, bias, batch)) return;
     if (gemm_use_splitk(d)) launch_gemm_splitk(s, d, C, A, W, bias, res, scale, total_rows);
     else launch_gemm_tiled(s, d, C, A, W, bias, res, scale, total_rows);
 }

@@ -137,6 +137,11 @@ def test_conv1d_folded_dft_framing(bn, n_fft, hop, kind, bias, monkeypatch):
     assert text.count("~") == (1 if kind == "real" else 2), text
     got, ref = run_both(bn, data, batch=2)
     assert_close(got, ref, f"folded conv1d n_fft={n_fft} {kind}")
+    # the LDS-resident-signal kernel and the generic folded GEMM use the same K order and fold expression
+    monkeypatch.setenv("BN_FRAMELDS", "0")
+    generic, _ = run_both(bn, data, batch=2)
+    assert np.array_equal(got.view(np.uint32), generic.view(np.uint32))
+    monkeypatch.delenv("BN_FRAMELDS")
     monkeypatch.setenv("BN_CONVFOLD", "0")
     assert "~" not in bn.plan_describe(write_model(data))
     plain, _ = run_both(bn, data, batch=2)
