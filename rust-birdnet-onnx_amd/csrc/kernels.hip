@@ -819,7 +819,6 @@ __global__ __launch_bounds__(640) void frame_fold_kernel(FrameDesc d, float *__r
     const int b = blockIdx.x / d.tiles, rt = blockIdx.x - b * d.tiles;
     const int row0 = rt * FRAME_BM;
     const int rows_here = min(FRAME_BM, d.rows - row0);
-    const int n0 = blockIdx.y * BN;
     const float *src = A + (int64_t)b * d.a_bs + (int64_t)row0 * d.hop;
     const int count = (rows_here - 1) * d.hop + d.L;
     if (d.vec4) {
@@ -834,12 +833,13 @@ __global__ __launch_bounds__(640) void frame_fold_kernel(FrameDesc d, float *__r
     // filter tile staging: BN rows x 32 taps = BN * 8 float4, up to 2 per thread (BN <= 160, T = 4 * BN)
     const int wq = tid & 7, wr = tid >> 3;  // float4 column, row of this thread's first filter vector
     const int wrows_per_pass = T >> 3;      // = BN / 2
+    int n0 = 0;
     auto w_ptr = [&](int pass, int k0) {
         int n = n0 + wr + pass * wrows_per_pass;
         n = n < d.N ? n : d.N - 1;
         return reinterpret_cast<const float4 *>(W + (int64_t)n * d.K + k0 + 4 * wq);
     };
-    float4 rw0 = *w_ptr(0, 0), rw1 = *w_ptr(1, 0);
+    float4 rw0, rw1;
     const int ksteps = d.K / GEMM_BK;
     // operand staging: a thread owns up to 4 (row, column pair) slots of the 64 x 32 tile, fixed over the K loop, so the
     // row offsets are resolved once; per K step it reads the forward and mirrored pairs and writes one float2
@@ -869,14 +869,17 @@ __global__ __launch_bounds__(640) void frame_fold_kernel(FrameDesc d, float *__r
         *reinterpret_cast<float4 *>(dst + wr * GEMM_LD + 4 * wq) = rw0;
         *reinterpret_cast<float4 *>(dst + (wr + wrows_per_pass) * GEMM_LD + 4 * wq) = rw1;
     };
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
     __syncthreads();  // signal span complete
+    // N tiles of this row tile: with grid.y == 1 one block walks all of them and the span is loaded once
+    for (int ny = blockIdx.y; ny * BN < d.N; ny += gridDim.y) {
+    n0 = ny * BN;
+    rw0 = *w_ptr(0, 0); rw1 = *w_ptr(1, 0);
     stage_a(0, As);
     store_w(Ws);
     if (ksteps > 1) { rw0 = *w_ptr(0, GEMM_BK); rw1 = *w_ptr(1, GEMM_BK); }
     __syncthreads();
-
-    const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;
     floatx16 acc[1];
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[0][r] = 0.0f;
@@ -894,13 +897,16 @@ __global__ __launch_bounds__(640) void frame_fold_kernel(FrameDesc d, float *__r
         __syncthreads();
     }
     const int n = n0 + wn * 32 + lr;
-    if (n >= d.N) return;
-    const float bv = d.has_bias ? bias[n] : 0.0f;
-    float *cb = C + (int64_t)b * d.c_bs + (int64_t)row0 * d.ldc + n;
+    if (n < d.N) {
+        const float bv = d.has_bias ? bias[n] : 0.0f;
+        float *cb = C + (int64_t)b * d.c_bs + (int64_t)row0 * d.ldc + n;
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-        const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        if (r < rows_here) cb[(int64_t)r * d.ldc] = acc[0][reg] + bv;
+        for (int reg = 0; reg < 16; reg++) {
+            const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (r < rows_here) cb[(int64_t)r * d.ldc] = acc[0][reg] + bv;
+        }
+    }
+    // (the last K step ended with a barrier: every wave is done with both tile buffers)
     }
 }
 
@@ -2281,7 +2287,11 @@ static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const 
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(frame_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         configured = lds;
     }
-    dim3 grid((unsigned)(f.tiles * batch), (unsigned)((d.N + bn - 1) / bn));
+    // enough row tiles to fill the chip: one block walks all N tiles of its rows (span loaded once); else spread them
+    const int64_t row_blocks = (int64_t)f.tiles * batch;
+    const int walk_env = getenv("BN_FRAME_WALK") ? atoi(getenv("BN_FRAME_WALK")) : -1;  // tests / experiments
+    const bool walk = walk_env >= 0 ? walk_env != 0 : row_blocks >= 256;
+    dim3 grid((unsigned)row_blocks, walk ? 1u : (unsigned)((d.N + bn - 1) / bn));
     hipLaunchKernelGGL(frame_fold_kernel, grid, dim3(128 * wn), lds, s, f, C, A, W, bias);
     return true;
 }

@@ -142,6 +142,13 @@ def test_conv1d_folded_dft_framing(bn, n_fft, hop, kind, bias, monkeypatch):
     generic, _ = run_both(bn, data, batch=2)
     assert np.array_equal(got.view(np.uint32), generic.view(np.uint32))
     monkeypatch.delenv("BN_FRAMELDS")
+    # ... and so do its two launch shapes (one block per N tile at small batches, one block walking all N tiles of its
+    # rows once the row tiles alone fill the chip)
+    for walk in ("0", "1"):
+        monkeypatch.setenv("BN_FRAME_WALK", walk)
+        shaped, _ = run_both(bn, data, batch=2)
+        assert np.array_equal(got.view(np.uint32), shaped.view(np.uint32)), walk
+    monkeypatch.delenv("BN_FRAME_WALK")
     monkeypatch.setenv("BN_CONVFOLD", "0")
     assert "~" not in bn.plan_describe(write_model(data))
     plain, _ = run_both(bn, data, batch=2)
