@@ -115,7 +115,7 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
             launch_eltwise(c->stream, op.elt, out, a, eb, batch);
             break;
         }
-        case OpKind::REDUCE: launch_reduce(c->stream, op.red, out, a, batch); break;
+        case OpKind::REDUCE: launch_reduce(c->stream, op.red, out, a, batch, op.red.pair ? resolve(c, op.b, d_in) : nullptr); break;
         case OpKind::GEMM:
             launch_gemm(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in),
                         resolve(c, op.scale, d_in), batch);

@@ -2224,7 +2224,44 @@ class Builder {
             }
         }
         absorb_chains_into_gemms();
+        pair_minmax_reductions();
         recompute_liveness();
+    }
+
+    // (F) The chunk stages of a whole-range min and a whole-range max over the SAME input (the min-max normalisation
+    // after the max(x - s) rewrite) read it in one pass: the later launch is folded into the earlier one (kernels.h,
+    // ReduceDesc::pair).  Exact, order-independent operations: same bits.  BN_REDUCE_PAIR=0 disables.
+    void pair_minmax_reductions() {
+        if (getenv("BN_REDUCE_PAIR") && std::string(getenv("BN_REDUCE_PAIR")) == "0") return;
+        for (size_t i = 0; i < plan_.ops.size(); i++) {
+            PlanOp &a = plan_.ops[i];
+            if (a.kind != OpKind::REDUCE || a.red.pair || a.red.op != RED_MIN) continue;
+            for (size_t j = i + 1; j < plan_.ops.size() && j < i + 4; j++) {
+                PlanOp &b = plan_.ops[j];
+                if (b.kind != OpKind::REDUCE || b.red.pair || b.red.op != RED_MAX) continue;
+                const ReduceDesc &x = a.red, &y = b.red;
+                const bool same_in = a.a.space == b.a.space && a.a.id == b.a.id && a.a.offset == b.a.offset;
+                const bool chunks = x.nk == 1 && x.nr == 1 && x.rin[0] == 1 && x.kout[0] == 1 && x.red % 4 == 0 && x.kin[0] % 4 == 0 && x.bi % 4 == 0 &&
+                                    a.a.offset % 4 == 0 && x.inner_kept == 0;
+                const bool same_shape = y.nk == 1 && y.nr == 1 && y.rin[0] == 1 && y.kout[0] == 1 && x.ksize[0] == y.ksize[0] && x.kin[0] == y.kin[0] &&
+                                        x.red == y.red && x.bi == y.bi && x.kept == y.kept;
+                if (!same_in || !chunks || !same_shape) continue;
+                // nothing in between may write the shared input or read the max partials (they are only read later)
+                bool clash = false;
+                for (size_t k = i + 1; k < j; k++) {
+                    const PlanOp &m = plan_.ops[k];
+                    clash = clash || (m.out.space == a.a.space && m.out.id == a.a.id) || (m.a.space == b.out.space && m.a.id == b.out.id);
+                }
+                if (clash) continue;
+                a.red.pair = 1;
+                a.red.bo2 = y.bo;
+                a.b = b.out;
+                a.name += "+" + b.name;
+                a.bytes += 4.0 * (double)y.kept;
+                plan_.ops.erase(plan_.ops.begin() + (long)j);
+                break;
+            }
+        }
     }
 
     // (E) An elementwise chain of unary stages (power-law compression, affine maps, layout copies) whose primary

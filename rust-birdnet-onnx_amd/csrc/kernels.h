@@ -77,6 +77,10 @@ struct ReduceDesc {
     int64_t kept, red;  // products
     int32_t op;
     int32_t inner_kept;  // 1: some kept dim has input stride 1 (threads map to kept index)
+    // pair = 1: a min reduction and a max reduction over the same contiguous chunks run as ONE pass over the input
+    // (op is RED_MIN and lands in out, the max lands in out2 with batch stride bo2); planner rule, chunk stage only
+    int32_t pair;
+    int64_t bo2;
 };
 
 // C[r, n] = act(sum_k A[r, k] * W[n, k] + bias[n]) (+ res[r, n]) where row
@@ -186,7 +190,7 @@ void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, 
 
 void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a,
                     const float *const (&b)[ELT_MAX_STAGES], int64_t batch);
-void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *in, int64_t batch);
+void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *in, int64_t batch, float *out2 = nullptr);
 // Which of the two GEMM kernels runs is decided from per-sample quantities only, so that the
 // summation order of every output element -- and with it the result bits -- does not depend on
 // how many segments share a batch (a shard's last, shorter batch matches the single-GPU run).

@@ -2127,8 +2127,46 @@ void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a,
     }
 }
 
-void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *in, int64_t batch) {
+// min and max of contiguous chunks in one pass (ReduceDesc::pair): grid (chunks, batch), 1024 threads, float4 loads.
+// Both are exact and independent of evaluation order, so the bits equal those of the two separate launches.
+__global__ __launch_bounds__(1024) void minmax_chunks_kernel(ReduceDesc d, float *__restrict__ out_min, float *__restrict__ out_max,
+                                                             const float *__restrict__ in) {
+    __shared__ float pmin[16], pmax[16];
+    const int64_t b = blockIdx.y;
+    const float4 *p4 = reinterpret_cast<const float4 *>(in + b * d.bi + (int64_t)blockIdx.x * d.kin[0]);
+    const uint32_t n4 = (uint32_t)(d.red >> 2);
+    float lo0 = INFINITY, lo1 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY;
+    uint32_t r = threadIdx.x;
+    for (; r + 1024 < n4; r += 2048) {
+        const float4 u = p4[r], v = p4[r + 1024];
+        lo0 = fminf(fminf(lo0, fminf(u.x, u.y)), fminf(u.z, u.w)); hi0 = fmaxf(fmaxf(hi0, fmaxf(u.x, u.y)), fmaxf(u.z, u.w));
+        lo1 = fminf(fminf(lo1, fminf(v.x, v.y)), fminf(v.z, v.w)); hi1 = fmaxf(fmaxf(hi1, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    if (r < n4) {
+        const float4 u = p4[r];
+        lo0 = fminf(fminf(lo0, fminf(u.x, u.y)), fminf(u.z, u.w)); hi0 = fmaxf(fmaxf(hi0, fmaxf(u.x, u.y)), fmaxf(u.z, u.w));
+    }
+    float lo = fminf(lo0, lo1), hi = fmaxf(hi0, hi1);
+    for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_down(lo, off)); hi = fmaxf(hi, __shfl_down(hi, off)); }
+    if ((threadIdx.x & 63) == 0) { pmin[threadIdx.x >> 6] = lo; pmax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) { lo = fminf(lo, pmin[w]); hi = fmaxf(hi, pmax[w]); }
+        out_min[b * d.bo + blockIdx.x] = lo;
+        out_max[b * d.bo2 + blockIdx.x] = hi;
+    }
+}
+
+void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *in, int64_t batch, float *out2) {
     if (batch <= 0) return;
+    if (d.pair) {  // planner guarantees: one kept dim of contiguous chunks, chunk length % 4 == 0, 16-byte aligned rows
+        if (!out2 || d.nk != 1 || d.nr != 1 || d.rin[0] != 1 || d.red % 4 || d.kin[0] % 4 || d.bi % 4 || !aligned16(in) || d.kout[0] != 1) {
+            fprintf(stderr, "birdnet_hip: paired min/max reduction launched with an unsupported layout\n");
+            abort();
+        }
+        hipLaunchKernelGGL(minmax_chunks_kernel, dim3((unsigned)d.kept, (unsigned)batch), dim3(1024), 0, s, d, out, out2, in);
+        return;
+    }
     if (d.inner_kept) {
         dim3 grid((unsigned)((d.kept + 63) / 64), (unsigned)batch);
         hipLaunchKernelGGL(reduce_inner_kept_kernel, grid, dim3(64, 16), 0, s, d, out, in);

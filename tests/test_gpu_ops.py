@@ -267,6 +267,13 @@ def test_minmax_normalisation_reads_the_signal_once_less(bn, monkeypatch):
     assert "/unshifted" in text and sum(l.split()[1] == "ELT" and "n=144000" in l for l in text.splitlines() if l[:3].strip().isdigit()) == 1, text
     got, ref = run_both(bn, data, batch=3, scale=0.3)
     assert_close(got, ref, "min-max normalisation", atol=1e-6, rtol=1e-6)
+    # the chunk stages of the min and of the (now unshifted) max read the segment in ONE paired launch
+    assert "/chunks+ReduceMax" in text, text
+    monkeypatch.setenv("BN_REDUCE_PAIR", "0")
+    assert "/chunks+ReduceMax" not in bn.plan_describe(path)
+    unpaired, _ = run_both(bn, data, batch=3, scale=0.3)
+    assert np.array_equal(got.view(np.uint32), unpaired.view(np.uint32))
+    monkeypatch.delenv("BN_REDUCE_PAIR")
     monkeypatch.setenv("BN_REDUCE_SHIFT", "0")
     assert "/unshifted" not in bn.plan_describe(path)
     plain, _ = run_both(bn, data, batch=3, scale=0.3)
