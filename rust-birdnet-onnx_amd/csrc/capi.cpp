@@ -82,9 +82,13 @@ struct bn_ctx {
     float *d_tk_conf = nullptr;
     size_t tk_cap = 0;  // elements of idx/conf
     // pinned mirrors for bn_step_device
-    uint32_t *h_tk_idx = nullptr, *h_tk_cnt = nullptr;
+    // bn_step_device: top-K rows of a step live packed [idx: batch*k][conf: batch*k][count: batch] in one device block
+    // and one pinned host block, so they cross the bus as ONE copy (each async copy is a ~7 us blit launch)
+    uint32_t *d_step = nullptr, *h_step = nullptr;
+    size_t step_cap = 0;  // words
+    uint32_t *h_tk_idx = nullptr, *h_tk_cnt = nullptr;  // views into h_step for the last step
     float *h_tk_conf = nullptr;
-    size_t h_tk_cap = 0, step_k = 0;
+    size_t step_k = 0;
     struct GraphKey {
         size_t batch;
         const float *in;
@@ -435,9 +439,8 @@ void bn_ctx_destroy(bn_ctx *c) {
     if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
     if (c->d_tk_cnt) (void)hipFree(c->d_tk_cnt);
     if (c->d_tk_flags) (void)hipFree(c->d_tk_flags);
-    if (c->h_tk_idx) (void)hipHostFree(c->h_tk_idx);
-    if (c->h_tk_conf) (void)hipHostFree(c->h_tk_conf);
-    if (c->h_tk_cnt) (void)hipHostFree(c->h_tk_cnt);
+    if (c->d_step) (void)hipFree(c->d_step);
+    if (c->h_step) (void)hipHostFree(c->h_step);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -701,27 +704,34 @@ bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch, size_t top
     if (st != BN_OK) return st;
     st = ensure_topk_buffers(c, k);
     if (st != BN_OK) return st;
-    if (c->max_batch * k > c->h_tk_cap) {
-        if (c->h_tk_idx) (void)hipHostFree(c->h_tk_idx);
-        if (c->h_tk_conf) (void)hipHostFree(c->h_tk_conf);
-        c->h_tk_idx = nullptr;
-        c->h_tk_conf = nullptr;
-        HIP_TRY(hipHostMalloc(&c->h_tk_idx, c->max_batch * k * sizeof(uint32_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(&c->h_tk_conf, c->max_batch * k * sizeof(float), hipHostMallocDefault));
-        c->h_tk_cap = c->max_batch * k;
+    {
+        const size_t need = c->max_batch * (2 * k + 1);
+        if (need > c->step_cap) {
+            if (c->d_step) (void)hipFree(c->d_step);
+            if (c->h_step) (void)hipHostFree(c->h_step);
+            c->d_step = c->h_step = nullptr;
+            c->h_tk_idx = c->h_tk_cnt = nullptr;
+            c->h_tk_conf = nullptr;
+            c->step_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_step, need * sizeof(uint32_t)));
+            HIP_TRY(hipHostMalloc(&c->h_step, need * sizeof(uint32_t), hipHostMallocDefault));
+            c->step_cap = need;
+        }
     }
-    if (!c->h_tk_cnt) HIP_TRY(hipHostMalloc(&c->h_tk_cnt, c->max_batch * sizeof(uint32_t), hipHostMallocDefault));
     st = enqueue_plan(c, d_pcm, batch, nullptr);
     if (st != BN_OK) return st;
     c->last_batch = batch;
     const float *d_logits = resolve(c, lo.ref, d_pcm);
     (void)hipGetLastError();
-    launch_topk(c->stream, d_logits, (int64_t)batch, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, c->d_tk_idx, c->d_tk_conf, c->d_tk_cnt, c->d_tk_flags);
+    uint32_t *d_idx = c->d_step, *d_cnt = c->d_step + 2 * batch * k;
+    float *d_conf = reinterpret_cast<float *>(c->d_step + batch * k);
+    launch_topk(c->stream, d_logits, (int64_t)batch, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, d_idx, d_conf, d_cnt, c->d_tk_flags);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_out, d_logits, batch * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_tk_idx, c->d_tk_idx, batch * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_tk_conf, c->d_tk_conf, batch * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_tk_cnt, c->d_tk_cnt, batch * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_step, c->d_step, batch * (2 * k + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    c->h_tk_idx = c->h_step;
+    c->h_tk_conf = reinterpret_cast<float *>(c->h_step + batch * k);
+    c->h_tk_cnt = c->h_step + 2 * batch * k;
     c->step_k = k;
     if (sync) HIP_TRY(hipStreamSynchronize(c->stream));
     return BN_OK;
