@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile set, run ON THE GPU BOX from the repo root:   bash tools/profile_round.sh <tag>
-# Produces under gpurun_out/<tag>/: bench JSON lines (default = 3 contexts, and 1 context), the
+# Produces under gpurun_out/<tag>/: bench JSON lines (default = 4 contexts, and 1 context), the
 # rocprofv3 --kernel-trace --stats CSVs of the same two commands, and the FETCH_SIZE / WRITE_SIZE
 # PMC passes (separate passes, no trace domains combined with --pmc) of one batch-32 plan.
 set -o pipefail
