@@ -105,6 +105,9 @@ bn_status bn_model_load(const char *onnx_path, int32_t device, int32_t model_typ
                         bn_model **out);
 bn_status bn_model_load_buffer(const void *onnx_bytes, size_t len, int32_t device,
                                int32_t model_type_override, bn_model **out);
+/* Drops the caller's reference.  Contexts created from the model keep it alive: the order of
+ * bn_model_free and bn_ctx_destroy does not matter (the reference's BatchInferenceContext is an owned
+ * value, src/batch_context.rs:70-85). */
 void bn_model_free(bn_model *m);
 /* session.inputs()/outputs() metadata (classifier.rs:387-420) */
 bn_status bn_model_io_info(const bn_model *m, bn_io_info *out);
@@ -150,6 +153,8 @@ bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch_size, float
 
 /* Same computation with the batch already resident in HBM as one contiguous
  * [batch_size, sample_count] f32 array; outputs stay on the device.
+ * d_pcm must be 16-byte aligned (the kernels read it as float4); a pointer that is
+ * not is refused with BN_ERR_INVALID_ARG, nothing is launched.
  * Asynchronous on the context's stream unless `sync` is non-zero. */
 bn_status bn_infer_device(bn_ctx *c, const float *d_pcm, size_t batch_size, int32_t sync);
 /* Device pointer and row length of graph output `index` after the last run

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -54,6 +55,10 @@ bool device_is_gfx950(int dev) {
 }  // namespace
 
 struct bn_model {
+    // one reference for the handle bn_model_load returned + one per context created from it: a context may outlive
+    // the caller's bn_model_free (the reference's BatchInferenceContext is an owned value with no lifetime tie to
+    // the Classifier, src/batch_context.rs:70-85), the model goes when the last holder does
+    std::atomic<int> refs{1};
     int device = 0;
     OnnxModel onnx;  // kept for the lazily built all-outputs plan
     bn_model_config cfg{};
@@ -75,6 +80,7 @@ struct bn_ctx {
     float *h_out = nullptr;    // pinned staging for logits + embeddings
     size_t h_out_elems = 0;
     size_t device_bytes = 0;
+    bool holds_model = false;  // counted in model->refs (set once creation succeeded)
     bool in_flight = false;  // a cancelled/timed-out run may still be executing
     size_t last_batch = 0;
     // top-K scratch
@@ -154,11 +160,19 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             hipError_t le = hipSuccess;
             std::string bad;
+            (void)take_launch_error();
+            std::string refused;
             for (auto &op : p.ops) {
                 launch_op(c, op, d_in, (int64_t)batch);
                 if (le == hipSuccess && (le = hipGetLastError()) != hipSuccess) bad = op.name;
+                if (refused.empty())
+                    if (const char *why = take_launch_error()) refused = "launch of '" + op.name + "' refused: " + why;
             }
             hipError_t e = hipStreamEndCapture(c->stream, &g);
+            if (!refused.empty()) {
+                if (g) (void)hipGraphDestroy(g);
+                return fail(BN_ERR_INVALID_ARG, refused);
+            }
             if (le != hipSuccess) {
                 if (g) (void)hipGraphDestroy(g);
                 return fail(BN_ERR_BACKEND, "launch of '" + bad + "' failed during capture: " + hipGetErrorString(le));
@@ -178,9 +192,11 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
         HIP_TRY(hipGraphLaunch(it->second, c->stream));
     } else {
         (void)hipGetLastError();  // drop stale sticky errors of unrelated earlier calls
+        (void)take_launch_error();
         for (auto &op : p.ops) {
             if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
             launch_op(c, op, d_in, (int64_t)batch);
+            if (const char *why = take_launch_error()) return fail(BN_ERR_INVALID_ARG, "launch of '" + op.name + "' refused: " + why);
             hipError_t le = hipGetLastError();
             if (le != hipSuccess) return fail(BN_ERR_BACKEND, "launch of '" + op.name + "' failed: " + hipGetErrorString(le));
         }
@@ -337,7 +353,13 @@ bn_status bn_model_load_buffer(const void *bytes, size_t len, int32_t device, in
     return finish_load(std::move(m), device, model_type_override, out);
 }
 
-void bn_model_free(bn_model *m) { delete m; }
+static void model_unref(bn_model *m) {
+    if (m && m->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        (void)hipSetDevice(m->device);
+        delete m;
+    }
+}
+void bn_model_free(bn_model *m) { model_unref(m); }
 
 bn_status bn_model_io_info(const bn_model *m, bn_io_info *out) {
     if (!m || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
@@ -422,6 +444,8 @@ bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **
     }
     HIP_TRY(hipHostMalloc(&c->h_out, c->h_out_elems * sizeof(float), hipHostMallocDefault));
     c->device_bytes = arena_b + in_b;
+    m->refs.fetch_add(1, std::memory_order_relaxed);
+    c->holds_model = true;
     *out = c.release();
     return BN_OK;
 }
@@ -442,7 +466,9 @@ void bn_ctx_destroy(bn_ctx *c) {
     if (c->d_step) (void)hipFree(c->d_step);
     if (c->h_step) (void)hipHostFree(c->h_step);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    bn_model *m = c->holds_model ? c->model : nullptr;
     delete c;
+    model_unref(m);
 }
 
 size_t bn_ctx_max_batch(const bn_ctx *c) { return c ? c->max_batch : 0; }
@@ -461,6 +487,7 @@ bn_status bn_infer_device(bn_ctx *c, const float *d_pcm, size_t batch, int32_t s
     if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
     if (batch == 0) return BN_OK;
     if (!d_pcm) return fail(BN_ERR_INVALID_ARG, "null input");
+    if (reinterpret_cast<uintptr_t>(d_pcm) & 15u) return fail(BN_ERR_INVALID_ARG, "device input must be 16-byte aligned");
     if (batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(batch) + " exceeds context max " + std::to_string(c->max_batch));
     HIP_TRY(hipSetDevice(c->model->device));
     bn_status st = drain_if_needed(c);
@@ -694,6 +721,7 @@ bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch, size_t top
     if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
     if (batch == 0) return BN_OK;
     if (!d_pcm || batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "bad input / batch size exceeds context max");
+    if (reinterpret_cast<uintptr_t>(d_pcm) & 15u) return fail(BN_ERR_INVALID_ARG, "device input must be 16-byte aligned");
     const Plan &p = *c->pd->plan;
     const OutputInfo &lo = p.outputs[c->model->cfg.logits_output];
     const size_t n = (size_t)lo.row_elems;

@@ -227,6 +227,16 @@ void launch_windows(hipStream_t s, float *dst, const void *src, int32_t is_i16, 
 void launch_resample(hipStream_t s, float *dst, const void *src, int32_t is_i16, const float *table, uint64_t n_src, uint64_t n_dst, uint32_t L, uint32_t M,
                      uint32_t T);
 void launch_null(hipStream_t s);  // empty kernel (timing calibration)
+
+// A launcher that is handed a layout its kernel cannot take (a caller's device pointer without the required
+// alignment, a descriptor the planner should never have produced) launches NOTHING and records a message for the
+// calling thread instead of aborting the host process; the C ABI turns it into BN_ERR_INVALID_ARG / BN_ERR_BACKEND.
+void launch_error(const char *msg);
+// message of the first launch_error since the last call on this thread (NULL if none); clears it
+const char *take_launch_error();
+// hipFuncAttributeMaxDynamicSharedMemorySize applies to the CURRENT device's function object: the opt-in is cached
+// per (kernel, device) and is safe to call from several threads.  Returns false if the runtime refuses.
+bool ensure_dynamic_lds(const void *kernel, size_t bytes);
 size_t topk_lds_bytes(int64_t n, int64_t k);
 size_t mbconv_lds_bytes(const MbDesc &d);  // dynamic LDS of mbconv_expand_dw_kernel for this shape
 

@@ -16,10 +16,49 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <string>
+#include <utility>
 
 #include "kernels.h"
 
 namespace bn {
+
+namespace {
+thread_local std::string g_launch_error;
+thread_local bool g_launch_failed = false;
+thread_local std::string g_launch_error_out;
+}  // namespace
+void launch_error(const char *msg) {
+    if (!g_launch_failed) {
+        g_launch_failed = true;
+        g_launch_error = msg;
+    }
+}
+const char *take_launch_error() {
+    if (!g_launch_failed) return nullptr;
+    g_launch_failed = false;
+    g_launch_error_out = g_launch_error;
+    return g_launch_error_out.c_str();
+}
+bool ensure_dynamic_lds(const void *kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return true;  // within the default limit
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &have = done[{kernel, dev}];
+    if (bytes <= have) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    have = bytes;
+    return true;
+}
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -2161,8 +2200,8 @@ void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *
     if (batch <= 0) return;
     if (d.pair) {  // planner guarantees: one kept dim of contiguous chunks, chunk length % 4 == 0, 16-byte aligned rows
         if (!out2 || d.nk != 1 || d.nr != 1 || d.rin[0] != 1 || d.red % 4 || d.kin[0] % 4 || d.bi % 4 || !aligned16(in) || d.kout[0] != 1) {
-            fprintf(stderr, "birdnet_hip: paired min/max reduction launched with an unsupported layout\n");
-            abort();
+            launch_error("paired min/max reduction: the input rows must be 16-byte aligned contiguous chunks (device input pointers must be 16-byte aligned)");
+            return;
         }
         hipLaunchKernelGGL(minmax_chunks_kernel, dim3((unsigned)d.kept, (unsigned)batch), dim3(1024), 0, s, d, out, out2, in);
         return;
@@ -2190,8 +2229,8 @@ static void launch_gemm_bn(hipStream_t s, const GemmDesc &d, float *C, const flo
     if constexpr (!SPLITK) {
         if (d.fold) {  // planner guarantees: K % 32 == 0 (no K tail), 16-byte aligned W, no gate
             if (d.K % GEMM_BK || d.fold_n != 2 * d.K || !w4 || d.has_scale) {
-                fprintf(stderr, "birdnet_hip: folded GEMM launched with an unsupported layout\n");
-                abort();
+                launch_error("folded GEMM launched with an unsupported layout");
+                return;
             }
             hipLaunchKernelGGL((gemm_mfma_kernel<BN, 2, 4, false, true>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows);
             return;
@@ -2202,8 +2241,8 @@ static void launch_gemm_bn(hipStream_t s, const GemmDesc &d, float *C, const flo
     if constexpr (!SPLITK && BN == 32) {
         if (d.npost || d.out_strided) {  // absorbed elementwise chain: ungated 32-wide tiles only (gemm_accepts_post)
             if (d.has_scale || d.has_res || d.fold) {
-                fprintf(stderr, "birdnet_hip: GEMM post stages launched with an unsupported layout\n");
-                abort();
+                launch_error("GEMM post stages launched with an unsupported layout");
+                return;
             }
 #define BN_LAUNCH_POST(AV, WV) hipLaunchKernelGGL((gemm_mfma_kernel<32, AV, WV, false, false, true>), grid, dim3(256), 0, s, d, C, A, W, bias, res, scale, total_rows)
             if (w4) {
@@ -2320,11 +2359,7 @@ static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const 
     const int bn = 32 * wn;
     const size_t lds = (size_t)(((f.span + 3) & ~3) + 2 * FRAME_BM * GEMM_LD + 2 * bn * GEMM_LD) * sizeof(float);
     if (lds > 160 * 1024) return false;
-    static size_t configured = 0;
-    if (lds > configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(frame_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
-        configured = lds;
-    }
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(frame_fold_kernel), lds)) return false;
     // enough row tiles to fill the chip: one block walks all N tiles of its rows (span loaded once); else spread them
     const int64_t row_blocks = (int64_t)f.tiles * batch;
     const int walk_env = getenv("BN_FRAME_WALK") ? atoi(getenv("BN_FRAME_WALK")) : -1;  // tests / experiments
@@ -2411,11 +2446,7 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
         dim3 gridm((unsigned)((d.C + 31) / 32), (unsigned)batch);
 #define MBM_LAUNCH(K, S)                                                                                                                           \
     do {                                                                                                                                         \
-        static size_t attr = 0;                                                                                                                  \
-        if (lds > attr) {                                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mbconv_map_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr = lds;                                                                                                                          \
-        }                                                                                                                                        \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(mbconv_map_kernel<K, S>), lds)) { launch_error("kernel needs more LDS than the device grants"); break; } \
         hipLaunchKernelGGL((mbconv_map_kernel<K, S>), gridm, dim3(256), lds, s, d, out, in, w1, b1, w2, b2, gap);                                \
     } while (0)
         if (d.k == 3 && d.s == 1) MBM_LAUNCH(3, 1);
@@ -2436,11 +2467,7 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
     if (pipe && d.C > 32 && plds <= 160 * 1024) {
 #define MBP_LAUNCH2(K, S, IM)                                                                                                    \
     do {                                                                                                                         \
-        static size_t attr = 0;                                                                                                  \
-        if (plds > attr) {                                                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mbconv_pipe_kernel<K, S, IM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds); \
-            attr = plds;                                                                                                         \
-        }                                                                                                                        \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(mbconv_pipe_kernel<K, S, IM>), plds)) { launch_error("kernel needs more LDS than the device grants"); break; } \
         hipLaunchKernelGGL((mbconv_pipe_kernel<K, S, IM>), grid, dim3(512), plds, s, d, out, in, w1, b1, w2, b2, gap);           \
     } while (0)
 #define MBP_LAUNCH(K, S)                       \
@@ -2458,11 +2485,7 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
     }
 #define MB_LAUNCH2(K, S, IM)                                                                                                     \
     do {                                                                                                                         \
-        static size_t attr = 0;                                                                                                  \
-        if (lds > attr) {                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mbconv_expand_dw_kernel<K, S, IM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr = lds;                                                                                                          \
-        }                                                                                                                        \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(mbconv_expand_dw_kernel<K, S, IM>), lds)) { launch_error("kernel needs more LDS than the device grants"); break; } \
         hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, IM>), grid, dim3(256), lds, s, d, out, in, w1, b1, w2, b2, gap);       \
     } while (0)
 #define MB_LAUNCH(K, S)                  \
@@ -2486,11 +2509,7 @@ void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, 
         const size_t lds = ((size_t)d.H * d.W * 32 + 256) * sizeof(float);
 #define DWM_LAUNCH(K, S)                                                                                                                           \
     do {                                                                                                                                         \
-        static size_t attr = 0;                                                                                                                  \
-        if (lds > attr) {                                                                                                                        \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(dwconv_map_kernel<K, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr = lds;                                                                                                                          \
-        }                                                                                                                                        \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(dwconv_map_kernel<K, S>), lds)) { launch_error("kernel needs more LDS than the device grants"); break; } \
         hipLaunchKernelGGL((dwconv_map_kernel<K, S>), grid, dim3(256), lds, s, d, out, in, w, bias, gap);                                        \
     } while (0)
         if (d.kw == 3 && d.sw == 1) DWM_LAUNCH(3, 1);

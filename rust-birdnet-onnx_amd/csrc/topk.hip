@@ -263,6 +263,11 @@ __global__ __launch_bounds__(64) void topk_kernel(const float *__restrict__ logi
             co[rank] = ci;
         }
     }
+    // slots past the count are defined (zero): callers that ship whole [rows, k] blocks never see stale memory
+    for (uint32_t j = m + lane; j < k; j += 64) {
+        io[j] = 0u;
+        co[j] = 0.0f;
+    }
     if (lane == 0) count_out[row] = m;
 }
 
@@ -379,9 +384,9 @@ __global__ __launch_bounds__(64) void topk_fast_kernel(const float *__restrict__
     }
     const bool keep = lane < k && (!has_min || c0 >= min_conf);  // a prefix: confidences are descending
     const uint64_t km = __ballot(keep);
-    if (keep) {
-        idx_out[row * k_stride + lane] = sidx[lane];
-        conf_out[row * k_stride + lane] = c0;
+    if (lane < k) {  // slots past the count are defined (zero)
+        idx_out[row * k_stride + lane] = keep ? sidx[lane] : 0u;
+        conf_out[row * k_stride + lane] = keep ? c0 : 0.0f;
     }
     if (lane == 0) {
         count_out[row] = (uint32_t)__popcll(km);
@@ -407,11 +412,9 @@ void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, in
         hipLaunchKernelGGL(topk_fast_kernel, dim3((unsigned)rows), dim3(64), 0, s, logits, n, (uint32_t)k, has_min, min_conf, k_stride, idx,
                            conf, count, flags);
     const size_t lds = topk_lds_bytes(n, k);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(topk_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
+    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(topk_kernel), lds)) {
+        launch_error("top-K heap needs more LDS than the device grants");
+        return;
     }
     hipLaunchKernelGGL(topk_kernel, dim3((unsigned)rows), dim3(64), lds, s, logits, n, (uint32_t)k,
                        has_min, min_conf, k_stride, idx, conf, count, (const uint32_t *)flags);

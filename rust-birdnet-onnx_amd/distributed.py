@@ -107,6 +107,19 @@ def shard_sample_range(n_samples: int, segment_samples: int, step_samples: int, 
     return lo * step_samples, min(n_samples, (hi - 1) * step_samples + segment_samples)
 
 
+def chunk_step(segment_samples: int, overlap_secs: float, sample_rate: int) -> int:
+    """Window step of the reference's chunk_audio (src/bin/birdnet-analyze.rs:718-723):
+    `overlap_samples = (overlap_secs * sample_rate as f32) as usize` -- a Rust float-to-usize cast truncates toward
+    zero and SATURATES (negative and NaN give 0) -- then `segment_samples.saturating_sub(overlap_samples)`; a step
+    of 0 means chunk_audio returns no windows."""
+    prod = np.float32(overlap_secs) * np.float32(sample_rate)
+    if not np.isfinite(prod):
+        overlap = 0 if (np.isnan(prod) or prod < 0) else (1 << 64) - 1
+    else:
+        overlap = max(0, int(prod))
+    return max(0, int(segment_samples) - overlap)
+
+
 def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: float, batch: int = 32, streams: int = 4, top_k: int = 10,
                               min_confidence: Optional[float] = None, dist=None, gather: str = "logits", ctxs=None):
     """BASELINE.json configs[4]: a long mono recording (int16 or float32), sharded by window across the
@@ -121,11 +134,14 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     cfg = model.config
     S, sr = int(cfg.sample_count), int(cfg.sample_rate)
-    step = S - int(np.float32(overlap_secs) * np.float32(sr))
-    if step <= 0:
-        raise ValueError("overlap must be shorter than the segment duration")
+    step = chunk_step(S, overlap_secs, sr)
     n = int(samples.shape[0])
-    G = (n + step - 1) // step if n > 0 else 0
+    # chunk_audio returns no windows at all when the step saturates to 0 (birdnet-analyze.rs:720-723)
+    G = (n + step - 1) // step if n > 0 and step > 0 else 0
+    if G == 0:
+        k0 = min(top_k, int(cfg.num_species))
+        empty = np.empty((0, int(cfg.num_species)), dtype=np.float32) if gather == "logits" else None
+        return empty, np.zeros((0, k0), dtype=np.uint32), np.zeros((0, k0), dtype=np.float32), np.zeros(0, dtype=np.uint32)
     lo, hi = shard_range(G, rank, world)
     a, b = shard_sample_range(n, S, step, lo, hi)
     rec = bn.Recording(np.ascontiguousarray(samples[a:b]), device=model.device)
