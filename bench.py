@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="contexts (HIP streams) in flight per GPU")
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host (bn_infer_submit / collect) measurement")
+    ap.add_argument("--host-steps", type=int, default=60, help="minimum number of steps of the host-to-host leg")
     ap.add_argument("--cpu-sample", type=int, default=96, help="segments the CPU oracle is timed on (about 15-30 s of host work)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -217,6 +219,51 @@ def main():
     total_segments = args.steps * B * world
     value = total_segments / dt
 
+    # ---- the drop-in call, host to host (never `value`): the same batches as HOST f32 slices through
+    # bn_infer_submit / bn_infer_collect -- what Classifier::predict_batch_with_context costs a caller
+    # (reference src/batch_context.rs:188-226, src/bin/birdnet-analyze.rs:637-647 times exactly this, wall clock):
+    # staging into pinned memory by the library's pool, PCIe upload, plan, top-K, logits + top-K rows back to
+    # pageable host arrays.  Same contexts, two batches in flight per context.
+    host_to_host = None
+    if rank == 0 and world == 1 and not args.no_host_leg:
+        from collections import deque
+
+        hbufs = [b_.cpu().numpy() for b_ in bufs]
+        hsteps = max(args.steps, args.host_steps)
+        outstanding = [deque() for _ in ctxs]
+        last = {}
+
+        def hstep(i):
+            q = outstanding[i % S_]
+            if len(q) == 2:
+                last[i % S_] = ctxs[i % S_].collect(q.popleft(), want_embeddings=True)
+            q.append(ctxs[i % S_].submit(hbufs[i % NBUF], args.top_k, 0.1))
+
+        def hdrain():
+            for j, q in enumerate(outstanding):
+                while q:
+                    last[j] = ctxs[j].collect(q.popleft(), want_embeddings=True)
+
+        for i in range(max(args.warmup, 2 * S_)):
+            hstep(i)
+        hdrain()
+        t1 = time.perf_counter()
+        for i in range(hsteps):
+            hstep(i)
+        hdrain()
+        hdt = time.perf_counter() - t1
+        # same bits as the device-resident step of the same batch
+        chk = (hsteps - 1) % S_
+        ctxs[chk].step_device(bufs[(hsteps - 1) % NBUF].data_ptr(), B, args.top_k, 0.1, sync=True)
+        dlg, dix, dcf, dct = ctxs[chk].step_results(B)
+        hlg, _, hix, hcf, hct = last[chk]
+        assert np.array_equal(hlg.view(np.uint32), dlg.view(np.uint32)), "host-slice logits differ from the device-resident step"
+        assert np.array_equal(hct, dct) and all(np.array_equal(hix[r, :hct[r]], dix[r, :dct[r]]) for r in range(B))
+        hv = hsteps * B / hdt
+        host_to_host = {"value": round(hv, 1), "unit": "segments/s", "ms_per_step": round(hdt / hsteps * 1e3, 4), "steps": hsteps,
+                        "h2d_GBs": round(hv * S * 4 / 1e9, 2), "contexts": S_, "in_flight_per_context": 2,
+                        "path": "host f32 slices -> bn_infer_submit (pool staging + PCIe) -> plan + top-K -> bn_infer_collect -> host logits + top-K rows"}
+
     out = {
         "metric": f"audio-segments/sec (batch) {model_name} {seg_name}",
         "value": round(value, 2),
@@ -241,6 +288,8 @@ def main():
         },
     }
 
+    if host_to_host is not None:
+        out["host_to_host"] = host_to_host
     if rank == 0:
         # ---- per-kernel device times (HIP events on the context's stream), roofline of the dominant kernel
         ctxs[0].infer(bufs[0].cpu().numpy())  # puts a real batch into the context's own input buffer

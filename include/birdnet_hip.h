@@ -151,6 +151,35 @@ size_t bn_ctx_device_bytes(const bn_ctx *c);
 bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch_size, float *logits_out,
                    float *emb_out, const volatile int32_t *cancel, uint64_t timeout_ns);
 
+/*
+ * The same hot call split in two, so that the host staging and the PCIe upload of batch k+1 overlap the device
+ * work of batch k (a synchronous call leaves the GPU idle while the caller's 576 KB per segment are copied and
+ * uploaded, and the link idle while the plan runs):
+ *
+ *   bn_infer_submit   validates, copies the caller's slices into pinned staging (prepare_input,
+ *                     batch_context.rs:188-226; a persistent pool of staging threads copies segment by segment
+ *                     and every finished chunk goes on the wire while the next is still being copied), enqueues
+ *                     the plan, the top-K kernel (top_k > 0: top_k_predictions, postprocess.rs:40-87, with the
+ *                     same has_min / min_conf meaning as bn_topk) and the device-to-host copies of logits,
+ *                     embeddings and top-K rows, and returns a ticket.  The caller's slices are no longer
+ *                     referenced once it returns.
+ *   bn_infer_collect  waits for that batch (cancel / timeout_ns as in bn_infer) and copies its results out:
+ *                     logits_out [batch * num_species], emb_out [batch * embedding_dim] or NULL, and -- when
+ *                     count_out is not NULL -- idx_out / conf_out [batch * k_stride] and count_out [batch] as
+ *                     bn_topk writes them (k_stride >= min(top_k, num_species)).
+ *
+ * A context holds at most TWO submitted batches (a third submit before a collect is BN_ERR_INVALID_ARG);
+ * batches complete in submission order.  More batches in flight = more contexts, each on its own stream.
+ * A batch that timed out or was cancelled in bn_infer_collect is abandoned: its ticket is gone and the context
+ * drains before its next use.  batch_size == 0 yields ticket 0, which collects to nothing.  Same threading rule
+ * as every context call: one thread at a time per context.
+ */
+bn_status bn_infer_submit(bn_ctx *c, const float *const *segs, size_t batch_size, size_t top_k,
+                          int32_t has_min, float min_conf, uint64_t *ticket);
+bn_status bn_infer_collect(bn_ctx *c, uint64_t ticket, float *logits_out, float *emb_out,
+                           size_t k_stride, uint32_t *idx_out, float *conf_out, uint32_t *count_out,
+                           const volatile int32_t *cancel, uint64_t timeout_ns);
+
 /* Same computation with the batch already resident in HBM as one contiguous
  * [batch_size, sample_count] f32 array; outputs stay on the device.
  * d_pcm must be 16-byte aligned (the kernels read it as float4); a pointer that is

@@ -42,7 +42,7 @@ BN_CTX_DEFAULT, BN_CTX_ALL_OUTPUTS, BN_CTX_NO_GRAPH = 0, 1, 2
 ENGINE_SYMBOLS = [
     "bn_abi_version", "bn_device_count", "bn_model_load", "bn_model_load_buffer", "bn_model_free",
     "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create",
-    "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_device",
+    "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_submit", "bn_infer_collect", "bn_infer_device",
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
     "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
     "bn_recording_create", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
@@ -109,6 +109,8 @@ def _load() -> C.CDLL:
         "bn_ctx_max_batch": (sz, [vp]),
         "bn_ctx_device_bytes": (sz, [vp]),
         "bn_infer": (i32, [vp, C.POINTER(f32p), sz, f32p, f32p, C.POINTER(C.c_int32), C.c_uint64]),
+        "bn_infer_submit": (i32, [vp, C.POINTER(f32p), sz, sz, i32, C.c_float, C.POINTER(C.c_uint64)]),
+        "bn_infer_collect": (i32, [vp, C.c_uint64, f32p, f32p, sz, u32p, f32p, u32p, C.POINTER(C.c_int32), C.c_uint64]),
         "bn_infer_device": (i32, [vp, vp, sz, i32]),
         "bn_ctx_output_device": (i32, [vp, i32, C.POINTER(vp), C.POINTER(sz)]),
         "bn_ctx_read_output": (i32, [vp, i32, sz, f32p]),
@@ -592,6 +594,45 @@ class Context:
         if st:
             raise EngineError(st)
         return logits, emb
+
+    def submit(self, segments, top_k: int = 0, min_confidence: Optional[float] = None) -> int:
+        """bn_infer_submit: stage + upload + enqueue one batch of host segments ([b, S] array or a list of 1-D
+        arrays); returns a ticket for collect().  At most two tickets may be outstanding per context."""
+        f32p = C.POINTER(C.c_float)
+        if isinstance(segments, np.ndarray):
+            x = np.ascontiguousarray(segments, dtype=np.float32)
+            rows = [x[i] for i in range(x.shape[0])]
+        else:
+            rows = [np.ascontiguousarray(r, dtype=np.float32) for r in segments]
+        b = len(rows)
+        ptrs = (f32p * max(b, 1))(*[r.ctypes.data_as(f32p) for r in rows])
+        t = C.c_uint64(0)
+        st = lib.bn_infer_submit(self._h, ptrs, b, top_k, 0 if min_confidence is None else 1, C.c_float(min_confidence or 0.0), C.byref(t))
+        if st:
+            raise EngineError(st)
+        self._tickets = getattr(self, "_tickets", {})
+        self._tickets[t.value] = (b, min(top_k, self.output_device(self.model.config.logits_output)[1]))
+        return t.value
+
+    def collect(self, ticket: int, want_embeddings: bool = True, timeout_ns: int = 0, cancel=None):
+        """bn_infer_collect: (logits, embeddings or None, idx, conf, count) of a submitted batch (the top-K arrays
+        are None when it was submitted with top_k = 0)."""
+        f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        b, k = self._tickets.pop(ticket, (0, 0))
+        cfg = self.model.config
+        logits = np.empty((b, self.output_device(cfg.logits_output)[1]), dtype=np.float32)
+        emb = None
+        if cfg.has_embedding and want_embeddings:
+            emb = np.empty((b, self.output_device(cfg.embedding_output)[1]), dtype=np.float32)
+        idx = conf = cnt = None
+        if k:
+            idx, conf, cnt = np.zeros((b, k), dtype=np.uint32), np.zeros((b, k), dtype=np.float32), np.zeros(b, dtype=np.uint32)
+        st = lib.bn_infer_collect(self._h, ticket, logits.ctypes.data_as(f32p), None if emb is None else emb.ctypes.data_as(f32p), k,
+                                  None if idx is None else idx.ctypes.data_as(u32p), None if conf is None else conf.ctypes.data_as(f32p),
+                                  None if cnt is None else cnt.ctypes.data_as(u32p), cancel, timeout_ns)
+        if st:
+            raise EngineError(st)
+        return logits, emb, idx, conf, cnt
 
     def infer_device(self, d_ptr: int, batch: int, sync: bool = False):
         st = lib.bn_infer_device(self._h, C.c_void_p(d_ptr), batch, 1 if sync else 0)

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <deque>
 #include <cstdlib>
 #include <algorithm>
 #include <atomic>
@@ -52,6 +54,85 @@ bool device_is_gfx950(int dev) {
     return strncmp(p.gcnArchName, "gfx950", 6) == 0;
 }
 
+// ---- persistent host staging pool ----
+// The reference's prepare_input copies every caller slice into one contiguous buffer on the calling thread
+// (batch_context.rs:199-211).  At 10 000+ segments per second that copy is 6+ GB/s -- more than one core moves -- so
+// the copies of a batch are handed to a small pool of long-lived threads (one task per segment) while the calling
+// thread copies too and puts each finished chunk on the wire.  Started on first use, joined at library unload; no
+// thread is created per call.  BN_STAGE_THREADS overrides the worker count (0 = the caller copies alone).
+struct StageTask {
+    const void *src;
+    void *dst;
+    size_t bytes;
+    std::atomic<uint32_t> *done;  // incremented (release) when the copy has landed
+};
+class StagePool {
+   public:
+    static StagePool &get() {
+        static StagePool pool;
+        return pool;
+    }
+    void push(const StageTask *tasks, size_t n) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t k = 0; k < n; k++) q_.push_back(tasks[k]);
+        }
+        if (n > 1) cv_.notify_all();
+        else cv_.notify_one();
+    }
+    // the caller helps: run one queued task if there is one
+    bool try_run_one() {
+        StageTask t;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (q_.empty()) return false;
+            t = q_.front();
+            q_.pop_front();
+        }
+        run(t);
+        return true;
+    }
+    size_t workers() const { return th_.size(); }
+
+   private:
+    StagePool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        long n = hw > 2 ? std::min<long>(6, (long)hw / 2) : 0;
+        if (const char *e = getenv("BN_STAGE_THREADS")) n = std::max<long>(0, std::min<long>(64, atol(e)));
+        for (long k = 0; k < n; k++) th_.emplace_back([this] { loop(); });
+    }
+    ~StagePool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    static void run(const StageTask &t) {
+        memcpy(t.dst, t.src, t.bytes);
+        t.done->fetch_add(1, std::memory_order_release);
+    }
+    void loop() {
+        for (;;) {
+            StageTask t;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;  // stop_
+                t = q_.front();
+                q_.pop_front();
+            }
+            run(t);
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<StageTask> q_;
+    std::vector<std::thread> th_;
+    bool stop_ = false;
+};
+
 }  // namespace
 
 struct bn_model {
@@ -95,6 +176,20 @@ struct bn_ctx {
     uint32_t *h_tk_idx = nullptr, *h_tk_cnt = nullptr;  // views into h_step for the last step
     float *h_tk_conf = nullptr;
     size_t step_k = 0;
+    // ---- asynchronous host-slice path (bn_infer_submit / bn_infer_collect): a ring of two batches per context.
+    // Slot 0 is the context's own staging (d_input / h_input / h_out), slot 1 is allocated on first use.
+    struct HostSlot {
+        float *d_input = nullptr, *h_input = nullptr, *h_out = nullptr;
+        uint32_t *h_tk = nullptr;  // pinned [idx: batch*k][conf: batch*k][count: batch]
+        size_t tk_cap = 0;         // words
+        hipEvent_t h2d_done = nullptr, plan_done = nullptr, out_done = nullptr;
+        bool owned = false, used = false, busy = false;
+        uint64_t ticket = 0;
+        size_t batch = 0, k = 0;
+    };
+    HostSlot slots[2];
+    hipStream_t copy_stream = nullptr;
+    uint64_t next_ticket = 1;
     struct GraphKey {
         size_t batch;
         const float *in;
@@ -465,6 +560,21 @@ void bn_ctx_destroy(bn_ctx *c) {
     if (c->d_tk_flags) (void)hipFree(c->d_tk_flags);
     if (c->d_step) (void)hipFree(c->d_step);
     if (c->h_step) (void)hipHostFree(c->h_step);
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
+    for (auto &sl : c->slots) {
+        if (sl.owned) {
+            if (sl.d_input) (void)hipFree(sl.d_input);
+            if (sl.h_input) (void)hipHostFree(sl.h_input);
+            if (sl.h_out) (void)hipHostFree(sl.h_out);
+        }
+        if (sl.h_tk) (void)hipHostFree(sl.h_tk);
+        if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
+        if (sl.plan_done) (void)hipEventDestroy(sl.plan_done);
+        if (sl.out_done) (void)hipEventDestroy(sl.out_done);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     bn_model *m = c->holds_model ? c->model : nullptr;
     delete c;
@@ -499,7 +609,7 @@ bn_status bn_infer_device(bn_ctx *c, const float *d_pcm, size_t batch, int32_t s
     return BN_OK;
 }
 
-// Tail shared by bn_infer / bn_infer_windows once the plan is enqueued on d_input: output copies to
+// Tail shared by bn_infer_windows once the plan is enqueued on d_input: output copies to
 // pinned staging, wait with cancel / timeout polling, copy out.
 static bn_status finish_infer(bn_ctx *c, size_t batch, float *logits_out, float *emb_out, const volatile int32_t *cancel, uint64_t timeout_ns) {
     const Plan &p = *c->pd->plan;
@@ -524,53 +634,233 @@ static bn_status finish_infer(bn_ctx *c, size_t batch, float *logits_out, float 
     return BN_OK;
 }
 
+// ---- asynchronous host-slice path ------------------------------------------------------------------------------
+static bn_status ensure_step_block(bn_ctx *c, size_t k);
+
+static bn_status ensure_slot(bn_ctx *c, bn_ctx::HostSlot &sl, int index) {
+    const Plan &p = *c->pd->plan;
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!sl.h2d_done) {
+        HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.plan_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming));
+    }
+    if (sl.d_input) return BN_OK;
+    if (index == 0) {
+        sl.d_input = c->d_input;
+        sl.h_input = c->h_input;
+        sl.h_out = c->h_out;
+        return BN_OK;
+    }
+    const size_t in_b = (size_t)p.sample_count * c->max_batch * sizeof(float);
+    sl.owned = true;
+    HIP_TRY(hipMalloc(&sl.d_input, in_b));
+    HIP_TRY(hipHostMalloc(&sl.h_input, in_b, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&sl.h_out, c->h_out_elems * sizeof(float), hipHostMallocDefault));
+    c->device_bytes += in_b;
+    return BN_OK;
+}
+
+bn_status bn_infer_submit(bn_ctx *c, const float *const *segs, size_t batch, size_t top_k, int32_t has_min, float min_conf, uint64_t *ticket) {
+    if (!c || !ticket) return fail(BN_ERR_INVALID_ARG, "null argument");
+    *ticket = 0;
+    if (batch == 0) return BN_OK;  // nothing to run (classifier.rs:681-683); ticket 0 collects to nothing
+    if (!segs) return fail(BN_ERR_INVALID_ARG, "null argument");
+    if (batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(batch) + " exceeds context max " + std::to_string(c->max_batch));
+    for (size_t b = 0; b < batch; b++)
+        if (!segs[b]) return fail(BN_ERR_INVALID_ARG, "segment " + std::to_string(b) + " is null");
+    const Plan &p = *c->pd->plan;
+    const bn_model_config &cfg = c->model->cfg;
+    const OutputInfo &lo = p.outputs[cfg.logits_output];
+    const size_t N = (size_t)lo.row_elems;
+    const size_t k = std::min(top_k, N);
+    if (k && topk_lds_bytes((int64_t)N, (int64_t)k) == 0) return fail(BN_ERR_INVALID_ARG, "top_k too large for the on-chip heap (k <= 9000)");
+    HIP_TRY(hipSetDevice(c->model->device));
+    bn_ctx::HostSlot *slp = nullptr;
+    int index = 0;
+    for (int q = 0; q < 2 && !slp; q++) {
+        const int cand = (int)((c->next_ticket + q) & 1u);
+        if (!c->slots[cand].busy) { slp = &c->slots[cand]; index = cand; }
+    }
+    if (!slp) return fail(BN_ERR_INVALID_ARG, "two batches are already in flight on this context: collect one first");
+    bn_ctx::HostSlot &sl = *slp;
+    bn_status st = ensure_slot(c, sl, index);
+    if (st != BN_OK) return st;
+    if (c->in_flight) {  // a timed-out / cancelled batch may still be running: let everything settle first
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        c->in_flight = false;
+    }
+    if (k) {
+        st = ensure_step_block(c, k);
+        if (st != BN_OK) return st;
+        const size_t need = c->max_batch * (2 * k + 1);
+        if (need > sl.tk_cap) {
+            if (sl.h_tk) (void)hipHostFree(sl.h_tk);
+            sl.h_tk = nullptr;
+            sl.tk_cap = 0;
+            HIP_TRY(hipHostMalloc(&sl.h_tk, need * sizeof(uint32_t), hipHostMallocDefault));
+            sl.tk_cap = need;
+        }
+    }
+    const size_t S = (size_t)p.sample_count;
+    if (sl.used) {
+        HIP_TRY(hipEventSynchronize(sl.h2d_done));                      // the pinned buffer's last upload has left it
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, sl.plan_done, 0));  // the plan that read the device buffer is through
+    }
+    // stage + upload in chunks: pool threads (and this one) copy segment by segment; a chunk goes on the wire as soon
+    // as its segments have landed in pinned memory, while the later chunks are still being copied
+    {
+        const size_t bytes_total = batch * S * sizeof(float);
+        const size_t nchunk = bytes_total >= (2u << 20) ? std::min<size_t>(8, batch) : 1;
+        StagePool &pool = StagePool::get();
+        std::vector<StageTask> tasks(batch);
+        std::atomic<uint32_t> done[8];
+        size_t clo[9];
+        for (size_t q = 0; q <= nchunk; q++) clo[q] = batch * q / nchunk;
+        for (size_t q = 0; q < nchunk; q++) {
+            done[q].store(0, std::memory_order_relaxed);
+            for (size_t b = clo[q]; b < clo[q + 1]; b++) tasks[b] = StageTask{segs[b], sl.h_input + b * S, S * sizeof(float), &done[q]};
+        }
+        if (pool.workers() && batch > 1) pool.push(tasks.data(), batch);
+        else
+            for (size_t b = 0; b < batch; b++) {
+                memcpy(tasks[b].dst, tasks[b].src, tasks[b].bytes);
+                tasks[b].done->fetch_add(1, std::memory_order_release);
+            }
+        hipError_t e = hipSuccess;
+        for (size_t q = 0; q < nchunk; q++) {
+            const uint32_t want = (uint32_t)(clo[q + 1] - clo[q]);
+            while (done[q].load(std::memory_order_acquire) < want)
+                if (!pool.try_run_one()) std::this_thread::yield();
+            if (e == hipSuccess && want)
+                e = hipMemcpyAsync(sl.d_input + clo[q] * S, sl.h_input + clo[q] * S, (size_t)want * S * sizeof(float), hipMemcpyHostToDevice, c->copy_stream);
+        }
+        // (every task of this call has completed here: `tasks` and `done` may go out of scope)
+        if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("input upload failed: ") + hipGetErrorString(e));
+    }
+    sl.used = true;
+    HIP_TRY(hipEventRecord(sl.h2d_done, c->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, sl.h2d_done, 0));
+    st = enqueue_plan(c, sl.d_input, batch, nullptr);
+    if (st != BN_OK) {
+        c->in_flight = true;
+        return st;
+    }
+    HIP_TRY(hipEventRecord(sl.plan_done, c->stream));
+    c->last_batch = batch;
+    const float *d_logits = resolve(c, lo.ref, sl.d_input);
+    if (k) {
+        (void)hipGetLastError();
+        uint32_t *d_idx = c->d_step, *d_cnt = c->d_step + 2 * batch * k;
+        float *d_conf = reinterpret_cast<float *>(c->d_step + batch * k);
+        launch_topk(c->stream, d_logits, (int64_t)batch, (int64_t)N, (int64_t)k, has_min, min_conf, (int64_t)k, d_idx, d_conf, d_cnt, c->d_tk_flags);
+        if (const char *why = take_launch_error()) return fail(BN_ERR_INVALID_ARG, std::string("top-K launch refused: ") + why);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(sl.h_out, d_logits, batch * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (cfg.embedding_output >= 0) {
+        const OutputInfo &eo = p.outputs[cfg.embedding_output];
+        HIP_TRY(hipMemcpyAsync(sl.h_out + N * c->max_batch, resolve(c, eo.ref, sl.d_input), batch * (size_t)eo.row_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (k) HIP_TRY(hipMemcpyAsync(sl.h_tk, c->d_step, batch * (2 * k + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(sl.out_done, c->stream));
+    sl.busy = true;
+    sl.batch = batch;
+    sl.k = k;
+    sl.ticket = c->next_ticket++;
+    *ticket = sl.ticket;
+    return BN_OK;
+}
+
+bn_status bn_infer_collect(bn_ctx *c, uint64_t ticket, float *logits_out, float *emb_out, size_t k_stride, uint32_t *idx_out, float *conf_out,
+                           uint32_t *count_out, const volatile int32_t *cancel, uint64_t timeout_ns) {
+    if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
+    if (ticket == 0) return BN_OK;  // the empty batch
+    bn_ctx::HostSlot *slp = nullptr;
+    for (auto &q : c->slots)
+        if (q.busy && q.ticket == ticket) slp = &q;
+    if (!slp) return fail(BN_ERR_INVALID_ARG, "unknown or already collected ticket");
+    bn_ctx::HostSlot &sl = *slp;
+    // batches complete in submission order: collecting the younger one first simply waits for both
+    HIP_TRY(hipSetDevice(c->model->device));
+    const auto start = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (true) {
+        hipError_t q = hipEventQuery(sl.out_done);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) {
+            sl.busy = false;
+            c->in_flight = true;
+            return fail(BN_ERR_BACKEND, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        }
+        if (cancel && *cancel) {
+            sl.busy = false;
+            c->in_flight = true;
+            return fail(BN_ERR_CANCELLED, "inference was cancelled");
+        }
+        if (timeout_ns) {
+            const uint64_t el = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - start).count();
+            if (el >= timeout_ns) {
+                sl.busy = false;
+                c->in_flight = true;
+                return fail(BN_ERR_TIMEOUT, "inference timed out after " + std::to_string(timeout_ns) + " ns");
+            }
+        }
+        if (!cancel && !timeout_ns) {  // nothing to poll for: block
+            hipError_t e = hipEventSynchronize(sl.out_done);
+            if (e != hipSuccess) {
+                sl.busy = false;
+                c->in_flight = true;
+                return fail(BN_ERR_BACKEND, std::string("hipEventSynchronize: ") + hipGetErrorString(e));
+            }
+            break;
+        }
+        if (++spins > 200) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else std::this_thread::yield();
+    }
+    const Plan &p = *c->pd->plan;
+    const bn_model_config &cfg = c->model->cfg;
+    const size_t N = (size_t)p.outputs[cfg.logits_output].row_elems;
+    const size_t batch = sl.batch, k = sl.k;
+    if (logits_out) memcpy(logits_out, sl.h_out, batch * N * sizeof(float));
+    if (emb_out && cfg.embedding_output >= 0) {
+        const size_t E = (size_t)p.outputs[cfg.embedding_output].row_elems;
+        memcpy(emb_out, sl.h_out + N * c->max_batch, batch * E * sizeof(float));
+    }
+    if (count_out) {
+        if (k == 0) {
+            for (size_t r = 0; r < batch; r++) count_out[r] = 0;
+        } else {
+            if (!idx_out || !conf_out || k_stride < k) {
+                sl.busy = false;
+                return fail(BN_ERR_INVALID_ARG, "top-K outputs need idx / conf buffers with k_stride >= min(top_k, num_species)");
+            }
+            const uint32_t *h_idx = sl.h_tk, *h_cnt = sl.h_tk + 2 * batch * k;
+            const float *h_conf = reinterpret_cast<const float *>(sl.h_tk + batch * k);
+            for (size_t r = 0; r < batch; r++) {
+                count_out[r] = h_cnt[r];
+                for (size_t j = 0; j < h_cnt[r]; j++) {
+                    idx_out[r * k_stride + j] = h_idx[r * k + j];
+                    conf_out[r * k_stride + j] = h_conf[r * k + j];
+                }
+            }
+        }
+    }
+    sl.busy = false;
+    return BN_OK;
+}
 
 bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch, float *logits_out, float *emb_out, const volatile int32_t *cancel,
                    uint64_t timeout_ns) {
     if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
     if (batch == 0) return BN_OK;
     if (!segs || !logits_out) return fail(BN_ERR_INVALID_ARG, "null argument");
-    if (batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(batch) + " exceeds context max " + std::to_string(c->max_batch));
-    const Plan &p = *c->pd->plan;
-    HIP_TRY(hipSetDevice(c->model->device));
-    bn_status st = drain_if_needed(c);
-    if (st != BN_OK) return st;
     if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
-    const size_t S = (size_t)p.sample_count;
-    for (size_t b = 0; b < batch; b++)
-        if (!segs[b]) return fail(BN_ERR_INVALID_ARG, "segment " + std::to_string(b) + " is null");
-    // Stage the caller's slices into pinned memory and upload in up to 4 chunks: a helper thread per chunk copies
-    // while the previous chunk's H2D transfer is already on the wire (a single-threaded 18 MB memcpy alone costs
-    // more than the whole plan at batch 32).
-    {
-        const size_t bytes_total = batch * S * sizeof(float);
-        const size_t nchunk = bytes_total >= (4u << 20) ? std::min<size_t>(4, batch) : 1;
-        if (nchunk == 1) {
-            for (size_t b = 0; b < batch; b++) memcpy(c->h_input + b * S, segs[b], S * sizeof(float));
-            HIP_TRY(hipMemcpyAsync(c->d_input, c->h_input, bytes_total, hipMemcpyHostToDevice, c->stream));
-        } else {
-            std::vector<std::thread> workers;
-            std::vector<size_t> lo(nchunk + 1);
-            for (size_t k = 0; k <= nchunk; k++) lo[k] = batch * k / nchunk;
-            for (size_t k = 0; k < nchunk; k++)
-                workers.emplace_back([&, k] {
-                    for (size_t b = lo[k]; b < lo[k + 1]; b++) memcpy(c->h_input + b * S, segs[b], S * sizeof(float));
-                });
-            hipError_t e = hipSuccess;
-            for (size_t k = 0; k < nchunk; k++) {
-                workers[k].join();
-                if (e == hipSuccess && lo[k + 1] > lo[k])
-                    e = hipMemcpyAsync(c->d_input + lo[k] * S, c->h_input + lo[k] * S, (lo[k + 1] - lo[k]) * S * sizeof(float), hipMemcpyHostToDevice, c->stream);
-            }
-            if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("input upload failed: ") + hipGetErrorString(e));
-        }
-    }
-    st = enqueue_plan(c, c->d_input, batch, cancel);
-    if (st != BN_OK) {
-        c->in_flight = true;
-        return st;
-    }
-    return finish_infer(c, batch, logits_out, emb_out, cancel, timeout_ns);
+    uint64_t ticket = 0;
+    bn_status st = bn_infer_submit(c, segs, batch, 0, 0, 0.0f, &ticket);
+    if (st != BN_OK) return st;
+    return bn_infer_collect(c, ticket, logits_out, emb_out, 0, nullptr, nullptr, nullptr, cancel, timeout_ns);
 }
 
 bn_status bn_ctx_output_device(const bn_ctx *c, int32_t index, const float **d_ptr, size_t *row_elems) {
@@ -717,6 +1007,27 @@ static bn_status ensure_topk_buffers(bn_ctx *c, size_t k) {
     return BN_OK;
 }
 
+// device + pinned blocks of the packed top-K rows of one step (grown on demand; nothing of this context may be in
+// flight when they grow: the stream is drained first)
+static bn_status ensure_step_block(bn_ctx *c, size_t k) {
+    bn_status st = ensure_topk_buffers(c, k);
+    if (st != BN_OK) return st;
+    const size_t need = c->max_batch * (2 * k + 1);
+    if (need > c->step_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_step) (void)hipFree(c->d_step);
+        if (c->h_step) (void)hipHostFree(c->h_step);
+        c->d_step = c->h_step = nullptr;
+        c->h_tk_idx = c->h_tk_cnt = nullptr;
+        c->h_tk_conf = nullptr;
+        c->step_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_step, need * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(&c->h_step, need * sizeof(uint32_t), hipHostMallocDefault));
+        c->step_cap = need;
+    }
+    return BN_OK;
+}
+
 bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch, size_t top_k, int32_t has_min, float min_conf, int32_t sync) {
     if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
     if (batch == 0) return BN_OK;
@@ -730,22 +1041,8 @@ bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch, size_t top
     HIP_TRY(hipSetDevice(c->model->device));
     bn_status st = drain_if_needed(c);
     if (st != BN_OK) return st;
-    st = ensure_topk_buffers(c, k);
+    st = ensure_step_block(c, k);
     if (st != BN_OK) return st;
-    {
-        const size_t need = c->max_batch * (2 * k + 1);
-        if (need > c->step_cap) {
-            if (c->d_step) (void)hipFree(c->d_step);
-            if (c->h_step) (void)hipHostFree(c->h_step);
-            c->d_step = c->h_step = nullptr;
-            c->h_tk_idx = c->h_tk_cnt = nullptr;
-            c->h_tk_conf = nullptr;
-            c->step_cap = 0;
-            HIP_TRY(hipMalloc(&c->d_step, need * sizeof(uint32_t)));
-            HIP_TRY(hipHostMalloc(&c->h_step, need * sizeof(uint32_t), hipHostMallocDefault));
-            c->step_cap = need;
-        }
-    }
     st = enqueue_plan(c, d_pcm, batch, nullptr);
     if (st != BN_OK) return st;
     c->last_batch = batch;

@@ -138,10 +138,47 @@ std::vector<PredictionResult> run_on_ctx_with(ClassifierInner &in, bn_ctx *ctx, 
     return out;
 }
 
+// results of one batch from flat host arrays (process_batch_outputs_from_flat, classifier.rs:872-911)
+std::vector<PredictionResult> build_results(ClassifierInner &in, size_t n, size_t N, size_t E, size_t kstride, const std::vector<float> &logits,
+                                            const std::vector<float> &emb, const std::vector<uint32_t> &idx, const std::vector<float> &conf,
+                                            const std::vector<uint32_t> &cnt) {
+    std::vector<PredictionResult> out(n);
+    for (size_t i = 0; i < n; i++) {
+        PredictionResult &r = out[i];
+        r.model_type = in.config.model_type;
+        r.raw_scores.assign(logits.begin() + i * N, logits.begin() + (i + 1) * N);
+        if (E) r.embeddings = std::vector<float>(emb.begin() + i * E, emb.begin() + (i + 1) * E);
+        for (size_t j = 0; j < cnt[i]; j++) {
+            const size_t id = idx[i * kstride + j];
+            r.predictions.push_back(Prediction{id < in.labels.size() ? in.labels[id] : "unknown_" + std::to_string(id), conf[i * kstride + j], id});
+        }
+    }
+    return out;
+}
+
+// The host-slice call (prepare_input + run + extract_outputs + top-K, classifier.rs:826-867) as ONE submit and ONE
+// collect: staging by the library's persistent pool, plan, top-K kernel and all device-to-host copies on the
+// context's stream, a single wait.
 std::vector<PredictionResult> run_on_ctx(ClassifierInner &in, bn_ctx *ctx, const float *const *segs, size_t n, const InferenceOptions &opt) {
-    return run_on_ctx_with(in, ctx, n, opt, [&](float *logits, float *emb, const volatile int32_t *cancel, uint64_t timeout_ns) {
-        return bn_infer(ctx, segs, n, logits, emb, cancel, timeout_ns);
-    });
+    size_t N = in.config.num_species, E = in.config.embedding_dim.value_or(0);
+    {
+        const float *dp = nullptr;
+        size_t row = 0;
+        if (bn_ctx_output_device(ctx, in.raw_cfg.logits_output, &dp, &row) == BN_OK) N = row;
+        if (E && bn_ctx_output_device(ctx, in.raw_cfg.embedding_output, &dp, &row) == BN_OK) E = row;
+    }
+    const volatile int32_t *cancel = opt.cancellation_token ? opt.cancellation_token->raw() : nullptr;
+    const uint64_t timeout_ns = opt.timeout ? std::max<uint64_t>((uint64_t)opt.timeout->count(), 1) : 0;
+    if (cancel && *cancel) throw from_status(BN_ERR_CANCELLED, opt);
+    const size_t k = std::min(in.top_k, N), kstride = std::max<size_t>(k, 1);
+    uint64_t ticket = 0;
+    bn_status st = bn_infer_submit(ctx, segs, n, in.top_k, in.min_confidence ? 1 : 0, in.min_confidence.value_or(0.0f), &ticket);
+    if (st != BN_OK) throw from_status(st, opt);
+    std::vector<float> logits(n * N), emb(n * E), conf(n * kstride);
+    std::vector<uint32_t> idx(n * kstride), cnt(n);
+    st = bn_infer_collect(ctx, ticket, logits.data(), E ? emb.data() : nullptr, kstride, idx.data(), conf.data(), cnt.data(), cancel, timeout_ns);
+    if (st != BN_OK) throw from_status(st, opt);
+    return build_results(in, n, N, E, kstride, logits, emb, idx, conf, cnt);
 }
 
 bn_ctx *ensure_default_ctx(ClassifierInner &in, size_t n) {
