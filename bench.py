@@ -43,7 +43,8 @@ def main():
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host (bn_infer_submit / collect) measurement")
-    ap.add_argument("--host-steps", type=int, default=60, help="minimum number of steps of the host-to-host leg")
+    ap.add_argument("--host-steps", type=int, default=120, help="minimum number of steps of the host-to-host leg")
+    ap.add_argument("--host-warmup", type=int, default=96, help="minimum number of warm-up steps of the host-to-host leg")
     ap.add_argument("--cpu-sample", type=int, default=96, help="segments the CPU oracle is timed on (about 15-30 s of host work)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -230,6 +231,9 @@ def main():
 
         hbufs = [b_.cpu().numpy() for b_ in bufs]
         hsteps = max(args.steps, args.host_steps)
+        # this leg has its own warm-up: the host side (staging pool, pinned slots, page placement of the source
+        # arrays) needs ~80 steps to settle on the pool's boxes (tools/host_path_trace.py: submit 0.8 ms -> 0.3 ms)
+        hwarm = max(args.warmup, args.host_warmup)
         outstanding = [deque() for _ in ctxs]
         last = {}
 
@@ -244,7 +248,7 @@ def main():
                 while q:
                     last[j] = ctxs[j].collect(q.popleft(), want_embeddings=True)
 
-        for i in range(max(args.warmup, 2 * S_)):
+        for i in range(max(hwarm, 2 * S_)):
             hstep(i)
         hdrain()
         t1 = time.perf_counter()
@@ -261,7 +265,7 @@ def main():
         assert np.array_equal(hct, dct) and all(np.array_equal(hix[r, :hct[r]], dix[r, :dct[r]]) for r in range(B))
         hv = hsteps * B / hdt
         host_to_host = {"value": round(hv, 1), "unit": "segments/s", "ms_per_step": round(hdt / hsteps * 1e3, 4), "steps": hsteps,
-                        "h2d_GBs": round(hv * S * 4 / 1e9, 2), "contexts": S_, "in_flight_per_context": 2,
+                        "warmup": max(hwarm, 2 * S_), "h2d_GBs": round(hv * S * 4 / 1e9, 2), "contexts": S_, "in_flight_per_context": 2,
                         "path": "host f32 slices -> bn_infer_submit (pool staging + PCIe) -> plan + top-K -> bn_infer_collect -> host logits + top-K rows"}
 
     out = {
@@ -302,7 +306,7 @@ def main():
         desc = bn.plan_describe(path_for_describe(model_bytes))
         kind_of = [l.split()[1] for l in desc.splitlines() if l[:3].strip().isdigit()]
         fam_name = {"GEMM": "gemm_mfma_kernel", "DWCONV": "dwconv_kernel", "CONV": "conv_direct_kernel", "MBCONV": "mbconv_expand_dw_kernel",
-                    "REDUCE": "reduce_kernel", "ELT": "elt_kernel", "GAP": "gap_partial_kernel", "SEFC": "se_fc_kernel", "POOL": "pool_kernel"}
+                    "REDUCE": "reduce_kernel", "ELT": "elt_kernel", "GAP": "gap_partial_kernel", "SEFC": "se_fc_kernel", "POOL": "pool_kernel", "FFT": "stft_kernel"}
         fam = {}
         for (name, us, macs, byts), k in zip(rows, kind_of):
             f_ = fam.setdefault(fam_name[k], {"us": 0.0, "macs": 0.0, "bytes": 0.0, "launches": 0})

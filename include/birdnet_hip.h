@@ -92,6 +92,12 @@ typedef struct bn_model_cost {
     double weight_bytes;       /* resident parameter bytes after folding/pruning */
     double activation_bytes;   /* bytes of intermediates written to HBM per segment by the current plan */
     int32_t n_launches;        /* kernel launches per batch in the current plan */
+    /* The front end's windowed-DFT filter banks (+ absorbed mel product) counted two ways, SURVEY.md 8(d):
+     * multiply-accumulates of the matrix-product evaluation the exporter's graph spells out, and flops of the
+     * FFT formulation the plan runs where it can (2.5 L log2 L per real frame + 2 per mel non-zero); both 0
+     * when the graph has no such bank.  macs_valu contains fft_flops / 2 for banks that run as FFTs. */
+    double dft_gemm_macs;
+    double fft_flops;
 } bn_model_cost;
 
 /* ---- version / device ------------------------------------------------- */

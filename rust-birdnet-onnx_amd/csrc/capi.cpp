@@ -235,6 +235,22 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
             launch_mbconv(c->stream, op.mb, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
                           resolve(c, op.bias2, d_in), resolve(c, op.b, d_in), batch);
             break;
+        case OpKind::FFT: {
+            StftPtrs sp{};
+            sp.out = out;
+            sp.in = a;
+            sp.window = resolve(c, op.w, d_in);
+            sp.tw = reinterpret_cast<const float2 *>(resolve(c, op.w2, d_in));
+            sp.otab = resolve(c, op.bias2, d_in);
+            sp.bias = resolve(c, op.bias, d_in);
+            for (int k = 0; k < ELT_MAX_STAGES; k++) sp.pre[k] = resolve(c, op.eb[k], d_in);
+            sp.mstart = resolve(c, op.x[0], d_in);
+            sp.mcol = resolve(c, op.x[1], d_in);
+            sp.mval = resolve(c, op.x[2], d_in);
+            sp.mel_bias = resolve(c, op.x[3], d_in);
+            launch_stft(c->stream, op.fft, sp, batch);
+            break;
+        }
         case OpKind::SEFC:
             launch_se_fc(c->stream, op.se, out, resolve(c, op.b, d_in), a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
                          resolve(c, op.bias2, d_in), batch);
@@ -485,6 +501,8 @@ bn_status bn_model_get_cost(const bn_model *m, bn_model_cost *out) {
     out->weight_bytes = p.weight_bytes;
     out->activation_bytes = p.act_bytes;
     out->n_launches = (int32_t)p.ops.size();
+    out->dft_gemm_macs = p.dft_gemm_macs;
+    out->fft_flops = p.fft_flops;
     return BN_OK;
 }
 
@@ -1371,7 +1389,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
             if (cfg.embedding_output >= 0) wanted.push_back(cfg.embedding_output);
         }
         auto p = build_plan(om, wanted);
-        static const char *kinds[] = {"ELT", "REDUCE", "GEMM", "CONV", "DWCONV", "GAP", "SEFC", "MBCONV", "POOL"};
+        static const char *kinds[] = {"ELT", "REDUCE", "GEMM", "CONV", "DWCONV", "GAP", "SEFC", "MBCONV", "POOL", "FFT"};
         char line[512];
         for (size_t k = 0; k < p->ops.size(); k++) {
             const PlanOp &op = p->ops[k];
@@ -1408,6 +1426,10 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
             } else if (op.kind == OpKind::SEFC) {
                 snprintf(line, sizeof(line), " C=%d Cr=%d act1=%d act2=%d", op.se.C, op.se.Cr, op.se.act1, op.se.act2);
                 extra = line;
+            } else if (op.kind == OpKind::FFT) {
+                snprintf(line, sizeof(line), " frames=%d L=%d hop=%d bins=%d mel=%d pre=%d post=%d out_rs=%lld out_cs=%lld fft_flops=%.3g", op.fft.frames, op.fft.L,
+                         op.fft.hop, op.fft.nout, op.fft.nmel, op.fft.npre, op.fft.npost, (long long)op.fft.out_rs, (long long)op.fft.out_cs, op.flops_fft);
+                extra = line;
             } else {
                 snprintf(line, sizeof(line), " kept=%lld red=%lld op=%d inner_kept=%d", (long long)op.red.kept, (long long)op.red.red, op.red.op, op.red.inner_kept);
                 extra = line;
@@ -1415,8 +1437,8 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
             snprintf(line, sizeof(line), "%3zu %-6s %-40s macs=%.3g bytes=%.3g", k, kinds[(int)op.kind], op.name.c_str(), op.macs, op.bytes);
             text += line + extra + "\n";
         }
-        snprintf(line, sizeof(line), "TOTAL launches=%zu macs_mfma=%.6g macs_valu=%.6g act_bytes=%.6g weight_bytes=%.6g arena_bytes_per_sample=%lld consts_bytes=%lld\n",
-                 p->ops.size(), p->macs_mfma, p->macs_valu, p->act_bytes, p->weight_bytes, (long long)p->arena_elems * 4, (long long)p->consts_elems * 4);
+        snprintf(line, sizeof(line), "TOTAL launches=%zu macs_mfma=%.6g macs_valu=%.6g act_bytes=%.6g weight_bytes=%.6g arena_bytes_per_sample=%lld consts_bytes=%lld dft_gemm_macs=%.6g fft_flops=%.6g\n",
+                 p->ops.size(), p->macs_mfma, p->macs_valu, p->act_bytes, p->weight_bytes, (long long)p->arena_elems * 4, (long long)p->consts_elems * 4, p->dft_gemm_macs, p->fft_flops);
         text += line;
         for (size_t k = 0; k < p->outputs.size(); k++) {
             snprintf(line, sizeof(line), "OUTPUT %zu %s computed=%d row_elems=%lld\n", k, p->outputs[k].name.c_str(), (int)p->outputs[k].computed, (long long)p->outputs[k].row_elems);

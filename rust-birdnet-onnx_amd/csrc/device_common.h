@@ -1,0 +1,129 @@
+// Device helpers shared by the kernel translation units (kernels.hip, stft.hip): the logistic / exp / log / pow
+// forms of the network path and the one-dispatch-per-stage unary / binary stage functions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "kernels.h"
+
+namespace bn {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// Logistic function inside the network (SE gates, SiLU): hardware exp2 and reciprocal
+// (v_exp_f32 / v_rcp_f32, ~1 ulp each; the argument scaling adds |x| * 2^-24 relative), 6
+// instructions instead of ~30 for the IEEE expf + division.  Saturates correctly: x -> -inf gives
+// rcp(inf) = 0, x -> +inf gives rcp(1) = 1.  The CONFIDENCE sigmoid of the post-processing
+// (topk.hip) does not use this: it is bit-exact against the reference's f32 sigmoid.
+__device__ __forceinline__ float net_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+// exp / log / pow of the front end's dynamic-range compression (power spectrum -> x^p, log-mel):
+// hardware exp2 / log2 (v_exp_f32 / v_log_f32, ~1 ulp each).  pow(x, p) = exp2(p * log2 x) for
+// x > 0 has a relative error of about |p * log2 x| * 2^-23 (<= 1e-5 over the 1e-30..1e30 range a
+// spectrogram can span), against ~150 instructions for the correctly rounded powf -- the two Pow
+// chains of the v2.4 front end were VALU-bound on it.  Non-positive bases keep the libm path
+// (signs, zeros, NaN rules).
+__device__ __forceinline__ float net_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float net_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309417f; }
+__device__ __forceinline__ float net_pow(float x, float p) {
+    return x > 0.0f ? __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)) : powf(x, p);
+}
+
+template <int N, class F>
+__device__ __forceinline__ void map_array(float (&v)[N], F f) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = f(v[i]);
+}
+
+__device__ __forceinline__ float act_apply(int act, float x, float p0, float p1) {
+    switch (act) {
+        case ACT_NONE: return x;
+        case ACT_RELU: return fmaxf(x, 0.0f);
+        case ACT_CLIP: return fminf(fmaxf(x, p0), p1);
+        case ACT_SIGMOID: return net_sigmoid(x);
+        case ACT_SILU: return x * net_sigmoid(x);
+        case ACT_HSIGMOID: return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f);
+        case ACT_HSWISH: return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f);
+        case ACT_LEAKY: return x >= 0.0f ? x : p0 * x;
+        case ACT_TANH: return tanhf(x);
+        case ACT_EXP: return net_exp(x);
+        case ACT_LOG: return net_log(x);
+        case ACT_SQRT: return sqrtf(x);
+        case ACT_ABS: return fabsf(x);
+        case ACT_NEG: return -x;
+        case ACT_RECIP: return 1.0f / x;
+        case ACT_POW: return net_pow(x, p0);
+        case ACT_AFFINE: return p0 * x + p1;
+        case ACT_MAXC: return fmaxf(x, p0);
+        case ACT_MINC: return fminf(x, p0);
+        case ACT_RSUB: return p0 - x;
+        case ACT_RDIV: return p0 / x;
+        case ACT_SQUARE: return x * x;
+        case ACT_FLOOR: return floorf(x);
+        case ACT_CEIL: return ceilf(x);
+        case ACT_ERF: return erff(x);
+        case ACT_SOFTPLUS: return log1pf(expf(x));
+        default: return x;
+    }
+}
+
+// Stage ops over a small register array with ONE dispatch on the (launch-uniform) op code: the
+// per-element switch of act_apply / bin_apply costs a branch tree per element per stage.
+template <int N>
+__device__ __forceinline__ void act_array_all(int act, float p0, float p1, float (&v)[N]) {
+    switch (act) {
+        case ACT_NONE: return;
+        case ACT_RELU: map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); }); return;
+        case ACT_CLIP: map_array<N>(v, [=](float x) { return fminf(fmaxf(x, p0), p1); }); return;
+        case ACT_SIGMOID: map_array<N>(v, [](float x) { return net_sigmoid(x); }); return;
+        case ACT_SILU: map_array<N>(v, [](float x) { return x * net_sigmoid(x); }); return;
+        case ACT_HSIGMOID: map_array<N>(v, [=](float x) { return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f); }); return;
+        case ACT_HSWISH: map_array<N>(v, [](float x) { return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f); }); return;
+        case ACT_LEAKY: map_array<N>(v, [=](float x) { return x >= 0.0f ? x : p0 * x; }); return;
+        case ACT_TANH: map_array<N>(v, [](float x) { return tanhf(x); }); return;
+        case ACT_EXP: map_array<N>(v, [](float x) { return net_exp(x); }); return;
+        case ACT_LOG: map_array<N>(v, [](float x) { return net_log(x); }); return;
+        case ACT_SQRT: map_array<N>(v, [](float x) { return sqrtf(x); }); return;
+        case ACT_ABS: map_array<N>(v, [](float x) { return fabsf(x); }); return;
+        case ACT_NEG: map_array<N>(v, [](float x) { return -x; }); return;
+        case ACT_RECIP: map_array<N>(v, [](float x) { return 1.0f / x; }); return;
+        case ACT_POW: map_array<N>(v, [=](float x) { return net_pow(x, p0); }); return;
+        case ACT_AFFINE: map_array<N>(v, [=](float x) { return p0 * x + p1; }); return;
+        case ACT_MAXC: map_array<N>(v, [=](float x) { return fmaxf(x, p0); }); return;
+        case ACT_MINC: map_array<N>(v, [=](float x) { return fminf(x, p0); }); return;
+        case ACT_RSUB: map_array<N>(v, [=](float x) { return p0 - x; }); return;
+        case ACT_RDIV: map_array<N>(v, [=](float x) { return p0 / x; }); return;
+        case ACT_SQUARE: map_array<N>(v, [](float x) { return x * x; }); return;
+        case ACT_FLOOR: map_array<N>(v, [](float x) { return floorf(x); }); return;
+        case ACT_CEIL: map_array<N>(v, [](float x) { return ceilf(x); }); return;
+        case ACT_ERF: map_array<N>(v, [](float x) { return erff(x); }); return;
+        case ACT_SOFTPLUS: map_array<N>(v, [](float x) { return log1pf(expf(x)); }); return;
+        default: return;
+    }
+}
+template <int N, class F>
+__device__ __forceinline__ void zip_array(float (&v)[N], const float (&w)[N], F f) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = f(v[i], w[i]);
+}
+template <int N>
+__device__ __forceinline__ void bin_array(int bin, int bsq, float (&v)[N], float (&w)[N]) {
+    if (bsq) map_array<N>(w, [](float x) { return x * x; });
+    switch (bin) {
+        case BIN_ADD: zip_array<N>(v, w, [](float a, float b) { return a + b; }); return;
+        case BIN_SUB: zip_array<N>(v, w, [](float a, float b) { return a - b; }); return;
+        case BIN_MUL: zip_array<N>(v, w, [](float a, float b) { return a * b; }); return;
+        case BIN_DIV: zip_array<N>(v, w, [](float a, float b) { return a / b; }); return;
+        case BIN_POW: zip_array<N>(v, w, [](float a, float b) { return net_pow(a, b); }); return;
+        case BIN_MAX: zip_array<N>(v, w, [](float a, float b) { return fmaxf(a, b); }); return;
+        case BIN_MIN: zip_array<N>(v, w, [](float a, float b) { return fminf(a, b); }); return;
+        default: return;
+    }
+}
+
+}  // namespace
+}  // namespace bn

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -186,7 +187,9 @@ class Builder {
             plan_.macs_mfma += op.macs_mfma_extra;
             plan_.act_bytes += op.bytes;
             plan_.weight_bytes += op.weight_bytes;
+            plan_.fft_flops += op.flops_fft;
         }
+        plan_.dft_gemm_macs = dft_gemm_macs_;
     }
 
    private:
@@ -198,6 +201,7 @@ class Builder {
     std::set<std::string> graph_outputs_, wanted_names_;
     std::vector<bool> live_, absorbed_;
     int cur_ = 0;
+    double dft_gemm_macs_ = 0;
 
     // ------------------------------------------------------------------ utils
     const Val &get(const OnnxNode &n, size_t idx) {
@@ -292,6 +296,7 @@ class Builder {
         touch(op.w2, idx);
         touch(op.bias2, idx);
         for (auto &r : op.eb) touch(r, idx);
+        for (auto &r : op.x) touch(r, idx);
         plan_.ops.push_back(std::move(op));
     }
 
@@ -570,6 +575,313 @@ class Builder {
         }
     }
 
+    // ------------------------------------------------------------- windowed-DFT filter banks -> real FFT
+    // A single-channel 1-D filter bank whose every row is  a_c * w[n] * cos(2 pi k_c n / L)  (symmetric rows) or
+    // b_c * w[n] * sin(2 pi k_c n / L)  (antisymmetric rows) for ONE common window w and integer bins k_c is a
+    // short-time Fourier transform: out[c] = a_c Re Y[k_c] - b_c Im Y[k_c] with Y = FFT(w . frame).  The bank is
+    // recognised from the numbers alone (the exporter's node names say nothing): bins by the peak of each row's
+    // spectrum, window and amplitudes by alternating least squares over all rows, and the model is accepted only if
+    // every tap of every row agrees with it within f32 rounding of the taps (BN_STFT_TOL x max|row|, default 4e-7).
+    // Then ONE launch of stft_kernel (kernels.h, FftDesc) computes all rows -- cos and sin blocks together -- instead
+    // of one folded GEMM per symmetry run.  L must be a power of two in 128..2048.  BN_STFT=1 enables (see emit_stft).
+    struct DftBank {
+        int64_t L = 0;
+        std::vector<float> window;
+        std::vector<int> k;
+        std::vector<double> a, b;
+    };
+    static void host_fft(std::vector<double> &re, std::vector<double> &im) {  // in-place radix-2, n a power of two
+        const size_t n = re.size();
+        for (size_t i = 1, j = 0; i < n; i++) {
+            size_t bit = n >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+        }
+        for (size_t len = 2; len <= n; len <<= 1) {
+            const double ang = -2.0 * M_PI / (double)len;
+            for (size_t i = 0; i < n; i += len)
+                for (size_t k = 0; k < len / 2; k++) {
+                    const double wr = std::cos(ang * (double)k), wi = std::sin(ang * (double)k);
+                    const size_t u = i + k, v = i + k + len / 2;
+                    const double xr = re[v] * wr - im[v] * wi, xi = re[v] * wi + im[v] * wr;
+                    re[v] = re[u] - xr; im[v] = im[u] - xi;
+                    re[u] += xr; im[u] += xi;
+                }
+        }
+    }
+    bool detect_dft_bank(const std::vector<float> &wf, int64_t Cout, int64_t L, const std::vector<int> &cls, DftBank &bank) {
+        if (L < 128 || L > 2048 || (L & (L - 1))) return false;
+        const double tol = getenv("BN_STFT_TOL") ? atof(getenv("BN_STFT_TOL")) : 4e-7;
+        bank.L = L;
+        bank.k.assign((size_t)Cout, 0);
+        bank.a.assign((size_t)Cout, 0.0);
+        bank.b.assign((size_t)Cout, 0.0);
+        std::vector<double> rowmax((size_t)Cout, 0.0);
+        std::vector<char> is_sin((size_t)Cout, 0), live((size_t)Cout, 0);
+        double gmax = 0;
+        for (float v : wf) gmax = std::max(gmax, (double)std::fabs(v));
+        for (int64_t c = 0; c < Cout; c++) {
+            const float *w = &wf[(size_t)(c * L)];
+            double mx = 0;
+            for (int64_t n = 0; n < L; n++) mx = std::max(mx, (double)std::fabs(w[n]));
+            rowmax[(size_t)c] = mx;
+            // a row whose largest tap is below f32 resolution of the bank's largest tap (sin(pi n) of the Nyquist bin
+            // evaluated in floating point: ~1e-13) counts as the zero row it stands for
+            if (!(mx > 1e-7 * gmax)) continue;
+            live[(size_t)c] = 1;
+            is_sin[(size_t)c] = cls[(size_t)c] < 0;
+            std::vector<double> re(w, w + L), im((size_t)L, 0.0);
+            host_fft(re, im);
+            int best = 0;
+            double bm = -1;
+            for (int64_t q = 0; q <= L / 2; q++) {
+                const double m2 = re[(size_t)q] * re[(size_t)q] + im[(size_t)q] * im[(size_t)q];
+                if (m2 > bm) { bm = m2; best = (int)q; }
+            }
+            bank.k[(size_t)c] = best;
+        }
+        // unit sinusoids of every live row, from one table of cos(2 pi t / L)
+        std::vector<double> ctab((size_t)L);
+        for (int64_t t = 0; t < L; t++) ctab[(size_t)t] = std::cos(2.0 * M_PI * (double)t / (double)L);
+        auto trig = [&](int64_t c, int64_t n) {
+            const int64_t ph = ((int64_t)bank.k[(size_t)c] * n) % L;  // exact phase reduction
+            return is_sin[(size_t)c] ? ctab[(size_t)((ph + 3 * L / 4) % L)] : ctab[(size_t)ph];  // sin x = cos(x - pi/2)
+        };
+        std::vector<double> amp((size_t)Cout, 0.0), win((size_t)L, 0.0), energy((size_t)Cout, 0.0);
+        for (int64_t c = 0; c < Cout; c++) {
+            if (!live[(size_t)c]) continue;
+            double e = 0;
+            for (int64_t n = 0; n < L; n++) e += (double)wf[(size_t)(c * L + n)] * wf[(size_t)(c * L + n)];
+            energy[(size_t)c] = e;
+        }
+        // start from the row energy: sum (w t)^2 is ~ sum w^2 / 2 for a sinusoid, sum w^2 for the DC / Nyquist rows
+        // (the sign settles in the first amplitude step)
+        auto init_amp = [&](int64_t c) {
+            const int k = bank.k[(size_t)c];
+            amp[(size_t)c] = std::sqrt(energy[(size_t)c] * ((k == 0 || k == L / 2) ? 1.0 : 2.0));
+        };
+        std::vector<char> use((size_t)Cout, 0);
+        auto als = [&](int max_it) {
+            for (int it = 0; it < max_it; it++) {
+                for (int64_t n = 0; n < L; n++) {
+                    double num = 0, den = 0;
+                    for (int64_t c = 0; c < Cout; c++) {
+                        if (!use[(size_t)c]) continue;
+                        const double t = amp[(size_t)c] * trig(c, n);
+                        num += t * (double)wf[(size_t)(c * L + n)];
+                        den += t * t;
+                    }
+                    win[(size_t)n] = den > 0 ? num / den : 0.0;
+                }
+                double wmax = 0;
+                for (double v : win) wmax = std::max(wmax, std::fabs(v));
+                if (!(wmax > 0)) return false;
+                for (double &v : win) v /= wmax;
+                double change = 0;
+                for (int64_t c = 0; c < Cout; c++) {
+                    if (!use[(size_t)c]) continue;
+                    double num = 0, den = 0;
+                    for (int64_t n = 0; n < L; n++) {
+                        const double t = win[(size_t)n] * trig(c, n);
+                        num += t * (double)wf[(size_t)(c * L + n)];
+                        den += t * t;
+                    }
+                    if (!(den > 0)) return false;  // e.g. a sine row at bin 0: identically zero model, non-zero row
+                    const double na = num / den;
+                    change = std::max(change, std::fabs(na - amp[(size_t)c]) / std::max(std::fabs(na), 1e-300));
+                    amp[(size_t)c] = na;
+                }
+                if (it > 0 && change < 1e-11) break;
+            }
+            return true;
+        };
+        // stage 1: rows whose spectral peak is unambiguous (bins 3 .. L/2 - 3: near DC and Nyquist the two mirror
+        // lobes of a windowed sinusoid overlap and the peak can sit one bin off) give a first window estimate
+        int64_t n_sure = 0;
+        for (int64_t c = 0; c < Cout; c++) {
+            use[(size_t)c] = live[(size_t)c] && bank.k[(size_t)c] >= 3 && bank.k[(size_t)c] <= L / 2 - 3;
+            n_sure += use[(size_t)c];
+            if (live[(size_t)c]) init_amp(c);
+        }
+        if (n_sure == 0)
+            for (int64_t c = 0; c < Cout; c++) use[(size_t)c] = live[(size_t)c];
+        // The amplitude SIGNS are unknown at this point (exporters write -sin rows next to +cos rows: with all-positive
+        // starting amplitudes the cos^2 and sin^2 contributions to a least-squares window cancel), so the first window
+        // comes from energies, which do not see signs: sum_c R_c[n]^2 = w[n]^2 sum_c a_c^2 t_c[n]^2, w >= 0 as every
+        // analysis window in use is.  The first amplitude step then settles the signs.
+        {
+            double wmax = 0;
+            for (int64_t n = 0; n < L; n++) {
+                double num = 0, den = 0;
+                for (int64_t c = 0; c < Cout; c++) {
+                    if (!use[(size_t)c]) continue;
+                    const double t = amp[(size_t)c] * trig(c, n), r = (double)wf[(size_t)(c * L + n)];
+                    num += r * r;
+                    den += t * t;
+                }
+                win[(size_t)n] = den > 0 ? std::sqrt(num / den) : 0.0;
+                wmax = std::max(wmax, win[(size_t)n]);
+            }
+            if (!(wmax > 0)) return false;
+            for (double &v : win) v /= wmax;
+            for (int64_t c = 0; c < Cout; c++) {
+                if (!use[(size_t)c]) continue;
+                double num = 0, den = 0;
+                for (int64_t n = 0; n < L; n++) {
+                    const double t = win[(size_t)n] * trig(c, n);
+                    num += t * (double)wf[(size_t)(c * L + n)];
+                    den += t * t;
+                }
+                if (!(den > 0)) return false;
+                amp[(size_t)c] = num / den;
+            }
+        }
+        if (!als(3)) return false;
+        // stage 2: every row's bin re-decided among the neighbours of its peak by the least-squares residual against
+        // that window
+        for (int64_t c = 0; c < Cout; c++) {
+            if (!live[(size_t)c]) continue;
+            const int k0 = bank.k[(size_t)c];
+            int best = k0;
+            double best_res = INFINITY;
+            for (int k = std::max(0, k0 - 2); k <= std::min<int>((int)(L / 2), k0 + 2); k++) {
+                bank.k[(size_t)c] = k;
+                double num = 0, den = 0;
+                for (int64_t n = 0; n < L; n++) {
+                    const double t = win[(size_t)n] * trig(c, n);
+                    num += t * (double)wf[(size_t)(c * L + n)];
+                    den += t * t;
+                }
+                const double res = den > 0 ? energy[(size_t)c] - num * num / den : INFINITY;
+                if (res < best_res) { best_res = res; best = k; }
+            }
+            if (getenv("BN_STFT_DEBUG") && (c < 4 || best != k0))
+                fprintf(stderr, "stft: row %lld %s peak bin %d -> %d (residual %.3g of energy %.3g)\n", (long long)c, is_sin[(size_t)c] ? "sin" : "cos", k0, best,
+                        best_res, energy[(size_t)c]);
+            bank.k[(size_t)c] = best;
+            {  // amplitude (with its sign) against the stage-1 window
+                double num = 0, den = 0;
+                for (int64_t n = 0; n < L; n++) {
+                    const double t = win[(size_t)n] * trig(c, n);
+                    num += t * (double)wf[(size_t)(c * L + n)];
+                    den += t * t;
+                }
+                if (!(den > 0)) return false;
+                amp[(size_t)c] = num / den;
+            }
+            use[(size_t)c] = 1;
+        }
+        // stage 3: all rows
+        if (!als(40)) return false;
+        // the window in f32 (what the kernel multiplies by); amplitudes refitted against the rounded window, then verify
+        bank.window.resize((size_t)L);
+        for (int64_t n = 0; n < L; n++) bank.window[(size_t)n] = (float)win[(size_t)n];
+        for (int64_t c = 0; c < Cout; c++) {
+            if (!live[(size_t)c]) continue;
+            for (int64_t n = 0; n < L; n++) {
+                const double model = amp[(size_t)c] * win[(size_t)n] * trig(c, n);
+                if (!(std::fabs(model - (double)wf[(size_t)(c * L + n)]) <= tol * rowmax[(size_t)c])) {
+                    if (getenv("BN_STFT_DEBUG"))
+                        fprintf(stderr, "stft: row %lld (bin %d, %s) tap %lld: model %.9g vs %.9g (row max %.3g)\n", (long long)c, bank.k[(size_t)c],
+                                is_sin[(size_t)c] ? "sin" : "cos", (long long)n, model, (double)wf[(size_t)(c * L + n)], rowmax[(size_t)c]);
+                    return false;
+                }
+            }
+            if (is_sin[(size_t)c]) bank.b[(size_t)c] = amp[(size_t)c];
+            else bank.a[(size_t)c] = amp[(size_t)c];
+        }
+        return true;
+    }
+    // digit-reversed position of output k of an in-place DIF transform with the given radix sequence
+    static int dif_position(int k, int n, const std::vector<int> &radix, size_t idx) {
+        if (n == 1) return 0;
+        const int r = radix[idx];
+        return (k % r) * (n / r) + dif_position(k / r, n / r, radix, idx + 1);
+    }
+    bool emit_stft(const OnnxNode &n, const PlanOp &base, const DftBank &bank, int64_t Cout, int64_t OW, bool has_bias) {
+        // Opt-in for now (BN_STFT=1): correct for every supported size, but at batch 32 the launch pair of the v2.4 front
+        // end takes 189 us against 178 us for the folded GEMMs + mel GEMMs + normalisation pass it replaces, and 41.9 k
+        // against 44.5 k segments/s with four contexts (latency-bound at two waves per SIMD).
+        const char *env = getenv("BN_STFT");
+        if (!env || std::string(env) != "1") return false;
+        const GemmDesc &g = base.gemm;
+        if (g.act != ACT_NONE || g.has_res || g.has_scale || g.lda <= 0 || g.lda > 4096 || g.ldc != Cout) return false;
+        const int L = (int)bank.L, M = L / 2;
+        PlanOp op;
+        op.kind = OpKind::FFT;
+        op.name = "stft:" + n.name;
+        op.out = base.out;
+        op.a = base.a;
+        op.bias = base.bias;
+        FftDesc &d = op.fft;
+        d.L = L; d.M = M; d.hop = (int32_t)g.lda; d.frames = (int32_t)OW; d.nout = (int32_t)Cout;
+        d.logM = 0;
+        while ((1 << d.logM) < M) d.logM++;
+        d.F = 1024 / M;
+        // frames per tile: as many as keep the tile's signal span within the kernel's staging registers (8192 floats)
+        d.tpb = 16;
+        while (d.tpb > d.F && (int64_t)(d.tpb - 1) * g.lda + L > 8192) d.tpb /= 2;
+        if ((int64_t)(d.tpb - 1) * g.lda + L > 8192 || d.tpb % d.F) return false;
+        d.a_bs = g.a_bs; d.ldc = g.ldc; d.c_bs = g.c_bs; d.has_bias = has_bias ? 1 : 0;
+        d.out_rs = g.ldc; d.out_cs = 1;
+        // pass structure: radix 2 first when log2 M is odd, radix 4 down to 16-point blocks (registers)
+        std::vector<int> radix;
+        std::vector<float> tw;
+        int nn = M;
+        d.npass = 0;
+        while (nn > 16) {
+            const int r = (d.npass == 0 && (d.logM & 1)) ? 2 : 4;
+            const int q = nn / r;
+            d.pass_n[d.npass] = nn; d.pass_r[d.npass] = r; d.pass_tw[d.npass] = (int32_t)(tw.size() / 2);
+            for (int pw = 1; pw < r; pw++)
+                for (int j = 0; j < q; j++) {
+                    const double ang = -2.0 * M_PI * (double)((int64_t)j * pw % nn) / (double)nn;
+                    tw.push_back((float)std::cos(ang));
+                    tw.push_back((float)std::sin(ang));
+                }
+            radix.push_back(r);
+            nn = q;
+            d.npass++;
+        }
+        if (nn != 16 || d.npass > 4) return false;
+        radix.push_back(4);
+        radix.push_back(4);
+        d.tw_count = (int32_t)(tw.size() / 2);
+        if (stft_lds_bytes(d, 8) > 156 * 1024) return false;
+        // per-output table
+        std::vector<float> otab((size_t)Cout * 8, 0.0f);  // per output: positions of Z[k], Z[M-k] (as floats), 4 coefficients, 2 pad
+        auto physpos = [&](int k) {
+            const int pp = dif_position(k, M, radix, 0);
+            return pp + 2 * (pp >> 4);
+        };
+        for (int64_t c = 0; c < Cout; c++) {
+            const int k = bank.k[(size_t)c];
+            const double a = bank.a[(size_t)c], b = bank.b[(size_t)c];
+            const double th = 2.0 * M_PI * (double)k / (double)L, cs = std::cos(th), sn = std::sin(th);
+            float *e = &otab[(size_t)c * 8];
+            e[0] = (float)physpos(k % M);
+            e[1] = (float)physpos((M - k % M) % M);
+            e[2] = (float)(0.5 * (a * (1.0 - sn) + b * cs));
+            e[3] = (float)(0.5 * (a * cs - b * (1.0 - sn)));
+            e[4] = (float)(0.5 * (a * (1.0 + sn) - b * cs));
+            e[5] = (float)(0.5 * (a * cs + b * (1.0 + sn)));
+        }
+        op.w = Ref{Space::CONSTS, add_const(bank.window), 0};
+        op.w2 = Ref{Space::CONSTS, add_const(tw), 0};
+        op.bias2 = Ref{Space::CONSTS, add_const(otab), 0};
+        double log2L = 0;
+        while ((1 << (int)log2L) < L) log2L += 1;
+        op.flops_fft = (double)OW * 2.5 * L * log2L;
+        op.macs = op.flops_fft / 2;  // multiply-add equivalents actually performed (vector ALU)
+        op.mfma = false;
+        op.weight_bytes = 4.0 * (bank.window.size() + tw.size() + otab.size() + (has_bias ? Cout : 0));
+        op.bytes = base.bytes;
+        dft_gemm_macs_ += (double)OW * Cout * L;  // what the matrix-product evaluation of this bank multiplies
+        push_op(std::move(op));
+        return true;
+    }
+
     // ------------------------------------------------------------- folded framing convolutions
     // A long single-channel 1-D filter bank whose rows are symmetric (w[n] == w[L-n], windowed cosine bases) or
     // antisymmetric (w[n] == -w[L-n], windowed sine bases) about the frame centre, with w[0] == 0 (Hann-type
@@ -602,6 +914,10 @@ class Builder {
             if (!sym && !anti) return false;
             cls[(size_t)o] = (sym && anti) ? 0 : (sym ? 1 : -1);  // 0: an all-zero row joins either neighbour
         }
+        {
+            DftBank bank;
+            if (detect_dft_bank(wf, Cout, L, cls, bank) && emit_stft(n, base, bank, Cout, OW, has_bias)) return true;
+        }
         struct Run { int64_t n0, n1; int sign; };
         std::vector<Run> runs;
         for (int64_t o = 0; o < Cout; o++) {
@@ -612,6 +928,7 @@ class Builder {
             } else runs.push_back(Run{o, o + 1, c});
         }
         if (runs.size() > 4) return false;
+        dft_gemm_macs_ += (double)OW * Cout * L;
         const int64_t K = L / 2;
         for (const Run &r : runs) {
             const int sign = r.sign == 0 ? 1 : r.sign;
@@ -2090,6 +2407,7 @@ class Builder {
     void all_refs(PlanOp &op, std::vector<Ref *> &out) {
         out = {&op.out, &op.a, &op.b, &op.res, &op.scale, &op.w2, &op.bias2};
         for (auto &r : op.eb) out.push_back(&r);
+        for (auto &r : op.x) out.push_back(&r);
     }
     void recompute_liveness() {
         for (auto &st : plan_.storages) { st.first = -1; st.last = -1; }
@@ -2224,8 +2542,133 @@ class Builder {
             }
         }
         absorb_chains_into_gemms();
+        absorb_into_stft();
         pair_minmax_reductions();
         recompute_liveness();
+    }
+
+    // (G) Neighbours of an STFT launch move into it:
+    //  * the mel filter bank -- a GEMM over the spectrum rows with a SPARSE constant matrix (triangular filters: a few
+    //    bins per band) -- together with whatever rule E put into that GEMM's epilogue (compression chain, layout copy
+    //    into the spectrogram image): the spectrum rows never leave LDS.  BN_STFT_MEL=0 disables.
+    //  * the elementwise chain that produced the signal, when every stage operand is one number per sample (the
+    //    min-max normalisation of the v2.4 graph) and every reader of its result is an STFT launch: the chain runs
+    //    while the span is loaded, the normalised segment is never written.  BN_STFT_PRE=0 disables.
+    void absorb_into_stft() {
+        const bool mel_on = !(getenv("BN_STFT_MEL") && std::string(getenv("BN_STFT_MEL")) == "0");
+        const bool pre_on = !(getenv("BN_STFT_PRE") && std::string(getenv("BN_STFT_PRE")) == "0");
+        auto users_of = [&]() {
+            std::vector<std::vector<int>> users(plan_.storages.size());
+            std::vector<Ref *> refs;
+            for (size_t k = 0; k < plan_.ops.size(); k++) {
+                all_refs(plan_.ops[k], refs);
+                for (Ref *r : refs)
+                    if (r->space == Space::ARENA && (users[r->id].empty() || users[r->id].back() != (int)k)) users[r->id].push_back((int)k);
+            }
+            return users;
+        };
+        bool changed = mel_on;
+        while (changed) {
+            changed = false;
+            auto users = users_of();
+            for (size_t i = 0; i < plan_.ops.size() && !changed; i++) {
+                PlanOp &f = plan_.ops[i];
+                if (f.kind != OpKind::FFT || f.fft.nmel || f.out.space != Space::ARENA || plan_.storages[f.out.id].pinned) continue;
+                const auto &u = users[f.out.id];
+                if (u.size() != 2 || u[0] != (int)i) continue;
+                PlanOp &g = plan_.ops[u[1]];
+                const GemmDesc &gd = g.gemm;
+                if (g.kind != OpKind::GEMM || g.a.space != Space::ARENA || g.a.id != f.out.id || g.a.offset != f.out.offset) continue;
+                if (gd.fold || gd.has_scale || gd.has_res || gd.rows != f.fft.frames || gd.K != f.fft.nout || gd.lda != gd.K || gd.a_bs != f.fft.c_bs ||
+                    f.fft.ldc != f.fft.nout || g.w.space != Space::CONSTS)
+                    continue;
+                bool stages_ok = stft_act_supported(gd.act);
+                for (int q = 0; q < gd.npost; q++) stages_ok = stages_ok && stft_act_supported(gd.post_act[q]);
+                if (!stages_ok) continue;
+                const std::vector<float> &W = plan_.consts[g.w.id];  // [N][K]
+                const int64_t N = gd.N, K = gd.K;
+                std::vector<float> mstart, ment;  // row starts; (column, value) pairs
+                for (int64_t nn = 0; nn < N; nn++) {
+                    mstart.push_back((float)(ment.size() / 2));
+                    for (int64_t k = 0; k < K; k++) {
+                        const float v = W[(size_t)(g.w.offset + nn * K + k)];
+                        if (v != 0.0f) { ment.push_back((float)k); ment.push_back(v); }
+                    }
+                }
+                mstart.push_back((float)(ment.size() / 2));
+                const size_t nnz_count = ment.size() / 2;
+                if ((double)nnz_count > 0.3 * (double)N * (double)K || nnz_count >= (1u << 23) || N > 1024) continue;  // dense: stays a GEMM
+                FftDesc probe = f.fft;
+                probe.nmel = (int32_t)N;
+                probe.mel_nnz = (int32_t)nnz_count;
+                if (stft_lds_bytes(probe, 8) > 156 * 1024) continue;
+                FftDesc &d = f.fft;
+                d.nmel = (int32_t)N;
+                d.mel_nnz = (int32_t)nnz_count;
+                if (ment.empty()) { ment.push_back(0.0f); ment.push_back(0.0f); }
+                d.mel_has_bias = gd.has_bias;
+                d.mel_act = gd.act; d.mel_p0 = gd.p0; d.mel_p1 = gd.p1;
+                d.npost = gd.npost;
+                for (int q = 0; q < 4; q++) { d.post_act[q] = gd.post_act[q]; d.post_p0[q] = gd.post_p0[q]; d.post_p1[q] = gd.post_p1[q]; }
+                d.c_bs = gd.c_bs;
+                if (gd.out_strided) { d.out_rs = gd.out_rs; d.out_cs = gd.out_cs; }
+                else { d.out_rs = gd.ldc; d.out_cs = 1; }
+                f.x[0] = Ref{Space::CONSTS, add_const(mstart), 0};
+                f.x[1] = Ref{Space::CONSTS, add_const(ment), 0};
+                f.x[3] = g.bias;
+                f.out = g.out;
+                f.name += "+" + g.name;
+                const double nnz = (double)nnz_count;
+                f.flops_fft += 2.0 * nnz * (double)d.frames;
+                f.macs += nnz * (double)d.frames;
+                f.weight_bytes += 4.0 * (mstart.size() + ment.size());
+                f.bytes += g.bytes - 8.0 * (double)d.frames * (double)d.nout;  // the spectrum rows never touch memory
+                dft_gemm_macs_ += g.macs;  // the dense mel product belongs to the matrix-product count of the front end
+                plan_.ops.erase(plan_.ops.begin() + u[1]);
+                changed = true;
+            }
+        }
+        changed = pre_on;
+        while (changed) {
+            changed = false;
+            auto users = users_of();
+            for (size_t e = 0; e < plan_.ops.size() && !changed; e++) {
+                PlanOp &el = plan_.ops[e];
+                const EltDesc &ed = el.elt;
+                if (el.kind != OpKind::ELT || el.out.space != Space::ARENA || plan_.storages[el.out.id].pinned) continue;
+                if (ed.nd != 1 || ed.so[0] != 1 || ed.sa[0] != 1 || el.out.offset != 0) continue;
+                bool scalar_ops = true;
+                for (int k = 0; k < ed.nstages; k++)
+                    scalar_ops = scalar_ops && stft_act_supported(ed.st[k].act) &&
+                                 (ed.st[k].bin == BIN_NONE || (ed.st[k].sb[0] == 0 && !ed.st[k].bsq && stft_bin_supported(ed.st[k].bin)));
+                if (!scalar_ops) continue;
+                const auto &u = users[el.out.id];
+                if (u.size() < 2 || u[0] != (int)e) continue;
+                bool all_fft = true;
+                for (size_t q = 1; q < u.size(); q++) {
+                    const PlanOp &f = plan_.ops[u[q]];
+                    all_fft = all_fft && f.kind == OpKind::FFT && f.fft.npre == 0 && f.a.space == Space::ARENA && f.a.id == el.out.id && f.a.offset == 0 &&
+                              f.fft.a_bs == ed.bo && (int64_t)(f.fft.frames - 1) * f.fft.hop + f.fft.L <= ed.per_sample;
+                    // (the STFT must read the chain's result only through `a`)
+                    for (const Ref &r : f.eb) all_fft = all_fft && !(r.space == Space::ARENA && r.id == el.out.id);
+                }
+                if (!all_fft) continue;
+                for (size_t q = 1; q < u.size(); q++) {
+                    PlanOp &f = plan_.ops[u[q]];
+                    f.a = el.a;
+                    f.fft.a_bs = ed.ba;
+                    f.fft.npre = ed.nstages;
+                    for (int k = 0; k < ed.nstages; k++) {
+                        f.fft.pre_bin[k] = ed.st[k].bin; f.fft.pre_act[k] = ed.st[k].act;
+                        f.fft.pre_p0[k] = ed.st[k].p0; f.fft.pre_p1[k] = ed.st[k].p1; f.fft.pre_bb[k] = ed.st[k].bb;
+                        f.eb[k] = el.eb[k];
+                    }
+                    f.name = el.name + "+" + f.name;
+                }
+                plan_.ops.erase(plan_.ops.begin() + (long)e);
+                changed = true;
+            }
+        }
     }
 
     // (F) The chunk stages of a whole-range min and a whole-range max over the SAME input (the min-max normalisation

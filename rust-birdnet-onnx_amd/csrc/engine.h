@@ -28,13 +28,14 @@ struct Ref {
     int64_t offset = 0;  // elements (per sample for INPUT/ARENA)
 };
 
-enum class OpKind : int32_t { ELT, REDUCE, GEMM, CONV, DWCONV, GAP, SEFC, MBCONV, POOL };
+enum class OpKind : int32_t { ELT, REDUCE, GEMM, CONV, DWCONV, GAP, SEFC, MBCONV, POOL, FFT };
 
 struct PlanOp {
     OpKind kind;
     std::string name;
     Ref out, a, b, w, bias, res, scale, w2, bias2;
-    Ref eb[ELT_MAX_STAGES];  // ELT: second operand of each chain stage
+    Ref eb[ELT_MAX_STAGES];  // ELT: second operand of each chain stage; FFT: operands of the absorbed prologue chain
+    Ref x[4];                // FFT: mel filter bank in CSR form (row starts, columns, values) and its bias
     EltDesc elt{};
     ReduceDesc red{};
     GemmDesc gemm{};
@@ -44,6 +45,8 @@ struct PlanOp {
     SeFcDesc se{};
     MbDesc mb{};
     PoolDesc pool{};
+    FftDesc fft{};
+    double flops_fft = 0;   // FFT: algorithmic flops per sample counted as an FFT (2.5 L log2 L per real frame) + sparse mel
     double macs = 0;        // per sample
     double macs_mfma_extra = 0;  // MBCONV: the expand part runs on the matrix cores
     double bytes = 0;       // algorithmic bytes read+written per sample (weights excluded)
@@ -85,6 +88,9 @@ struct Plan {
     std::vector<OutputInfo> outputs;
     IoMeta io;
     double macs_mfma = 0, macs_valu = 0, act_bytes = 0, weight_bytes = 0;
+    // Front end counted two ways: the multiply-adds a DFT-as-matrix-product evaluation of the planned
+    // filter banks performs (dft_gemm_macs: what the GEMM fallback runs) and the flops of the FFT formulation
+    double dft_gemm_macs = 0, fft_flops = 0;
 };
 
 // wanted_outputs: graph output indices that must be computed (others are dead code).

@@ -226,6 +226,46 @@ void launch_windows(hipStream_t s, float *dst, const void *src, int32_t is_i16, 
 // polyphase FIR resampler: table [L][T], output n reads phase (n*M)%L at source position (n*M)/L
 void launch_resample(hipStream_t s, float *dst, const void *src, int32_t is_i16, const float *table, uint64_t n_src, uint64_t n_dst, uint32_t L, uint32_t M,
                      uint32_t T);
+// Windowed-DFT filter bank as a real FFT (stft.hip).  Frames of L samples (L = 2 M, M a power of two in 64..1024) at
+// `hop`, per sample `frames` of them; a wave transforms F = 1024 / M frames at a time in place in LDS: `npass`
+// strided decimation-in-frequency passes (sub-problem size pass_n, radix pass_r, twiddles at tw + pass_tw), then
+// 16-point blocks in registers.  Output c (< nout) = otab[c] . (Re Z[k], Im Z[k], Re Z[M-k], Im Z[M-k]) read at
+// two precomputed buffer positions.  Optional stages around it: a per-sample scalar elementwise chain on the signal
+// (npre), a sparse mel filter bank (nmel rows in CSR form) with the GEMM-style post chain and strided store.
+struct FftDesc {
+    int32_t L, M, logM, hop, frames, nout;
+    int32_t tpb, F;  // frames per block, frames per wave pass
+    int32_t npass, pass_n[4], pass_r[4], pass_tw[4], tw_count;
+    int64_t a_bs;
+    int32_t a_vec4;  // set by the launcher
+    int32_t dbg;     // experiments (BN_STFT_DBG bit mask, set by the launcher): skip phases to time the rest
+    int32_t npre, pre_bin[ELT_MAX_STAGES], pre_act[ELT_MAX_STAGES];
+    float pre_p0[ELT_MAX_STAGES], pre_p1[ELT_MAX_STAGES];
+    int64_t pre_bb[ELT_MAX_STAGES];
+    int64_t ldc, c_bs;
+    int32_t has_bias;
+    int32_t nmel, mel_nnz, mel_has_bias, mel_act;
+    float mel_p0, mel_p1;
+    int32_t npost, post_act[4];
+    float post_p0[4], post_p1[4];
+    int64_t out_rs, out_cs;  // mel element (t, m) of sample b is stored at out + b*c_bs + t*out_rs + m*out_cs
+};
+struct StftPtrs {
+    float *out;
+    const float *in;
+    const float *window;  // [L]
+    const float2 *tw;     // [tw_count]
+    const float *otab;    // [nout][8]: position of Z[k], position of Z[M-k] (as floats), 4 coefficients, 2 pad
+    const float *bias;    // [nout] or NULL
+    const float *pre[ELT_MAX_STAGES];
+    const float *mstart, *mcol, *mval, *mel_bias;  // CSR of the mel filter bank: row starts, (column, value) pairs in mcol (indices stored as floats); mval unused
+};
+// stage codes stft_kernel implements (a compact subset: no libm bodies); the planner absorbs only chains made of these
+inline bool stft_act_supported(int act) { return act != ACT_TANH && act != ACT_ERF && act != ACT_SOFTPLUS && act != ACT_HSIGMOID && act != ACT_HSWISH; }
+inline bool stft_bin_supported(int bin) { return bin != BIN_POW; }
+void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t batch);
+size_t stft_lds_bytes(const FftDesc &d, int nwaves);
+
 void launch_null(hipStream_t s);  // empty kernel (timing calibration)
 
 // A launcher that is handed a layout its kernel cannot take (a caller's device pointer without the required

@@ -1,0 +1,526 @@
+// Windowed-DFT filter bank as a real FFT (gfx950, wave64).
+//
+// The exporters write the STFT of the audio front end as a strided 1-D convolution whose filters are
+// window[n] * cos(2 pi k n / L) and -window[n] * sin(2 pi k n / L) (reference: the graph ORT executes at
+// src/classifier.rs:637-639, 721-723, 851-853).  Evaluated as a matrix product that is
+// O(L) multiplications per output bin; this kernel computes the same numbers with ONE real FFT per frame:
+//
+//   block = (sample, TPB consecutive frames)
+//   1. the PCM span the frames cover ((TPB-1)*hop + L samples; frames overlap, hop << L) is read ONCE from HBM with
+//      coalesced 16-byte loads into LDS; an absorbed per-sample normalisation chain (min-max scaling of the v2.4
+//      graph) is applied on the way
+//   2. a wave transforms 1024/M frames at a time (M = L/2): the windowed frame is packed as M complex numbers
+//      z[m] = y[2m] + i y[2m+1], transformed IN PLACE in LDS by decimation-in-frequency passes (radix 4, one radix-2
+//      pass first when log2 M is odd) down to 16-point sub-problems, which every lane finishes in registers; the
+//      result sits in digit-reversed order, which costs nothing because
+//   3. only the bins the mel filter bank uses are produced: output c is a fixed linear combination
+//      a*Z[k] + b*Z*[M-k] ("untangling" the packed transform, folded with the filter's own amplitude and phase)
+//      of two LDS positions, both precomputed at plan time
+//   4. optionally the mel filter bank (sparse: triangles), its compression chain and the layout copy into the CNN's
+//      input image follow in the same launch (spectrum and mel rows stay in LDS)
+//
+// Per frame: 5 M log2 M flops instead of 2 L nbins; LDS traffic ~ 80 KB.  Numerics: the FFT's rounding error grows
+// with log2 L instead of L; the filters themselves are taken as exactly window x cosine (the plan-time detector
+// accepts a bank only if every tap agrees within f32 rounding).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace bn {
+namespace {
+
+constexpr int WBUF = 1024 + 128;  // complex slots of one wave's transform buffer: 64 blocks of 16 + 2 slots of padding each
+
+__device__ __forceinline__ int phys(int i) { return i + 2 * (i >> 4); }
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x); }
+
+// forward radix-4 butterfly (omega_4 = -i): v_p = sum_m u_m omega_4^(m p)
+__device__ __forceinline__ void bfly4(float2 &u0, float2 &u1, float2 &u2, float2 &u3) {
+    const float2 t0 = make_float2(u0.x + u2.x, u0.y + u2.y), t1 = make_float2(u0.x - u2.x, u0.y - u2.y);
+    const float2 t2 = make_float2(u1.x + u3.x, u1.y + u3.y);
+    const float2 t3 = make_float2(u1.y - u3.y, -(u1.x - u3.x));  // -i (u1 - u3)
+    u0 = make_float2(t0.x + t2.x, t0.y + t2.y);
+    u2 = make_float2(t0.x - t2.x, t0.y - t2.y);
+    u1 = make_float2(t1.x + t3.x, t1.y + t3.y);
+    u3 = make_float2(t1.x - t3.x, t1.y - t3.y);
+}
+
+// one in-place DIF pass over the wave's 1024 slots: sub-problems of size n, radix R, twiddles tw[(p-1)*q + j].
+// Two butterflies per lane are in flight at a time (register budget: 256 per lane at 8 waves per CU).
+template <int R>
+__device__ __forceinline__ void strided_pass(float2 *__restrict__ x, const float2 *__restrict__ tw, int logn, int lane) {
+    constexpr int LR = R == 4 ? 2 : 1;
+    const int lq = logn - LR, q = 1 << lq;
+    constexpr int PER_LANE = 1024 / R / 64, INFL = 4;
+#pragma unroll 1
+    for (int h = 0; h < PER_LANE; h += INFL) {
+        float2 u[INFL][R];
+        int base[INFL], j[INFL];
+#pragma unroll
+        for (int t = 0; t < INFL; t++) {
+            const int g = lane + 64 * (h + t);
+            j[t] = g & (q - 1);
+            base[t] = ((g >> lq) << logn) + j[t];
+#pragma unroll
+            for (int m = 0; m < R; m++) u[t][m] = x[phys(base[t] + m * q)];
+        }
+#pragma unroll
+        for (int t = 0; t < INFL; t++) {
+            if constexpr (R == 4) {
+                const float2 w1 = tw[j[t]], w2 = tw[q + j[t]], w3 = tw[2 * q + j[t]];
+                bfly4(u[t][0], u[t][1], u[t][2], u[t][3]);
+                x[phys(base[t])] = u[t][0];
+                x[phys(base[t] + q)] = cmul(u[t][1], w1);
+                x[phys(base[t] + 2 * q)] = cmul(u[t][2], w2);
+                x[phys(base[t] + 3 * q)] = cmul(u[t][3], w3);
+            } else {
+                const float2 w1 = tw[j[t]];
+                x[phys(base[t])] = make_float2(u[t][0].x + u[t][1].x, u[t][0].y + u[t][1].y);
+                x[phys(base[t] + q)] = cmul(make_float2(u[t][0].x - u[t][1].x, u[t][0].y - u[t][1].y), w1);
+            }
+        }
+    }
+}
+
+// the last two radix-4 passes (n = 16, n = 4) of one 16-slot block, in registers
+__device__ __forceinline__ void block16(float2 *__restrict__ blk) {
+    float2 x[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const float4 v = *reinterpret_cast<const float4 *>(blk + 2 * i);
+        x[2 * i] = make_float2(v.x, v.y);
+        x[2 * i + 1] = make_float2(v.z, v.w);
+    }
+    // n = 16, q = 4: element j + 4p <- v_p * omega_16^(j p)
+    constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, R2 = 0.70710678118654752440f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        bfly4(x[j], x[j + 4], x[j + 8], x[j + 12]);
+        if (j == 1) {
+            x[5] = cmul(x[5], make_float2(C1, -S1));
+            x[9] = cmul(x[9], make_float2(R2, -R2));
+            x[13] = cmul(x[13], make_float2(S1, -C1));
+        } else if (j == 2) {
+            x[6] = cmul(x[6], make_float2(R2, -R2));
+            x[10] = make_float2(x[10].y, -x[10].x);  // omega_16^4 = -i
+            x[14] = cmul(x[14], make_float2(-R2, -R2));
+        } else if (j == 3) {
+            x[7] = cmul(x[7], make_float2(S1, -C1));
+            x[11] = cmul(x[11], make_float2(-R2, -R2));
+            x[15] = cmul(x[15], make_float2(-C1, S1));  // omega_16^9
+        }
+    }
+    // n = 4, q = 1: no twiddles
+#pragma unroll
+    for (int b4 = 0; b4 < 4; b4++) bfly4(x[4 * b4], x[4 * b4 + 1], x[4 * b4 + 2], x[4 * b4 + 3]);
+#pragma unroll
+    for (int i = 0; i < 8; i++) *reinterpret_cast<float4 *>(blk + 2 * i) = make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y);
+}
+
+// Stage functions of the absorbed chains, COMPACT on purpose: the generic act_array_all / bin_array dispatchers inline
+// libm (tanhf, erff, powf, ...) for every instantiation -- with nine stage slots that made this kernel 676 KB of code,
+// and walking through it ran at instruction-fetch speed (a 4-stage chain over 16 floats per thread cost 19 us per
+// tile).  Only codes with a few-instruction body are accepted here (kernels.h, stft_stage_supported: the planner
+// absorbs nothing else), dispatched by compare chains on the launch-uniform code.
+__device__ __forceinline__ float pow_compact(float x, float p) {
+    // x^p without libm: exp2(p log2 |x|) (hardware exp2 / log2, ~1e-6 relative), the sign and the special cases by hand
+    const float ax = fabsf(x);
+    float r = __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(ax));
+    if (x < 0.0f) {
+        const float fl = floorf(p);
+        if (fl != p) r = __builtin_nanf("");                 // negative base, non-integer exponent
+        else if (fl * 0.5f != floorf(fl * 0.5f)) r = -r;     // odd integer exponent keeps the sign
+    }
+    if (p == 0.0f) r = 1.0f;
+    return r;
+}
+// ONE dispatch per stage for a whole register array (the code is launch-uniform): a compare chain per element would
+// be re-evaluated, operands reloaded, for every value.
+template <int N>
+__device__ __forceinline__ void act_small(int act, float p0, float p1, float (&v)[N]) {
+    if (act == ACT_NONE) return;
+    if (act == ACT_AFFINE) map_array<N>(v, [=](float x) { return p0 * x + p1; });
+    else if (act == ACT_SQUARE) map_array<N>(v, [](float x) { return x * x; });
+    else if (act == ACT_POW) map_array<N>(v, [=](float x) { return pow_compact(x, p0); });
+    else if (act == ACT_LOG) map_array<N>(v, [](float x) { return net_log(x); });
+    else if (act == ACT_EXP) map_array<N>(v, [](float x) { return net_exp(x); });
+    else if (act == ACT_SQRT) map_array<N>(v, [](float x) { return sqrtf(x); });
+    else if (act == ACT_ABS) map_array<N>(v, [](float x) { return fabsf(x); });
+    else if (act == ACT_MAXC) map_array<N>(v, [=](float x) { return fmaxf(x, p0); });
+    else if (act == ACT_MINC) map_array<N>(v, [=](float x) { return fminf(x, p0); });
+    else if (act == ACT_RELU) map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); });
+    else if (act == ACT_CLIP) map_array<N>(v, [=](float x) { return fminf(fmaxf(x, p0), p1); });
+    else if (act == ACT_NEG) map_array<N>(v, [](float x) { return -x; });
+    else if (act == ACT_RECIP) map_array<N>(v, [](float x) { return 1.0f / x; });
+    else if (act == ACT_RSUB) map_array<N>(v, [=](float x) { return p0 - x; });
+    else if (act == ACT_RDIV) map_array<N>(v, [=](float x) { return p0 / x; });
+    else if (act == ACT_SIGMOID) map_array<N>(v, [](float x) { return net_sigmoid(x); });
+    else if (act == ACT_SILU) map_array<N>(v, [](float x) { return x * net_sigmoid(x); });
+    else if (act == ACT_LEAKY) map_array<N>(v, [=](float x) { return x >= 0.0f ? x : p0 * x; });
+    else if (act == ACT_FLOOR) map_array<N>(v, [](float x) { return floorf(x); });
+    else if (act == ACT_CEIL) map_array<N>(v, [](float x) { return ceilf(x); });
+}
+template <int N>
+__device__ __forceinline__ void bin_small(int bin, float b, float (&v)[N]) {
+    if (bin == BIN_ADD) map_array<N>(v, [=](float a) { return a + b; });
+    else if (bin == BIN_SUB) map_array<N>(v, [=](float a) { return a - b; });
+    else if (bin == BIN_MUL) map_array<N>(v, [=](float a) { return a * b; });
+    else if (bin == BIN_DIV) map_array<N>(v, [=](float a) { return a / b; });
+    else if (bin == BIN_MAX) map_array<N>(v, [=](float a) { return fmaxf(a, b); });
+    else if (bin == BIN_MIN) map_array<N>(v, [=](float a) { return fminf(a, b); });
+}
+
+// The absorbed per-sample chain: up to four stages  v = act(bin(v, scalar)).  All indices are literals so that the
+// fields stay in registers.
+struct PreChain {
+    int n, bin[4], act[4];
+    float sc[4], p0[4], p1[4];
+};
+template <int S, int N>
+__device__ __forceinline__ void pre_stage(const PreChain &c, float (&v)[N]) {
+    if (S < c.n) {
+        bin_small<N>(c.bin[S], c.sc[S], v);
+        act_small<N>(c.act[S], c.p0[S], c.p1[S], v);
+    }
+}
+template <int N>
+__device__ __forceinline__ void pre_chain(const PreChain &c, float (&v)[N]) {
+    pre_stage<0, N>(c, v);
+    pre_stage<1, N>(c, v);
+    pre_stage<2, N>(c, v);
+    pre_stage<3, N>(c, v);
+}
+
+// LDS carve-up (floats), shared by the kernel and stft_lds_bytes.  Table regions are whole KiB: the asynchronous
+// global -> LDS copies write 1 KiB per wave instruction.
+struct StftLds {
+    int sig, tw, wbuf, window, otab, mstart, ment, spec, mel, total;
+};
+__host__ __device__ __forceinline__ int kib(int floats) { return (floats + 255) & ~255; }
+__host__ __device__ __forceinline__ StftLds stft_layout(const FftDesc &d, int nw) {
+    StftLds l;
+    int o = 0;
+    l.sig = o; o += ((d.tpb - 1) * d.hop + d.L + 3) & ~3;
+    l.wbuf = o; o += 2 * nw * WBUF;
+    l.tw = o; o += kib(2 * d.tw_count);
+    l.window = o; o += kib(d.L);
+    l.otab = o; o += kib(8 * d.nout);
+    l.mstart = o; o += d.nmel ? kib(d.nmel + 1) : 0;
+    l.ment = o; o += d.nmel ? kib(2 * d.mel_nnz) : 0;  // (column, value) pairs
+    l.spec = o; o += d.nmel ? d.tpb * d.nout : 0;  // the tile's spectrum rows (mel fusion only)
+    l.mel = o;
+    l.total = o;
+    return l;
+}
+
+// contiguous global -> LDS copy without registers (global_load_lds_dwordx4: each lane names its 16 source bytes, the
+// wave writes 1 KiB at a wave-uniform LDS address).  `floats` is rounded up to whole 16-byte chunks; lanes past the
+// end re-read the last chunk into the region's padding.  Completion: s_waitcnt vmcnt(0) by every wave, then a barrier.
+template <int NW>
+__device__ __forceinline__ void async_copy(float *lds_dst, const float *gsrc, int floats, int wave, int lane) {
+    const int n16 = (floats + 3) >> 2;
+    for (int c0 = wave * 64; c0 < n16; c0 += NW * 64) {
+        int c = c0 + lane;
+        c = c < n16 ? c : n16 - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + 4 * c),
+                                         (__attribute__((address_space(3))) void *)(lds_dst + 4 * c0), 16, 0, 0);
+    }
+}
+
+constexpr int SPAN_R = 4;  // float4 per thread of a tile's signal span held in registers (<= 8192 floats per 512 threads)
+
+// first DIF pass fused with the frame load: element i of frame fi is (w[2i] x[2i], w[2i+1] x[2i+1]) straight from the span
+template <int R>
+__device__ __forceinline__ void first_pass(float2 *__restrict__ x, const float2 *__restrict__ tw, const float *__restrict__ sig,
+                                           const float2 *__restrict__ wnd, int M, int logM, int hop, int frame0, int rows_here, int lane) {
+    constexpr int LR = R == 4 ? 2 : 1;
+    const int q = M >> LR;
+    constexpr int PER_LANE = 1024 / R / 64, INFL = 2;
+#pragma unroll 1
+    for (int h = 0; h < PER_LANE; h += INFL) {
+        float2 u[INFL][R];
+        int base[INFL], j[INFL];
+#pragma unroll
+        for (int t = 0; t < INFL; t++) {
+            const int g = lane + 64 * (h + t);
+            const int fi = g >> (logM - LR);
+            j[t] = g & (q - 1);
+            base[t] = (fi << logM) + j[t];
+            int fr = frame0 + fi;
+            fr = fr < rows_here ? fr : rows_here - 1;
+            const float *sp = sig + fr * hop;
+#pragma unroll
+            for (int m = 0; m < R; m++) {
+                const int i = j[t] + m * q;
+                const float2 w2 = wnd[i];
+                u[t][m] = make_float2(sp[2 * i] * w2.x, sp[2 * i + 1] * w2.y);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < INFL; t++) {
+            if constexpr (R == 4) {
+                const float2 w1 = tw[j[t]], w2 = tw[q + j[t]], w3 = tw[2 * q + j[t]];
+                bfly4(u[t][0], u[t][1], u[t][2], u[t][3]);
+                x[phys(base[t])] = u[t][0];
+                x[phys(base[t] + q)] = cmul(u[t][1], w1);
+                x[phys(base[t] + 2 * q)] = cmul(u[t][2], w2);
+                x[phys(base[t] + 3 * q)] = cmul(u[t][3], w3);
+            } else {
+                const float2 w1 = tw[j[t]];
+                x[phys(base[t])] = make_float2(u[t][0].x + u[t][1].x, u[t][0].y + u[t][1].y);
+                x[phys(base[t] + q)] = cmul(make_float2(u[t][0].x - u[t][1].x, u[t][0].y - u[t][1].y), w1);
+            }
+        }
+    }
+}
+
+// Persistent blocks: a block walks the (sample, frame tile) work items blockIdx.x, + gridDim.x, ...; the tables are
+// copied to LDS once, and the NEXT tile's signal span is fetched into registers while the current tile is transformed.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, int total_tiles, int tiles_per_sample) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const StftLds lay = stft_layout(d, NW);
+    float *sig = lds + lay.sig;
+    float2 *tw = reinterpret_cast<float2 *>(lds + lay.tw);
+    float2 *wbuf = reinterpret_cast<float2 *>(lds + lay.wbuf) + wave * WBUF;
+    float2 *wnd = reinterpret_cast<float2 *>(lds + lay.window);
+    float *otab = lds + lay.otab;
+    float *mstart = lds + lay.mstart;
+    float2 *ment = reinterpret_cast<float2 *>(lds + lay.ment);
+    float *spec = lds + lay.spec;
+    const int M = d.M, logM = d.logM, hop = d.hop, nout = d.nout, nmel = d.nmel, F = d.F;
+    const int dbg = d.dbg;
+
+    // ---- tables -> LDS, once per block
+    async_copy<NW>(lds + lay.tw, reinterpret_cast<const float *>(p.tw), 2 * d.tw_count, wave, lane);
+    async_copy<NW>(lds + lay.window, p.window, d.L, wave, lane);
+    async_copy<NW>(otab, p.otab, 8 * nout, wave, lane);
+    if (nmel) {
+        async_copy<NW>(mstart, p.mstart, nmel + 1, wave, lane);
+        async_copy<NW>(lds + lay.ment, p.mcol, 2 * d.mel_nnz, wave, lane);
+    }
+
+    // (literal indices into the descriptor arrays everywhere: a loop the compiler does not unroll would index the
+    // kernel argument dynamically and move ALL of it into scratch memory)
+    static_assert(ELT_MAX_STAGES == 4, "the stages below are spelled out");
+    PreChain chain{d.npre, {d.pre_bin[0], d.pre_bin[1], d.pre_bin[2], d.pre_bin[3]}, {d.pre_act[0], d.pre_act[1], d.pre_act[2], d.pre_act[3]},
+                   {0.f, 0.f, 0.f, 0.f}, {d.pre_p0[0], d.pre_p0[1], d.pre_p0[2], d.pre_p0[3]}, {d.pre_p1[0], d.pre_p1[1], d.pre_p1[2], d.pre_p1[3]}};
+    const int64_t bb0 = d.pre_bb[0], bb1 = d.pre_bb[1], bb2 = d.pre_bb[2], bb3 = d.pre_bb[3];
+    const float *pre0 = p.pre[0], *pre1 = p.pre[1], *pre2 = p.pre[2], *pre3 = p.pre[3];
+    const bool use0 = 0 < chain.n && chain.bin[0] != BIN_NONE, use1 = 1 < chain.n && chain.bin[1] != BIN_NONE;
+    const bool use2 = 2 < chain.n && chain.bin[2] != BIN_NONE, use3 = 3 < chain.n && chain.bin[3] != BIN_NONE;
+    const int npost = d.npost;
+    const int po_a0 = d.post_act[0], po_a1 = d.post_act[1], po_a2 = d.post_act[2], po_a3 = d.post_act[3];
+    const float po_p00 = d.post_p0[0], po_p01 = d.post_p0[1], po_p02 = d.post_p0[2], po_p03 = d.post_p0[3];
+    const float po_p10 = d.post_p1[0], po_p11 = d.post_p1[1], po_p12 = d.post_p1[2], po_p13 = d.post_p1[3];
+    // log2 of the sub-problem sizes of the strided passes after the first (each a quarter of its predecessor)
+    const int ln1 = logM - (d.pass_r[0] == 2 ? 1 : 2), ln2 = ln1 - 2, ln3 = ln1 - 4;
+    const int pt0 = d.pass_tw[0], pt1 = d.pass_tw[1], pt2 = d.pass_tw[2], pt3 = d.pass_tw[3];
+    const int npass = d.npass, first_radix = d.pass_r[0];
+
+    // the span of a tile: up to SPAN_R float4 per thread, clamped loads, written to LDS (through the chain) later.
+    // (macros, not lambdas: a by-reference closure would put the staged registers into scratch memory)
+    float4 sr[SPAN_R];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int tpb = d.tpb, frames = d.frames, L = d.L, a_vec4 = d.a_vec4;
+    const int64_t a_bs = d.a_bs;
+#define BN_TILE_GEOM(TILE)                                              \
+    const int64_t b = (TILE) / tiles_per_sample;                        \
+    const int t0 = ((TILE) - (int)b * tiles_per_sample) * tpb;          \
+    const int rows_here = min(tpb, frames - t0);                        \
+    const int count = (rows_here - 1) * hop + L;
+#define BN_ISSUE_SPAN(TILE)                                                                                              \
+    do {                                                                                                                 \
+        BN_TILE_GEOM(TILE)                                                                                               \
+        const float *src = p.in + b * a_bs + (int64_t)t0 * hop;                                                          \
+        const int n4 = (count + 3) >> 2;                                                                                 \
+        _Pragma("unroll") for (int k = 0; k < SPAN_R; k++) {                                                             \
+            int c = tid + k * NW * 64;                                                                                   \
+            c = c < n4 ? c : n4 - 1;                                                                                     \
+            if (dbg & 32) {                                                                                              \
+                sr[k] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                 \
+            } else if (a_vec4) {                                                                                         \
+                sr[k] = reinterpret_cast<const float4 *>(src)[c];                                                        \
+            } else { /* unaligned rows: element loads, the last chunk clamped element by element */                     \
+                const int e = 4 * c;                                                                                     \
+                sr[k] = make_float4(src[e], src[min(e + 1, count - 1)], src[min(e + 2, count - 1)], src[min(e + 3, count - 1)]); \
+            }                                                                                                            \
+        }                                                                                                                \
+        if (use0) s0 = pre0[b * bb0];                                                                                    \
+        if (use1) s1 = pre1[b * bb1];                                                                                    \
+        if (use2) s2 = pre2[b * bb2];                                                                                    \
+        if (use3) s3 = pre3[b * bb3];                                                                                    \
+    } while (0)
+#define BN_WRITE_SPAN(TILE)                                                                       \
+    do {                                                                                          \
+        BN_TILE_GEOM(TILE)                                                                        \
+        (void)b;                                                                                  \
+        const int n4 = (count + 3) >> 2;                                                          \
+        chain.sc[0] = s0; chain.sc[1] = s1; chain.sc[2] = s2; chain.sc[3] = s3;                   \
+        float v[4 * SPAN_R];                                                                      \
+        _Pragma("unroll") for (int k = 0; k < SPAN_R; k++) {                                      \
+            v[4 * k] = sr[k].x; v[4 * k + 1] = sr[k].y; v[4 * k + 2] = sr[k].z; v[4 * k + 3] = sr[k].w; \
+        }                                                                                         \
+        if (!(dbg & 16)) pre_chain<4 * SPAN_R>(chain, v);                                         \
+        _Pragma("unroll") for (int k = 0; k < SPAN_R; k++) {                                      \
+            const int c = tid + k * NW * 64;                                                      \
+            if (c < n4) reinterpret_cast<float4 *>(sig)[c] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]); \
+        }                                                                                         \
+    } while (0)
+
+    int tile = blockIdx.x;
+    if (tile >= total_tiles) return;
+    BN_ISSUE_SPAN(tile);
+    BN_WRITE_SPAN(tile);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the table copies
+    __syncthreads();
+    if (dbg & 8) return;
+
+    const int fstride = M + (M >> 3);
+    for (; tile < total_tiles;) {
+        const int next = tile + gridDim.x;
+        if (next < total_tiles) BN_ISSUE_SPAN(next);
+        BN_TILE_GEOM(tile)
+        (void)count;
+        const int groups = (rows_here + F - 1) / F;
+        for (int g = wave; g < groups; g += NW) {
+            if (!(dbg & 1)) {
+                if (first_radix == 2) first_pass<2>(wbuf, tw + pt0, sig, wnd, M, logM, hop, g * F, rows_here, lane);
+                else first_pass<4>(wbuf, tw + pt0, sig, wnd, M, logM, hop, g * F, rows_here, lane);
+                wave_sync();
+                if (1 < npass) { strided_pass<4>(wbuf, tw + pt1, ln1, lane); wave_sync(); }
+                if (2 < npass) { strided_pass<4>(wbuf, tw + pt2, ln2, lane); wave_sync(); }
+                if (3 < npass) { strided_pass<4>(wbuf, tw + pt3, ln3, lane); wave_sync(); }
+                block16(wbuf + 18 * lane);
+                wave_sync();
+            }
+            if (dbg & 2) continue;
+            // the kept bins: out[c] = alpha Re Z[k] + beta Im Z[k] + gamma Re Z[M-k] + delta Im Z[M-k]
+            for (int rep = 0; rep < ((dbg & 64) ? 4 : 1); rep++)
+            for (int fi = 0; fi < F; fi++) {
+                const int t = g * F + fi;
+                const float2 *zf = wbuf + fi * fstride;
+                for (int c = lane; c < nout; c += 64) {
+                    const float4 e0 = *reinterpret_cast<const float4 *>(otab + 8 * c);
+                    const float2 e1 = *reinterpret_cast<const float2 *>(otab + 8 * c + 4);
+                    const float2 za = zf[(int)e0.x], zb = zf[(int)e0.y];
+                    float v = e0.z * za.x + e0.w * za.y + e1.x * zb.x + e1.y * zb.y;
+                    if (d.has_bias) v += p.bias[c];
+                    if (nmel) spec[t * nout + c] = v;
+                    else if (t < rows_here) p.out[b * d.c_bs + (int64_t)(t0 + t) * d.ldc + c] = v;
+                }
+            }
+            wave_sync();  // the transform buffer is rewritten by this wave's next group
+        }
+        __syncthreads();  // every wave is done with the span; the tile's spectrum rows are complete
+        if (nmel && !(dbg & 4)) {
+            // Mel filter bank over the whole tile: four threads share a band (entries e0 + j, e0 + j + 4, ...); a
+            // thread keeps its entries in registers and walks the tile's frames -- independent LDS reads, no
+            // dependent chain per entry -- then the partial sums of the four are added in a fixed order and the
+            // compression chain runs ONCE per stage over the thread's 16 frame values.  Results go straight to the
+            // target view (frames are its contiguous direction; the L2 merges the partial lines).
+            constexpr int MAXE = 6, TPB = 16;
+            float *ob = p.out + b * d.c_bs;
+            for (int m0 = 0; m0 < nmel; m0 += NW * 16) {
+                const int m = m0 + (tid >> 2), jj = tid & 3;
+                const bool live = m < nmel;
+                const int e0 = live ? (int)mstart[m] + jj : 0, e1 = live ? (int)mstart[m + 1] : 0;
+                float2 ent[MAXE];
+#pragma unroll
+                for (int q = 0; q < MAXE; q++) ent[q] = e0 + 4 * q < e1 ? ment[e0 + 4 * q] : make_float2(0.0f, 0.0f);
+                float acc[TPB];
+#pragma unroll
+                for (int t = 0; t < TPB; t++) {
+                    const float *sp = spec + (t < rows_here ? t : 0) * nout;
+                    float a = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < MAXE; q++) a = fmaf(sp[(int)ent[q].x], ent[q].y, a);
+                    for (int e = e0 + 4 * MAXE; e < e1; e += 4) {  // bands wider than 4 * MAXE bins
+                        const float2 cv = ment[e];
+                        a = fmaf(sp[(int)cv.x], cv.y, a);
+                    }
+                    acc[t] = a;
+                }
+                const float mb = (live && d.mel_has_bias) ? p.mel_bias[m] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < TPB; t++) {
+                    const float a1 = __shfl_xor(acc[t], 1);
+                    const float pair = (lane & 1) ? a1 + acc[t] : acc[t] + a1;  // lower lane's value first: the same sum in both
+                    const float a2 = __shfl_xor(pair, 2);
+                    acc[t] = ((lane & 2) ? a2 + pair : pair + a2) + mb;
+                }
+                act_small<TPB>(d.mel_act, d.mel_p0, d.mel_p1, acc);
+                if (0 < npost) act_small<TPB>(po_a0, po_p00, po_p10, acc);
+                if (1 < npost) act_small<TPB>(po_a1, po_p01, po_p11, acc);
+                if (2 < npost) act_small<TPB>(po_a2, po_p02, po_p12, acc);
+                if (3 < npost) act_small<TPB>(po_a3, po_p03, po_p13, acc);
+                if (jj == 0 && live) {
+                    float *om = ob + (int64_t)t0 * d.out_rs + (int64_t)m * d.out_cs;
+#pragma unroll
+                    for (int t = 0; t < TPB; t++)
+                        if (t < rows_here) om[(int64_t)t * d.out_rs] = acc[t];
+                }
+            }
+        }
+        if (next < total_tiles) BN_WRITE_SPAN(next);
+        __syncthreads();  // next span in place, spectrum rows read
+        tile = next;
+    }
+#undef BN_TILE_GEOM
+#undef BN_ISSUE_SPAN
+#undef BN_WRITE_SPAN
+}
+
+}  // namespace
+
+size_t stft_lds_bytes(const FftDesc &d, int nwaves) { return (size_t)stft_layout(d, nwaves).total * sizeof(float); }
+
+void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t batch) {
+    if (batch <= 0) return;
+    constexpr int NW = 8;
+    const size_t lds = stft_lds_bytes(d, NW);
+    const int span = (d.tpb - 1) * d.hop + d.L;
+    if (lds > 160 * 1024 || span > SPAN_R * 4 * NW * 64 || !ensure_dynamic_lds(reinterpret_cast<const void *>(stft_kernel<NW>), lds)) {
+        launch_error("STFT kernel: the frame span does not fit the LDS / the staging registers");
+        return;
+    }
+    FftDesc dd = d;
+    dd.dbg = getenv("BN_STFT_DBG") ? atoi(getenv("BN_STFT_DBG")) : 0;
+    // float4 span loads need 16-byte aligned tile starts (base pointer, batch stride, a tile's first sample) and must
+    // not run past the sample row: the last chunk of a span is rounded up to 4 floats
+    dd.a_vec4 = (reinterpret_cast<uintptr_t>(p.in) & 15u) == 0 && d.a_bs % 4 == 0 && ((int64_t)d.tpb * d.hop) % 4 == 0 &&
+                (int64_t)(d.frames - 1) * d.hop + d.L + 3 <= d.a_bs;
+    const int tps = (d.frames + d.tpb - 1) / d.tpb;
+    const int64_t total = (int64_t)tps * batch;
+    int ncu = 256;
+    {
+        static std::atomic<int> cached[64];  // compute units per device ordinal (0 = not asked yet)
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            int v = cached[dev].load(std::memory_order_relaxed);
+            if (v == 0) {
+                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+                cached[dev].store(v, std::memory_order_relaxed);
+            }
+            ncu = v;
+        }
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>(total, ncu);  // one block per CU (LDS-bound), persistent over its tiles
+    hipLaunchKernelGGL(stft_kernel<NW>, dim3(grid), dim3(NW * 64), lds, s, dd, p, (int)total, tps);
+}
+
+}  // namespace bn

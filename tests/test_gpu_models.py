@@ -106,6 +106,30 @@ def test_v24_full_size_model(bn, v24_full):
     check_results(clf.predict_batch(list(x)), ref, None, 10, None)
 
 
+def test_fft_front_end_whole_models(bn, v24_full, v30_small, monkeypatch):
+    """BN_STFT=1: the windowed-DFT banks run as real FFTs (v2.4: both branches with the mel filter banks, compression
+    chains and the min-max normalisation absorbed; v3.0: cos and sin blocks from ONE transform) -- same tolerance
+    against the oracle's plain convolutions, same top-1, and top-K rows identical to the default plan's."""
+    monkeypatch.setenv("BN_STFT", "1")
+    data, path = v24_full
+    assert bn.plan_describe(path).count(" FFT ") == 2
+    clf = bn.Classifier.builder().model_path(path).labels(labels(6522)).with_rocm().build()
+    x = synth.synthetic_segments(5, 144000, 48000)
+    ref = onnx_ref.run_model(data, x)["output"]
+    res = clf.predict_batch(list(x))
+    check_results(res, ref, None, 10, None)
+    data3, path3 = v30_small
+    assert bn.plan_describe(path3).count(" FFT ") == 1 and "~" not in bn.plan_describe(path3)
+    clf3 = bn.Classifier.builder().model_path(path3).labels(labels(300)).top_k(5).with_rocm().build()
+    x3 = synth.synthetic_segments(3, 160000, 32000)
+    out3 = onnx_ref.run_model(data3, x3)
+    check_results(clf3.predict_batch(list(x3)), out3["output_1"], out3["output_0"], 5, None)
+    monkeypatch.delenv("BN_STFT")
+    dflt = bn.Classifier.builder().model_path(path).labels(labels(6522)).with_rocm().build().predict_batch(list(x))
+    for a, b in zip(res, dflt):
+        assert [p.index for p in a.predictions] == [p.index for p in b.predictions]
+
+
 def test_v30_embeddings_and_logits(bn, v30_small):
     data, path = v30_small
     clf = bn.Classifier.builder().model_path(path).labels(labels(300)).top_k(5).with_rocm().build()

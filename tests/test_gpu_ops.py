@@ -132,11 +132,25 @@ def test_conv1d_folded_dft_framing(bn, n_fft, hop, kind, bias, monkeypatch):
         u = g.node("Unsqueeze", [x, g.const(np.array([1], dtype=np.int64))])
         return g.node("Conv", [u, g.const(w)] + ([g.const(b)] if bias else []), kernel_shape=[n_fft], strides=[hop])
     data = op_graph(build, [w.shape[0], frames])
+    pow2 = n_fft & (n_fft - 1) == 0
+    monkeypatch.setenv("BN_STFT", "1")
+    text = bn.plan_describe(write_model(data))
+    if pow2:
+        # recognised as a windowed-DFT bank (bins, window and per-row amplitudes recovered from the taps): ONE real-FFT
+        # launch for all rows, cos and sin blocks together
+        assert text.count(" FFT ") == 1 and "~" not in text, text
+        fft_out, ref = run_both(bn, data, batch=2)
+        assert_close(fft_out, ref, f"stft n_fft={n_fft} {kind}", atol=2e-5 * float(np.abs(ref).max()), rtol=0)
+        fft3, ref3 = run_both(bn, data, batch=3)  # 511 frames: the last block is ragged either way; odd batch
+        assert_close(fft3, ref3, f"stft n_fft={n_fft} {kind} batch 3", atol=2e-5 * float(np.abs(ref3).max()), rtol=0)
+    monkeypatch.delenv("BN_STFT")
     text = bn.plan_describe(write_model(data))
     assert "~sym" in text or "~anti" in text, text
     assert text.count("~") == (1 if kind == "real" else 2), text
     got, ref = run_both(bn, data, batch=2)
     assert_close(got, ref, f"folded conv1d n_fft={n_fft} {kind}")
+    if pow2:
+        assert_close(fft_out, got, "stft vs folded GEMM", atol=2e-5 * float(np.abs(got).max()), rtol=0)
     # the LDS-resident-signal kernel and the generic folded GEMM use the same K order and fold expression
     monkeypatch.setenv("BN_FRAMELDS", "0")
     generic, _ = run_both(bn, data, batch=2)
@@ -153,6 +167,34 @@ def test_conv1d_folded_dft_framing(bn, n_fft, hop, kind, bias, monkeypatch):
     assert "~" not in bn.plan_describe(write_model(data))
     plain, _ = run_both(bn, data, batch=2)
     assert_close(got, plain, "folded vs unfolded plan", atol=2e-5 * float(np.abs(plain).max()), rtol=0)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(128, 64), (256, 100), (512, 160), (1024, 320), (2048, 278)])
+def test_stft_every_transform_size(bn, n_fft, hop, monkeypatch):
+    """All supported frame lengths (one radix-2 pass first when log2 of the half length is odd), a non-Hann window,
+    rows in scrambled bin order with per-row gains and a bias."""
+    rng = np.random.default_rng(n_fft)
+    n = np.arange(n_fft, dtype=np.float64)
+    win = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / n_fft)  # periodic Hamming: w[0] != 0 ...
+    win = win * np.sin(np.pi * n / n_fft) ** 2             # ... so taper it to the w[0] == 0 the folding rule asks for
+    bins = rng.permutation(n_fft // 2 + 1)[:24]
+    rows = []
+    for i, k in enumerate(bins):
+        ang = 2.0 * np.pi * k * n / n_fft
+        rows.append(win * (np.cos(ang) if i % 3 else -np.sin(ang)) * rng.uniform(0.3, 3.0))
+    w = np.ascontiguousarray(np.array(rows, dtype=np.float32)[:, None, :])
+    b = rng.standard_normal(w.shape[0]).astype(np.float32)
+    frames = (144000 - n_fft) // hop + 1
+
+    def build(g, x):
+        u = g.node("Unsqueeze", [x, g.const(np.array([1], dtype=np.int64))])
+        return g.node("Conv", [u, g.const(w), g.const(b)], kernel_shape=[n_fft], strides=[hop])
+    data = op_graph(build, [w.shape[0], frames])
+    monkeypatch.setenv("BN_STFT", "1")
+    text = bn.plan_describe(write_model(data))
+    assert text.count(" FFT ") == 1, text
+    got, ref = run_both(bn, data, batch=2)
+    assert_close(got, ref, f"stft n_fft={n_fft}", atol=2e-5 * float(np.abs(ref).max()), rtol=0)
 
 
 def test_conv1d_not_folded_when_not_symmetric(bn):

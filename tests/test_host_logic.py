@@ -94,9 +94,23 @@ def test_chunk_plan_matches_oracle(bn, n, seg, ov, sr):  # birdnet-analyze.rs:70
     assert t.tobytes() == to.tobytes()
 
 
-def test_plan_of_v24_model(bn, tmp_path):
+def test_plan_of_v24_model(bn, tmp_path, monkeypatch):
     p = tmp_path / "m.onnx"
     p.write_bytes(synth.birdnet_v24(num_species=100, width=0.5, depth=0.5, head=128))
+    # BN_STFT=1: both windowed-DFT banks are recognised and run as real FFTs, with the sparse mel filter banks, their
+    # compression chains / layout copies and the min-max normalisation of the signal absorbed into the same launches
+    monkeypatch.setenv("BN_STFT", "1")
+    full = bn.plan_describe(str(p))
+    fft = [l for l in full.splitlines() if " FFT " in l]
+    assert len(fft) == 2 and all("mel=96" in l and "pre=4" in l and "post=3" in l for l in fft), fft
+    assert " L=2048 hop=278 " in fft[0] and " L=1024 hop=280 " in fft[1]
+    assert max(int(l.split("bins=")[1].split()[0]) for l in fft) < 400  # mel-dead bins are not even untangled
+    assert "~" not in full and "Sub:Sub_2" in fft[0] and "Sub:Sub_2" in fft[1]
+    tot = full.splitlines()[[i for i, l in enumerate(full.splitlines()) if l.startswith("TOTAL")][0]]
+    fft_flops, dft_macs = float(tot.split("fft_flops=")[1].split()[0]), float(tot.split("dft_gemm_macs=")[1].split()[0])
+    assert 3e7 < fft_flops < 6e7 and dft_macs > 5 * fft_flops  # ~42 MFLOP as FFTs vs the matrix-product count
+    # the default plan: folded GEMMs (the FFT launches are opt-in until they beat them)
+    monkeypatch.delenv("BN_STFT")
     text = bn.plan_describe(str(p))
     lines = text.splitlines()
     kinds = [l.split()[1] for l in lines if l[:3].strip().isdigit()]
@@ -112,6 +126,19 @@ def test_plan_of_v24_model(bn, tmp_path):
     assert len(gemm_n) == 2 and max(gemm_n) < 400, gemm_n
 
 
+def test_stft_absorption_switches(bn, tmp_path, monkeypatch):
+    p = tmp_path / "m.onnx"
+    p.write_bytes(synth.birdnet_v24(num_species=100, width=0.5, depth=0.5, head=128))
+    monkeypatch.setenv("BN_STFT", "1")
+    monkeypatch.setenv("BN_STFT_MEL", "0")
+    lines = bn.plan_describe(str(p)).splitlines()
+    assert sum(" FFT " in l and "mel=0" in l for l in lines) == 2 and sum("MatMul:MatMul_11" in l and " GEMM " in l for l in lines) == 1
+    monkeypatch.delenv("BN_STFT_MEL")
+    monkeypatch.setenv("BN_STFT_PRE", "0")
+    lines = bn.plan_describe(str(p)).splitlines()
+    assert sum(" FFT " in l and "pre=0" in l for l in lines) == 2 and sum(" ELT " in l and "Sub:Sub_2" in l for l in lines) == 1
+
+
 def test_plan_without_folding(bn, tmp_path, monkeypatch):
     monkeypatch.setenv("BN_CONVFOLD", "0")
     p = tmp_path / "m.onnx"
@@ -123,7 +150,7 @@ def test_plan_without_folding(bn, tmp_path, monkeypatch):
     # a looser tolerance than the bases' rounding noise is never needed; a zero tolerance only folds exact mirror images
     monkeypatch.delenv("BN_CONVFOLD")
     monkeypatch.setenv("BN_CONVFOLD_TOL", "0")
-    assert not any("~" in l for l in bn.plan_describe(str(p)).splitlines())
+    assert not any("~" in l or " FFT " in l for l in bn.plan_describe(str(p)).splitlines())
 
 
 def test_dead_outputs_are_not_planned(bn, tmp_path):
