@@ -210,6 +210,21 @@ float *resolve(const bn_ctx *c, const Ref &r, const float *d_in) {
     }
 }
 
+SeTail se_tail_of(const bn_ctx *c, const PlanOp &op, const float *d_in) {
+    SeTail t{};
+    if (!op.se_fused) return t;
+    t.on = 1;
+    t.se = op.se;
+    t.w1 = resolve(c, op.x[0], d_in);
+    t.b1 = resolve(c, op.x[1], d_in);
+    t.w2t = resolve(c, op.x[2], d_in);
+    t.b2 = resolve(c, op.x[3], d_in);
+    t.gate = resolve(c, op.res, d_in);
+    t.counter = reinterpret_cast<uint32_t *>(resolve(c, op.scale, d_in));
+    t.cnt_bs = c->pd->plan->storages[op.scale.id].elems;
+    return t;
+}
+
 void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t batch) {
     float *out = resolve(c, op.out, d_in);
     const float *a = resolve(c, op.a, d_in);
@@ -228,13 +243,20 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
         case OpKind::CONV:
             launch_conv(c->stream, op.conv, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in), batch);
             break;
-        case OpKind::DWCONV: launch_dwconv(c->stream, op.dw, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.b, d_in), batch); break;
+        case OpKind::DWCONV: {
+            SeTail tail = se_tail_of(c, op, d_in);
+            launch_dwconv(c->stream, op.dw, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.b, d_in), batch, tail.on ? &tail : nullptr);
+            break;
+        }
         case OpKind::GAP: launch_gap_partial(c->stream, op.gap, out, a, batch); break;
         case OpKind::POOL: launch_pool(c->stream, op.pool, out, a, batch); break;
         case OpKind::MBCONV:
+        {
+            SeTail tail = se_tail_of(c, op, d_in);
             launch_mbconv(c->stream, op.mb, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
-                          resolve(c, op.bias2, d_in), resolve(c, op.b, d_in), batch);
+                          resolve(c, op.bias2, d_in), resolve(c, op.b, d_in), batch, tail.on ? &tail : nullptr);
             break;
+        }
         case OpKind::FFT: {
             StftPtrs sp{};
             sp.out = out;
@@ -548,6 +570,7 @@ bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **
     const size_t arena_b = (size_t)p.arena_elems * max_batch * sizeof(float);
     const size_t in_b = (size_t)p.sample_count * max_batch * sizeof(float);
     HIP_TRY(hipMalloc(&c->d_arena, arena_b));
+    HIP_TRY(hipMemset(c->d_arena, 0, arena_b));  // the squeeze-excite ticket counters live here and must start at zero
     HIP_TRY(hipMalloc(&c->d_input, in_b));
     HIP_TRY(hipHostMalloc(&c->h_input, in_b, hipHostMallocDefault));
     {
@@ -1403,7 +1426,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                     extra += line;
                 }
             } else if (op.kind == OpKind::DWCONV) {
-                snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%d act=%d tiled=%d squeeze=%d nblk=%d", op.dw.H, op.dw.W, op.dw.C, op.dw.OH, op.dw.OW, op.dw.kh, op.dw.kw, op.dw.sh, op.dw.act, op.dw.tiled, op.dw.has_gap, op.dw.nblk);
+                snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%d act=%d tiled=%d squeeze=%d nblk=%d se=%d", op.dw.H, op.dw.W, op.dw.C, op.dw.OH, op.dw.OW, op.dw.kh, op.dw.kw, op.dw.sh, op.dw.act, op.dw.tiled, op.dw.has_gap, op.dw.nblk, op.se_fused);
                 extra = line;
             } else if (op.kind == OpKind::CONV) {
                 snprintf(line, sizeof(line), " %dx%dx%d->%dx%dx%d k=%dx%d s=%d g=%d act=%d", op.conv.H, op.conv.W, op.conv.Cin, op.conv.OH, op.conv.OW, op.conv.Cout, op.conv.kh, op.conv.kw, op.conv.sh, op.conv.groups, op.conv.act);
@@ -1414,7 +1437,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                     w += snprintf(line + w, sizeof(line) - w, "%s%lld/%lld/%lld", q ? "," : "", (long long)op.elt.size[q], (long long)op.elt.so[q], (long long)op.elt.sa[q]);
                 extra = line;
             } else if (op.kind == OpKind::MBCONV) {
-                snprintf(line, sizeof(line), " %dx%dx%d->(%d)->%dx%dx%d k=%d s=%d tiles=%dx%d squeeze=%d", op.mb.H, op.mb.W, op.mb.Cin, op.mb.C, op.mb.OH, op.mb.OW, op.mb.C, op.mb.k, op.mb.s, op.mb.tiles_y, op.mb.tiles_x, op.mb.has_gap);
+                snprintf(line, sizeof(line), " %dx%dx%d->(%d)->%dx%dx%d k=%d s=%d tiles=%dx%d squeeze=%d se=%d", op.mb.H, op.mb.W, op.mb.Cin, op.mb.C, op.mb.OH, op.mb.OW, op.mb.C, op.mb.k, op.mb.s, op.mb.tiles_y, op.mb.tiles_x, op.mb.has_gap, op.se_fused);
                 extra = line;
             } else if (op.kind == OpKind::POOL) {
                 snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%dx%d max=%d", op.pool.H, op.pool.W, op.pool.C, op.pool.OH, op.pool.OW, op.pool.kh, op.pool.kw,

@@ -1806,7 +1806,47 @@ class Builder {
         }
         Val gate = new_act(Dims{C, 1, 1}, Dims{1, 0, 0});
         plan_.storages[gate.storage].elems = (C + 3) / 4 * 4;
+        std::vector<float> w2t(w2.size());  // [C][Cr] -> [Cr][C]: coalesced reads in the excite product
+        for (int64_t c = 0; c < C; c++)
+            for (int64_t j = 0; j < Cr; j++) w2t[j * C + c] = w2[c * Cr + j];
+        SeFcDesc sd{};
+        sd.C = (int32_t)C; sd.Cr = (int32_t)Cr; sd.splits = splits; sd.inv_hw = 1.0f / (float)HW;
+        sd.act1 = act1.act; sd.p0_1 = act1.p0; sd.p1_1 = act1.p1;
+        sd.act2 = act2.act; sd.p0_2 = act2.p0; sd.p1_2 = act2.p1;
+        sd.in_bs = plan_.storages[partial.storage].elems; sd.out_bs = plan_.storages[gate.storage].elems;
+        // Rule H: the launch that produced the squeeze sums finishes the squeeze-excite itself -- its last block per sample
+        // (ticket counter, write-through partial sums: no fence, kernels.h SeTail) -- when that launch is a fused MBConv
+        // or a whole-map depthwise conv.  One launch less per block (16 in the v2.4 plan).  BN_SEFUSE=0 disables.
+        PlanOp *host = nullptr;
         {
+            // Opt-in (BN_SEFUSE = dw | mb | 1): correct, but slower than the separate excite launch on every block of the
+            // v2.4 plan -- the last block streams both excite matrices through ONE compute unit (442 KB at C = 1152:
+            // +26 us per whole-map depthwise launch against 8-10 us for the multi-block excite kernel), and every block of
+            // a fused MBConv launch pays a store drain + returning atomic (+13 us per launch); DESIGN.md section 4.12.
+            const std::string mode = getenv("BN_SEFUSE") ? getenv("BN_SEFUSE") : "0";  // 0 | dw | mb | 1 (both)
+            if (mbp && !mbp->mb.whole_map && (mode == "1" || mode == "mb")) host = mbp;
+            else if (dwp && dwp->dw.tiled == 2 && (mode == "1" || mode == "dw")) host = dwp;
+        }
+        if (host) {
+            Val cnt = new_act(Dims{1}, Dims{1});
+            plan_.storages[cnt.storage].pinned = true;      // never recycled ...
+            plan_.storages[cnt.storage].persistent = true;  // ... and never shared with an earlier tensor either: the word must stay zero between launches
+            const int hidx = (int)plan_.ops.size() - 1;
+            host->se_fused = 1;
+            host->se = sd;
+            host->x[0] = Ref{Space::CONSTS, add_const(w1), 0};
+            if (!b1.empty()) host->x[1] = Ref{Space::CONSTS, add_const(b1), 0};
+            host->x[2] = Ref{Space::CONSTS, add_const(w2t), 0};
+            if (!b2.empty()) host->x[3] = Ref{Space::CONSTS, add_const(b2), 0};
+            host->res = ref_of(gate);
+            host->scale = ref_of(cnt);
+            touch(host->res, hidx);
+            touch(host->scale, hidx);
+            host->name += "+se";
+            host->macs += 2.0 * (double)C * Cr;
+            host->weight_bytes += 4.0 * (w1.size() + w2.size() + b1.size() + b2.size());
+            host->bytes += 4.0 * (double)(splits * C + C);
+        } else {
             PlanOp op;
             Val hidden = new_act(Dims{Cr}, Dims{1});
             op.kind = OpKind::SEFC;
@@ -1816,15 +1856,9 @@ class Builder {
             op.b = ref_of(hidden);  // scratch between the two excite launches
             op.w = Ref{Space::CONSTS, add_const(w1), 0};
             if (!b1.empty()) op.bias = Ref{Space::CONSTS, add_const(b1), 0};
-            std::vector<float> w2t(w2.size());  // [C][Cr] -> [Cr][C]: coalesced reads in the excite product
-            for (int64_t c = 0; c < C; c++)
-                for (int64_t j = 0; j < Cr; j++) w2t[j * C + c] = w2[c * Cr + j];
             op.w2 = Ref{Space::CONSTS, add_const(w2t), 0};
             if (!b2.empty()) op.bias2 = Ref{Space::CONSTS, add_const(b2), 0};
-            op.se.C = (int32_t)C; op.se.Cr = (int32_t)Cr; op.se.splits = splits; op.se.inv_hw = 1.0f / (float)HW;
-            op.se.act1 = act1.act; op.se.p0_1 = act1.p0; op.se.p1_1 = act1.p1;
-            op.se.act2 = act2.act; op.se.p0_2 = act2.p0; op.se.p1_2 = act2.p1;
-            op.se.in_bs = plan_.storages[partial.storage].elems; op.se.out_bs = plan_.storages[gate.storage].elems;
+            op.se = sd;
             op.macs = 2.0 * (double)C * Cr;
             op.weight_bytes = 4.0 * (w1.size() + w2.size() + b1.size() + b2.size());
             op.bytes = 4.0 * (double)(splits * C + C);
@@ -2819,8 +2853,11 @@ class Builder {
             if (!st.pinned) ends[st.last].push_back((int)s);
         }
         int64_t peak = 0;
+        for (size_t s = 0; s < plan_.storages.size(); s++)
+            if (plan_.storages[s].persistent && plan_.storages[s].first >= 0) plan_.storages[s].arena_off = alloc(rounded(plan_.storages[s].elems));
         for (int k = 0; k < nops; k++) {
-            for (int s : starts[k]) plan_.storages[s].arena_off = alloc(rounded(plan_.storages[s].elems));
+            for (int s : starts[k])
+                if (!plan_.storages[s].persistent) plan_.storages[s].arena_off = alloc(rounded(plan_.storages[s].elems));
             peak = std::max(peak, top);
             for (int s : ends[k]) release(plan_.storages[s].arena_off, rounded(plan_.storages[s].elems));
         }

@@ -46,6 +46,10 @@ struct PlanOp {
     MbDesc mb{};
     PoolDesc pool{};
     FftDesc fft{};
+    // DWCONV / MBCONV: the squeeze-excite that follows is finished by the launch's last block per sample (kernels.h,
+    // SeTail): `se` holds its shape, x[0..3] its weights (w1, b1, w2 transposed, b2), res the gate, scale the
+    // per-sample ticket counters (a pinned arena storage of one word per sample, zero between launches)
+    int32_t se_fused = 0;
     double flops_fft = 0;   // FFT: algorithmic flops per sample counted as an FFT (2.5 L log2 L per real frame) + sparse mel
     double macs = 0;        // per sample
     double macs_mfma_extra = 0;  // MBCONV: the expand part runs on the matrix cores
@@ -58,6 +62,7 @@ struct Storage {
     int64_t elems = 0;  // per sample
     int32_t first = -1, last = -1;  // op indices
     bool pinned = false;            // graph output: never recycled
+    bool persistent = false;        // owns its arena region for the WHOLE plan (state that must survive from launch to launch)
     int64_t arena_off = -1;         // elements per sample
 };
 

@@ -162,8 +162,9 @@ struct PoolDesc {
 };
 void launch_pool(hipStream_t s, const PoolDesc &d, float *out, const float *in, int64_t batch);
 
+struct SeTail;
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1,
-                   const float *b1, const float *w2, const float *b2, float *gap, int64_t batch);
+                   const float *b1, const float *w2, const float *b2, float *gap, int64_t batch, const SeTail *tail = nullptr);
 
 // Squeeze-excite, stage 1: per-(sample, split) channel sums of an NHWC tensor [HW][C]
 // -> partial [splits][C].  Stage 2 (SeFcDesc) sums the splits in a fixed order (deterministic).
@@ -183,6 +184,23 @@ struct SeFcDesc {
     int64_t in_bs, out_bs;
 };
 
+// Squeeze-excite finished INSIDE the kernel that produced the squeeze sums (depthwise / fused MBConv launches): every
+// block publishes its partial sums write-through, takes a ticket on a per-sample counter, and the block that draws
+// the last ticket of its sample reduces the partials and runs both excite products -- no separate launch, no
+// release fence (the sums are the only hand-off and they are stored with sc1 / read with sc1, MI355X guide
+// "Valid forms", counter row).  counter[b] must be 0 on entry; the last block resets it.  se.splits = blocks per
+// sample of the producing launch.
+struct SeTail {
+    int32_t on;
+    SeFcDesc se;
+    const float *w1, *b1, *w2t, *b2;
+    float *gate;
+    uint32_t *counter;  // one word per sample, stride cnt_bs words
+    int64_t cnt_bs;
+    int32_t nblocks;    // blocks per sample of the hosting launch (set by the launcher)
+};
+// dynamic LDS the tail needs (floats): s[C] | h[Cr] | 1024 scratch
+inline size_t se_tail_lds_bytes(const SeFcDesc &d) { return (size_t)(d.C + d.Cr + 2048 + 8) * sizeof(float); }
 void launch_gap_partial(hipStream_t s, const GapDesc &d, float *partial, const float *in, int64_t batch);
 // hidden: scratch [batch][Cr]
 void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, const float *partial,
@@ -210,7 +228,7 @@ void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, con
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w,
                  const float *bias, const float *res, int64_t batch);
 void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w,
-                   const float *bias, float *gap, int64_t batch);
+                   const float *bias, float *gap, int64_t batch, const SeTail *tail = nullptr);
 
 // top-K + sigmoid + filter + stable sort, bit-exact with the reference's
 // BinaryHeap semantics (topk.hip).  idx/conf/count are device buffers with row

@@ -12,6 +12,7 @@
 // All tensors are f32, the batch is the outermost dimension.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -1083,6 +1084,99 @@ __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restri
     }
 }
 
+// ------------------------------------------------------------------ squeeze-excite tail (SeTail, kernels.h)
+// Called by EVERY thread of a block after the block's squeeze partials have been stored with se_store().  Returns in
+// all but the last block of the sample.  `sm` is dynamic LDS the caller no longer needs (se_tail_lds_bytes).
+__device__ __forceinline__ void se_store(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // sc1: write-through
+__device__ __forceinline__ float se_load(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // sc1: past the L1
+__device__ void se_tail(const SeTail &t, int64_t b, const float *__restrict__ partial_sample, float *__restrict__ sm) {
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const SeFcDesc &d = t.se;
+    // publish: every storing wave drains its stores, the block meets, ONE lane takes the ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned *flag = reinterpret_cast<unsigned *>(sm);
+    if (tid == 0) {
+        uint32_t *cnt = t.counter + b * t.cnt_bs;
+        const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned last = ticket == (unsigned)t.nblocks - 1u ? 1u : 0u;
+        if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+    __syncthreads();  // flag read by everyone before the region is reused
+    float *sq = sm, *hid = sm + d.C, *red = hid + d.Cr;
+    // squeeze finish (sc1 loads: the other blocks' stores bypassed their L2 lines): G thread groups share the partial rows
+    // (group g takes rows g, g + G, ...: eight loads in flight per thread), the G sums are added in group order --
+    // the order of every sum is fixed, whichever block happens to be last
+    if (d.C <= nt) {
+        const int G = max(1, min(nt / d.C, d.splits));
+        const int g = tid / d.C, c = tid - g * d.C;
+        if (g < G) {
+            float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int sp = g;
+            for (; sp + 7 * G < d.splits; sp += 8 * G) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) a[u] += se_load(partial_sample + (int64_t)(sp + u * G) * d.C + c);
+            }
+            for (int u = 0; sp < d.splits; sp += G, u++) a[u & 7] += se_load(partial_sample + (int64_t)sp * d.C + c);
+            red[g * d.C + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        }
+        __syncthreads();
+        if (tid < d.C) {
+            float acc = red[tid];
+            for (int q = 1; q < G; q++) acc += red[q * d.C + tid];
+            sq[tid] = acc * d.inv_hw;
+        }
+    } else {  // more channels than threads: columns tid, tid + nt, ...
+        for (int cc = tid; cc < d.C; cc += nt) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int sp = 0;
+            for (; sp + 3 < d.splits; sp += 4) {
+                a0 += se_load(partial_sample + (int64_t)sp * d.C + cc);
+                a1 += se_load(partial_sample + (int64_t)(sp + 1) * d.C + cc);
+                a2 += se_load(partial_sample + (int64_t)(sp + 2) * d.C + cc);
+                a3 += se_load(partial_sample + (int64_t)(sp + 3) * d.C + cc);
+            }
+            for (; sp < d.splits; sp++) a0 += se_load(partial_sample + (int64_t)sp * d.C + cc);
+            sq[cc] = ((a0 + a1) + (a2 + a3)) * d.inv_hw;
+        }
+    }
+    __syncthreads();
+    // hidden units: a wave per row (rows w, w + nw, ...), four rows streamed together
+    const int wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    for (int j0 = wave; j0 < d.Cr; j0 += 4 * nw) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        const float *wr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = j0 + nw * r < d.Cr ? j0 + nw * r : d.Cr - 1;
+            wr[r] = t.w1 + (int64_t)j * d.C;
+        }
+        for (int c = lane; c < d.C; c += 64) {
+            const float sv = sq[c];
+#pragma unroll
+            for (int r = 0; r < 4; r++) a[r] = fmaf(sv, wr[r][c], a[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float acc = a[r];
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+            const int j = j0 + nw * r;
+            if (lane == 0 && j < d.Cr) hid[j] = act_apply(d.act1, acc + (t.b1 ? t.b1[j] : 0.f), d.p0_1, d.p1_1);
+        }
+    }
+    __syncthreads();
+    // excite: thread per channel, the Cr terms in index order
+    for (int c = tid; c < d.C; c += nt) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < d.Cr; j++) acc = fmaf(hid[j], t.w2t[(int64_t)j * d.C + c], acc);
+        t.gate[b * d.out_bs + c] = act_apply(d.act2, acc + (t.b2 ? t.b2[c] : 0.f), d.p0_2, d.p1_2);
+    }
+}
+
 // ------------------------------------------------------------------ fused expand + depthwise
 // One block = one output tile (TOH x TOW pixels), ALL mid channels in chunks of 32:
 //   0. the input halo tile ((TOH-1)*S+K) x ((TOW-1)*S+K) pixels x Cin is staged in LDS ONCE
@@ -1109,7 +1203,7 @@ template <int K, int S, bool IM2COL>
 __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                                const float *__restrict__ w1, const float *__restrict__ b1,
                                                                const float *__restrict__ w2, const float *__restrict__ b2,
-                                                               float *__restrict__ gap) {
+                                                               float *__restrict__ gap, SeTail tail) {
     constexpr int TOH = S == 1 ? 8 : 4, TOW = S == 1 ? 16 : 8;
     constexpr int IHT = (TOH - 1) * S + K, IWT = (TOW - 1) * S + K, HP = IHT * IWT;
     constexpr int MT = (HP + 31) / 32, MP = MT * 32;
@@ -1321,8 +1415,9 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
             float t = rp[0];
 #pragma unroll
             for (int y = 1; y < 8; y++) t += rp[y * 32];
-            gap[b * d.gap_bs + (int64_t)blockIdx.x * d.C + cc] = t;
+            se_store(gap + b * d.gap_bs + (int64_t)blockIdx.x * d.C + cc, t);
         }
+        if (tail.on) se_tail(tail, b, gap + b * d.gap_bs, msm);
     }
 }
 
@@ -1465,7 +1560,7 @@ template <int K, int S, bool IM2COL>
 __global__ __launch_bounds__(512) void mbconv_pipe_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                                const float *__restrict__ w1, const float *__restrict__ b1,
                                                                const float *__restrict__ w2, const float *__restrict__ b2,
-                                                               float *__restrict__ gap) {
+                                                               float *__restrict__ gap, SeTail tail) {
     constexpr int TOH = S == 1 ? 8 : 4, TOW = S == 1 ? 16 : 8;
     constexpr int IHT = (TOH - 1) * S + K, IWT = (TOW - 1) * S + K, HP = IHT * IWT;
     constexpr int MT = (HP + 31) / 32, MP = MT * 32;
@@ -1696,8 +1791,9 @@ __global__ __launch_bounds__(512) void mbconv_pipe_kernel(MbDesc d, float *__res
             float t = rp[0];
 #pragma unroll
             for (int y = 1; y < 8; y++) t += rp[y * 32];
-            gap[b * d.gap_bs + (int64_t)blockIdx.x * d.C + cc] = t;
+            se_store(gap + b * d.gap_bs + (int64_t)blockIdx.x * d.C + cc, t);
         }
+        if (tail.on) se_tail(tail, b, gap + b * d.gap_bs, msm);
     }
 }
 
@@ -1753,7 +1849,7 @@ __device__ __forceinline__ void dw_map_from_lds(const float *In, float *red, con
             float t = red[c];
 #pragma unroll
             for (int y = 1; y < 8; y++) t += red[y * 32 + c];
-            gap_sample[cg] = t;
+            se_store(gap_sample + cg, t);
         }
     }
 }
@@ -1767,7 +1863,7 @@ __device__ __forceinline__ void dw_map_from_lds(const float *In, float *red, con
 // grid (ceil(C/32), batch), 256 threads, dynamic LDS (H*W*32 + 256 floats).
 template <int K, int S>
 __global__ __launch_bounds__(256) void dwconv_map_kernel(DwDesc d, float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w,
-                                                         const float *__restrict__ bias, float *__restrict__ gap) {
+                                                         const float *__restrict__ bias, float *__restrict__ gap, SeTail tail) {
     extern __shared__ __align__(16) float dmsm[];
     const int HW = d.H * d.W;
     float *In = dmsm;
@@ -1804,6 +1900,7 @@ __global__ __launch_bounds__(256) void dwconv_map_kernel(DwDesc d, float *__rest
     __syncthreads();
     dw_map_from_lds<K, S>(In, red, wd, bz, d.H, d.W, d.OH, d.OW, d.pt, d.pl, d.C, d.act, d.p0, d.p1, out + b * d.out_bs, cg, cact,
                           d.has_gap ? gap + b * d.gap_bs : nullptr);
+    if (d.has_gap && tail.on) se_tail(tail, b, gap + b * d.gap_bs, dmsm);
 }
 
 // Fused expand + depthwise for a SMALL feature map (H*W <= 768): one block = (32 mid channels,
@@ -2326,9 +2423,13 @@ size_t mbconv_pipe_lds_bytes(const MbDesc &d) {
 }
 
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
-                   const float *b2, float *gap, int64_t batch) {
+                   const float *b2, float *gap, int64_t batch, const SeTail *tailp) {
     if (batch <= 0) return;
-    const size_t lds = mbconv_lds_bytes(d);
+    SeTail tail{};
+    if (tailp && !d.whole_map) tail = *tailp;
+    tail.nblocks = d.tiles_x * d.tiles_y;
+    size_t lds = mbconv_lds_bytes(d);
+    if (tail.on) lds = std::max(lds, se_tail_lds_bytes(tail.se));
     if (d.whole_map) {
         dim3 gridm((unsigned)((d.C + 31) / 32), (unsigned)batch);
 #define MBM_LAUNCH(K, S)                                                                                                                           \
@@ -2349,13 +2450,14 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
     // Where two or more plain blocks fit, those already overlap each other and the plain kernel is faster.
     // BN_MBPIPE=0 never, =1 always (results are bit-identical either way).
     const int pipe_mode = getenv("BN_MBPIPE") ? atoi(getenv("BN_MBPIPE")) : -1;  // read per launch (launches are captured once per graph)
-    const size_t plds = mbconv_pipe_lds_bytes(d);
-    const bool pipe = pipe_mode == 1 || (pipe_mode == -1 && lds > 80 * 1024);
+    size_t plds = mbconv_pipe_lds_bytes(d);
+    if (tail.on) plds = std::max(plds, se_tail_lds_bytes(tail.se));
+    const bool pipe = pipe_mode == 1 || (pipe_mode == -1 && mbconv_lds_bytes(d) > 80 * 1024);
     if (pipe && d.C > 32 && plds <= 160 * 1024) {
 #define MBP_LAUNCH2(K, S, IM)                                                                                                    \
     do {                                                                                                                         \
         if (!ensure_dynamic_lds(reinterpret_cast<const void *>(mbconv_pipe_kernel<K, S, IM>), plds)) { launch_error("kernel needs more LDS than the device grants"); break; } \
-        hipLaunchKernelGGL((mbconv_pipe_kernel<K, S, IM>), grid, dim3(512), plds, s, d, out, in, w1, b1, w2, b2, gap);           \
+        hipLaunchKernelGGL((mbconv_pipe_kernel<K, S, IM>), grid, dim3(512), plds, s, d, out, in, w1, b1, w2, b2, gap, tail);     \
     } while (0)
 #define MBP_LAUNCH(K, S)                       \
     do {                                       \
@@ -2373,7 +2475,7 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
 #define MB_LAUNCH2(K, S, IM)                                                                                                     \
     do {                                                                                                                         \
         if (!ensure_dynamic_lds(reinterpret_cast<const void *>(mbconv_expand_dw_kernel<K, S, IM>), lds)) { launch_error("kernel needs more LDS than the device grants"); break; } \
-        hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, IM>), grid, dim3(256), lds, s, d, out, in, w1, b1, w2, b2, gap);       \
+        hipLaunchKernelGGL((mbconv_expand_dw_kernel<K, S, IM>), grid, dim3(256), lds, s, d, out, in, w1, b1, w2, b2, gap, tail); \
     } while (0)
 #define MB_LAUNCH(K, S)                  \
     do {                                 \
@@ -2389,15 +2491,19 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
 }
 
 void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w, const float *bias, float *gap,
-                   int64_t batch) {
+                   int64_t batch, const SeTail *tailp) {
     if (batch <= 0) return;
     if (d.tiled == 2) {
         dim3 grid((unsigned)((d.C + 31) / 32), (unsigned)batch);
-        const size_t lds = ((size_t)d.H * d.W * 32 + 256) * sizeof(float);
+        SeTail tail{};
+        if (tailp) tail = *tailp;
+        tail.nblocks = (d.C + 31) / 32;
+        size_t lds = ((size_t)d.H * d.W * 32 + 256) * sizeof(float);
+        if (tail.on) lds = std::max(lds, se_tail_lds_bytes(tail.se));
 #define DWM_LAUNCH(K, S)                                                                                                                           \
     do {                                                                                                                                         \
         if (!ensure_dynamic_lds(reinterpret_cast<const void *>(dwconv_map_kernel<K, S>), lds)) { launch_error("kernel needs more LDS than the device grants"); break; } \
-        hipLaunchKernelGGL((dwconv_map_kernel<K, S>), grid, dim3(256), lds, s, d, out, in, w, bias, gap);                                        \
+        hipLaunchKernelGGL((dwconv_map_kernel<K, S>), grid, dim3(256), lds, s, d, out, in, w, bias, gap, tail);                                  \
     } while (0)
         if (d.kw == 3 && d.sw == 1) DWM_LAUNCH(3, 1);
         else if (d.kw == 3 && d.sw == 2) DWM_LAUNCH(3, 2);
