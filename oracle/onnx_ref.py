@@ -253,8 +253,23 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
                 dil = [int(s) for s in a.get("dilations", [1] * sp)]
                 pads = [int(p) for p in a.get("pads", [0] * (2 * sp))]
                 groups = int(a.get("group", 1))
-                if a.get("auto_pad", "NOTSET") != "NOTSET":
-                    raise NotImplementedError("auto_pad")
+                auto_pad = a.get("auto_pad", "NOTSET")
+                if isinstance(auto_pad, bytes):
+                    auto_pad = auto_pad.decode()
+                if auto_pad in ("SAME_UPPER", "SAME_LOWER"):
+                    # ONNX Conv: output = ceil(input / stride); total padding = max((out - 1) * stride + effective
+                    # kernel - input, 0); the odd element goes to the end (SAME_UPPER) or the beginning (SAME_LOWER)
+                    pads = [0] * (2 * sp)
+                    for d in range(sp):
+                        size, kk = xx.shape[2 + d], (w.shape[2 + d] - 1) * dil[d] + 1
+                        out_d = -(-size // strides[d])
+                        tot = max((out_d - 1) * strides[d] + kk - size, 0)
+                        lo_ = tot // 2 if auto_pad == "SAME_UPPER" else tot - tot // 2
+                        pads[d], pads[d + sp] = lo_, tot - lo_
+                elif auto_pad == "VALID":
+                    pads = [0] * (2 * sp)
+                elif auto_pad != "NOTSET":
+                    raise NotImplementedError("auto_pad " + str(auto_pad))
                 # explicit zero padding (begin/end may differ), then an unpadded convolution
                 padl = []
                 for d in reversed(range(sp)):

@@ -105,6 +105,9 @@ class GraphBuilder:
         self.outputs: list[bytes] = []
         self._n = 0
         self.node_count = 0
+        # every constant in creation order as (name, hint, array): lets tests rebuild the network from the raw weights
+        # without ever going through the serialised file
+        self.const_values: list = []
 
     def fresh(self, hint: str = "t") -> str:
         self._n += 1
@@ -113,6 +116,7 @@ class GraphBuilder:
     def const(self, arr, hint: str = "c") -> str:
         name = self.fresh(hint)
         self.inits.append(tensor_proto(name, np.asarray(arr)))
+        self.const_values.append((name, hint, np.asarray(arr)))
         return name
 
     def add_input(self, name: str, shape: Sequence):

@@ -195,9 +195,12 @@ def _mel_branch_real(g: GraphBuilder, x3: str, sr: int, n_fft: int, hop: int, n_
 
 
 def birdnet_v24(num_species: int = 6522, seed: int = 24, width: float = 1.0, depth: float = 1.0,
-                head: int = 1024, se: bool = True, bn_nodes: bool = True) -> bytes:
+                head: int = 1024, se: bool = True, bn_nodes: bool = True, builder_out: list | None = None) -> bytes:
+    """builder_out: if a list is given, the GraphBuilder is appended to it (tests read the raw constants from it)."""
     rng = np.random.RandomState(seed)
     g = GraphBuilder("birdnet_v24_synth")
+    if builder_out is not None:
+        builder_out.append(g)
     S, sr = 144000, 48000
     g.add_input("input", [None, S])
     x3 = _minmax_normalise(g, "input")
@@ -220,9 +223,11 @@ def birdnet_v24(num_species: int = 6522, seed: int = 24, width: float = 1.0, dep
 
 
 def birdnet_v30(num_species: int = 1000, seed: int = 30, width: float = 1.0, depth: float = 1.0,
-                emb: int = 1024) -> bytes:
+                emb: int = 1024, builder_out: list | None = None) -> bytes:
     rng = np.random.RandomState(seed)
     g = GraphBuilder("birdnet_v30_synth")
+    if builder_out is not None:
+        builder_out.append(g)
     S, sr, n_fft, hop, n_mels = 160000, 32000, 1024, 320, 128
     g.add_input("input", [None, S])
     u = g.node("Unsqueeze", ["input", g.const(np.array([1], dtype=np.int64))])
@@ -251,9 +256,11 @@ def birdnet_v30(num_species: int = 1000, seed: int = 30, width: float = 1.0, dep
 
 
 def perch_v2(num_species: int = 14795, seed: int = 2, width: float = 1.0, depth: float = 1.0,
-             emb: int = 1536) -> bytes:
+             emb: int = 1536, builder_out: list | None = None) -> bytes:
     rng = np.random.RandomState(seed)
     g = GraphBuilder("perch_v2_synth")
+    if builder_out is not None:
+        builder_out.append(g)
     S, sr, n_fft, hop, n_mels = 160000, 32000, 640, 320, 128
     g.add_input("inputs", [None, S])
     i64 = lambda *v: g.const(np.array(v, dtype=np.int64))

@@ -653,3 +653,25 @@ def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride):
     assert "MBCONV" not in bn.plan_describe(write_model(data))
     got2, _ = run_both(bn, data, batch=3)
     assert_close(got2, ref, f"gemm + dw map {cin}->{cmid} k{k} s{stride}")
+
+
+@pytest.mark.parametrize("auto_pad,cin,cout,k,stride,groups", [("SAME_UPPER", 3, 16, 3, 2, 1), ("SAME_LOWER", 3, 16, 4, 2, 1), ("SAME_UPPER", 32, 32, 5, 2, 32),
+                                                                ("SAME_LOWER", 32, 32, 3, 1, 32), ("VALID", 8, 24, 3, 2, 1), ("SAME_UPPER", 24, 40, 1, 1, 1)])
+def test_conv_auto_pad(bn, auto_pad, cin, cout, k, stride, groups):
+    """auto_pad (tf2onnx exports carry it instead of explicit pads): dense, depthwise and 1x1 convolutions against the
+    oracle, whose auto_pad rule is itself checked against torch in tests/test_oracle_independent.py."""
+    rng = np.random.default_rng(k + stride)
+    h, w = 23, 30
+    wgt = (rng.standard_normal((cout, cin // groups, k, k)) / np.sqrt(cin // groups * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    oh = (h - k) // stride + 1 if auto_pad == "VALID" else -(-h // stride)
+    ow = (w - k) // stride + 1 if auto_pad == "VALID" else -(-w // stride)
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(cin * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, cin, h, w)])
+        y = g.node("Conv", [x, g.const(wgt), g.const(b)], kernel_shape=[k, k], strides=[stride, stride], auto_pad=auto_pad, group=groups)
+        return g.node("Relu", [y])
+    got, ref = run_both(bn, op_graph(build, [cout, oh, ow]))
+    assert_close(got, ref, f"conv auto_pad={auto_pad} k={k} s={stride} g={groups}")

@@ -1,0 +1,108 @@
+"""The network oracle (oracle/onnx_ref.py) against formulations that never touch an ONNX file: torch.stft + an explicit
+mel matrix for the front ends, torch.nn.functional blocks on the raw synth weights for the CNN and the heads
+(tests/torch_reference.py).  fp64 on both sides pins the SEMANTICS (agreement to 1e-9: no shared misreading of an ONNX
+rule survives that); fp32 bounds what summation order alone costs.  Parity to the reference's real model files stays
+unpinned."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import torch_reference as tr
+from oracle import onnx_ref
+
+synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _image_name(g):
+    """name of the tensor the stem convolution reads (the spectrogram image)"""
+    for n in g.nodes:
+        if n.op == "Conv" and g.inits[n.inputs[1]].ndim == 4:
+            return n.inputs[0]
+    raise AssertionError("no 2-D convolution in the graph")
+
+
+CASES = {
+    "v24": (lambda out: synth.birdnet_v24(num_species=120, width=0.5, depth=0.5, head=128, builder_out=out), 144000, 48000,
+            lambda x, b, dt: tr.birdnet_v24(x, b, dt, width=0.5, depth=0.5, head=128, num_species=120), ["output"]),
+    "v30": (lambda out: synth.birdnet_v30(num_species=90, width=0.5, depth=0.34, emb=96, builder_out=out), 160000, 32000,
+            lambda x, b, dt: tr.birdnet_v30(x, b, dt, width=0.5, depth=0.34, emb=96, num_species=90), ["output_0", "output_1"]),
+    "perch": (lambda out: synth.perch_v2(num_species=70, width=0.25, depth=0.2, emb=64, builder_out=out), 160000, 32000,
+              lambda x, b, dt: tr.perch_v2(x, b, dt, width=0.25, depth=0.2, emb=64, num_species=70),
+              ["embedding", "spatial_embedding", "spectrogram", "label"]),
+}
+
+
+@pytest.mark.parametrize("family", list(CASES))
+def test_oracle_agrees_with_an_onnx_free_formulation(family):
+    make, S, sr, independent, names = CASES[family]
+    holder = []
+    data = make(holder)
+    x = synth.synthetic_segments(2, S, sr, first_index=3)
+    g = onnx_ref.load_graph(data)
+    extra = [_image_name(g)] if family != "perch" else []
+    # double precision on both sides: the two formulations denote the same function
+    want = independent(x, holder[0], torch.float64)
+    got = onnx_ref.run_graph(g, x, dtype=torch.float64, outputs=names + extra)
+    for n in names:
+        assert got[n].shape == want[n].shape, (n, got[n].shape, want[n].shape)
+        if n == "spectrogram":  # a front-end tensor: see the note on the image below
+            a, b_ = np.asarray(got[n], np.float64), np.asarray(want[n], np.float64)
+            assert np.abs(a - b_).max() < 1e-5 * np.abs(b_).max() and np.abs(a - b_).mean() < 1e-7 * np.abs(b_).max()
+        else:  # (feature maps right behind the front end inherit a little of its few 1e-6 pixels)
+            assert _rel(got[n], want[n]) < (1e-6 if n == "spatial_embedding" else 1e-9), (family, n, _rel(got[n], want[n]))
+    if extra:
+        # The front end on its own: torch.stft + mel matrix + compression vs the DFT-as-convolution graph.  The graph's
+        # DFT taps are float32-rounded (they are the model's weights), torch.stft's are exact: the spectra differ by
+        # ~1e-8, which the power law x^0.23 (v2.4) / the logarithm (v3.0) turns into a few 1e-7 at the handful of
+        # pixels where the mel energy is ~0 -- hence a loose bound on the worst pixel and a tight one on the mean.
+        a, b_ = np.asarray(got[extra[0]], np.float64), np.asarray(want["_image"], np.float64)
+        assert a.shape == b_.shape
+        assert np.abs(a - b_).max() < 5e-6 * np.abs(b_).max() and np.abs(a - b_).mean() < 1e-7 * np.abs(b_).max()
+    # single precision: only rounding separates them
+    want32 = independent(x, holder[0], torch.float32)
+    got32 = onnx_ref.run_graph(g, x, dtype=torch.float32, outputs=names)
+    for n in names:
+        assert _rel(got32[n], want32[n]) < 5e-4, (family, n, _rel(got32[n], want32[n]))
+        assert _rel(got32[n], want[n]) < 5e-4  # ... and the fp32 oracle is that close to the fp64 truth
+    if family == "v24":
+        assert int(np.argmax(got32["output"][0])) == int(np.argmax(want["output"][0]))
+
+
+@pytest.mark.parametrize("auto_pad,stride,k", [("SAME_UPPER", 1, 3), ("SAME_UPPER", 2, 3), ("SAME_LOWER", 2, 4), ("SAME_UPPER", 2, 5),
+                                                ("SAME_LOWER", 1, 2), ("VALID", 2, 3)])
+def test_oracle_conv_auto_pad_against_the_tensorflow_rule(auto_pad, stride, k):
+    """ONNX auto_pad: out = ceil(in / stride), total padding = max((out - 1) * stride + k - in, 0), the odd element at
+    the END for SAME_UPPER and at the BEGINNING for SAME_LOWER; VALID = no padding.  Checked against explicit
+    torch.nn.functional.pad + conv2d on the raw weights (and, for stride 1 / odd kernels, torch's own padding='same')."""
+    writer = importlib.import_module("rust-birdnet-onnx_amd.onnx_writer")
+    rng = np.random.default_rng(k * 10 + stride)
+    w = rng.standard_normal((5, 3, k, k)).astype(np.float32)
+    x = rng.standard_normal((2, 3, 11, 14)).astype(np.float32)
+    gb = writer.GraphBuilder()
+    gb.add_input("x", [None, 3, 11, 14])
+    y = gb.node("Conv", ["x", gb.const(w)], kernel_shape=[k, k], strides=[stride, stride], auto_pad=auto_pad)
+    gb.node("Identity", [y], outputs=["y"])
+    gb.add_output("y", None)
+    got = onnx_ref.run_model(gb.serialize(), x)["y"]
+    xt, wt = torch.from_numpy(x), torch.from_numpy(w)
+    if auto_pad == "VALID":
+        want = torch.nn.functional.conv2d(xt, wt, stride=stride)
+    else:
+        pads = []
+        for size in (14, 11):  # F.pad wants the LAST dimension first
+            out = -(-size // stride)
+            tot = max((out - 1) * stride + k - size, 0)
+            lo = tot // 2 if auto_pad == "SAME_UPPER" else tot - tot // 2
+            pads += [lo, tot - lo]
+        want = torch.nn.functional.conv2d(torch.nn.functional.pad(xt, pads), wt, stride=stride)
+        if stride == 1 and k % 2 == 1:
+            assert torch.allclose(want, torch.nn.functional.conv2d(xt, wt, padding="same"), atol=1e-6)
+    assert got.shape == tuple(want.shape)
+    assert np.abs(got - want.numpy()).max() < 1e-5
