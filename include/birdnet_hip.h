@@ -115,6 +115,8 @@ bn_status bn_model_load_buffer(const void *onnx_bytes, size_t len, int32_t devic
  * bn_model_free and bn_ctx_destroy does not matter (the reference's BatchInferenceContext is an owned
  * value, src/batch_context.rs:70-85). */
 void bn_model_free(bn_model *m);
+/* HIP device ordinal the model was loaded on (device_id of the reference's GPU configs, cuda_config.rs:179-182); -1 for NULL. */
+int32_t bn_model_device(const bn_model *m);
 /* session.inputs()/outputs() metadata (classifier.rs:387-420) */
 bn_status bn_model_io_info(const bn_model *m, bn_io_info *out);
 /* detect_model_type() result for the loaded graph (detection.rs:15-145) */
@@ -300,6 +302,40 @@ bn_status bn_infer_windows(bn_ctx *c, const bn_recording *r, size_t step_samples
  * (src/bin/birdnet-analyze.rs:556-600) with several contexts in flight. */
 bn_status bn_step_windows(bn_ctx *c, const bn_recording *r, size_t step_samples, size_t first_window,
                           size_t count, size_t top_k, int32_t has_min, float min_conf, int32_t sync);
+
+/* Device view of the packed top-K rows of the last bn_step_device / bn_step_windows on this context:
+ * [idx: m*k][conf: m*k (float bits)][count: m] for the m rows and k = min(top_k, num_species) of that step.
+ * Valid until the next step; reading it must be ordered after the step on bn_ctx_stream(). */
+bn_status bn_ctx_step_device_rows(const bn_ctx *c, const uint32_t **d_rows);
+
+/*
+ * Multi-GPU (BASELINE.json configs[4]).  The reference has no multi-device code -- its only
+ * knob is device_id (src/cuda_config.rs:179-182, src/tensorrt_config.rs:273-276) -- so the contract is "identical to
+ * running every window on one device": windows of chunk_audio (src/bin/birdnet-analyze.rs:707-743) are sharded by
+ * contiguous range, rank r of R owns [r * ceil(G/R), min(G, (r+1) * ceil(G/R))) (bn_shard_range).
+ *
+ * bn_group_create takes one model replica per device (load the same file once per device with bn_model_load) and
+ * creates contexts_per_device contexts (streams) of max_batch on each.  bn_group_analyze_recording cuts the recording
+ * (host int16 / f32 samples) into windows of the model's sample_count at step_samples, lets every rank upload and
+ * analyse only its own slice (one host thread per device inside the call), and assembles the results with ONE
+ * all-gather of the [G, num_species] logits (logits_out != NULL) and one of the packed top-K rows (count_out != NULL)
+ * -- RCCL ncclAllGather over xGMI when the ranks sit on distinct devices (librccl is loaded on first use), plain
+ * device copies when they share one (tests on a single GPU).  Outputs are host arrays in window order:
+ * logits_out [G * num_species], idx_out / conf_out [G * k_stride], count_out [G]; *n_windows_out = G.
+ * A step of 0 (overlap >= segment) yields G = 0 as chunk_audio does.  Errors: bn_group_last_error().
+ */
+typedef struct bn_group bn_group;
+bn_status bn_group_create(bn_model *const *models, const int32_t *devices, int32_t n, size_t max_batch,
+                          int32_t contexts_per_device, bn_group **out);
+void bn_group_destroy(bn_group *g);
+int32_t bn_group_size(const bn_group *g);
+int32_t bn_group_uses_rccl(const bn_group *g);
+void bn_shard_range(size_t n_windows, int32_t rank, int32_t world, size_t *lo, size_t *hi);
+bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samples, int32_t format,
+                                     size_t step_samples, size_t top_k, int32_t has_min, float min_conf,
+                                     float *logits_out, size_t k_stride, uint32_t *idx_out, float *conf_out,
+                                     uint32_t *count_out, size_t *n_windows_out);
+size_t bn_group_last_error(char *buf, size_t cap);
 
 /* Diagnostic, needs no device: parse the file, build the launch plan (all graph
  * outputs when all_outputs != 0, else logits + embeddings only) and write a

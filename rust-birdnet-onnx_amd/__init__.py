@@ -41,12 +41,13 @@ BN_CTX_DEFAULT, BN_CTX_ALL_OUTPUTS, BN_CTX_NO_GRAPH = 0, 1, 2
 # every symbol include/birdnet_hip.h and include/birdnet_host.h declare
 ENGINE_SYMBOLS = [
     "bn_abi_version", "bn_device_count", "bn_model_load", "bn_model_load_buffer", "bn_model_free",
-    "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create",
+    "bn_model_device", "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create",
     "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_submit", "bn_infer_collect", "bn_infer_device",
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
     "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
     "bn_recording_create", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
-    "bn_infer_windows", "bn_step_windows", "bn_recording_create_resampled", "bn_resample_table", "bn_recording_read_f32", "bn_last_error",
+    "bn_infer_windows", "bn_step_windows", "bn_ctx_step_device_rows", "bn_group_create", "bn_group_destroy", "bn_group_size",
+    "bn_group_uses_rccl", "bn_shard_range", "bn_group_analyze_recording", "bn_group_last_error", "bn_recording_create_resampled", "bn_resample_table", "bn_recording_read_f32", "bn_last_error",
 ]
 HOST_SYMBOLS = [
     "bnh_classifier_build", "bnh_classifier_free", "bnh_classifier_config", "bnh_classifier_provider",
@@ -100,6 +101,7 @@ def _load() -> C.CDLL:
         "bn_model_load": (i32, [C.c_char_p, i32, i32, C.POINTER(vp)]),
         "bn_model_load_buffer": (i32, [vp, sz, i32, i32, C.POINTER(vp)]),
         "bn_model_free": (None, [vp]),
+        "bn_model_device": (i32, [vp]),
         "bn_model_io_info": (i32, [vp, C.POINTER(BnIoInfo)]),
         "bn_model_get_config": (i32, [vp, C.POINTER(BnModelConfig)]),
         "bn_model_get_cost": (i32, [vp, C.POINTER(BnModelCost)]),
@@ -134,6 +136,14 @@ def _load() -> C.CDLL:
         "bn_resample_table": (sz, [C.c_uint32, C.c_uint32, C.c_uint32, f32p, sz, u32p, u32p, u32p]),
         "bn_recording_read_f32": (i32, [vp, sz, sz, f32p]),
         "bn_last_error": (sz, [C.c_char_p, sz]),
+        "bn_ctx_step_device_rows": (i32, [vp, C.POINTER(u32p)]),
+        "bn_group_create": (i32, [C.POINTER(vp), C.POINTER(C.c_int32), i32, sz, i32, C.POINTER(vp)]),
+        "bn_group_destroy": (None, [vp]),
+        "bn_group_size": (i32, [vp]),
+        "bn_group_uses_rccl": (i32, [vp]),
+        "bn_shard_range": (None, [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]),
+        "bn_group_analyze_recording": (i32, [vp, vp, sz, i32, sz, sz, i32, C.c_float, f32p, sz, u32p, f32p, u32p, C.POINTER(sz)]),
+        "bn_group_last_error": (sz, [C.c_char_p, sz]),
         # host mirror
         "bnh_classifier_build": (i32, [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), sz, i32, C.c_int64, i32,
                                        C.c_float, i32, C.POINTER(vp), C.POINTER(BnhError)]),
@@ -920,6 +930,61 @@ def topk_host(logits: np.ndarray, top_k: int, min_confidence: Optional[float] = 
     if st:
         raise EngineError(st)
     return idx, conf, cnt
+
+
+class Group:
+    """bn_group: one model replica per device, a recording sharded by window across them, results all-gathered on the
+    devices (RCCL between distinct devices, device copies between ranks that share one)."""
+
+    def __init__(self, models, max_batch: int = 32, contexts_per_device: int = 4):
+        self.models = list(models)
+        n = len(self.models)
+        hs = (C.c_void_p * n)(*[m._h for m in self.models])
+        devs = (C.c_int32 * n)(*[m.device for m in self.models])
+        h = C.c_void_p()
+        st = lib.bn_group_create(hs, devs, n, max_batch, contexts_per_device, C.byref(h))
+        if st:
+            raise RuntimeError(f"bn_group_create: status {st}: {group_last_error()}")
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.bn_group_destroy(self._h)
+            self._h = None
+
+    def size(self) -> int:
+        return lib.bn_group_size(self._h)
+
+    def uses_rccl(self) -> bool:
+        return bool(lib.bn_group_uses_rccl(self._h))
+
+    def analyze_recording(self, samples: np.ndarray, step_samples: int, top_k: int = 10, min_confidence: Optional[float] = None,
+                          want_logits: bool = True):
+        """(logits or None, idx, conf, count) for every window of the recording, in time order."""
+        x = np.ascontiguousarray(samples)
+        fmt = {np.dtype(np.int16): 0, np.dtype(np.float32): 1}[x.dtype]
+        cfg = self.models[0].config
+        G = lib.bn_chunk_count(x.shape[0], step_samples)
+        N = int(cfg.num_species)
+        k = min(top_k, N)
+        f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        logits = np.empty((G, N), dtype=np.float32) if want_logits else None
+        idx, conf, cnt = np.zeros((G, max(k, 1)), dtype=np.uint32), np.zeros((G, max(k, 1)), dtype=np.float32), np.zeros(G, dtype=np.uint32)
+        ng = C.c_size_t(0)
+        st = lib.bn_group_analyze_recording(self._h, x.ctypes.data_as(C.c_void_p), x.shape[0], fmt, step_samples, top_k,
+                                            0 if min_confidence is None else 1, C.c_float(min_confidence or 0.0),
+                                            None if logits is None else logits.ctypes.data_as(f32p), max(k, 1), idx.ctypes.data_as(u32p),
+                                            conf.ctypes.data_as(f32p), cnt.ctypes.data_as(u32p), C.byref(ng))
+        if st:
+            raise RuntimeError(f"bn_group_analyze_recording: status {st}: {group_last_error()}")
+        assert ng.value == G
+        return logits, idx[:, :k], conf[:, :k], cnt
+
+
+def group_last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    lib.bn_group_last_error(buf, 1024)
+    return buf.value.decode(errors="replace")
 
 
 def plan_describe(path: str, model_type: int = -1, all_outputs: bool = False) -> str:

@@ -494,6 +494,8 @@ static void model_unref(bn_model *m) {
 }
 void bn_model_free(bn_model *m) { model_unref(m); }
 
+int32_t bn_model_device(const bn_model *m) { return m ? m->device : -1; }
+
 bn_status bn_model_io_info(const bn_model *m, bn_io_info *out) {
     if (!m || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
     memset(out, 0, sizeof(*out));
@@ -1110,6 +1112,13 @@ bn_status bn_step_results(const bn_ctx *c, const float **logits, const uint32_t 
     if (conf) *conf = c->h_tk_conf;
     if (count) *count = c->h_tk_cnt;
     if (k_stride) *k_stride = c->step_k;
+    return BN_OK;
+}
+
+bn_status bn_ctx_step_device_rows(const bn_ctx *c, const uint32_t **d_rows) {
+    if (!c || !d_rows) return fail(BN_ERR_INVALID_ARG, "null argument");
+    if (!c->d_step) return fail(BN_ERR_INVALID_ARG, "no step has run on this context");
+    *d_rows = c->d_step;
     return BN_OK;
 }
 

@@ -150,7 +150,23 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
     N = ctxs[0].output_device(cfg.logits_output)[1]
     k = min(top_k, N)
     n_local = hi - lo
-    logits = np.empty((n_local, N), dtype=np.float32) if gather == "logits" else None
+    # With RCCL the logits never leave the device before the collective: every finished step's rows are copied from the
+    # context's device buffer into this rank's slab of the gather buffer ON THE CONTEXT'S STREAM (device to device), and
+    # the slab is all-gathered in place.  (Round 1 went device -> host -> numpy -> device -> all_gather -> host.)
+    on_gpu = dist is not None and dist.is_initialized() and dist.get_backend() == "nccl" and gather == "logits"  # (also a 1-rank rehearsal)
+    cap = shard_capacity(G, world)
+    slab = views = streams = None
+    if on_gpu:
+        class _DevView:  # zero-copy torch view of a context's device logits
+            def __init__(self, ptr, shape):
+                self.__cuda_array_interface__ = {"data": (ptr, False), "shape": shape, "typestr": "<f4", "version": 2}
+
+        torch.cuda.set_device(model.device)
+        full = torch.zeros((world * cap, N), dtype=torch.float32, device=torch.device("cuda", model.device))
+        slab = full[rank * cap:(rank + 1) * cap]
+        views = [torch.as_tensor(_DevView(c.output_device(cfg.logits_output)[0], (batch, N)), device=slab.device) for c in ctxs]
+        streams = [torch.cuda.ExternalStream(c.stream()) for c in ctxs]
+    logits = np.empty((n_local, N), dtype=np.float32) if gather == "logits" and not on_gpu else None
     idx = np.zeros((n_local, k), dtype=np.uint32)
     conf = np.zeros((n_local, k), dtype=np.float32)
     cnt = np.zeros(n_local, dtype=np.uint32)
@@ -169,10 +185,13 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
         if j >= len(ctxs):
             collect(j - len(ctxs))
         ctxs[j % len(ctxs)].step_windows(rec, step, f, m, top_k, min_confidence)
+        if on_gpu:  # the step's rows -> this rank's slab, ordered behind the step on the context's own stream
+            with torch.cuda.stream(streams[j % len(ctxs)]):
+                slab[f:f + m].copy_(views[j % len(ctxs)][:m], non_blocking=True)
     for j in range(max(0, len(jobs) - len(ctxs)), len(jobs)):
         collect(j)
 
-    if world == 1:
+    if world == 1 and not on_gpu:
         return logits, idx, conf, cnt
     dev = torch.device("cuda", model.device) if dist.get_backend() == "nccl" else torch.device("cpu")
 
@@ -182,5 +201,13 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
     g_idx = gather_np(idx.view(np.int32), np.int32).view(np.uint32)
     g_conf = gather_np(conf, np.float32)
     g_cnt = gather_np(cnt.view(np.int32).reshape(-1, 1), np.int32).view(np.uint32).reshape(-1)
-    g_logits = gather_np(logits, np.float32) if logits is not None else None
+    if on_gpu:
+        for c in ctxs:
+            c.synchronize()  # every slab copy has landed
+        dist.all_gather_into_tensor(full, slab)
+        g_logits = full[:G].cpu().numpy()
+        # (rows of rank r sit at [r * cap, r * cap + n_r): with equal capacities the first G rows are exactly the windows in
+        # time order, because only the LAST ranks can be short and their padding lies behind row G)
+    else:
+        g_logits = gather_np(logits, np.float32) if logits is not None else None
     return g_logits, g_idx, g_conf, g_cnt

@@ -168,6 +168,49 @@ def test_sharded_recording_ingest_two_ranks_equal_single_pass(bn, tmp_path, over
         assert np.array_equal(got["conf"].view(np.uint32), want_conf.view(np.uint32))
 
 
+def _rccl_rehearsal_worker(rank, port, model_path, pcm_path, out_dir):
+    import os
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+
+    bn = __import__("importlib").import_module("rust-birdnet-onnx_amd")
+    dmod = __import__("importlib").import_module("rust-birdnet-onnx_amd.distributed")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+    try:
+        model = bn.Model(model_path)
+        lg, ix, cf, ct = dmod.analyze_recording_sharded(bn, model, np.load(pcm_path), 1.0, batch=4, streams=2, top_k=5, dist=dist)
+        np.savez(os.path.join(out_dir, "rccl.npz"), logits=lg, idx=ix, conf=cf, cnt=ct)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_recording_device_resident_gather_over_rccl(bn, tmp_path):
+    """The torchrun path with backend nccl (= RCCL): every step's logits rows go device to device into the rank's slab
+    of the gather buffer on the context's stream and ONE all_gather_into_tensor runs in place -- rehearsed with a
+    single-rank RCCL process group (the one-GPU box cannot host two RCCL ranks), bit-identical to the plain run."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    dmod = __import__("importlib").import_module("rust-birdnet-onnx_amd.distributed")
+    S, sr = 144000, 48000
+    rng = np.random.default_rng(5)
+    pcm = np.clip(rng.normal(0, 3000, S * 5 + 999), -32768, 32767).astype(np.int16)
+    path = write_model(synth.birdnet_v24(num_species=300, width=0.5))
+    want = dmod.analyze_recording_sharded(bn, bn.Model(path), pcm, 1.0, batch=4, streams=2, top_k=5)
+    np.save(tmp_path / "pcm.npy", pcm)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_rehearsal_worker, args=(port, path, str(tmp_path / "pcm.npy"), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "rccl.npz")
+    assert np.array_equal(got["logits"].view(np.uint32), want[0].view(np.uint32))
+    assert np.array_equal(got["idx"], want[1]) and np.array_equal(got["cnt"], want[3]) and got["conf"].tobytes() == want[2].tobytes()
+
+
 @pytest.mark.parametrize("src,dst,dtype", [(44100, 48000, np.int16), (48000, 32000, np.int16), (22050, 48000, np.float32), (96000, 48000, np.int16),
                                            (44100, 32000, np.float32)])
 def test_device_resampler_matches_the_oracle(bn, src, dst, dtype):

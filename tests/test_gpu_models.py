@@ -4,6 +4,7 @@ hypothesised topologies through the C ABI / C++ Classifier mirror vs the CPU ora
 Tolerance (fp32, stated here as north_star asks): |gpu - oracle| <= 2e-4 + 2e-4*|oracle| on every
 logit / embedding value, identical top-1 index, and top-K sets equal to the oracle's top-K of the
 GPU's own logits (bit-exact post-processing)."""
+import ctypes as C
 import importlib
 import os
 
@@ -350,3 +351,63 @@ def test_sharded_recording_equals_single_pass(bn, v24_small):
     a, _ = ctx_all.infer(w[:16])
     b, _ = bn.Context(m, 4).infer(w[4:8])
     assert a[4:8].tobytes() == b.tobytes()
+
+
+def test_group_api_sharded_recording_through_the_c_abi(bn, v24_small):
+    """bn_group_*: the recording analysis of BASELINE.json configs[4] behind the C ABI.  One rank, and two / three ranks
+    sharing device 0 (the one-GPU box: the gather then runs as device copies instead of ncclAllGather -- same slabs, same
+    layout), with overlap so that shards share samples, must reproduce the single-context pass bit for bit: logits, top-K
+    indices, confidence bits and counts; the ragged last shard and an int16 recording included."""
+    data, path = v24_small
+    S, sr = 144000, 48000
+    pcm = (np.clip(synth.synthetic_segments(1, S * 6 + 7777, sr)[0], -1, 1) * 32767).astype(np.int16)
+    step = S - int(1.0 * sr)                                         # 1 s overlap: windows share samples across shards
+    m0 = bn.Model(path)
+    ctx = bn.Context(m0, 4)
+    rec = bn.Recording(pcm)
+    G = rec.n_windows(step)
+    assert G == bn.lib.bn_chunk_count(pcm.shape[0], step) and G >= 9
+    want_l, want_i, want_c, want_n = [], [], [], []
+    for f in range(0, G, 4):
+        n = min(4, G - f)
+        ctx.step_windows(rec, step, f, n, 5, 0.02)
+        ctx.synchronize()
+        lg, ix, cf, ct = ctx.step_results(n)
+        want_l.append(lg); want_i.append(ix); want_c.append(cf); want_n.append(ct)
+    want_l, want_i, want_c, want_n = np.concatenate(want_l), np.concatenate(want_i), np.concatenate(want_c), np.concatenate(want_n)
+    for world, batch, nctx in ((1, 4, 2), (2, 3, 2), (3, 2, 1)):
+        models = [bn.Model(path) for _ in range(world)]
+        grp = bn.Group(models, max_batch=batch, contexts_per_device=nctx)
+        assert grp.size() == world and not grp.uses_rccl()          # ranks share device 0
+        lg, ix, cf, ct = grp.analyze_recording(pcm, step, top_k=5, min_confidence=0.02)
+        assert lg.tobytes() == want_l.tobytes(), world
+        assert np.array_equal(ct, want_n)
+        for r in range(G):
+            assert np.array_equal(ix[r, :ct[r]], want_i[r, :ct[r]]) and cf[r, :ct[r]].tobytes() == want_c[r, :ct[r]].tobytes()
+        # top-K rows only (80 B instead of 26 KB per window cross the collective), and a second call on the same group
+        _, ix2, cf2, ct2 = grp.analyze_recording(pcm, step, top_k=5, min_confidence=0.02, want_logits=False)
+        assert np.array_equal(ct2, ct) and ix2.tobytes() == ix.tobytes() and cf2.tobytes() == cf.tobytes()
+    # chunk_audio semantics at the boundary: a saturated step yields no windows; shard ranges tile [0, G)
+    grp = bn.Group([bn.Model(path)], max_batch=2, contexts_per_device=1)
+    lg, ix, cf, ct = grp.analyze_recording(pcm, 0, top_k=3)
+    assert lg.shape[0] == 0 and ct.shape[0] == 0
+    lo, hi = C.c_size_t(), C.c_size_t()
+    cover = []
+    for r in range(8):
+        bn.lib.bn_shard_range(28800, r, 8, C.byref(lo), C.byref(hi))
+        cover.append((lo.value, hi.value))
+    assert cover[0] == (0, 3600) and cover[-1] == (25200, 28800) and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    dmod = importlib.import_module("rust-birdnet-onnx_amd.distributed")
+    assert [dmod.shard_range(13, r, 4) for r in range(4)] == [tuple(int(v) for v in _range(bn, 13, r, 4)) for r in range(4)]
+    # a model of another device in the group is refused
+    with pytest.raises(RuntimeError):
+        h = C.c_void_p()
+        hs, devs = (C.c_void_p * 1)(m0._h), (C.c_int32 * 1)(1)
+        if bn.lib.bn_group_create(hs, devs, 1, 2, 1, C.byref(h)):
+            raise RuntimeError(bn.group_last_error())
+
+
+def _range(bn, G, r, world):
+    lo, hi = C.c_size_t(), C.c_size_t()
+    bn.lib.bn_shard_range(G, r, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
