@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host (bn_infer_submit / collect) measurement")
     ap.add_argument("--host-steps", type=int, default=120, help="minimum number of steps of the host-to-host leg")
     ap.add_argument("--host-warmup", type=int, default=96, help="minimum number of warm-up steps of the host-to-host leg")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="segments the CPU oracle is timed on (about 15-30 s of host work)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="segments the CPU oracle is timed on (about 15-30 s of host work)")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
@@ -315,6 +315,7 @@ def main():
             f_["bytes"] += byts
             f_["launches"] += 1
         total_us = sum(v["us"] for v in fam.values())
+        cost = model.cost()
         dom = max(fam.items(), key=lambda kv: kv[1]["us"])
         dname, d = dom
         tf = 2.0 * d["macs"] / (d["us"] * 1e-6) / 1e12
@@ -334,10 +335,24 @@ def main():
                 traffic_src = f"profiles/{tj['tag']}_pmc_traffic.json"
         except (OSError, ValueError, KeyError):
             pass
+        # matrix-pipe utilisation of the same family from the committed SQ counter pass (profiles/pmc_mfma.json)
+        mfma_busy, mfma_src = None, None
+        try:
+            mj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_mfma.json")))
+            if mj.get("batch") == B and dname in mj.get("families", {}):
+                mfma_busy = mj["families"][dname]["mfma_busy"]
+                mfma_src = f"profiles/{mj['tag']}_pmc_mfma.json"
+        except (OSError, ValueError, KeyError):
+            pass
+        roof.update({"mfma_busy": mfma_busy, "mfma_busy_source": mfma_src})
         roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                      "kernel": dname, "launches_per_step": d["launches"],
                      "avg_launch_us": round(d["us"] / d["launches"], 2), "share_of_step": round(d["us"] / total_us, 3),
                      "alt_frac": {"hbm": round(frac_hbm, 4), "mfma_f32": round(frac_mfma, 4)},
+                     "flops_performed_per_segment": round(2.0 * (cost.macs_mfma + cost.macs_valu)),
+                     "flops_fft_counted_per_segment": round(2.0 * (cost.macs_mfma + cost.macs_valu - cost.dft_performed_macs) + cost.dft_fft_equiv_flops),
+                     "flops_note": "achieved/frac use flops PERFORMED; flops_fft_counted prices the windowed-DFT banks at 2.5 L log2 L per frame "
+                                   "(SURVEY.md 8(d)) instead of the folded matrix product the plan runs -- multiply value x flops_fft_counted for the FFT-normalised rate",
                      "flops_counted": "multiply-adds the launches perform (planner's walk after its rewrites: mel-dead DFT bins pruned, "
                                       "mirror-symmetric DFT bases folded to half their taps) -- not the exporter graph's nominal count"})
         out["roofline"] = roof
@@ -357,23 +372,43 @@ def main():
             for (name, us, macs, byts), k in sorted(zip(rows, kind_of), key=lambda t: -t[0][1])[:40]:
                 print(f"{us:9.1f} us  {k:7s} {name:42s} {2 * macs / us / 1e6:8.2f} TF/s {byts / us / 1e3:8.1f} GB/s", file=sys.stderr)
 
-        # ---- CPU baseline: the oracle (port), bounded sample, rank 0, N=1 only
+        # ---- CPU baseline: the oracle (kind "port": torch CPU fp32 restatement of the graph -- ORT-CPU and
+        # the model files do not exist offline), batches of 8 like the reference CLI's CPU default
+        # (src/bin/birdnet-analyze.rs:38-39), with the same dead-bin pruning the GPU plan applies, at every host thread
+        # the box gives this process and at ONE thread; bounded samples, rank 0, N = 1 only
         if world == 1 and not args.no_cpu_baseline:
             import torch as _t
             from oracle import onnx_ref
 
-            g = onnx_ref.load_graph(model_bytes)
-            xs = synth.synthetic_segments(args.cpu_sample, S, SR)
-            onnx_ref.run_graph(g, xs[:2])  # warm
-            t1 = time.perf_counter()
-            done = 0
-            for k in range(0, args.cpu_sample, 8):  # the reference CLI's CPU batch size is 8 (birdnet-analyze.rs:38-39)
-                onnx_ref.run_graph(g, xs[k:k + 8])
-                done += len(xs[k:k + 8])
-            cdt = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": round(done / cdt, 3), "unit": "segments/s", "cores": int(_t.get_num_threads()),
-                                   "kind": "port",
-                                   "sample": f"{done} segments (batches of 8) of the same synthetic workload through oracle/onnx_ref.py (torch CPU fp32, unfused ONNX graph incl. full DFT conv), {cdt:.1f} s"}
+            g = onnx_ref.prune_dead_filter_rows(onnx_ref.load_graph(model_bytes))
+            cpu_model = "unknown"
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        cpu_model = line.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
+            nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+            def timed(threads, budget_s, max_segments):
+                _t.set_num_threads(threads)
+                xs = synth.synthetic_segments(max_segments, S, SR)
+                onnx_ref.run_graph(g, xs[:8])  # warm
+                t1 = time.perf_counter()
+                done = 0
+                while done < max_segments and (done == 0 or time.perf_counter() - t1 < budget_s):
+                    onnx_ref.run_graph(g, xs[done:done + 8])
+                    done += len(xs[done:done + 8])
+                return done, time.perf_counter() - t1
+
+            d_all, t_all = timed(nproc, 12.0, args.cpu_sample)
+            d_one, t_one = timed(1, 12.0, 16)
+            _t.set_num_threads(nproc)
+            out["cpu_baseline"] = {"value": round(d_all / t_all, 3), "unit": "segments/s", "cores": int(nproc), "kind": "port",
+                                   "cpu_model": cpu_model, "single_thread": {"value": round(d_one / t_one, 3), "cores": 1, "sample": f"{d_one} segments, {t_one:.1f} s"},
+                                   "sample": f"{d_all} segments (batches of 8) of the same synthetic workload through oracle/onnx_ref.py (torch CPU fp32, the "
+                                             f"graph as exported minus the DFT rows no mel filter reads, as the GPU plan), {t_all:.1f} s on {nproc} threads"}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -98,6 +98,12 @@ typedef struct bn_model_cost {
      * when the graph has no such bank.  macs_valu contains fft_flops / 2 for banks that run as FFTs. */
     double dft_gemm_macs;
     double fft_flops;
+    /* what the current plan spends on those banks (folded matrix product: half the taps; FFT: fft_flops / 2), and the
+     * real-FFT flop count of the same frames (2.5 L log2 L each) whichever way they run: a roofline quoted on
+     * 2 x (macs_mfma + macs_valu) counts the former ("flops performed"); replacing it by the latter gives the
+     * FFT-normalised count SURVEY.md 8(d) prices the front end at. */
+    double dft_performed_macs;
+    double dft_fft_equiv_flops;
 } bn_model_cost;
 
 /* ---- version / device ------------------------------------------------- */

@@ -476,3 +476,37 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
 
 def run_model(onnx_bytes: bytes, x: np.ndarray, dtype=torch.float32, outputs=None) -> dict:
     return run_graph(load_graph(onnx_bytes), x, dtype, outputs)
+
+
+def prune_dead_filter_rows(g: Graph) -> Graph:
+    """Conv -> Transpose(0,2,1) -> MatMul(const W): output channels of the convolution whose W row is all zero never
+    reach the result (mel filter banks cover a fraction of the DFT bins), so they can be dropped from both constants.
+    Only bench.py's cpu_baseline uses this (the CPU path is timed on the work the GPU plan performs, not on
+    dead bins); the parity tests run the graph as written.  Returns a new Graph sharing the untouched constants."""
+    inits = dict(g.inits)
+    consumers = {}
+    for n in g.nodes:
+        for i in n.inputs:
+            consumers.setdefault(i, []).append(n)
+    for n in g.nodes:
+        if n.op != "Conv" or len(consumers.get(n.outputs[0], [])) != 1:
+            continue
+        t = consumers[n.outputs[0]][0]
+        if t.op != "Transpose" or [int(p) for p in t.attrs.get("perm", [])] != [0, 2, 1] or len(consumers.get(t.outputs[0], [])) != 1:
+            continue
+        m = consumers[t.outputs[0]][0]
+        if m.op != "MatMul" or m.inputs[1] not in inits or n.inputs[1] not in inits:
+            continue
+        if len(consumers.get(m.inputs[1], [])) != 1 or len(consumers.get(n.inputs[1], [])) != 1:
+            continue
+        W, CW = inits[m.inputs[1]], inits[n.inputs[1]]
+        if W.ndim != 2 or W.shape[0] != CW.shape[0]:
+            continue
+        keep = np.flatnonzero(np.any(W != 0, axis=1))
+        if len(keep) in (0, W.shape[0]):
+            continue
+        inits[m.inputs[1]] = np.ascontiguousarray(W[keep])
+        inits[n.inputs[1]] = np.ascontiguousarray(CW[keep])
+        if len(n.inputs) > 2 and n.inputs[2] in inits and len(consumers.get(n.inputs[2], [])) == 1:
+            inits[n.inputs[2]] = np.ascontiguousarray(inits[n.inputs[2]][keep])
+    return Graph(g.nodes, inits, g.inputs, g.outputs)

@@ -527,6 +527,8 @@ bn_status bn_model_get_cost(const bn_model *m, bn_model_cost *out) {
     out->n_launches = (int32_t)p.ops.size();
     out->dft_gemm_macs = p.dft_gemm_macs;
     out->fft_flops = p.fft_flops;
+    out->dft_performed_macs = p.dft_performed_macs;
+    out->dft_fft_equiv_flops = p.dft_fft_equiv_flops;
     return BN_OK;
 }
 

@@ -190,6 +190,8 @@ class Builder {
             plan_.fft_flops += op.flops_fft;
         }
         plan_.dft_gemm_macs = dft_gemm_macs_;
+        plan_.dft_performed_macs = dft_performed_macs_;
+        plan_.dft_fft_equiv_flops = dft_fft_equiv_flops_;
     }
 
    private:
@@ -201,7 +203,7 @@ class Builder {
     std::set<std::string> graph_outputs_, wanted_names_;
     std::vector<bool> live_, absorbed_;
     int cur_ = 0;
-    double dft_gemm_macs_ = 0;
+    double dft_gemm_macs_ = 0, dft_performed_macs_ = 0, dft_fft_equiv_flops_ = 0;
 
     // ------------------------------------------------------------------ utils
     const Val &get(const OnnxNode &n, size_t idx) {
@@ -878,6 +880,8 @@ class Builder {
         op.weight_bytes = 4.0 * (bank.window.size() + tw.size() + otab.size() + (has_bias ? Cout : 0));
         op.bytes = base.bytes;
         dft_gemm_macs_ += (double)OW * Cout * L;  // what the matrix-product evaluation of this bank multiplies
+        dft_fft_equiv_flops_ += op.flops_fft;
+        dft_performed_macs_ += op.flops_fft / 2;
         push_op(std::move(op));
         return true;
     }
@@ -929,6 +933,12 @@ class Builder {
         }
         if (runs.size() > 4) return false;
         dft_gemm_macs_ += (double)OW * Cout * L;
+        dft_performed_macs_ += (double)OW * Cout * (L / 2);  // folded: half the taps
+        {
+            double lg = 0;
+            while ((1 << (int)lg) < L) lg += 1;
+            if ((int64_t)1 << (int)lg == L) dft_fft_equiv_flops_ += (double)OW * 2.5 * (double)L * lg;  // the same frames as real FFTs
+        }
         const int64_t K = L / 2;
         for (const Run &r : runs) {
             const int sign = r.sign == 0 ? 1 : r.sign;
@@ -2658,6 +2668,8 @@ class Builder {
                 f.weight_bytes += 4.0 * (mstart.size() + ment.size());
                 f.bytes += g.bytes - 8.0 * (double)d.frames * (double)d.nout;  // the spectrum rows never touch memory
                 dft_gemm_macs_ += g.macs;  // the dense mel product belongs to the matrix-product count of the front end
+                dft_performed_macs_ += nnz * (double)d.frames;
+                dft_fft_equiv_flops_ += 2.0 * nnz * (double)d.frames;
                 plan_.ops.erase(plan_.ops.begin() + u[1]);
                 changed = true;
             }

@@ -96,6 +96,9 @@ struct Plan {
     // Front end counted two ways: the multiply-adds a DFT-as-matrix-product evaluation of the planned
     // filter banks performs (dft_gemm_macs: what the GEMM fallback runs) and the flops of the FFT formulation
     double dft_gemm_macs = 0, fft_flops = 0;
+    // dft_performed_macs: multiply-adds the plan spends on those banks as it runs them (folded matrix product: half the
+    // taps; FFT: fft flops / 2); dft_fft_equiv_flops: 2.5 L log2 L per frame of the same banks, whichever way they run
+    double dft_performed_macs = 0, dft_fft_equiv_flops = 0;
 };
 
 // wanted_outputs: graph output indices that must be computed (others are dead code).

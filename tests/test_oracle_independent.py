@@ -106,3 +106,16 @@ def test_oracle_conv_auto_pad_against_the_tensorflow_rule(auto_pad, stride, k):
             assert torch.allclose(want, torch.nn.functional.conv2d(xt, wt, padding="same"), atol=1e-6)
     assert got.shape == tuple(want.shape)
     assert np.abs(got - want.numpy()).max() < 1e-5
+
+
+def test_pruned_oracle_graph_equals_the_graph_as_written():
+    """bench.py times the CPU oracle on the graph minus the DFT rows that no mel filter reads (the work the GPU plan
+    performs): dropping all-zero filter-bank rows changes nothing but summation order."""
+    data = synth.birdnet_v24(num_species=100, width=0.5, depth=0.5, head=128)
+    g = onnx_ref.load_graph(data)
+    gp = onnx_ref.prune_dead_filter_rows(g)
+    kept = sorted(v.shape[0] for v in gp.inits.values() if v.ndim == 3)
+    assert kept[0] < 200 and kept[1] < 400 and sorted(v.shape[0] for v in g.inits.values() if v.ndim == 3) == [513, 1025]
+    x = synth.synthetic_segments(2, 144000, 48000)
+    a, b = onnx_ref.run_graph(g, x)["output"], onnx_ref.run_graph(gp, x)["output"]
+    assert np.abs(a - b).max() < 1e-5 * np.abs(a).max()

@@ -25,7 +25,7 @@ def family(name):
     n = name.replace("bn::(anonymous namespace)::", "")
     for key, fam in (("gemm_mfma_kernel", "gemm_mfma_kernel"), ("gemm_splitk_kernel", "gemm_mfma_kernel"), ("frame_fold_kernel", "gemm_mfma_kernel"), ("mbconv_", "mbconv_expand_dw_kernel"),
                      ("dwconv_", "dwconv_kernel"), ("conv_small", "conv_direct_kernel"), ("conv_direct", "conv_direct_kernel"),
-                     ("se_fc", "se_fc_kernel"), ("gap_partial", "gap_partial_kernel"), ("elt_", "elt_kernel"), ("reduce_", "reduce_kernel"), ("minmax_chunks", "reduce_kernel"),
+                     ("stft_kernel", "stft_kernel"), ("se_fc", "se_fc_kernel"), ("gap_partial", "gap_partial_kernel"), ("elt_", "elt_kernel"), ("reduce_", "reduce_kernel"), ("minmax_chunks", "reduce_kernel"),
                      ("topk", "topk_kernel")):
         if key in n:
             return fam
@@ -46,6 +46,55 @@ def counter_by_family(path, counter):
                     seen.add(r["Dispatch_Id"])
                     out[fam][1] += 1
     return out
+
+
+def counters_by_family(path):
+    """{family: {counter: sum over dispatches and counter instances, "_launches": n}} of one --pmc pass"""
+    out = defaultdict(lambda: defaultdict(float))
+    seen = defaultdict(set)
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                fam = family(r["Kernel_Name"])
+                out[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Dispatch_Id"] not in seen[fam]:
+                    seen[fam].add(r["Dispatch_Id"])
+                    out[fam]["_launches"] += 1
+                    out[fam]["_dur_us"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0
+    return out
+
+
+def mfma_summary(src, tag):
+    """profiles/<tag>_pmc_mfma.json: per kernel family, per launch -- matrix-pipe busy fraction, LDS bank-conflict share,
+    wait breakdown, effective clock.  SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the chip's 1024 SIMDs;
+    GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back): cycles of the launch = GRBM / 8."""
+    sq = counters_by_family(os.path.join(src, "pmc_sq"))
+    inst = counters_by_family(os.path.join(src, "pmc_inst"))
+    fams = {}
+    for fam, c in sq.items():
+        n = max(c["_launches"], 1.0)
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+        wave = max(c["SQ_WAVE_CYCLES"], 1.0)
+        e = {"launches_profiled": int(n), "avg_us": round(c["_dur_us"] / n, 2),
+             "mfma_busy": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(1024.0 * cyc, 1.0), 4),
+             "clock_GHz": round(cyc / max(c["_dur_us"], 1e-9) / 1000.0, 3),
+             "wave_cycles_share": {"active": round(c["SQ_ACTIVE_INST_ANY"] / wave, 3), "issue_stall": round(c["SQ_WAIT_INST_ANY"] / wave, 3),
+                                   "waitcnt_or_barrier": round(c["SQ_WAIT_ANY"] / wave, 3)},
+             "lds_bank_conflict_share": round(c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), 3)}
+        i = inst.get(fam)
+        if i:
+            ni = max(i["_launches"], 1.0)
+            e["per_launch"] = {k[3:].lower(): round(i[k] / ni) for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES") if k in i}
+        fams[fam] = e
+    doc = {"tag": tag, "batch": 32,
+           "command": "rocprofv3 --pmc <SQ counters + GRBM_GUI_ACTIVE> (separate passes, no trace domains) -- python3 tools/pmc_run.py 32 3",
+           "definitions": {"mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
+                           "wave_cycles_share": "SQ_ACTIVE_INST_ANY | SQ_WAIT_INST_ANY | SQ_WAIT_ANY over SQ_WAVE_CYCLES",
+                           "lds_bank_conflict_share": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE"},
+           "families": fams}
+    json.dump(doc, open(f"profiles/{tag}_pmc_mfma.json", "w"), indent=1)
+    json.dump(doc, open("profiles/pmc_mfma.json", "w"), indent=1)
+    return doc
 
 
 def stats_by_family(path):
@@ -86,6 +135,11 @@ def main():
     json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
     print(json.dumps(doc["families"], indent=1))
     print(json.dumps(doc["kernel_stats_1stream"], indent=1))
+    if os.path.isdir(os.path.join(src, "pmc_sq")):
+        print(json.dumps(mfma_summary(src, tag)["families"], indent=1))
+    rec = os.path.join(src, "recording_24h.log")
+    if os.path.exists(rec):
+        shutil.copy(rec, f"profiles/{tag}_recording_24h.log")
 
 
 if __name__ == "__main__":
