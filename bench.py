@@ -389,7 +389,20 @@ def main():
                         break
             except OSError:
                 pass
-            nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            quota = None  # a container's CPU share may be far below the CPUs its affinity mask shows
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q != "max":
+                    quota = max(1, int(float(q) / float(per) + 0.5))
+            except (OSError, ValueError):
+                try:
+                    q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    if q > 0:
+                        quota = max(1, int(q / per + 0.5))
+                except (OSError, ValueError):
+                    pass
+            nproc = min(affinity, quota) if quota else affinity
 
             def timed(threads, budget_s, max_segments):
                 _t.set_num_threads(threads)
@@ -402,13 +415,28 @@ def main():
                     done += len(xs[done:done + 8])
                 return done, time.perf_counter() - t1
 
-            d_all, t_all = timed(nproc, 12.0, args.cpu_sample)
-            d_one, t_one = timed(1, 12.0, 16)
-            _t.set_num_threads(nproc)
-            out["cpu_baseline"] = {"value": round(d_all / t_all, 3), "unit": "segments/s", "cores": int(nproc), "kind": "port",
-                                   "cpu_model": cpu_model, "single_thread": {"value": round(d_one / t_one, 3), "cores": 1, "sample": f"{d_one} segments, {t_one:.1f} s"},
+            # "every thread the box gives this process": a thread count above the share the scheduler actually grants
+            # is slower, not faster (256 threads on a 16-CPU share: 0.1 segments/s), so the count is found by
+            # doubling from 4 up to nproc while one batch of 8 keeps getting faster -- the best count is the baseline
+            best_thr, best_rate, tried = 1, 0.0, []
+            thr = min(4, nproc)
+            while True:
+                dn, tt = timed(thr, 0.0, 8)
+                tried.append((thr, round(dn / tt, 1)))
+                if dn / tt > best_rate:
+                    best_thr, best_rate = thr, dn / tt
+                if dn / tt < 0.8 * best_rate or thr >= nproc:
+                    break
+                thr = min(2 * thr, nproc)
+            d_all, t_all = timed(best_thr, 12.0, args.cpu_sample)
+            d_one, t_one = timed(1, 8.0, 64)
+            _t.set_num_threads(best_thr)
+            out["cpu_baseline"] = {"value": round(d_all / t_all, 3), "unit": "segments/s", "cores": int(best_thr), "kind": "port",
+                                   "cpu_model": cpu_model, "cpus_visible": int(affinity), "cpu_quota": quota, "thread_counts_tried": tried,
+                                   "single_thread": {"value": round(d_one / t_one, 3), "cores": 1, "sample": f"{d_one} segments, {t_one:.1f} s"},
                                    "sample": f"{d_all} segments (batches of 8) of the same synthetic workload through oracle/onnx_ref.py (torch CPU fp32, the "
-                                             f"graph as exported minus the DFT rows no mel filter reads, as the GPU plan), {t_all:.1f} s on {nproc} threads"}
+                                             f"graph as exported minus the DFT rows no mel filter reads, as the GPU plan), {t_all:.1f} s on {best_thr} threads "
+                                             f"(the fastest of the thread counts tried)"}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

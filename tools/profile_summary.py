@@ -76,8 +76,9 @@ def mfma_summary(src, tag):
         cyc = c["GRBM_GUI_ACTIVE"] / 8.0
         wave = max(c["SQ_WAVE_CYCLES"], 1.0)
         e = {"launches_profiled": int(n), "avg_us": round(c["_dur_us"] / n, 2),
-             "mfma_busy": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(1024.0 * cyc, 1.0), 4),
-             "clock_GHz": round(cyc / max(c["_dur_us"], 1e-9) / 1000.0, 3),
+             "mfma_busy": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(1024.0 * 2400.0 * c["_dur_us"], 1.0), 4),
+             "mfma_busy_grbm": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(1024.0 * cyc, 1.0), 4),
+             "grbm_cycles_per_us": round(cyc / max(c["_dur_us"], 1e-9), 1),
              "wave_cycles_share": {"active": round(c["SQ_ACTIVE_INST_ANY"] / wave, 3), "issue_stall": round(c["SQ_WAIT_INST_ANY"] / wave, 3),
                                    "waitcnt_or_barrier": round(c["SQ_WAIT_ANY"] / wave, 3)},
              "lds_bank_conflict_share": round(c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0), 3)}
@@ -88,7 +89,10 @@ def mfma_summary(src, tag):
         fams[fam] = e
     doc = {"tag": tag, "batch": 32,
            "command": "rocprofv3 --pmc <SQ counters + GRBM_GUI_ACTIVE> (separate passes, no trace domains) -- python3 tools/pmc_run.py 32 3",
-           "definitions": {"mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
+           "definitions": {"mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES (= 64 per v_mfma_f32_32x32x2_f32, per SIMD) / (1024 SIMDs x launch duration x 2.4 GHz): "
+                                        "the fraction of the matrix pipes' peak-clock cycles the launch kept busy",
+                           "mfma_busy_grbm": "the same over GRBM_GUI_ACTIVE / 8; that quotient reads high on dispatches under ~0.3 ms "
+                                             "(MI355X_MICROARCH.md, DVFS give-back), so this one reads LOW here -- kept for reference",
                            "wave_cycles_share": "SQ_ACTIVE_INST_ANY | SQ_WAIT_INST_ANY | SQ_WAIT_ANY over SQ_WAVE_CYCLES",
                            "lds_bank_conflict_share": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE"},
            "families": fams}
