@@ -654,6 +654,40 @@ bn_status bn_infer_device(bn_ctx *c, const float *d_pcm, size_t batch, int32_t s
     return BN_OK;
 }
 
+// Device results -> pinned host buffers on the context's stream, by ONE kernel launch storing straight into the
+// (device-mapped) pinned memory (topk.hip, copy_out_kernel) instead of one copy-engine transfer per region.
+// BN_SDMA_COPY=1 restores the hipMemcpyAsync transfers (A/B measurements).
+struct OutRegion {
+    void *host;
+    const void *dev;
+    size_t bytes;
+};
+static bn_status results_to_host(bn_ctx *c, const OutRegion *regs, int n) {
+    static const bool sdma = getenv("BN_SDMA_COPY") && atoi(getenv("BN_SDMA_COPY")) != 0;
+    CopyOut co{};
+    bool kernel_ok = !sdma && n <= 3;
+    for (int r = 0; r < n && kernel_ok; r++) {
+        void *dp = nullptr;
+        if (regs[r].bytes % 4 || regs[r].bytes / 4 > 0xffffffffull || hipHostGetDevicePointer(&dp, regs[r].host, 0) != hipSuccess || !dp) {
+            (void)hipGetLastError();
+            kernel_ok = false;
+            break;
+        }
+        co.dst[r] = dp;
+        co.src[r] = regs[r].dev;
+        co.words[r] = (uint32_t)(regs[r].bytes / 4);
+    }
+    if (kernel_ok) {
+        co.n = n;
+        launch_copy_out(c->stream, co);
+        HIP_TRY(hipGetLastError());
+        return BN_OK;
+    }
+    for (int r = 0; r < n; r++)
+        if (regs[r].bytes) HIP_TRY(hipMemcpyAsync(regs[r].host, regs[r].dev, regs[r].bytes, hipMemcpyDeviceToHost, c->stream));
+    return BN_OK;
+}
+
 // Tail shared by bn_infer_windows once the plan is enqueued on d_input: output copies to
 // pinned staging, wait with cancel / timeout polling, copy out.
 static bn_status finish_infer(bn_ctx *c, size_t batch, float *logits_out, float *emb_out, const volatile int32_t *cancel, uint64_t timeout_ns) {
@@ -665,13 +699,16 @@ static bn_status finish_infer(bn_ctx *c, size_t batch, float *logits_out, float 
     const size_t N = (size_t)lo.row_elems;
     float *h_logits = c->h_out;
     float *h_emb = c->h_out + N * c->max_batch;
-    HIP_TRY(hipMemcpyAsync(h_logits, resolve(c, lo.ref, c->d_input), batch * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    OutRegion regs[2] = {{h_logits, resolve(c, lo.ref, c->d_input), batch * N * sizeof(float)}, {nullptr, nullptr, 0}};
+    int nreg = 1;
     size_t E = 0;
     if (emb_out && cfg.embedding_output >= 0) {
         const OutputInfo &eo = p.outputs[cfg.embedding_output];
         E = (size_t)eo.row_elems;
-        HIP_TRY(hipMemcpyAsync(h_emb, resolve(c, eo.ref, c->d_input), batch * E * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        regs[nreg++] = OutRegion{h_emb, resolve(c, eo.ref, c->d_input), batch * E * sizeof(float)};
     }
+    st = results_to_host(c, regs, nreg);
+    if (st != BN_OK) return st;
     st = wait_stream(c, cancel, timeout_ns);
     if (st != BN_OK) return st;
     memcpy(logits_out, h_logits, batch * N * sizeof(float));
@@ -803,12 +840,20 @@ bn_status bn_infer_submit(bn_ctx *c, const float *const *segs, size_t batch, siz
         if (const char *why = take_launch_error()) return fail(BN_ERR_INVALID_ARG, std::string("top-K launch refused: ") + why);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemcpyAsync(sl.h_out, d_logits, batch * N * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    if (cfg.embedding_output >= 0) {
-        const OutputInfo &eo = p.outputs[cfg.embedding_output];
-        HIP_TRY(hipMemcpyAsync(sl.h_out + N * c->max_batch, resolve(c, eo.ref, sl.d_input), batch * (size_t)eo.row_elems * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    {
+        OutRegion regs[3] = {{sl.h_out, d_logits, batch * N * sizeof(float)}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};
+        int nreg = 1;
+        if (cfg.embedding_output >= 0) {
+            const OutputInfo &eo = p.outputs[cfg.embedding_output];
+            regs[nreg++] = OutRegion{sl.h_out + N * c->max_batch, resolve(c, eo.ref, sl.d_input), batch * (size_t)eo.row_elems * sizeof(float)};
+        }
+        if (k) regs[nreg++] = OutRegion{sl.h_tk, c->d_step, batch * (2 * k + 1) * sizeof(uint32_t)};
+        st = results_to_host(c, regs, nreg);
+        if (st != BN_OK) {
+            c->in_flight = true;
+            return st;
+        }
     }
-    if (k) HIP_TRY(hipMemcpyAsync(sl.h_tk, c->d_step, batch * (2 * k + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipEventRecord(sl.out_done, c->stream));
     sl.busy = true;
     sl.batch = batch;
@@ -1097,8 +1142,11 @@ bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch, size_t top
     float *d_conf = reinterpret_cast<float *>(c->d_step + batch * k);
     launch_topk(c->stream, d_logits, (int64_t)batch, (int64_t)n, (int64_t)k, has_min, min_conf, (int64_t)k, d_idx, d_conf, d_cnt, c->d_tk_flags);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_out, d_logits, batch * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_step, c->d_step, batch * (2 * k + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    {
+        const OutRegion regs[2] = {{c->h_out, d_logits, batch * n * sizeof(float)}, {c->h_step, c->d_step, batch * (2 * k + 1) * sizeof(uint32_t)}};
+        st = results_to_host(c, regs, 2);
+        if (st != BN_OK) return st;
+    }
     c->h_tk_idx = c->h_step;
     c->h_tk_conf = reinterpret_cast<float *>(c->h_step + batch * k);
     c->h_tk_cnt = c->h_step + 2 * batch * k;

@@ -296,6 +296,16 @@ const char *take_launch_error();
 // per (kernel, device) and is safe to call from several threads.  Returns false if the runtime refuses.
 bool ensure_dynamic_lds(const void *kernel, size_t bytes);
 size_t topk_lds_bytes(int64_t n, int64_t k);
+
+// device -> pinned host memory by a kernel's own stores (topk.hip): up to three regions of 32-bit words per launch;
+// dst are the DEVICE addresses of pinned host buffers (hipHostGetDevicePointer)
+struct CopyOut {
+    void *dst[3];
+    const void *src[3];
+    uint32_t words[3];
+    int n;
+};
+void launch_copy_out(hipStream_t s, const CopyOut &c);
 size_t mbconv_lds_bytes(const MbDesc &d);  // dynamic LDS of mbconv_expand_dw_kernel for this shape
 
 }  // namespace bn

@@ -394,7 +394,41 @@ __global__ __launch_bounds__(64) void topk_fast_kernel(const float *__restrict__
     }
 }
 
+// Results to the host without the copy engines: the blocks store straight into pinned (device-mapped, coherent) host
+// memory, 16 bytes per lane where both ends are 16-byte aligned.  Up to three regions per launch (logits, embeddings,
+// packed top-K rows).  hipMemcpyAsync would hand each region to an SDMA engine picked per call; with several
+// contexts copying at once the runtime brings further engines up lazily, a few ms each -- measured as three rounds of
+// 4 concurrent steps at 6 ms instead of 3 ms after every process start (tools/warmup_profile.py) -- and every copy is
+// a host API call of its own.
+__global__ void __launch_bounds__(256) copy_out_kernel(CopyOut c) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x, nth = gridDim.x * 256u;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        if (r >= c.n) break;
+        const uint32_t words = c.words[r];
+        const uint32_t *src = static_cast<const uint32_t *>(c.src[r]);
+        uint32_t *dst = static_cast<uint32_t *>(c.dst[r]);
+        uint32_t done = 0;
+        if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+            const uint32_t n4 = words >> 2;
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+            for (uint32_t i = tid; i < n4; i += nth) d4[i] = s4[i];
+            done = n4 << 2;
+        }
+        for (uint32_t i = done + tid; i < words; i += nth) dst[i] = src[i];
+    }
+}
+
 }  // namespace
+
+void launch_copy_out(hipStream_t s, const CopyOut &c) {
+    uint64_t words = 0;
+    for (int r = 0; r < c.n && r < 3; r++) words += c.words[r];
+    if (words == 0) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(64, (words / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(copy_out_kernel, dim3(blocks), dim3(256), 0, s, c);
+}
 
 size_t topk_lds_bytes(int64_t n, int64_t k) {
     (void)n;
