@@ -67,6 +67,49 @@ impl crate::Classifier {
     }
 }
 
+/// Pipelined variant for a stream of batches (e.g. the CLI's batch loop, birdnet-analyze.rs:556-600): two batches in
+/// flight on ONE context -- while batch k runs on the GPU, batch k+1 is being copied into pinned staging and uploaded.
+/// Top-K runs on the device as part of the submitted work; `collect` returns the same `PredictionResult`s as
+/// `predict_batch_with_context`.  More overlap = more contexts (up to four per device), each driven like this.
+impl crate::Classifier {
+    pub fn submit_batch(&self, context: &mut BatchInferenceContext, segments: &[&[f32]]) -> Result<u64> {
+        if segments.len() > context.max_batch_size() {
+            return Err(Error::Inference(format!("batch size {} exceeds context max {}", segments.len(), context.max_batch_size())));
+        }
+        for (i, s) in segments.iter().enumerate() {
+            if s.len() != context.sample_count() {
+                return Err(Error::BatchInputSize { index: i, expected: context.sample_count(), got: s.len() });
+            }
+        }
+        let ptrs: Vec<*const f32> = segments.iter().map(|s| s.as_ptr()).collect();
+        let (has_min, min) = self.inner.min_confidence.map_or((0, 0.0), |m| (1, m));
+        let mut ticket = 0u64;
+        match unsafe { bn_infer_submit(context.ctx, ptrs.as_ptr(), segments.len(), self.inner.top_k, has_min, min, &mut ticket) } {
+            BN_OK => Ok(ticket), // the slices are no longer referenced: they were copied into pinned staging
+            _ => Err(Error::Inference(last_error())),
+        }
+    }
+
+    pub fn collect_batch(&self, context: &mut BatchInferenceContext, ticket: u64, n: usize, options: &InferenceOptions)
+        -> Result<(Vec<f32>, Vec<f32>, Vec<u32>, Vec<f32>, Vec<u32>)> {
+        let cfg = &self.inner.config;
+        let (nsp, emb_dim, k) = (cfg.num_species, cfg.embedding_dim.unwrap_or(0), self.inner.top_k.min(cfg.num_species).max(1));
+        let (mut logits, mut emb) = (vec![0f32; n * nsp], vec![0f32; n * emb_dim]);
+        let (mut idx, mut conf, mut cnt) = (vec![0u32; n * k], vec![0f32; n * k], vec![0u32; n]);
+        let cancel = options.cancellation_token.as_ref().map_or(std::ptr::null(), |t| t.cancelled.as_ptr() as *const i32);
+        let timeout_ns = options.timeout.map_or(0, |d| d.as_nanos().max(1) as u64);
+        match unsafe {
+            bn_infer_collect(context.ctx, ticket, logits.as_mut_ptr(), if emb_dim > 0 { emb.as_mut_ptr() } else { std::ptr::null_mut() },
+                             k, idx.as_mut_ptr(), conf.as_mut_ptr(), cnt.as_mut_ptr(), cancel, timeout_ns)
+        } {
+            BN_OK => Ok((logits, emb, idx, conf, cnt)), // assembled into PredictionResult exactly as above
+            BN_ERR_TIMEOUT => Err(Error::Timeout { duration: options.timeout.unwrap_or_default() }),
+            BN_ERR_CANCELLED => Err(Error::Cancelled),
+            _ => Err(Error::Inference(last_error())),
+        }
+    }
+}
+
 fn last_error() -> String {
     let mut buf = vec![0u8; 1024];
     unsafe { bn_last_error(buf.as_mut_ptr() as *mut _, buf.len()) };

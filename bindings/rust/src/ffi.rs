@@ -7,6 +7,8 @@ pub struct bn_model { _p: [u8; 0] }
 #[repr(C)]
 pub struct bn_recording { _p: [u8; 0] }
 #[repr(C)]
+pub struct bn_group { _p: [u8; 0] }
+#[repr(C)]
 pub struct bn_ctx { _p: [u8; 0] }
 
 #[repr(C)]
@@ -42,6 +44,23 @@ extern "C" {
     pub fn bn_topk(c: *mut bn_ctx, batch: usize, top_k: usize, has_min: i32, min_conf: f32, k_stride: usize,
                    idx_out: *mut u32, conf_out: *mut f32, count_out: *mut u32) -> i32;
     pub fn bn_last_error(buf: *mut c_char, cap: usize) -> usize;
+    // asynchronous host-slice path: two batches in flight per context (staging + upload of batch k+1 overlap batch k)
+    pub fn bn_infer_submit(c: *mut bn_ctx, segs: *const *const f32, batch: usize, top_k: usize, has_min: i32, min_conf: f32,
+                           ticket: *mut u64) -> i32;
+    pub fn bn_infer_collect(c: *mut bn_ctx, ticket: u64, logits_out: *mut f32, emb_out: *mut f32, k_stride: usize,
+                            idx_out: *mut u32, conf_out: *mut f32, count_out: *mut u32, cancel: *const i32, timeout_ns: u64) -> i32;
+    // one node, several GPUs: windows sharded by contiguous range, one RCCL all-gather of logits / top-K rows
+    pub fn bn_group_create(models: *const *mut bn_model, devices: *const i32, n: i32, max_batch: usize,
+                           contexts_per_device: i32, out: *mut *mut bn_group) -> i32;
+    pub fn bn_group_destroy(g: *mut bn_group);
+    pub fn bn_group_size(g: *const bn_group) -> i32;
+    pub fn bn_group_uses_rccl(g: *const bn_group) -> i32;
+    pub fn bn_shard_range(n_windows: usize, rank: i32, world: i32, lo: *mut usize, hi: *mut usize);
+    pub fn bn_group_analyze_recording(g: *mut bn_group, pcm: *const core::ffi::c_void, n_samples: usize, format: i32,
+                                      step_samples: usize, top_k: usize, has_min: i32, min_conf: f32, logits_out: *mut f32,
+                                      k_stride: usize, idx_out: *mut u32, conf_out: *mut f32, count_out: *mut u32,
+                                      n_windows_out: *mut usize) -> i32;
+    pub fn bn_group_last_error(buf: *mut c_char, cap: usize) -> usize;
     // recording-level ingest (optional; birdnet-analyze.rs read_wav + chunk_audio on the device)
     pub fn bn_recording_create(device: i32, pcm: *const core::ffi::c_void, n_samples: usize, format: i32, out: *mut *mut bn_recording) -> i32;
     pub fn bn_recording_free(r: *mut bn_recording);
