@@ -468,6 +468,22 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
                 r = torch.index_select(i[0], int(a.get("axis", 0)), i[1].reshape(-1).to(torch.int64))
                 if i[1].dim() == 0:
                     r = r.squeeze(int(a.get("axis", 0)))
+            elif op == "Expand":
+                shape = [int(v) for v in i[1].reshape(-1).tolist()]
+                r = i[0] * torch.ones(shape, dtype=i[0].dtype)  # ONNX Expand: numpy broadcasting against ones(shape)
+            elif op == "STFT":
+                # ONNX opset 17: signal [B, L] / [B, L, 1] real, frame_step, optional window, optional frame_length;
+                # out[b, f, k, (re, im)] = sum_n signal[b, f*step + n] window[n] exp(-2 pi i k n / N), no padding.
+                # Written with an FFT of the windowed frames (NOT as the convolution the product path builds).
+                sig = i[0].reshape(i[0].shape[0], -1) if i[0].dim() == 3 else i[0]
+                step = int(i[1].reshape(-1)[0])
+                win = i[2] if len(i) > 2 and i[2] is not None else None
+                N = int(i[3].reshape(-1)[0]) if len(i) > 3 and i[3] is not None else int(win.numel())
+                frames = sig.unfold(1, N, step)  # [B, F, N]
+                if win is not None:
+                    frames = frames * win.to(frames.dtype)
+                spec = torch.fft.rfft(frames, dim=-1) if int(a.get("onesided", 1)) else torch.fft.fft(frames, dim=-1)
+                r = torch.view_as_real(spec).to(sig.dtype)
             else:
                 raise NotImplementedError(f"oracle: operator {op}")
             env[n.outputs[0]] = r

@@ -991,9 +991,121 @@ class Builder {
         if (t == "BatchNormalization") return lower_batchnorm(n);
         if (t == "Add" || t == "Sub" || t == "Mul" || t == "Div" || t == "Pow" || t == "Max" || t == "Min") return lower_binary(n);
         if (t == "GlobalAveragePool" || t == "GlobalMaxPool" || t.rfind("Reduce", 0) == 0) return lower_reduce(n);
+        if (t == "STFT") return lower_stft(n);
+        if (t == "Expand") return lower_expand(n);
         ActSpec a;
         if (unary_spec(n, a)) return lower_unary(n, a);
+        // exporter dialects this path has met but does not map: say what the node is and what to export instead
+        if (t == "DFT") unsupported(n, "DFT nodes are not mapped; export the spectrogram as an STFT node (opset 17, mapped to the framing kernels) or as a Conv with the windowed DFT basis");
+        if (t == "Resize" || t == "Upsample") unsupported(n, "resampling of feature maps is outside the native subset (no BirdNET / Perch graph needs it)");
+        if (t == "Where") unsupported(n, "element selection is outside the native subset; express clamps as Clip / Max / Min");
+        if (t == "Equal" || t == "Greater" || t == "Less" || t == "GreaterOrEqual" || t == "LessOrEqual" || t == "Not" || t == "And" || t == "Or")
+            unsupported(n, "boolean tensors computed from activations are outside the native subset");
         unsupported(n, "operator is outside the native subset");
+    }
+
+    // ------------------------------------------------------------- STFT (opset 17)
+    // output[b, f, k, 0/1] = Re / Im of sum_n signal[b, f*step + n] * window[n] * exp(-2 pi i k n / N), no padding,
+    // k = 0 .. N/2 (onesided, the default) or 0 .. N-1.  That is a 1-D framing convolution with 2*bins filters of N
+    // taps and stride `step`: the filters are built here (double-precision cos / sin, rounded once) in the order
+    // [all real rows | all imaginary rows], so that the mirror-symmetry fold and the FFT recognition of the framing
+    // conv see one cos block and one sin block; the node's [frames, bins, 2] result is a strided VIEW of the conv's
+    // channels-last output (no copy).
+    void lower_stft(const OnnxNode &n) {
+        const Val x = get(n, 0);
+        if (x.is_const) unsupported(n, "STFT of a constant signal");
+        const Val *stepv = opt(n, 1), *win = opt(n, 2), *flen = opt(n, 3);
+        if (!stepv || !stepv->is_const) unsupported(n, "frame_step must be a constant");
+        const int64_t step = const_ints(n, *stepv).at(0);
+        if (win && !win->is_const) unsupported(n, "window must be a constant");
+        if (flen && !flen->is_const) unsupported(n, "frame_length must be a constant");
+        int64_t N = flen ? const_ints(n, *flen).at(0) : (win ? win->numel() : 0);
+        if (N <= 0 || step <= 0) unsupported(n, "needs a window or a frame_length, and a positive frame_step");
+        if (win && (win->is_int || win->numel() != N)) unsupported(n, "window length " + std::to_string(win ? win->numel() : 0) + " differs from frame_length " + std::to_string(N));
+        // signal: [L], [L, 1] (real); [L, 2] would be complex
+        int64_t L = 0, sL = 0;
+        if (x.dims.size() == 1) { L = x.dims[0]; sL = x.strides[0]; }
+        else if (x.dims.size() == 2 && x.dims[1] == 1) { L = x.dims[0]; sL = x.strides[0]; }
+        else unsupported(n, "signal must be real: [batch, length] or [batch, length, 1], got per-sample dims " + dims_str(x.dims));
+        if (L < N) unsupported(n, "signal shorter than one frame");
+        const bool onesided = n.attr_i("onesided", 1) != 0;
+        const int64_t bins = onesided ? N / 2 + 1 : N;
+        if (N * 2 * bins > ((int64_t)1 << 28)) unsupported(n, "DFT basis too large");
+        Val w;
+        w.is_const = true;
+        w.dims = {2 * bins, 1, N};
+        w.f.resize((size_t)(2 * bins * N));
+        for (int64_t k = 0; k < bins; k++)
+            for (int64_t t = 0; t < N; t++) {
+                const double wv = win ? (double)win->f[(size_t)t] : 1.0;
+                const double th = 2.0 * M_PI * (double)((k * t) % N) / (double)N;
+                w.f[(size_t)(k * N + t)] = (float)(wv * std::cos(th));
+                w.f[(size_t)((bins + k) * N + t)] = (float)(-wv * std::sin(th));
+            }
+        const std::string base = "stft:" + (n.name.empty() ? n.outputs[0] : n.name);
+        Val xv = x;
+        xv.dims = {1, L};
+        xv.strides = {L * sL, sL};
+        vals_[base + "/signal"] = xv;
+        vals_[base + "/basis"] = std::move(w);
+        OnnxNode conv;
+        conv.name = base;
+        conv.op_type = "Conv";
+        conv.inputs = {base + "/signal", base + "/basis"};
+        conv.outputs = {base + "/frames"};
+        OnnxAttr st;
+        st.name = "strides";
+        st.type = 7;
+        st.ints = {step};
+        conv.attrs["strides"] = st;
+        lower_conv(conv);
+        auto yit = vals_.find(base + "/frames");
+        if (yit == vals_.end()) unsupported(n, "internal: the framing conv defined no output");
+        const Val y = yit->second;
+        if (y.is_const || y.dims.size() != 2 || y.dims[0] != 2 * bins) unsupported(n, "internal: framing conv produced " + dims_str(y.dims));
+        Val out = y;
+        out.dims = {y.dims[1], bins, 2};
+        out.strides = {y.strides[1], y.strides[0], bins * y.strides[0]};
+        define(n.outputs[0], out);
+    }
+
+    // Expand(x, shape): x * ones(broadcast shape) -- exact for every float including -0, infinities and NaN payloads
+    // that survive a multiplication by 1; goes through the elementwise lowering, so it fuses into its neighbours.
+    void lower_expand(const OnnxNode &n) {
+        const Val &x = get(n, 0);
+        const Val *shp = opt(n, 1);
+        if (!shp || !shp->is_const) unsupported(n, "Expand needs a constant shape");
+        std::vector<int64_t> target = const_ints(n, *shp);
+        Dims full = x.dims;
+        if (!x.is_const) full.insert(full.begin(), BATCH_SENTINEL);
+        while (full.size() < target.size()) full.insert(full.begin(), 1);
+        while (target.size() < full.size()) target.insert(target.begin(), 1);
+        Dims ones_dims;
+        for (size_t k = 0; k < full.size(); k++) {
+            int64_t tdim = target[k], xdim = full[k];
+            if (xdim == BATCH_SENTINEL || tdim == BATCH_SENTINEL) {
+                if (k != 0 || (xdim != BATCH_SENTINEL && xdim != 1) || (tdim != BATCH_SENTINEL && tdim != 1))
+                    unsupported(n, "Expand may only keep the batch dimension as it is");
+                continue;  // the batch dimension is not part of the ones operand
+            }
+            if (tdim != 1 && xdim != 1 && tdim != xdim) unsupported(n, "shape " + dims_str(target) + " does not broadcast with " + dims_str(full));
+            ones_dims.push_back(std::max(tdim, xdim));
+        }
+        if (!x.is_const && full.size() != x.dims.size() + 1) unsupported(n, "Expand would add dimensions in front of the batch");
+        if (prod(ones_dims) > ((int64_t)1 << 28)) unsupported(n, "Expand target too large");
+        Val ones;
+        ones.is_const = true;
+        ones.dims = ones_dims;
+        ones.f.assign((size_t)prod(ones_dims), 1.0f);
+        if (x.is_const && x.is_int) unsupported(n, "Expand of an integer constant");
+        const std::string oname = "expand:" + n.outputs[0] + "/ones";
+        vals_[oname] = std::move(ones);
+        OnnxNode mul;
+        mul.name = n.name.empty() ? "expand:" + n.outputs[0] : n.name;
+        mul.op_type = "Mul";
+        mul.inputs = {n.inputs[0], oname};
+        mul.outputs = {n.outputs[0]};
+        lower(mul);
     }
 
     void lower_constant(const OnnxNode &n) {

@@ -675,3 +675,93 @@ def test_conv_auto_pad(bn, auto_pad, cin, cout, k, stride, groups):
         return g.node("Relu", [y])
     got, ref = run_both(bn, op_graph(build, [cout, oh, ow]))
     assert_close(got, ref, f"conv auto_pad={auto_pad} k={k} s={stride} g={groups}")
+
+
+# ---------------------------------------------------------------- exporter dialects (round 2)
+def _hann(n, periodic=True):
+    k = np.arange(n, dtype=np.float64)
+    return (0.5 - 0.5 * np.cos(2 * np.pi * k / (n if periodic else n - 1))).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nfft,hop,window,onesided,rank3", [
+    (512, 128, "hann", 1, True),        # torch.stft-style export: [B, L, 1] signal, periodic Hann -> folded framing GEMMs
+    (1024, 280, "hann_sym", 1, False),  # symmetric Hann: rows are not mirror images about N/2 -> plain framing GEMM
+    (256, 64, None, 1, False),          # no window input: rectangular, frame_length given
+    (128, 32, "hann", 0, True),         # two-sided
+])
+def test_stft_node_opset17(bn, nfft, hop, window, onesided, rank3):
+    """An opset-17 STFT node (what torch.onnx writes for torch.stft) is mapped to the framing kernels: magnitude and the
+    raw [frames, bins, 2] tensor against the oracle, which evaluates the node with an FFT of the windowed frames."""
+    L = 48000
+    bins = nfft // 2 + 1 if onesided else nfft
+    frames = (L - nfft) // hop + 1
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(L), i64(1), i64(1)])
+        if rank3:
+            x = g.node("Unsqueeze", [x, i64(2)])
+        ins = [x, g.const(np.array(hop, dtype=np.int64))]
+        if window:
+            ins.append(g.const(_hann(nfft, periodic=(window == "hann"))))
+        else:
+            ins += ["", g.const(np.array(nfft, dtype=np.int64))]
+        s = g.node("STFT", ins, onesided=onesided)                     # [B, frames, bins, 2]
+        re = g.node("Slice", [s, i64(0), i64(1), i64(3), i64(1)])
+        im = g.node("Slice", [s, i64(1), i64(2), i64(3), i64(1)])
+        p = g.node("Add", [g.node("Mul", [re, re]), g.node("Mul", [im, im])])
+        mag = g.node("Sqrt", [g.node("Add", [p, g.const(np.array(1e-6, dtype=np.float32))])])
+        return g.node("Concat", [s, mag], axis=3)                      # raw spectrum and magnitude side by side
+
+    data = op_graph(build, [frames, bins, 3])
+    got, ref = run_both(bn, data)
+    # a bin is a sum of nfft products of O(1) terms: absolute error grows like sqrt(nfft) * 2^-24 * |frame|
+    assert_close(got, ref, f"STFT n={nfft} hop={hop} window={window}", atol=2e-4 * np.sqrt(nfft / 256), rtol=2e-4)
+    text = bn.plan_describe(write_model(data))
+    assert ("fold=" in text) == (window == "hann"), text  # periodic Hann rows fold to half their taps, the others do not
+
+
+@pytest.mark.gpu
+def test_expand_and_nhwc_sandwich(bn):
+    """Expand (broadcast against a constant shape, the way exporters spell tf.broadcast_to / x.expand) and an NHWC graph
+    whose convolutions sit between Transpose pairs (tf2onnx): both against the oracle."""
+    rng = np.random.default_rng(5)
+    h, w, c, co = 12, 20, 8, 16
+    wgt = (rng.standard_normal((co, c, 3, 3)) / np.sqrt(c * 9)).astype(np.float32)
+    scale = rng.standard_normal((1, 1, 1, co)).astype(np.float32)
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(h * w * c), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, h, w, c)])                          # NHWC activations
+        y = g.node("Transpose", [x], perm=[0, 3, 1, 2])                       # -> NCHW for the Conv
+        y = g.node("Conv", [y, g.const(wgt)], kernel_shape=[3, 3], pads=[1, 1, 1, 1])
+        y = g.node("Transpose", [y], perm=[0, 2, 3, 1])                       # back to NHWC
+        s = g.node("Expand", [g.const(scale), i64(1, h, w, co)])              # constant operand: folded at import
+        y = g.node("Mul", [y, s])
+        m = g.node("ReduceMean", [y], axes=[3], keepdims=1)                   # [B, h, w, 1]
+        e = g.node("Expand", [m, i64(1, h, w, co)])                           # activation operand: runs on the device
+        return g.node("Sub", [y, e])
+
+    got, ref = run_both(bn, op_graph(build, [h, w, co]))
+    assert_close(got, ref, "Expand + NHWC sandwich")
+
+
+@pytest.mark.gpu
+def test_stft_node_through_the_fft_kernel(bn, monkeypatch):
+    """The same STFT node under BN_STFT=1: the synthesized cos | sin bank is recognised and runs as ONE FFT launch."""
+    monkeypatch.setenv("BN_STFT", "1")
+    nfft, hop, L = 1024, 256, 64000
+    bins, frames = nfft // 2 + 1, (L - nfft) // hop + 1
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(L), i64(1), i64(1)])
+        return g.node("STFT", [x, g.const(np.array(hop, dtype=np.int64)), g.const(_hann(nfft))])
+
+    data = op_graph(build, [frames, bins, 2])
+    text = bn.plan_describe(write_model(data))
+    assert " FFT " in text and " GEMM " not in text, text
+    got, ref = run_both(bn, data)
+    assert_close(got, ref, "STFT node as FFT", atol=4e-4, rtol=2e-4)

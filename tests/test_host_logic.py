@@ -334,3 +334,46 @@ def test_resampler_oracle_against_scipy_on_band_limited_signals():
     t = np.arange(48000) / 48000
     y = R.resample((0.8 * np.sin(2 * np.pi * 20000.0 * t)).astype(np.float32), 48000, 32000)
     assert np.abs(y[2000:-2000]).max() < 1e-3
+
+
+@pytest.mark.parametrize("op,kwargs,extra,needle", [
+    ("DFT", {}, 0, "export the spectrogram as an STFT node"),
+    ("Resize", {"mode": "nearest"}, 0, "resampling of feature maps"),
+    ("Where", {}, 2, "element selection"),
+    ("Greater", {}, 1, "boolean tensors"),
+    ("NonMaxSuppression", {}, 0, "outside the native subset"),
+])
+def test_unmapped_exporter_nodes_are_refused_by_name(bn, tmp_path, op, kwargs, extra, needle):
+    """Exporter dialects the path does not map are refused at load with the node's name and type,
+    never run on some fallback: checked through the planner alone (bn_plan_describe needs no device)."""
+    g = writer.GraphBuilder()
+    g.add_input("input", [None, 144000])
+    ins = ["input"] + [g.const(np.ones((1,), dtype=np.float32)) for _ in range(extra)]
+    y = g.node(op, ins, **kwargs)  # the writer names it "<op>_1"
+    g.node("Identity", [y], outputs=["output"])
+    g.add_output("output", [None, 144000])
+    p = tmp_path / "m.onnx"
+    p.write_bytes(g.serialize())
+    with pytest.raises(bn.EngineError) as e:
+        bn.plan_describe(str(p))
+    msg = str(e.value)
+    assert f"'{op}_1'" in msg and f"({op})" in msg and needle in msg, msg
+
+
+def test_stft_node_plans_as_framing_convs(bn, tmp_path):
+    """An opset-17 STFT node with a periodic Hann window becomes one cos block and one sin block of folded framing GEMMs
+    (and, under BN_STFT=1, one FFT launch); its [frames, bins, 2] result is a view, not a copy."""
+    n, hop = 512, 128
+    k = np.arange(n, dtype=np.float64)
+    g = writer.GraphBuilder()
+    g.add_input("input", [None, 144000])
+    s = g.node("STFT", ["input", g.const(np.array(hop, dtype=np.int64)), g.const((0.5 - 0.5 * np.cos(2 * np.pi * k / n)).astype(np.float32))])
+    g.node("Identity", [s], outputs=["output"])
+    frames = (144000 - n) // hop + 1
+    g.add_output("output", [None, frames, n // 2 + 1, 2])
+    p = tmp_path / "m.onnx"
+    p.write_bytes(g.serialize())
+    text = bn.plan_describe(str(p))
+    gemms = [l for l in text.splitlines() if " GEMM " in l and "stft:STFT_1" in l]
+    assert len(gemms) == 2 and all("fold=" in l for l in gemms), text
+    assert f"K={n // 2}" in gemms[0], text

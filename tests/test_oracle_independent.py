@@ -119,3 +119,37 @@ def test_pruned_oracle_graph_equals_the_graph_as_written():
     x = synth.synthetic_segments(2, 144000, 48000)
     a, b = onnx_ref.run_graph(g, x)["output"], onnx_ref.run_graph(gp, x)["output"]
     assert np.abs(a - b).max() < 1e-5 * np.abs(a).max()
+
+
+@pytest.mark.parametrize("n,hop,onesided", [(512, 128, 1), (256, 100, 0)])
+def test_oracle_stft_and_expand_nodes_against_torch(n, hop, onesided):
+    """The oracle's STFT node (opset 17) against torch.stft(center=False) and an explicit O(N^2) DFT sum in fp64; Expand against
+    torch.broadcast_to."""
+    writer = importlib.import_module("rust-birdnet-onnx_amd.onnx_writer")
+    L = 6000
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((2, L))
+    win = np.hanning(n + 1)[:-1].astype(np.float32).astype(np.float64)  # the file carries f32 taps
+    g = writer.GraphBuilder()
+    g.add_input("input", [None, L])
+    s = g.node("STFT", ["input", g.const(np.array(hop, dtype=np.int64)), g.const(win.astype(np.float32))], onesided=onesided)
+    m = g.node("ReduceMean", [s], axes=[3], keepdims=1)
+    e = g.node("Expand", [m, g.const(np.array([1, 1, 1, 2], dtype=np.int64))])
+    g.node("Sub", [s, e], outputs=["output"])
+    frames, bins = (L - n) // hop + 1, (n // 2 + 1 if onesided else n)
+    g.add_output("output", [None, frames, bins, 2])
+    got = onnx_ref.run_model(g.serialize(), x, dtype=torch.float64)["output"]
+    ref = torch.view_as_real(torch.stft(torch.from_numpy(x), n, hop_length=hop, window=torch.from_numpy(win), center=False,
+                                        onesided=bool(onesided), return_complex=True)).permute(0, 2, 1, 3)
+    ref = ref - torch.broadcast_to(ref.mean(dim=3, keepdim=True), ref.shape)
+    assert got.shape == tuple(ref.shape)
+    assert np.abs(got - ref.numpy()).max() < 1e-9
+    # one frame by the defining sum
+    f, b = 3, 1
+    t = np.arange(n)
+    seg = x[b, f * hop:f * hop + n] * win
+    k = np.arange(bins)[:, None]
+    dft = (seg[None, :] * np.exp(-2j * np.pi * k * t[None, :] / n)).sum(axis=1)
+    want = np.stack([dft.real, dft.imag], axis=1)
+    want = want - want.mean(axis=1, keepdims=True)
+    assert np.abs(got[b, f] - want).max() < 1e-9
