@@ -966,6 +966,22 @@ class Builder {
         return true;
     }
 
+    // Fused MBConv blocks the row-streaming kernel takes (mbrow.hip: one wave per (band of output rows, strip of output
+    // columns, 32 mid channels), nothing in LDS): tiles_x / tiles_y become strips / bands -- the squeeze partials follow --
+    // and `halo` the pixels it expands per sample.  Per-sample shapes only, so a segment's bits do not depend on its batch.
+    // BN_MBROW=0 keeps the tiled kernels.
+    static void row_streaming(MbDesc &m, double &halo) {
+        const char *env = getenv("BN_MBROW");
+        if (env && std::string(env) == "0") return;
+        if (!mbconv_row_supported(m)) return;
+        const int outw = mbconv_row_outw(m.k, m.s);
+        m.row_mode = 1;
+        m.toh = std::min<int32_t>(m.OH, getenv("BN_MBROW_TOH") ? std::max(1, atoi(getenv("BN_MBROW_TOH"))) : (m.OH <= 12 ? 6 : 8));
+        m.tiles_x = (m.OW + outw - 1) / outw;
+        m.tiles_y = (m.OH + m.toh - 1) / m.toh;
+        halo = 32.0 * m.tiles_x * (double)m.tiles_y * ((m.toh - 1) * m.s + m.k);
+    }
+
     // ------------------------------------------------------------- lowering
     void lower(const OnnxNode &n) {
         const std::string &t = n.op_type;
@@ -1946,7 +1962,7 @@ class Builder {
             // +26 us per whole-map depthwise launch against 8-10 us for the multi-block excite kernel), and every block of
             // a fused MBConv launch pays a store drain + returning atomic (+13 us per launch); DESIGN.md section 4.12.
             const std::string mode = getenv("BN_SEFUSE") ? getenv("BN_SEFUSE") : "0";  // 0 | dw | mb | 1 (both)
-            if (mbp && !mbp->mb.whole_map && (mode == "1" || mode == "mb")) host = mbp;
+            if (mbp && !mbp->mb.whole_map && !mbp->mb.row_mode && (mode == "1" || mode == "mb")) host = mbp;  // the row-streaming form has no block that could be "last"
             else if (dwp && dwp->dw.tiled == 2 && (mode == "1" || mode == "dw")) host = dwp;
         }
         if (host) {
@@ -2380,7 +2396,8 @@ class Builder {
                     m.k1 = cd.kh; m.s1 = cd.sh; m.pt1 = cd.pt; m.pl1 = cd.pl; m.H1 = cd.H; m.W1 = cd.W; m.Cin1 = cd.Cin;
                     const int toh = m.s == 1 ? 8 : 4, tow = m.s == 1 ? 16 : 8;
                     m.tiles_x = (int32_t)((OW + tow - 1) / tow); m.tiles_y = (int32_t)((OH + toh - 1) / toh);
-                    const double halo = (double)((toh - 1) * m.s + m.k) * ((tow - 1) * m.s + m.k) * m.tiles_x * m.tiles_y;
+                    double halo = (double)((toh - 1) * m.s + m.k) * ((tow - 1) * m.s + m.k) * m.tiles_x * m.tiles_y;
+                    row_streaming(m, halo);
                     mb.macs = op.macs;
                     mb.weight_bytes = op.weight_bytes + pe.weight_bytes;
                     mb.bytes = 4.0 * ((double)cd.H * cd.W * cd.Cin + (double)OH * OW * Cin);
@@ -2457,6 +2474,8 @@ class Builder {
                         m.whole_map = 1;
                         m.tiles_x = m.tiles_y = 1;  // one squeeze partial per sample
                         halo = (double)H * W;
+                    } else {
+                        row_streaming(m, halo);
                     }
                     mb.macs = op.macs;                                   // depthwise part (VALU)
                     mb.weight_bytes = op.weight_bytes + pe.weight_bytes;

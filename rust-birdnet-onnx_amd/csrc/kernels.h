@@ -151,6 +151,9 @@ struct MbDesc {
     int32_t k1, s1, pt1, pl1, H1, W1, Cin1;
     int32_t has_gap;
     int64_t gap_bs;
+    // row-streaming form (mbrow.hip): tiles_x = strips of mbconv_row_outw(k, s) output columns, tiles_y = bands of
+    // toh output rows; 0 = the tiled kernels above
+    int32_t row_mode, toh;
 };
 // MaxPool / AveragePool over an NHWC tensor (1-D pooling = H == 1).
 struct PoolDesc {
@@ -162,6 +165,20 @@ struct PoolDesc {
 };
 void launch_pool(hipStream_t s, const PoolDesc &d, float *out, const float *in, int64_t batch);
 
+// Row-streaming form (mbrow.hip): which blocks it takes (planner and launcher agree through these), outputs per strip
+inline bool mbconv_row_act_supported(int act) { return act == ACT_NONE || act == ACT_RELU || act == ACT_CLIP || act == ACT_SILU || act == ACT_HSWISH; }
+inline bool mbconv_row_supported(const MbDesc &d) {
+    const int ng = (d.Cin + 7) / 8;
+    if (d.whole_map) return false;
+    if (!((d.k == 3 || d.k == 5) && (d.s == 1 || d.s == 2))) return false;
+    if (!mbconv_row_act_supported(d.act1) || !mbconv_row_act_supported(d.act2)) return false;
+    if ((int64_t)d.OH * d.OW * d.C >= ((int64_t)1 << 31) || (int64_t)d.W * d.Cin >= ((int64_t)1 << 30)) return false;  // 32-bit lane offsets
+    if (d.k1 > 0) return ng >= 2 && ng <= 4 && d.k == 3 && d.k1 <= 4 && d.Cin1 >= 1;
+    return d.Cin % 4 == 0 && ng >= 2 && ng <= 6;
+}
+inline int mbconv_row_outw(int k, int s) { return (32 - k) / s + 1; }
+void launch_mbconv_row(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
+                       const float *b2, float *gap, int64_t batch);
 struct SeTail;
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1,
                    const float *b1, const float *w2, const float *b2, float *gap, int64_t batch, const SeTail *tail = nullptr);

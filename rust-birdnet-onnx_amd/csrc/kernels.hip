@@ -1199,6 +1199,21 @@ __device__ void se_tail(const SeTail &t, int64_t b, const float *__restrict__ pa
 // The expanded tensor never exists in HBM.  grid (tiles, 1, batch), 256 threads, dynamic LDS;
 // two barriers per chunk.
 constexpr int MB_MAX_NG = 6;  // Cin <= 48
+// In-kernel phase stamps for tools/mb_probe.cpp (which compiles this file with -DBN_MB_STAMPS); nothing in the product build.
+#ifdef BN_MB_STAMPS
+__device__ unsigned long long *bn_mb_stamps = nullptr;  // [blocks][32]: slot 0 wall clock (100 MHz), slots 1.. shader clock
+#define MB_STAMP(i)                                                                                                              \
+    do {                                                                                                                         \
+        if (bn_mb_stamps && threadIdx.x == 0) {                                                                                  \
+            unsigned long long *sp_ = bn_mb_stamps + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 32;                         \
+            if ((i) == 0) sp_[0] = wall_clock64();                                                                               \
+            if ((i) == 31) sp_[31] = wall_clock64();                                                                             \
+            else sp_[(i) + 1] = __builtin_amdgcn_s_memtime();                                                                    \
+        }                                                                                                                        \
+    } while (0)
+#else
+#define MB_STAMP(i)
+#endif
 template <int K, int S, bool IM2COL>
 __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                                const float *__restrict__ w1, const float *__restrict__ b1,
@@ -1233,6 +1248,7 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
     // expand filters of a chunk: lane (lr, lh) holds columns 8g + 4lh .. +3 of filter c0 + lr for
     // every K group g.  w1 is the planner's padded repack [C][ng*8] = weights | zeros, so these are
     // plain loads with nothing depending on them until the matrix instructions.
+    MB_STAMP(0);
     float4 bw[MB_MAX_NG], bnx[MB_MAX_NG];
     auto fetch_b = [&](float4 (&dst)[MB_MAX_NG], int c0) {
         const int n = c0 + lr < d.C ? c0 + lr : d.C - 1;
@@ -1249,6 +1265,7 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
         // (column = (ky*k1 + kx)*Cin1 + c); taps outside the input image are the conv's own zero padding, pixels
         // outside the output map are zero rows with Vs = 0.  Clamped loads, selection at LDS-store time.
         const int KK = d.k1 * d.k1;
+        const float inv_kk = 1.0f / (float)KK, inv_k1 = 1.0f / (float)d.k1;
         for (int r = tid; r < MP; r += 256) {
             const int iy = r / IWT, ix = r - iy * IWT;
             const int ih = ih0 + iy, iw = iw0 + ix;
@@ -1262,8 +1279,8 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int it = it0 + i * 256;
-                const int r = it / KK, t = it - r * KK;
-                const int ky = t / d.k1, kx = t - ky * d.k1;
+                const int r = (int)(((float)it + 0.5f) * inv_kk), t = it - r * KK;  // exact for it < 2^14 (no integer division by a run-time value)
+                const int ky = (int)(((float)t + 0.5f) * inv_k1), kx = t - ky * d.k1;
                 const int iy = r / IWT, ix = r - iy * IWT;
                 const int ih = ih0 + iy, iw = iw0 + ix;
                 const int y = ih * d.s1 + ky - d.pt1, x = iw * d.s1 + kx - d.pl1;
@@ -1277,7 +1294,7 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
             for (int i = 0; i < 4; i++) {
                 const int it = it0 + i * 256;
                 if (it < MP * KK) {
-                    const int r = it / KK, t = it - r * KK;
+                    const int r = (int)(((float)it + 0.5f) * inv_kk), t = it - r * KK;  // exact for it < 2^14 (no integer division by a run-time value)
 #pragma unroll
                     for (int cc = 0; cc < 4; cc++)
                         if (cc < d.Cin1) Xs[r * KS + t * d.Cin1 + cc] = okv[i] ? v[i][cc] : 0.0f;
@@ -1316,6 +1333,7 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
             }
         }
     }
+    MB_STAMP(1);  // staging issued
     // depthwise role: lane = channel, group g8 = PPG consecutive pixels of output row oy
     const int c = tid & 31, g8 = tid >> 5;
     const int oy = g8 / SEG, ox0 = (g8 - oy * SEG) * PPG;
@@ -1336,6 +1354,7 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
         const float bv = d.has_bias1 ? b1[c0 + lr < d.C ? c0 + lr : d.C - 1] : 0.0f;
         if (ch + 1 < nchunks) fetch_b(bnx, c0 + 32);  // next chunk's filters in flight during this chunk
         __syncthreads();  // Es of the previous chunk consumed; first pass: Xs complete
+        if (ch < 5) MB_STAMP(2 + 4 * ch);  // barrier A passed
 
         // ---- 1+2. expand -> Es
         const int wrole = (wave - ch) & 3;
@@ -1371,7 +1390,9 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
                 for (int reg = 0; reg < 16; reg++) ep[((reg & 3) + 8 * (reg >> 2)) * 32] = acc[0][reg];
             }
         }
+        if (ch < 5) MB_STAMP(3 + 4 * ch);  // this wave's expand done
         __syncthreads();
+        if (ch < 5) MB_STAMP(4 + 4 * ch);  // barrier B passed
         // ---- 3. depthwise from LDS, window sliding along the row
         float ov[PPG];
 #pragma unroll
@@ -1405,6 +1426,7 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
             }
         }
         red[(ch * 8 + g8) * 32 + c] = sum;
+        if (ch < 5) MB_STAMP(5 + 4 * ch);  // depthwise + stores issued
 #pragma unroll
         for (int g = 0; g < MB_MAX_NG; g++) bw[g] = bnx[g];
     }
@@ -1419,6 +1441,8 @@ __global__ __launch_bounds__(256) void mbconv_expand_dw_kernel(MbDesc d, float *
         }
         if (tail.on) se_tail(tail, b, gap + b * d.gap_bs, msm);
     }
+    MB_STAMP(30);
+    MB_STAMP(31);
 }
 
 // ------------------------------------------------------------------ depthwise conv
@@ -1608,6 +1632,7 @@ __global__ __launch_bounds__(512) void mbconv_pipe_kernel(MbDesc d, float *__res
         // (column = (ky*k1 + kx)*Cin1 + c); taps outside the input image are the conv's own zero padding, pixels
         // outside the output map are zero rows with Vs = 0.  Clamped loads, selection at LDS-store time.
         const int KK = d.k1 * d.k1;
+        const float inv_kk = 1.0f / (float)KK, inv_k1 = 1.0f / (float)d.k1;
         for (int r = tid; r < MP; r += 512) {
             const int iy = r / IWT, ix = r - iy * IWT;
             const int ih = ih0 + iy, iw = iw0 + ix;
@@ -1621,8 +1646,8 @@ __global__ __launch_bounds__(512) void mbconv_pipe_kernel(MbDesc d, float *__res
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int it = it0 + i * 512;
-                const int r = it / KK, t = it - r * KK;
-                const int ky = t / d.k1, kx = t - ky * d.k1;
+                const int r = (int)(((float)it + 0.5f) * inv_kk), t = it - r * KK;  // exact for it < 2^14 (no integer division by a run-time value)
+                const int ky = (int)(((float)t + 0.5f) * inv_k1), kx = t - ky * d.k1;
                 const int iy = r / IWT, ix = r - iy * IWT;
                 const int ih = ih0 + iy, iw = iw0 + ix;
                 const int y = ih * d.s1 + ky - d.pt1, x = iw * d.s1 + kx - d.pl1;
@@ -1636,7 +1661,7 @@ __global__ __launch_bounds__(512) void mbconv_pipe_kernel(MbDesc d, float *__res
             for (int i = 0; i < 4; i++) {
                 const int it = it0 + i * 512;
                 if (it < MP * KK) {
-                    const int r = it / KK, t = it - r * KK;
+                    const int r = (int)(((float)it + 0.5f) * inv_kk), t = it - r * KK;  // exact for it < 2^14 (no integer division by a run-time value)
 #pragma unroll
                     for (int cc = 0; cc < 4; cc++)
                         if (cc < d.Cin1) Xs[r * KS + t * d.Cin1 + cc] = okv[i] ? v[i][cc] : 0.0f;
@@ -2425,6 +2450,10 @@ size_t mbconv_pipe_lds_bytes(const MbDesc &d) {
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
                    const float *b2, float *gap, int64_t batch, const SeTail *tailp) {
     if (batch <= 0) return;
+    if (d.row_mode && !(tailp && tailp->on)) {
+        launch_mbconv_row(s, d, out, in, w1, b1, w2, b2, gap, batch);
+        return;
+    }
     SeTail tail{};
     if (tailp && !d.whole_map) tail = *tailp;
     tail.nblocks = d.tiles_x * d.tiles_y;

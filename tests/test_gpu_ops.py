@@ -482,10 +482,12 @@ def test_standalone_batchnorm_and_hard_activations(bn):
 @pytest.mark.parametrize("cin,h,w,cmid,k,stride,act", [(16, 24, 40, 96, 3, 2, "relu"), (24, 12, 40, 144, 3, 1, "relu"),
                                                        (24, 13, 37, 144, 5, 2, "silu"), (40, 9, 19, 240, 3, 2, "relu6"),
                                                        (8, 16, 32, 48, 5, 1, "relu"), (16, 7, 9, 40, 3, 1, None)])
-@pytest.mark.parametrize("variant", ["tiled", "pipe", "map"])
+@pytest.mark.parametrize("variant", ["tiled", "pipe", "map", "row"])
 def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
-    """expand 1x1 conv (+BN+act) -> depthwise KxK (+act): one MBCONV launch, expanded tensor only in LDS.
-    Both kernels: output tiles with halo recompute ("tiled") and whole small maps per block ("map")."""
+    """expand 1x1 conv (+BN+act) -> depthwise KxK (+act): one MBCONV launch, the expanded tensor never in HBM.
+    Kernels: output tiles with halo recompute in LDS ("tiled", its 512-thread "pipe" form), whole small maps per block ("map"),
+    and the register-resident row-streaming form ("row", the default where it applies) -- which must reproduce the tiled
+    kernel's output BIT FOR BIT (same accumulation order)."""
     rng = np.random.default_rng(11)
     assert cin * h * w <= 144000
     pad = k // 2
@@ -519,13 +521,24 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
     os.environ["BN_MBMAP"] = "1" if variant == "map" else "0"
     os.environ["BN_MBMAP_MAXHW"] = "1024"
     os.environ["BN_MBPIPE"] = "1" if variant == "pipe" else "0"   # pipelined 512-thread variant of the tiled kernel
+    os.environ["BN_MBROW"] = "1" if variant == "row" else "0"
+    os.environ["BN_MBROW_TOH"] = "5"                              # several bands, a ragged last one
     try:
         desc = bn.plan_describe(write_model(data))
         assert "MBCONV" in desc
-        assert ("tiles=1x1" in desc) == (variant == "map" or (oh <= (8 if stride == 1 else 4) and ow <= (16 if stride == 1 else 8)))
+        mb_rows = int([l for l in desc.splitlines() if " MBCONV " in l][0].rsplit("rows=", 1)[1])
+        if variant == "row":
+            assert mb_rows == (min(5, oh) if cin >= 12 else 0), desc  # Cin <= 8 (one K group) stays with the tiled kernel
+        else:
+            assert mb_rows == 0, desc
+            assert ("tiles=1x1" in desc) == (variant == "map" or (oh <= (8 if stride == 1 else 4) and ow <= (16 if stride == 1 else 8)))
         got, ref = run_both(bn, data)
+        if variant == "row":
+            os.environ["BN_MBROW"] = "0"
+            tiled, _ = run_both(bn, data)
+            assert np.array_equal(got.view(np.uint32), tiled.view(np.uint32)), "row-streaming kernel differs from the tiled kernel"
     finally:
-        for key in ("BN_MBFUSE", "BN_MBMAP", "BN_MBMAP_MAXHW", "BN_MBPIPE"):
+        for key in ("BN_MBFUSE", "BN_MBMAP", "BN_MBMAP_MAXHW", "BN_MBPIPE", "BN_MBROW", "BN_MBROW_TOH"):
             del os.environ[key]
     assert_close(got, ref, f"mbconv[{variant}] {cin}->{cmid} k{k} s{stride}")
 
@@ -568,9 +581,17 @@ def test_fused_stem_conv_depthwise(bn, cin, h, w, cout, k1, s1, k, stride, act):
     try:
         desc = bn.plan_describe(write_model(data))
         assert "stem:" in desc, desc
+        # 3x3 depthwise stems run in the row-streaming kernel (padding of the first conv included), the others tiled
+        mb_rows = lambda t: int([l for l in t.splitlines() if " MBCONV " in l][0].rsplit("rows=", 1)[1])
+        assert (mb_rows(desc) > 0) == (k == 3 and k1 * k1 * cin > 8), desc
         got, ref = run_both(bn, data)
+        os.environ["BN_MBROW"] = "0"
+        assert mb_rows(bn.plan_describe(write_model(data))) == 0
+        tiled, _ = run_both(bn, data)
+        assert np.array_equal(got.view(np.uint32), tiled.view(np.uint32)), "row-streaming stem differs from the tiled kernel"
     finally:
         del os.environ["BN_MBFUSE"]
+        os.environ.pop("BN_MBROW", None)
     assert_close(got, ref, f"stem {cin}->{cout} k1={k1} s1={s1} dw k{k} s{stride}")
     os.environ["BN_STEMFUSE"] = "0"
     try:
@@ -598,15 +619,16 @@ def test_pipelined_mbconv_is_bit_identical_to_the_plain_kernel(bn):
                                       pads=[k // 2] * 4, group=cmid)])
     data = op_graph(build, [cmid, h, w])
     outs = []
-    for mode in ("0", "1"):
+    for mode, row in (("0", "0"), ("1", "0"), ("0", "1")):
         os.environ["BN_MBPIPE"] = mode
+        os.environ["BN_MBROW"] = row
         os.environ["BN_MBFUSE"] = "force"
         try:
             assert "MBCONV" in bn.plan_describe(write_model(data))
             outs.append(run_both(bn, data, batch=3)[0].copy())
         finally:
-            del os.environ["BN_MBPIPE"], os.environ["BN_MBFUSE"]
-    assert outs[0].tobytes() == outs[1].tobytes()
+            del os.environ["BN_MBPIPE"], os.environ["BN_MBFUSE"], os.environ["BN_MBROW"]
+    assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes()
 
 
 @pytest.mark.parametrize("cin,h,w,cmid,k,stride", [(80, 6, 32, 480, 3, 1), (112, 6, 32, 672, 5, 2), (192, 3, 16, 1152, 5, 1),
