@@ -52,6 +52,20 @@ __device__ __forceinline__ float upper_half(float v) {
     return __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);
 }
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+
+#ifdef BN_MB_STAMPS  // tools/mb_probe.cpp: shader-clock stamps of the first main-loop steps of every unit
+__device__ unsigned long long *bn_row_stamps = nullptr;  // [units][64]
+#define ROW_STAMP()                                                                                                  \
+    do {                                                                                                             \
+        if (bn_row_stamps && lane == 0 && nst < 64) bn_row_stamps[(size_t)u * 64 + nst] = __builtin_amdgcn_s_memtime(); \
+        nst++;                                                                                                       \
+    } while (0)
+#else
+#define ROW_STAMP()
+#endif
+
 template <int K, int S>
 struct RowCfg {
     static constexpr int NOUT = 16 / S;             // outputs per lane and row
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
     const int ix0 = ox0 * S - d.pl;
     // every halo column inside the image / every output column inside the output map: the unit runs without masks
     const bool cols_in = ix0 >= 0 && ix0 + 32 <= d.W;
-    const bool outs_in = ox0 + OUTW <= d.OW && (d.C & 31) == 0;
+    const bool outs_in = ox0 + OUTW <= d.OW && ch * 32 + 32 <= d.C;  // a full chunk in an interior strip
 
     // ---- matrix-operand role: lane lr feeds accumulator row m = lr = pixel xm of the halo row
     const int xm = 16 * ((lr >> 2) & 1) + 4 * (lr >> 3) + (lr & 3);
@@ -190,8 +204,8 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
     }
 
     const int64_t a_rs = (int64_t)d.W * d.Cin;                        // floats per input row
-    const unsigned a_lane = (unsigned)(ixc * d.Cin + 4 * lh);         // this lane's pixel + K half within the row
-    const unsigned a_last = a_lane + (pad_lane ? 0u : 8u * (NG - 1));  // channel-padding lanes re-read group 0 (then zeroed)
+    const unsigned a_lane4 = 4u * (unsigned)(ixc * d.Cin + 4 * lh);      // byte offset of this lane's pixel + K half within the row
+    const unsigned a_last4 = a_lane4 + (pad_lane ? 0u : 32u * (NG - 1));  // channel-padding lanes re-read group 0 (then zeroed)
     float4 abuf[2][NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) abuf[0][g] = abuf[1][g] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -219,9 +233,9 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
                 }                                                                                                               \
             }                                                                                                                   \
         } else {                                                                                                                \
-            const float *prow_ = xin + (int64_t)iy_ * a_rs; /* wave-uniform row base, lanes add a 32-bit offset */             \
-            _Pragma("unroll") for (int g = 0; g < NG - 1; g++) dst[g] = *reinterpret_cast<const float4 *>(prow_ + a_lane + 8 * g); \
-            dst[NG - 1] = *reinterpret_cast<const float4 *>(prow_ + a_last);                                                    \
+            const char *prow_ = reinterpret_cast<const char *>(xin + (int64_t)iy_ * a_rs); /* wave-uniform row base */          \
+            _Pragma("unroll") for (int g = 0; g < NG - 1; g++) dst[g] = *reinterpret_cast<const float4 *>(prow_ + 32 * g + a_lane4); \
+            dst[NG - 1] = *reinterpret_cast<const float4 *>(prow_ + a_last4);                                                   \
             if (any_pad) {                                                                                                      \
                 if (pad_lane) dst[NG - 1] = make_float4(0.f, 0.f, 0.f, 0.f);                                                    \
             }                                                                                                                   \
@@ -235,23 +249,30 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
         for (int x = 0; x < XW; x++) rows[s_][x] = 0.0f;
 
     float *obase = out + b * d.out_bs;  // wave-uniform base, lanes add 32-bit offsets
-    const unsigned ocol = (unsigned)((ox0 + NOUT * lh) * d.C + cgc);
-    const int64_t o_rs = (int64_t)d.OW * d.C;  // floats per output row
-    float sum = 0.0f;
-    floatx16 acc;
+    const unsigned ocol4 = 4u * (unsigned)((ox0 + NOUT * lh) * d.C + cgc);  // this lane's byte offset within an output row
+    const int64_t o_rs = (int64_t)d.OW * d.C;                              // floats per output row
+    const size_t o_ps = 4 * (size_t)d.C;                                   // bytes per output pixel
+    int nst = 0;
+    (void)nst;
+    float2_t sum2 = {0.0f, 0.0f};  // squeeze partial of this lane, even / odd outputs
+    floatx16 acc, bvec;           // bvec: the expand bias in every accumulator slot, the C operand of a row's first matrix instruction
+#pragma unroll
+    for (int r = 0; r < 16; r++) bvec[r] = bv;
 
     // matrix instructions of one halo row (operands in A)
-#ifdef BN_MB_STAMPS
+#ifdef BN_MBROW_DBG  // tools/mb_probe.cpp phase experiments (the branches defeat the interleaving, so timings shift)
 #define MBROW_DBG(bit) ((d.row_mode >> 8) & (bit))
 #else
 #define MBROW_DBG(bit) 0
 #endif
 #define MBROW_EXPAND(A)                                                                                                         \
     do {                                                                                                                        \
-        _Pragma("unroll") for (int r = 0; r < 16; r++) acc[r] = bv;                                                             \
-        if (MBROW_DBG(1)) break;                                                                                                \
+        if (MBROW_DBG(1)) {                                                                                                     \
+            acc = bvec;                                                                                                         \
+            break;                                                                                                              \
+        }                                                                                                                       \
         _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                                        \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].x, bw[g].x, acc, 0, 0, 0);                                          \
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].x, bw[g].x, g == 0 ? bvec : acc, 0, 0, 0);                          \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].y, bw[g].y, acc, 0, 0, 0);                                          \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].z, bw[g].z, acc, 0, 0, 0);                                          \
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].w, bw[g].w, acc, 0, 0, 0);                                          \
@@ -281,30 +302,33 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
         } else                                                                                                                  \
             dw_rows<K, S, NEWEST>(rows, wd, bias2, ov);                                                                         \
         row_act_t<ACT, NOUT>(d.act2, d.p0_2, d.p1_2, ov);                                                                       \
-        float *orow_ = obase + (int64_t)(oy0 + (JO) / S) * o_rs; /* wave-uniform */                                             \
+        char *orow_ = reinterpret_cast<char *>(obase + (int64_t)(oy0 + (JO) / S) * o_rs); /* wave-uniform */                    \
         if (MBROW_DBG(4)) {                                                                                                     \
-            _Pragma("unroll") for (int q = 0; q < NOUT; q++) sum += ov[q];                                                      \
-        } else if (outs_in) {                                                                                                          \
-            _Pragma("unroll") for (int q = 0; q < QBOTH; q++) {                                                                 \
-                (orow_ + q * d.C)[ocol] = ov[q];                                                                                \
-                sum += ov[q];                                                                                                   \
-            }                                                                                                                   \
+            _Pragma("unroll") for (int q = 0; q < NOUT; q += 2) sum2 += float2_t{ov[q], ov[q + 1]};                             \
+        } else if (outs_in) {                                                                                                   \
+            _Pragma("unroll") for (int q = 0; q + 1 < QBOTH; q += 2) sum2 += float2_t{ov[q], ov[q + 1]};                        \
+            if constexpr (QBOTH & 1) sum2[0] += ov[QBOTH - 1];                                                                  \
             if (lh == 0) {                                                                                                      \
-                _Pragma("unroll") for (int q = QBOTH; q < NOUT; q++) {                                                          \
-                    (orow_ + q * d.C)[ocol] = ov[q];                                                                            \
-                    sum += ov[q];                                                                                               \
-                }                                                                                                               \
+                _Pragma("unroll") for (int q = QBOTH; q + 1 < NOUT; q += 2) sum2 += float2_t{ov[q], ov[q + 1]};                 \
+                if constexpr ((NOUT - QBOTH) & 1) sum2[1] += ov[NOUT - 1];                                                      \
+            }                                                                                                                   \
+            _Pragma("unroll") for (int q = 0; q < QBOTH; q++)                                                                   \
+                *reinterpret_cast<float *>(orow_ + (size_t)q * o_ps + ocol4) = ov[q];                                           \
+            if (lh == 0) {                                                                                                      \
+                _Pragma("unroll") for (int q = QBOTH; q < NOUT; q++)                                                            \
+                    *reinterpret_cast<float *>(orow_ + (size_t)q * o_ps + ocol4) = ov[q];                                       \
             }                                                                                                                   \
         } else {                                                                                                                \
             _Pragma("unroll") for (int q = 0; q < NOUT; q++)                                                                    \
                 if ((omask >> q) & 1u) {                                                                                        \
-                    (orow_ + q * d.C)[ocol] = ov[q];                                                                            \
-                    sum += ov[q];                                                                                               \
+                    *reinterpret_cast<float *>(orow_ + (size_t)q * o_ps + ocol4) = ov[q];                                       \
+                    sum2[q & 1] += ov[q];                                                                                       \
                 }                                                                                                               \
         }                                                                                                                       \
     } while (0)
 
     // ---- prologue: rows 0 .. K-1 (operand buffer = J & 1)
+    ROW_STAMP();
     MBROW_LOAD_A(abuf[0], 0);
 #define MBROW_PRO(J)                                  \
     do {                                              \
@@ -325,9 +349,11 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
     do {                                                                                         \
         const int j_ = jb + (I);                                                                 \
         if (j_ <= nrows) {                                                                       \
+            ROW_STAMP();                                                                         \
             MBROW_LOAD_A(abuf[(K + (I) + 1) & 1], j_ + 1);                                       \
             MBROW_EXPAND(abuf[(K + (I)) & 1]);                                                   \
             if constexpr (S == 1 || ((I) & 1) == 0) MBROW_EMIT(((I) + K - 1) % K, j_ - K);       \
+            ROW_STAMP();                                                                         \
             MBROW_COMMIT((I) % K, j_);                                                           \
         }                                                                                        \
     } while (0)
@@ -347,12 +373,14 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
             }
         }
     }
+    ROW_STAMP();
 #undef MBROW_MAIN
 #undef MBROW_EMIT
 #undef MBROW_COMMIT
 #undef MBROW_EXPAND
 #undef MBROW_LOAD_A
     if (d.has_gap) {
+        const float sum = sum2[0] + sum2[1];
         const float other = upper_half(sum);  // left half + right half, in that order
         if (lh == 0 && cact) gap[b * d.gap_bs + (int64_t)(band * d.tiles_x + strip) * d.C + cg] = sum + other;
     }

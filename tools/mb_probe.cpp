@@ -110,6 +110,31 @@ int main(int argc, char **argv) {
             hipMemset(dout2, 0xff, (size_t)d.out_bs * batch * 4);
             if (!mbconv_row_supported(r)) printf("   row kernel: shape not supported\n");
             else {
+                const long long nun = (long long)batch * r.tiles_x * r.tiles_y * ((d.C + 31) / 32);
+                unsigned long long *drs;
+                hipMalloc(&drs, (size_t)nun * 64 * 8); hipMemset(drs, 0, (size_t)nun * 64 * 8);
+                hipMemcpyToSymbol(HIP_SYMBOL(bn_row_stamps), &drs, sizeof(drs));
+                launch_mbconv_row(st, r, dout2, din, dw1, db1, dw2, db2, dgap2, batch);
+                hipStreamSynchronize(st);
+                {
+                    std::vector<unsigned long long> hs2((size_t)nun * 64);
+                    hipMemcpy(hs2.data(), drs, hs2.size() * 8, hipMemcpyDeviceToHost);
+                    // stamps: [0] unit start, then per main step: (top, after emit), last: end
+                    double pro = 0, blk = 0, com = 0, tot = 0; long long nb = 0, nu2 = 0;
+                    for (long long uu = 0; uu < nun; uu++) {
+                        const unsigned long long *q = &hs2[uu * 64];
+                        int n = 0; while (n < 64 && q[n]) n++;
+                        if (n < 4) continue;
+                        nu2++;
+                        pro += (double)(q[1] - q[0]); tot += (double)(q[n - 1] - q[0]);
+                        for (int k2 = 1; k2 + 2 < n; k2 += 2) { blk += (double)(q[k2 + 1] - q[k2]); com += (double)(q[k2 + 2] - q[k2 + 1]); nb++; }
+                    }
+                    printf("   row kernel stamps: unit lifetime %.0f cycles; prologue (setup + first K rows) %.0f; per main step: load+expand+emit %.0f, commit(+loop) %.0f  (%lld steps/unit)\n",
+                           tot / nu2, pro / nu2, blk / nb, com / nb, nb / nu2);
+                }
+                unsigned long long *nullq = nullptr;
+                hipMemcpyToSymbol(HIP_SYMBOL(bn_row_stamps), &nullq, sizeof(nullq));
+                hipFree(drs);
                 for (int i = 0; i < 3; i++) launch_mbconv_row(st, r, dout2, din, dw1, db1, dw2, db2, dgap2, batch);
                 hipEventRecord(e0, st);
                 for (int i = 0; i < 20; i++) launch_mbconv_row(st, r, dout2, din, dw1, db1, dw2, db2, dgap2, batch);
