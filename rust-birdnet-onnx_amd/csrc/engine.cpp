@@ -975,6 +975,11 @@ class Builder {
         if (env && std::string(env) == "0") return;
         if (!mbconv_row_supported(m)) return;
         const int outw = mbconv_row_outw(m.k, m.s);
+        // a strip expands 32 halo columns for `outw` outputs whatever the map's width: on narrow maps (Perch: 32 or 16
+        // columns against strips of 30 / 28 / 14) half of every strip is idle and the tiled kernel wins (measured: 0.53-0.57
+        // utilisation -> 1.2-2.5x slower, 0.71 and above -> faster); BN_MBROW=force takes it regardless (tests)
+        const int strips = (m.OW + outw - 1) / outw;
+        if (!(env && std::string(env) == "force") && (double)m.OW < 0.7 * (double)(strips * outw)) return;
         m.row_mode = 1;
         m.toh = std::min<int32_t>(m.OH, getenv("BN_MBROW_TOH") ? std::max(1, atoi(getenv("BN_MBROW_TOH"))) : (m.OH <= 12 ? 6 : 8));
         m.tiles_x = (m.OW + outw - 1) / outw;

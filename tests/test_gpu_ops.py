@@ -521,7 +521,7 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
     os.environ["BN_MBMAP"] = "1" if variant == "map" else "0"
     os.environ["BN_MBMAP_MAXHW"] = "1024"
     os.environ["BN_MBPIPE"] = "1" if variant == "pipe" else "0"   # pipelined 512-thread variant of the tiled kernel
-    os.environ["BN_MBROW"] = "1" if variant == "row" else "0"
+    os.environ["BN_MBROW"] = "force" if variant == "row" else "0"   # force: narrow maps too (the planner leaves those to the tiled kernel)
     os.environ["BN_MBROW_TOH"] = "5"                              # several bands, a ragged last one
     try:
         desc = bn.plan_describe(write_model(data))
@@ -578,6 +578,7 @@ def test_fused_stem_conv_depthwise(bn, cin, h, w, cout, k1, s1, k, stride, act):
     data = op_graph(build, [cout, oh, ow])
     import os
     os.environ["BN_MBFUSE"] = "force"   # fuse small feature maps too (the planner keeps those unfused by default)
+    os.environ["BN_MBROW"] = "force"    # ... and take the row-streaming kernel whatever the strip utilisation
     try:
         desc = bn.plan_describe(write_model(data))
         assert "stem:" in desc, desc
@@ -619,7 +620,7 @@ def test_pipelined_mbconv_is_bit_identical_to_the_plain_kernel(bn):
                                       pads=[k // 2] * 4, group=cmid)])
     data = op_graph(build, [cmid, h, w])
     outs = []
-    for mode, row in (("0", "0"), ("1", "0"), ("0", "1")):
+    for mode, row in (("0", "0"), ("1", "0"), ("0", "force")):
         os.environ["BN_MBPIPE"] = mode
         os.environ["BN_MBROW"] = row
         os.environ["BN_MBFUSE"] = "force"
