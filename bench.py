@@ -305,7 +305,7 @@ def main():
         # classify launches by the kernel that executes them (plan_describe gives the op kind per launch)
         desc = bn.plan_describe(path_for_describe(model_bytes))
         kind_of = [l.split()[1] for l in desc.splitlines() if l[:3].strip().isdigit()]
-        fam_name = {"GEMM": "gemm_mfma_kernel", "DWCONV": "dwconv_kernel", "CONV": "conv_direct_kernel", "MBCONV": "mbconv_expand_dw_kernel",
+        fam_name = {"GEMM": "gemm_mfma_kernel", "DWCONV": "dwconv_kernel", "CONV": "conv_direct_kernel", "MBCONV": "mbconv_row_kernel",
                     "REDUCE": "reduce_kernel", "ELT": "elt_kernel", "GAP": "gap_partial_kernel", "SEFC": "se_fc_kernel", "POOL": "pool_kernel", "FFT": "stft_kernel"}
         fam = {}
         for (name, us, macs, byts), k in zip(rows, kind_of):
