@@ -468,6 +468,12 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
                 r = torch.index_select(i[0], int(a.get("axis", 0)), i[1].reshape(-1).to(torch.int64))
                 if i[1].dim() == 0:
                     r = r.squeeze(int(a.get("axis", 0)))
+            elif op == "PRelu":
+                r = torch.clamp(i[0], min=0) + i[1] * torch.clamp(i[0], max=0)
+            elif op == "Tile":
+                r = i[0].repeat([int(v) for v in i[1].reshape(-1).tolist()])
+            elif op == "InstanceNormalization":
+                r = torch.nn.functional.instance_norm(i[0], weight=i[1], bias=i[2], eps=float(a.get("epsilon", 1e-5)))
             elif op == "Expand":
                 shape = [int(v) for v in i[1].reshape(-1).tolist()]
                 r = i[0] * torch.ones(shape, dtype=i[0].dtype)  # ONNX Expand: numpy broadcasting against ones(shape)

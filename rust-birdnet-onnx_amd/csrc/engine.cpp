@@ -1014,6 +1014,9 @@ class Builder {
         if (t == "GlobalAveragePool" || t == "GlobalMaxPool" || t.rfind("Reduce", 0) == 0) return lower_reduce(n);
         if (t == "STFT") return lower_stft(n);
         if (t == "Expand") return lower_expand(n);
+        if (t == "Tile") return lower_tile(n);
+        if (t == "PRelu") return lower_prelu(n);
+        if (t == "InstanceNormalization") return lower_instance_norm(n);
         ActSpec a;
         if (unary_spec(n, a)) return lower_unary(n, a);
         // exporter dialects this path has met but does not map: say what the node is and what to export instead
@@ -1088,6 +1091,110 @@ class Builder {
         out.dims = {y.dims[1], bins, 2};
         out.strides = {y.strides[1], y.strides[0], bins * y.strides[0]};
         define(n.outputs[0], out);
+    }
+
+    // ---- operators lowered as short sequences of operators the planner already has (each step is an ordinary node to
+    // the lowering: constants fold, elementwise steps fuse into chains)
+    OnnxNode synth_node(const std::string &op, const std::string &name, std::vector<std::string> ins, const std::string &out) {
+        OnnxNode s_;
+        s_.name = name;
+        s_.op_type = op;
+        s_.inputs = std::move(ins);
+        s_.outputs = {out};
+        return s_;
+    }
+    std::string synth_const(const std::string &name, Dims dims, std::vector<float> f) {
+        Val c;
+        c.is_const = true;
+        c.dims = std::move(dims);
+        c.f = std::move(f);
+        vals_[name] = std::move(c);
+        return name;
+    }
+    static void set_ints(OnnxNode &nd, const std::string &key, std::vector<int64_t> v) {
+        OnnxAttr a;
+        a.name = key;
+        a.type = 7;
+        a.ints = std::move(v);
+        nd.attrs[key] = a;
+    }
+    static void set_int(OnnxNode &nd, const std::string &key, int64_t v) {
+        OnnxAttr a;
+        a.name = key;
+        a.type = 2;
+        a.i = v;
+        nd.attrs[key] = a;
+    }
+
+    // PRelu(x, slope) = max(x, 0) + slope * min(x, 0); one slope for everything is LeakyRelu
+    void lower_prelu(const OnnxNode &n) {
+        const Val *sl = opt(n, 1);
+        if (!sl || !sl->is_const || sl->is_int) unsupported(n, "PRelu needs a constant slope");
+        const std::string base = "prelu:" + n.outputs[0];
+        if (sl->numel() == 1) {
+            OnnxNode lr = synth_node("LeakyRelu", n.name, {n.inputs[0]}, n.outputs[0]);
+            OnnxAttr a;
+            a.name = "alpha";
+            a.type = 1;
+            a.f = sl->f[0];
+            lr.attrs["alpha"] = a;
+            lower(lr);
+            return;
+        }
+        lower(synth_node("Relu", n.name + "/pos", {n.inputs[0]}, base + "/pos"));
+        lower(synth_node("Min", n.name + "/neg", {n.inputs[0], synth_const(base + "/zero", {1}, {0.0f})}, base + "/neg"));
+        lower(synth_node("Mul", n.name + "/scaled", {base + "/neg", n.inputs[1]}, base + "/scaled"));
+        lower(synth_node("Add", n.name, {base + "/pos", base + "/scaled"}, n.outputs[0]));
+    }
+
+    // Tile: only repeats of dimensions of size 1 (= Expand); anything else would need a gather
+    void lower_tile(const OnnxNode &n) {
+        const Val &x = get(n, 0);
+        const Val *rp = opt(n, 1);
+        if (!rp || !rp->is_const) unsupported(n, "Tile needs constant repeats");
+        std::vector<int64_t> rep = const_ints(n, *rp);
+        Dims full = x.dims;
+        if (!x.is_const) full.insert(full.begin(), 1);  // the batch dimension: repeats[0] must be 1
+        if (rep.size() != full.size()) unsupported(n, "repeats must have one entry per dimension");
+        std::vector<int64_t> target(full.size());
+        for (size_t k = 0; k < full.size(); k++) {
+            if (rep[k] != 1 && full[k] != 1) unsupported(n, "Tile repeats a dimension of size " + std::to_string(full[k]) + " (only size-1 dimensions, i.e. broadcasts, are mapped)");
+            if (k == 0 && !x.is_const && rep[k] != 1) unsupported(n, "Tile along the batch dimension");
+            target[k] = full[k] * rep[k];
+        }
+        const std::string sname = "tile:" + n.outputs[0] + "/shape";
+        Val sh = make_const_i({(int64_t)target.size()}, target);
+        vals_[sname] = sh;
+        lower_expand(synth_node("Expand", n.name, {n.inputs[0], sname}, n.outputs[0]));
+    }
+
+    // InstanceNormalization: per (sample, channel) over the spatial dimensions, (x - mean) / sqrt(var + eps) * scale + B
+    void lower_instance_norm(const OnnxNode &n) {
+        const Val &x = get(n, 0);
+        const Val *sc = opt(n, 1), *bi = opt(n, 2);
+        if (x.is_const || !sc || !bi || !sc->is_const || !bi->is_const) unsupported(n, "InstanceNormalization needs an activation input and constant scale / B");
+        const size_t r = x.dims.size();  // per-sample rank: [C, spatial...]
+        if (r < 2 || sc->numel() != x.dims[0] || bi->numel() != x.dims[0]) unsupported(n, "scale / B must have one entry per channel");
+        const std::string base = "inorm:" + n.outputs[0];
+        std::vector<int64_t> axes;
+        for (size_t k = 2; k <= r; k++) axes.push_back((int64_t)k);
+        Dims cdims(r, 1);
+        cdims[0] = x.dims[0];
+        auto mean_of = [&](const std::string &in, const std::string &out, const std::string &nm) {
+            OnnxNode m = synth_node("ReduceMean", nm, {in}, out);
+            set_ints(m, "axes", axes);
+            set_int(m, "keepdims", 1);
+            lower(m);
+        };
+        mean_of(n.inputs[0], base + "/mean", n.name + "/mean");
+        lower(synth_node("Sub", n.name + "/centred", {n.inputs[0], base + "/mean"}, base + "/d"));
+        lower(synth_node("Mul", n.name + "/sq", {base + "/d", base + "/d"}, base + "/sq"));
+        mean_of(base + "/sq", base + "/var", n.name + "/var");
+        lower(synth_node("Add", n.name + "/eps", {base + "/var", synth_const(base + "/epsc", {1}, {n.attr_f("epsilon", 1e-5f)})}, base + "/ve"));
+        lower(synth_node("Sqrt", n.name + "/std", {base + "/ve"}, base + "/std"));
+        lower(synth_node("Div", n.name + "/norm", {base + "/d", base + "/std"}, base + "/norm"));
+        lower(synth_node("Mul", n.name + "/scale", {base + "/norm", synth_const(base + "/scalec", cdims, sc->f)}, base + "/scaled"));
+        lower(synth_node("Add", n.name, {base + "/scaled", synth_const(base + "/biasc", cdims, bi->f)}, n.outputs[0]));
     }
 
     // Expand(x, shape): x * ones(broadcast shape) -- exact for every float including -0, infinities and NaN payloads

@@ -788,3 +788,27 @@ def test_stft_node_through_the_fft_kernel(bn, monkeypatch):
     assert " FFT " in text and " GEMM " not in text, text
     got, ref = run_both(bn, data)
     assert_close(got, ref, "STFT node as FFT", atol=4e-4, rtol=2e-4)
+
+
+@pytest.mark.gpu
+def test_prelu_tile_instance_norm(bn):
+    """More exporter spellings (first-contact readiness): PRelu with per-channel and with scalar slopes, Tile of
+    size-1 dimensions, InstanceNormalization -- each lowered to operators the planner already had, against the oracle
+    (whose versions of these three are one torch call each)."""
+    rng = np.random.default_rng(21)
+    c, h, w = 12, 10, 25
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(c * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, c, h, w)])
+        y = g.node("InstanceNormalization", [x, g.const(rng.uniform(0.5, 1.5, c).astype(np.float32)), g.const(rng.standard_normal(c).astype(np.float32))],
+                   epsilon=1e-3)
+        y = g.node("PRelu", [y, g.const(rng.uniform(0.05, 0.4, (c, 1, 1)).astype(np.float32))])
+        y = g.node("PRelu", [y, g.const(np.array([0.2], dtype=np.float32))])
+        m = g.node("ReduceMax", [y], axes=[3], keepdims=1)                     # [B, c, h, 1]
+        t = g.node("Tile", [m, i64(1, 1, 1, w)])                               # broadcast back along the width
+        return g.node("Sub", [y, t])
+
+    got, ref = run_both(bn, op_graph(build, [c, h, w]), scale=3.0)
+    assert_close(got, ref, "InstanceNormalization + PRelu + Tile")

@@ -377,3 +377,16 @@ def test_stft_node_plans_as_framing_convs(bn, tmp_path):
     gemms = [l for l in text.splitlines() if " GEMM " in l and "stft:STFT_1" in l]
     assert len(gemms) == 2 and all("fold=" in l for l in gemms), text
     assert f"K={n // 2}" in gemms[0], text
+
+
+def test_tile_of_a_real_dimension_is_refused(bn, tmp_path):
+    g = writer.GraphBuilder()
+    g.add_input("input", [None, 144000])
+    y = g.node("Tile", ["input", g.const(np.array([1, 2], dtype=np.int64))])
+    g.node("Identity", [y], outputs=["output"])
+    g.add_output("output", [None, 288000])
+    p = tmp_path / "m.onnx"
+    p.write_bytes(g.serialize())
+    with pytest.raises(bn.EngineError) as e:
+        bn.plan_describe(str(p))
+    assert "'Tile_1'" in str(e.value) and "only size-1 dimensions" in str(e.value)

@@ -153,3 +153,28 @@ def test_oracle_stft_and_expand_nodes_against_torch(n, hop, onesided):
     want = np.stack([dft.real, dft.imag], axis=1)
     want = want - want.mean(axis=1, keepdims=True)
     assert np.abs(got[b, f] - want).max() < 1e-9
+
+
+def test_oracle_prelu_tile_instance_norm_by_hand():
+    """The three one-call oracle operators against explicit numpy formulas (fp64)."""
+    writer = importlib.import_module("rust-birdnet-onnx_amd.onnx_writer")
+    rng = np.random.default_rng(3)
+    c, h, w = 5, 4, 6
+    x = rng.standard_normal((2, c * h * w))
+    sc, bi, sl = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.standard_normal(c).astype(np.float32), rng.uniform(0.1, 0.5, (c, 1, 1)).astype(np.float32)
+    g = writer.GraphBuilder()
+    g.add_input("input", [None, c * h * w])
+    t = g.node("Reshape", ["input", g.const(np.array([-1, c, h, w], dtype=np.int64))])
+    y = g.node("InstanceNormalization", [t, g.const(sc), g.const(bi)], epsilon=1e-3)
+    y = g.node("PRelu", [y, g.const(sl)])
+    m = g.node("ReduceMax", [y], axes=[3], keepdims=1)
+    r = g.node("Tile", [m, g.const(np.array([1, 1, 1, w], dtype=np.int64))])
+    g.node("Sub", [y, r], outputs=["output"])
+    g.add_output("output", [None, c, h, w])
+    got = onnx_ref.run_model(g.serialize(), x, dtype=torch.float64)["output"]
+    v = x.reshape(2, c, h, w)
+    mu, var = v.mean(axis=(2, 3), keepdims=True), v.var(axis=(2, 3), keepdims=True)
+    n = (v - mu) / np.sqrt(var + np.float64(np.float32(1e-3))) * sc.astype(np.float64)[None, :, None, None] + bi.astype(np.float64)[None, :, None, None]
+    p = np.maximum(n, 0) + sl.astype(np.float64)[None] * np.minimum(n, 0)
+    want = p - np.repeat(p.max(axis=3, keepdims=True), w, axis=3)
+    assert np.abs(got - want).max() < 1e-9
