@@ -115,3 +115,89 @@ fn last_error() -> String {
     unsafe { bn_last_error(buf.as_mut_ptr() as *mut _, buf.len()) };
     String::from_utf8_lossy(&buf).trim_end_matches('\0').to_string()
 }
+
+// ---- the rest of the Classifier surface on the same ABI (source only, mirrors csrc/host_classifier.cpp) ----------------
+
+/// `ClassifierBuilder::build` (reference src/classifier.rs:334-383): same validation order and error variants; the ORT
+/// session becomes a `bn_model`, the model type / shapes come from `bn_model_get_config` (same rules as detection.rs).
+impl crate::ClassifierBuilder {
+    pub fn build_hip(self, device: i32) -> Result<crate::Classifier> {
+        let model_path = self.model_path.ok_or(Error::ModelPathRequired)?;
+        if self.labels.is_none() && self.labels_path.is_none() {
+            return Err(Error::LabelsRequired);
+        }
+        let cpath = std::ffi::CString::new(model_path.as_str()).map_err(|e| Error::ModelLoad(e.to_string()))?;
+        let mut model: *mut bn_model = std::ptr::null_mut();
+        let override_ = self.model_type.map_or(-1, |t| t as i32);
+        match unsafe { bn_model_load(cpath.as_ptr(), device, override_, &mut model) } {
+            BN_OK => {}
+            BN_ERR_MODEL_DETECTION => return Err(Error::ModelDetection { reason: last_error() }),
+            _ => return Err(Error::ModelLoad(last_error())),
+        }
+        let mut cfg = bn_model_config::default();
+        unsafe { bn_model_get_config(model, &mut cfg) };
+        let config = crate::ModelConfig::from_native(&cfg); // model_type, sample_rate, segment_duration, sample_count, num_species, embedding_dim
+        let labels = match self.labels {
+            Some(v) => v,
+            None => crate::labels::load_labels_from_file(self.labels_path.as_ref().unwrap(), config.model_type)?,
+        };
+        if labels.len() != config.num_species {
+            unsafe { bn_model_free(model) };
+            return Err(Error::LabelCount { expected: config.num_species, got: labels.len() });
+        }
+        // the default context the reference keeps behind its `Mutex<Session>` (classifier.rs:435)
+        let mut ctx: *mut bn_ctx = std::ptr::null_mut();
+        if unsafe { bn_ctx_create(model, 1, 0, &mut ctx) } != BN_OK {
+            unsafe { bn_model_free(model) };
+            return Err(Error::ModelLoad(last_error()));
+        }
+        Ok(crate::Classifier::from_native(model, ctx, config, labels, self.top_k, self.min_confidence))
+    }
+}
+
+impl crate::Classifier {
+    /// `predict` (classifier.rs:610-643): one segment; the size check stays in Rust, the default context grows on demand.
+    pub fn predict_with_options(&self, segment: &[f32], options: &InferenceOptions) -> Result<PredictionResult> {
+        if segment.len() != self.inner.config.sample_count {
+            return Err(Error::InputSize { expected: self.inner.config.sample_count, got: segment.len() });
+        }
+        let mut guard = self.inner.default_context.lock().map_err(|_| Error::Inference("context lock poisoned".into()))?;
+        guard.ensure_capacity(self, 1)?; // re-creates the bn_ctx when max_batch is too small
+        let mut out = self.predict_batch_with_context(&mut guard, &[segment], options)?;
+        Ok(out.remove(0))
+    }
+
+    /// `predict_batch` (classifier.rs:676-727): empty input -> empty output before anything else, per-segment size errors
+    /// carry the index (`BatchInputSize`), then one pass through the default context.
+    pub fn predict_batch_with_options(&self, segments: &[&[f32]], options: &InferenceOptions) -> Result<Vec<PredictionResult>> {
+        if segments.is_empty() {
+            return Ok(Vec::new());
+        }
+        let mut guard = self.inner.default_context.lock().map_err(|_| Error::Inference("context lock poisoned".into()))?;
+        guard.ensure_capacity(self, segments.len())?;
+        self.predict_batch_with_context(&mut guard, segments, options)
+    }
+
+    /// `create_batch_context` (classifier.rs:777-792, batch_context.rs:70-133): the reference refuses Perch v2 here and so
+    /// does this shim; `create_native_batch_context` lifts the refusal (the native context runs Perch).
+    pub fn create_batch_context(&self, max_batch_size: usize) -> Result<BatchInferenceContext> {
+        if self.inner.config.model_type == crate::ModelType::PerchV2 {
+            return Err(Error::Inference("BatchInferenceContext is not supported for PerchV2 models".into()));
+        }
+        self.create_native_batch_context(max_batch_size)
+    }
+
+    pub fn create_native_batch_context(&self, max_batch_size: usize) -> Result<BatchInferenceContext> {
+        let mut ctx: *mut bn_ctx = std::ptr::null_mut();
+        match unsafe { bn_ctx_create(self.inner.model, max_batch_size, 0, &mut ctx) } {
+            BN_OK => Ok(BatchInferenceContext::from_native(ctx, max_batch_size, self.inner.config.sample_count)),
+            _ => Err(Error::Inference(last_error())),
+        }
+    }
+}
+
+impl Drop for BatchInferenceContext {
+    fn drop(&mut self) {
+        unsafe { bn_ctx_destroy(self.ctx) } // the model is reference-counted on the native side: order does not matter
+    }
+}
