@@ -47,6 +47,10 @@ int main(int argc, char **argv) {
         {"head 320->1024 relu", 48, 320, 1024, 0, 0, 1, 0, 0},
         {"fc 1024->6522", 1, 1024, 6522, 0, 0, 0, 0, 0},
     };
+    if (getenv("SHAPE")) {  // SHAPE="rows K N gate res act": one custom shape instead of the model's list
+        long long r_; int k_, n_, g_, rs_, a_;
+        if (sscanf(getenv("SHAPE"), "%lld %d %d %d %d %d", &r_, &k_, &n_, &g_, &rs_, &a_) == 6) shapes = {{"custom", r_, k_, n_, 0, 0, a_, g_, rs_}};
+    }
     hipStream_t st;
     hipStreamCreate(&st);
     hipEvent_t e0, e1;
