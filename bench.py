@@ -97,11 +97,6 @@ def main():
     S, SR, SEC, make_model, model_name, seg_name = MODELS[args.model]
     B = args.batch
     model_bytes = make_model()  # full-size hypothesised topology, seeded synthetic weights
-    # synthetic inputs: this rank's contiguous shard of NBUF global batches (global segment index =
-    # (buffer * world + rank) * B + i), generated on the host BEFORE anything touches the GPU -- a second of numpy
-    # work between context creation and the first step would leave the device idle long enough to drop its clocks
-    NBUF = 4
-    host_bufs = [synth.synthetic_segments(B, S, SR, first_index=(b * world + rank) * B) for b in range(NBUF)]
     with tempfile.NamedTemporaryFile(suffix=".onnx", delete=False) as f:
         f.write(model_bytes)
         path = f.name
@@ -110,8 +105,17 @@ def main():
     cfg = model.config
     N = cfg.num_species
     ctxs = [bn.Context(model, B) for _ in range(max(1, args.streams))]
-    # ... and resident in HBM before the timed region
-    bufs = [torch.from_numpy(x).cuda() for x in host_bufs]
+
+    # synthetic inputs, resident in HBM before the timed region: this rank's contiguous shard of
+    # NBUF global batches (global segment index = (buffer * world + rank) * B + i).  The host copies are NOT kept:
+    # with 4 x 18 MB of source arrays still alive the N > 1 path (staging copies + all-gather) ran a quarter slower
+    # (single-rank RCCL rehearsal 36 k vs 48 k segments/s, same timed loop) -- the host leg below re-reads them.
+    NBUF = 4
+    bufs = []
+    for b in range(NBUF):
+        x = synth.synthetic_segments(B, S, SR, first_index=(b * world + rank) * B)
+        bufs.append(torch.from_numpy(x).cuda())
+        del x
     torch.cuda.synchronize()
 
     gathered = None
@@ -228,7 +232,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_host_leg:
         from collections import deque
 
-        hbufs = host_bufs
+        hbufs = [b_.cpu().numpy() for b_ in bufs]
         hsteps = max(args.steps, args.host_steps)
         # this leg has its own warm-up: the host side (staging pool, pinned slots, page placement of the source
         # arrays) needs ~80 steps to settle on the pool's boxes (tools/host_path_trace.py: submit 0.8 ms -> 0.3 ms)
