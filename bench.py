@@ -307,7 +307,10 @@ def main():
         rows = [(n_, us / 5.0, m_, by_) for n_, us, m_, by_ in rows]
         # classify launches by the kernel that executes them (plan_describe gives the op kind per launch)
         desc = bn.plan_describe(path_for_describe(model_bytes))
-        kind_of = [l.split()[1] for l in desc.splitlines() if l[:3].strip().isdigit()]
+        plan_lines = [l for l in desc.splitlines() if l[:3].strip().isdigit()]
+        kind_of = [l.split()[1] for l in plan_lines]
+        gemm_kernel_of = [("frame_fold_kernel" if " kernel=frame_fold" in l else "gemm_splitk_kernel" if " kernel=splitk" in l else "gemm_mfma_kernel")
+                          if l.split()[1] == "GEMM" else None for l in plan_lines]
         fam_name = {"GEMM": "gemm_mfma_kernel", "DWCONV": "dwconv_kernel", "CONV": "conv_direct_kernel", "MBCONV": "mbconv_row_kernel",
                     "REDUCE": "reduce_kernel", "ELT": "elt_kernel", "GAP": "gap_partial_kernel", "SEFC": "se_fc_kernel", "POOL": "pool_kernel", "FFT": "stft_kernel"}
         fam = {}
@@ -367,6 +370,17 @@ def main():
             tops.append({"launch": name, "kind": k, "us": round(us, 1), "TFLOPs": round(tfl, 1), "GBs": round(gb, 1),
                          "frac_mfma_f32": round(tfl / MFMA_F32_PEAK_TF, 3), "frac_hbm": round(gb / HBM_PEAK_GBS, 3)})
         out["roofline_top_launches"] = tops
+        # the GEMM family by the kernel function that runs each launch (the names rocprofv3 reports)
+        gk = {}
+        for (name, us, macs, byts), kn in zip(rows, gemm_kernel_of):
+            if kn is None:
+                continue
+            e_ = gk.setdefault(kn, {"us": 0.0, "macs": 0.0, "launches": 0})
+            e_["us"] += us
+            e_["macs"] += macs
+            e_["launches"] += 1
+        out["gemm_family_by_kernel"] = {k: {"us_per_step": round(v["us"], 1), "launches": v["launches"], "TFLOPs": round(2 * v["macs"] / (v["us"] * 1e-6) / 1e12, 2),
+                                            "frac_mfma_f32": round(2 * v["macs"] / (v["us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 3)} for k, v in gk.items()}
         out["kernel_families"] = {k: {"us_per_step": round(v["us"], 1), "launches": v["launches"],
                                       "TFLOPs": round(2 * v["macs"] / (v["us"] * 1e-6) / 1e12, 2),
                                       "GBs": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1)} for k, v in fam.items()}

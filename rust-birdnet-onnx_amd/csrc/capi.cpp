@@ -1493,6 +1493,9 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 snprintf(line, sizeof(line), " rows=%lld K=%d N=%d lda=%lld act=%d bias=%d res=%d gate=%d", (long long)op.gemm.rows, op.gemm.K, op.gemm.N, (long long)op.gemm.lda, op.gemm.act, op.gemm.has_bias, op.gemm.has_res, op.gemm.has_scale);
                 extra = line;
                 if (op.gemm.fold) { snprintf(line, sizeof(line), " fold=%d/%d", op.gemm.fold, op.gemm.fold_n); extra += line; }
+                // which of the three matrix kernels the launcher picks (the LDS-resident framing kernel may still fall back to
+                // the generic one at launch: BN_FRAMELDS=0 or a span that does not fit)
+                extra += op.gemm.fold ? " kernel=frame_fold" : (!(op.gemm.npost || op.gemm.out_strided) && gemm_use_splitk(op.gemm) ? " kernel=splitk" : " kernel=tiled");
                 if (op.gemm.npost || op.gemm.out_strided) {
                     snprintf(line, sizeof(line), " post=%d out_rs=%lld out_cs=%lld", op.gemm.npost, (long long)op.gemm.out_rs, (long long)op.gemm.out_cs);
                     extra += line;
