@@ -178,7 +178,16 @@ __device__ __forceinline__ void bin_small(int bin, float b, float (&v)[N]) {
     if (bin == BIN_ADD) map_array<N>(v, [=](float a) { return a + b; });
     else if (bin == BIN_SUB) map_array<N>(v, [=](float a) { return a - b; });
     else if (bin == BIN_MUL) map_array<N>(v, [=](float a) { return a * b; });
-    else if (bin == BIN_DIV) map_array<N>(v, [=](float a) { return a / b; });
+    else if (bin == BIN_DIV) {
+        // one divisor for the whole array: 1 / b once, then q = a r corrected by one residual step, which is what the
+        // hardware's division sequence computes minus its scaling for denormal / overflowing quotients (3 instructions per
+        // element instead of ~10; the absorbed chain divides the whole segment by max - min)
+        const float r = 1.0f / b;
+        map_array<N>(v, [=](float a) {
+            const float q = a * r;
+            return fmaf(fmaf(-q, b, a), r, q);
+        });
+    }
     else if (bin == BIN_MAX) map_array<N>(v, [=](float a) { return fmaxf(a, b); });
     else if (bin == BIN_MIN) map_array<N>(v, [=](float a) { return fminf(a, b); });
 }
@@ -428,52 +437,37 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
         }
         __syncthreads();  // every wave is done with the span; the tile's spectrum rows are complete
         if (nmel && !(dbg & 4)) {
-            // Mel filter bank over the whole tile: four threads share a band (entries e0 + j, e0 + j + 4, ...); a
-            // thread keeps its entries in registers and walks the tile's frames -- independent LDS reads, no
-            // dependent chain per entry -- then the partial sums of the four are added in a fixed order and the
-            // compression chain runs ONCE per stage over the thread's 16 frame values.  Results go straight to the
-            // target view (frames are its contiguous direction; the L2 merges the partial lines).
-            constexpr int MAXE = 6, TPB = 16;
+            // Mel filter bank over the whole tile: one work item per (band, frame), frames fastest -- the 16 lanes of a band
+            // read the same (column, weight) entry (an LDS broadcast) and 16 different spectrum rows (row stride nout is
+            // odd: conflict-free), sum the band's entries in index order, run the compression chain on the one value and
+            // store it; the 16 frames of a band are neighbours in the target view.  (The first version gave four threads a
+            // band and 16 frames each: 650 instructions per thread, a quarter of the lanes idle, as long as the transform.)
+            constexpr int TPB = 16;
             float *ob = p.out + b * d.c_bs;
-            for (int m0 = 0; m0 < nmel; m0 += NW * 16) {
-                const int m = m0 + (tid >> 2), jj = tid & 3;
-                const bool live = m < nmel;
-                const int e0 = live ? (int)mstart[m] + jj : 0, e1 = live ? (int)mstart[m + 1] : 0;
-                float2 ent[MAXE];
-#pragma unroll
-                for (int q = 0; q < MAXE; q++) ent[q] = e0 + 4 * q < e1 ? ment[e0 + 4 * q] : make_float2(0.0f, 0.0f);
-                float acc[TPB];
-#pragma unroll
-                for (int t = 0; t < TPB; t++) {
-                    const float *sp = spec + (t < rows_here ? t : 0) * nout;
-                    float a = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < MAXE; q++) a = fmaf(sp[(int)ent[q].x], ent[q].y, a);
-                    for (int e = e0 + 4 * MAXE; e < e1; e += 4) {  // bands wider than 4 * MAXE bins
-                        const float2 cv = ment[e];
-                        a = fmaf(sp[(int)cv.x], cv.y, a);
-                    }
-                    acc[t] = a;
+            for (int i0 = 0; i0 < nmel * TPB; i0 += NW * 64) {
+                const int i = i0 + tid;
+                const int m = i >> 4, t = i & (TPB - 1);
+                const bool live = m < nmel && t < rows_here;
+                const int e0 = live ? (int)mstart[m] : 0, e1 = live ? (int)mstart[m + 1] : 0;
+                const float *sp = spec + (live ? t : 0) * nout;
+                float a0 = 0.0f, a1 = 0.0f;
+                int e = e0;
+                for (; e + 1 < e1; e += 2) {  // two entries in flight; combined in a fixed order below
+                    const float2 c0 = ment[e], c1 = ment[e + 1];
+                    a0 = fmaf(sp[(int)c0.x], c0.y, a0);
+                    a1 = fmaf(sp[(int)c1.x], c1.y, a1);
                 }
-                const float mb = (live && d.mel_has_bias) ? p.mel_bias[m] : 0.0f;
-#pragma unroll
-                for (int t = 0; t < TPB; t++) {
-                    const float a1 = __shfl_xor(acc[t], 1);
-                    const float pair = (lane & 1) ? a1 + acc[t] : acc[t] + a1;  // lower lane's value first: the same sum in both
-                    const float a2 = __shfl_xor(pair, 2);
-                    acc[t] = ((lane & 2) ? a2 + pair : pair + a2) + mb;
+                if (e < e1) {
+                    const float2 c0 = ment[e];
+                    a0 = fmaf(sp[(int)c0.x], c0.y, a0);
                 }
-                act_small<TPB>(d.mel_act, d.mel_p0, d.mel_p1, acc);
-                if (0 < npost) act_small<TPB>(po_a0, po_p00, po_p10, acc);
-                if (1 < npost) act_small<TPB>(po_a1, po_p01, po_p11, acc);
-                if (2 < npost) act_small<TPB>(po_a2, po_p02, po_p12, acc);
-                if (3 < npost) act_small<TPB>(po_a3, po_p03, po_p13, acc);
-                if (jj == 0 && live) {
-                    float *om = ob + (int64_t)t0 * d.out_rs + (int64_t)m * d.out_cs;
-#pragma unroll
-                    for (int t = 0; t < TPB; t++)
-                        if (t < rows_here) om[(int64_t)t * d.out_rs] = acc[t];
-                }
+                float acc[1] = {(a0 + a1) + ((live && d.mel_has_bias) ? p.mel_bias[m] : 0.0f)};
+                act_small<1>(d.mel_act, d.mel_p0, d.mel_p1, acc);
+                if (0 < npost) act_small<1>(po_a0, po_p00, po_p10, acc);
+                if (1 < npost) act_small<1>(po_a1, po_p01, po_p11, acc);
+                if (2 < npost) act_small<1>(po_a2, po_p02, po_p12, acc);
+                if (3 < npost) act_small<1>(po_a3, po_p03, po_p13, acc);
+                if (live) ob[(int64_t)(t0 + t) * d.out_rs + (int64_t)m * d.out_cs] = acc[0];
             }
         }
         if (next < total_tiles) BN_WRITE_SPAN(next);
@@ -484,6 +478,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
 #undef BN_ISSUE_SPAN
 #undef BN_WRITE_SPAN
 }
+
 
 }  // namespace
 
