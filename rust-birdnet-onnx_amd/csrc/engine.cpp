@@ -802,11 +802,23 @@ class Builder {
         return (k % r) * (n / r) + dif_position(k / r, n / r, radix, idx + 1);
     }
     bool emit_stft(const OnnxNode &n, const PlanOp &base, const DftBank &bank, int64_t Cout, int64_t OW, bool has_bias) {
-        // Opt-in for now (BN_STFT=1): correct for every supported size, but at batch 32 the launch pair of the v2.4 front
-        // end takes 189 us against 178 us for the folded GEMMs + mel GEMMs + normalisation pass it replaces, and 41.9 k
-        // against 44.5 k segments/s with four contexts (latency-bound at two waves per SIMD).
+        // Which banks run as FFTs.  The alternative is the pruned + folded matrix product on the exact-f32 MFMA path, whose
+        // cost follows the number of LIVE bins: Cout * L/2 multiply-adds at 32 per SIMD-cycle, against roughly
+        // 0.18 * L * log2 L cycles of vector butterflies, address arithmetic and LDS traffic for the FFT plus its untangle
+        // and mel phases (both calibrated on the v2.4 banks, DESIGN.md section 4.11: L = 2048 with 127 live bins -- matrix
+        // product 69 us, FFT 76-93 us; L = 1024 with 309 live bins -- 85 us vs 62-75 us).  Default ("auto"): FFT when the
+        // matrix product is estimated at more than 1.5x the FFT.  BN_STFT=1: every recognised bank; BN_STFT=0: none;
+        // BN_STFT_MINBINS=<n> additionally keeps banks with fewer live bins on the matrix path.
         const char *env = getenv("BN_STFT");
-        if (!env || std::string(env) != "1") return false;
+        const std::string mode = env ? env : "auto";
+        if (mode == "0") return false;
+        if (getenv("BN_STFT_MINBINS") && Cout < atoll(getenv("BN_STFT_MINBINS"))) return false;
+        if (mode != "1") {
+            double lg = 0;
+            while ((1 << (int)lg) < bank.L) lg += 1;
+            const double gemm_cycles = (double)Cout * (double)(bank.L / 2) / 32.0, fft_cycles = 0.18 * (double)bank.L * lg;
+            if (!(gemm_cycles > 1.5 * fft_cycles)) return false;
+        }
         const GemmDesc &g = base.gemm;
         if (g.act != ACT_NONE || g.has_res || g.has_scale || g.lda <= 0 || g.lda > 4096 || g.ldc != Cout) return false;
         const int L = (int)bank.L, M = L / 2;

@@ -125,10 +125,17 @@ def test_fft_front_end_whole_models(bn, v24_full, v30_small, monkeypatch):
     x3 = synth.synthetic_segments(3, 160000, 32000)
     out3 = onnx_ref.run_model(data3, x3)
     check_results(clf3.predict_batch(list(x3)), out3["output_1"], out3["output_0"], 5, None)
-    monkeypatch.delenv("BN_STFT")
-    dflt = bn.Classifier.builder().model_path(path).labels(labels(6522)).with_rocm().build().predict_batch(list(x))
-    for a, b in zip(res, dflt):
-        assert [p.index for p in a.predictions] == [p.index for p in b.predictions]
+    # the all-matrix plan and the default (per-bank choice: v2.4 runs its 309-bin bank as an FFT, the 127-bin one folded)
+    for mode, nfft in (("0", 0), (None, 1)):
+        if mode is None:
+            monkeypatch.delenv("BN_STFT")
+        else:
+            monkeypatch.setenv("BN_STFT", mode)
+        assert bn.plan_describe(path).count(" FFT ") == nfft
+        other = bn.Classifier.builder().model_path(path).labels(labels(6522)).with_rocm().build().predict_batch(list(x))
+        check_results(other, ref, None, 10, None)
+        for a, b in zip(res, other):
+            assert [p.index for p in a.predictions] == [p.index for p in b.predictions]
 
 
 def test_v30_embeddings_and_logits(bn, v30_small):

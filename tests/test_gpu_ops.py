@@ -143,7 +143,7 @@ def test_conv1d_folded_dft_framing(bn, n_fft, hop, kind, bias, monkeypatch):
         assert_close(fft_out, ref, f"stft n_fft={n_fft} {kind}", atol=2e-5 * float(np.abs(ref).max()), rtol=0)
         fft3, ref3 = run_both(bn, data, batch=3)  # 511 frames: the last block is ragged either way; odd batch
         assert_close(fft3, ref3, f"stft n_fft={n_fft} {kind} batch 3", atol=2e-5 * float(np.abs(ref3).max()), rtol=0)
-    monkeypatch.delenv("BN_STFT")
+    monkeypatch.setenv("BN_STFT", "0")   # the matrix-product path (the default picks per bank by estimated cost)
     text = bn.plan_describe(write_model(data))
     assert "~sym" in text or "~anti" in text, text
     assert text.count("~") == (1 if kind == "real" else 2), text
@@ -713,7 +713,7 @@ def _hann(n, periodic=True):
     (256, 64, None, 1, False),          # no window input: rectangular, frame_length given
     (128, 32, "hann", 0, True),         # two-sided
 ])
-def test_stft_node_opset17(bn, nfft, hop, window, onesided, rank3):
+def test_stft_node_opset17(bn, nfft, hop, window, onesided, rank3, monkeypatch):
     """An opset-17 STFT node (what torch.onnx writes for torch.stft) is mapped to the framing kernels: magnitude and the
     raw [frames, bins, 2] tensor against the oracle, which evaluates the node with an FFT of the windowed frames."""
     L = 48000
@@ -738,10 +738,17 @@ def test_stft_node_opset17(bn, nfft, hop, window, onesided, rank3):
         return g.node("Concat", [s, mag], axis=3)                      # raw spectrum and magnitude side by side
 
     data = op_graph(build, [frames, bins, 3])
+    # default plan: the planner picks FFT or matrix product per bank by estimated cost (every case here with a window
+    # the FFT recognition accepts has enough bins for the FFT)
     got, ref = run_both(bn, data)
     # a bin is a sum of nfft products of O(1) terms: absolute error grows like sqrt(nfft) * 2^-24 * |frame|
     assert_close(got, ref, f"STFT n={nfft} hop={hop} window={window}", atol=2e-4 * np.sqrt(nfft / 256), rtol=2e-4)
+    # the matrix-product path on its own
+    monkeypatch.setenv("BN_STFT", "0")
+    got, ref = run_both(bn, data)
+    assert_close(got, ref, f"STFT as framing GEMMs n={nfft} hop={hop} window={window}", atol=2e-4 * np.sqrt(nfft / 256), rtol=2e-4)
     text = bn.plan_describe(write_model(data))
+    assert " FFT " not in text
     assert ("fold=" in text) == (window == "hann"), text  # periodic Hann rows fold to half their taps, the others do not
 
 

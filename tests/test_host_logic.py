@@ -109,8 +109,16 @@ def test_plan_of_v24_model(bn, tmp_path, monkeypatch):
     tot = full.splitlines()[[i for i, l in enumerate(full.splitlines()) if l.startswith("TOTAL")][0]]
     fft_flops, dft_macs = float(tot.split("fft_flops=")[1].split()[0]), float(tot.split("dft_gemm_macs=")[1].split()[0])
     assert 3e7 < fft_flops < 6e7 and dft_macs > 5 * fft_flops  # ~42 MFLOP as FFTs vs the matrix-product count
-    # the default plan: folded GEMMs (the FFT launches are opt-in until they beat them)
+    # the default plan picks per bank by estimated cost: the L = 2048 bank keeps few live bins and stays a
+    # folded matrix product, the L = 1024 bank with its ~300 live bins runs as an FFT with its mel bank absorbed; the
+    # normalisation pass stays a launch of its own because the matrix branch still reads its output
     monkeypatch.delenv("BN_STFT")
+    auto = bn.plan_describe(str(p))
+    afft = [l for l in auto.splitlines() if " FFT " in l]
+    assert len(afft) == 1 and " L=1024 hop=280 " in afft[0] and "mel=96" in afft[0] and "pre=0" in afft[0], afft
+    assert sum("~sym" in l and " K=1024 " in l for l in auto.splitlines()) == 1, auto
+    # BN_STFT=0: both banks as folded GEMMs
+    monkeypatch.setenv("BN_STFT", "0")
     text = bn.plan_describe(str(p))
     lines = text.splitlines()
     kinds = [l.split()[1] for l in lines if l[:3].strip().isdigit()]
@@ -360,7 +368,7 @@ def test_unmapped_exporter_nodes_are_refused_by_name(bn, tmp_path, op, kwargs, e
     assert f"'{op}_1'" in msg and f"({op})" in msg and needle in msg, msg
 
 
-def test_stft_node_plans_as_framing_convs(bn, tmp_path):
+def test_stft_node_plans_as_framing_convs(bn, tmp_path, monkeypatch):
     """An opset-17 STFT node with a periodic Hann window becomes one cos block and one sin block of folded framing GEMMs
     (and, under BN_STFT=1, one FFT launch); its [frames, bins, 2] result is a view, not a copy."""
     n, hop = 512, 128
@@ -373,10 +381,15 @@ def test_stft_node_plans_as_framing_convs(bn, tmp_path):
     g.add_output("output", [None, frames, n // 2 + 1, 2])
     p = tmp_path / "m.onnx"
     p.write_bytes(g.serialize())
+    monkeypatch.setenv("BN_STFT", "0")
     text = bn.plan_describe(str(p))
     gemms = [l for l in text.splitlines() if " GEMM " in l and "stft:STFT_1" in l]
     assert len(gemms) == 2 and all("fold=" in l for l in gemms), text
     assert f"K={n // 2}" in gemms[0], text
+    # default: 257 complex bins of a 512-point transform -- the FFT is estimated far cheaper and takes the node
+    monkeypatch.delenv("BN_STFT")
+    text = bn.plan_describe(str(p))
+    assert text.count(" FFT ") == 1 and " GEMM " not in text, text
 
 
 def test_tile_of_a_real_dimension_is_refused(bn, tmp_path):
