@@ -585,7 +585,7 @@ class Builder {
     // spectrum, window and amplitudes by alternating least squares over all rows, and the model is accepted only if
     // every tap of every row agrees with it within f32 rounding of the taps (BN_STFT_TOL x max|row|, default 4e-7).
     // Then ONE launch of stft_kernel (kernels.h, FftDesc) computes all rows -- cos and sin blocks together -- instead
-    // of one folded GEMM per symmetry run.  L must be a power of two in 128..2048.  BN_STFT=1 enables (see emit_stft).
+    // of one folded GEMM per symmetry run.  L must be a power of two in 128..2048.  Whether a recognised bank runs as an FFT: emit_stft.
     struct DftBank {
         int64_t L = 0;
         std::vector<float> window;
