@@ -196,6 +196,8 @@ struct bn_ctx {
         bool operator<(const GraphKey &o) const { return batch != o.batch ? batch < o.batch : in < o.in; }
     };
     std::map<GraphKey, hipGraphExec_t> graphs;
+    std::map<GraphKey, uint64_t> graph_used;  // replay counter value at each graph's last launch (least recently used goes first)
+    uint64_t graph_tick = 0;
 };
 
 namespace {
@@ -326,15 +328,28 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
                 (void)hipGetLastError();
                 use_graph = false;
             } else {
-                if (c->graphs.size() >= 16) {  // bounded cache; nothing of this context may still be replaying one of them
+                if (c->graphs.size() >= 16) {
+                    // bounded cache: the least recently replayed graph goes (a caller cycling through up to 16 input
+                    // buffers or batch sizes never re-captures; the whole cache used to be dropped at once); nothing of
+                    // this context may still be replaying it
+                    auto victim = c->graph_used.begin();
+                    for (auto u = c->graph_used.begin(); u != c->graph_used.end(); ++u)
+                        if (u->second < victim->second) victim = u;
                     (void)hipStreamSynchronize(c->stream);
-                    for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
-                    c->graphs.clear();
+                    auto g_old = c->graphs.find(victim->first);
+                    if (g_old != c->graphs.end()) {
+                        (void)hipGraphExecDestroy(g_old->second);
+                        c->graphs.erase(g_old);
+                    }
+                    c->graph_used.erase(victim);
                 }
                 it = c->graphs.emplace(key, ge).first;
             }
         }
-        if (use_graph) HIP_TRY(hipGraphLaunch(it->second, c->stream));
+        if (use_graph) {
+            c->graph_used[it->first] = ++c->graph_tick;
+            HIP_TRY(hipGraphLaunch(it->second, c->stream));
+        }
     }
     if (!use_graph) {
         (void)hipGetLastError();  // drop stale sticky errors of unrelated earlier calls

@@ -184,3 +184,21 @@ def test_misaligned_device_input_is_refused_not_fatal(bn):
         assert "16-byte aligned" in bn.last_error()
         assert bn.lib.bn_step_device(ctx._h, C.c_void_p(buf.data_ptr() + 4 * off), 2, 3, 0, C.c_float(0), 1) == 1
     assert bn.lib.bn_infer_device(ctx._h, C.c_void_p(buf.data_ptr() + 16), 2, 1) == 0
+
+
+def test_many_input_buffers_through_one_context(bn, small):
+    """The per-context hipGraph cache is keyed by (batch, input pointer) and bounded at 16 graphs with least-recently-used
+    eviction: a caller cycling through more device buffers and batch sizes than that keeps getting the right answer (and the
+    buffers it comes back to first are still cached)."""
+    import torch
+    data, path = small
+    m = bn.Model(path)
+    ctx = bn.Context(m, 4)
+    xs = [synth.synthetic_segments(4, 160000, 32000, first_index=10 * i) for i in range(6)]
+    want = [ctx.infer(x)[0] for x in xs]
+    bufs = [torch.from_numpy(xs[i % 6]).cuda() for i in range(22)]
+    for rnd in range(2):
+        for i, d in enumerate(bufs):
+            n = 4 if (i + rnd) % 3 else 3           # two batch sizes per buffer over the rounds: > 16 distinct keys
+            ctx.infer_device(d.data_ptr(), n, sync=True)
+            assert ctx.read_output(1, n).tobytes() == want[i % 6][:n].tobytes(), (rnd, i)
