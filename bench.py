@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--host-steps", type=int, default=120, help="minimum number of steps of the host-to-host leg")
     ap.add_argument("--host-warmup", type=int, default=96, help="minimum number of warm-up steps of the host-to-host leg")
     ap.add_argument("--cpu-sample", type=int, default=512, help="segments the CPU oracle is timed on (about 15-30 s of host work)")
+    ap.add_argument("--no-extras", action="store_true", help="skip latency_b1 (configs[0]) and the v3.0 b64 / Perch b128 lines (configs[2], [3])")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="HIP device ordinal (default: LOCAL_RANK)")
@@ -177,11 +178,21 @@ def main():
                 parts = [torch.empty((B, N), dtype=torch.float32) for _ in range(world)]
                 dist.all_gather(parts, logit_views[j % S_].cpu())
 
-    def step(i):
+    # one HIP event per step, recorded on the step's own stream right behind its last kernel (the result store):
+    # consecutive events give the completion-to-completion interval of the steps on the device clock (SURVEY 8(d):
+    # median and p10 / p90 over the timed steps, next to the wall-clock mean that `value` is)
+    ev_streams = [torch.cuda.ExternalStream(c.stream()) for c in ctxs]
+    step_events = []
+
+    def step(i, record=False):
         # contexts are used round-robin; a context's previous results are consumed just before it is reused
         if i >= S_:
             finish(i - S_)
         ctxs[i % S_].step_device(bufs[i % NBUF].data_ptr(), B, args.top_k, 0.1, sync=False)
+        if record:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(ev_streams[i % S_])
+            step_events.append(ev)
 
     def drain(total):
         for j in range(max(0, total - S_), total):
@@ -200,10 +211,17 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, record=True)
     drain(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    # completion intervals: steps complete in issue order per stream but not across streams, so sort the completion
+    # times (each measured from the first step's event) and difference them
+    done_ms = sorted(step_events[0].elapsed_time(e) for e in step_events)
+    gaps = np.diff(np.array(done_ms)) if len(done_ms) > 1 else np.array([dt * 1e3])
+    step_stats = {"median_ms": round(float(np.median(gaps)), 4), "p10_ms": round(float(np.percentile(gaps, 10)), 4),
+                  "p90_ms": round(float(np.percentile(gaps, 90)), 4), "n": int(len(gaps)),
+                  "what": "interval between consecutive step completions (one HIP event per step on the step's stream), all contexts"}
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -279,6 +297,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "median_ms": step_stats["median_ms"],
+        "p10_ms": step_stats["p10_ms"],
+        "p90_ms": step_stats["p90_ms"],
+        "step_interval_stats": step_stats,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -297,7 +319,72 @@ def main():
 
     if host_to_host is not None:
         out["host_to_host"] = host_to_host
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- BASELINE configs[0]: ONE 3 s segment through predict's path, host slice in -> logits + top-K on the host
+        # (bn_infer_submit + collect on a batch-1 context, what Classifier::predict costs a caller, classifier.rs:610-643),
+        # and the same segment device-resident (bn_step_device, batch 1); median of 60 calls after 10 warm-up calls
+        c1 = bn.Context(model, 1)
+        x1 = bufs[0][:1].cpu().numpy()
+
+        def med_ms(fn, reps=60, warm=10):
+            ts = []
+            for r_ in range(warm + reps):
+                t_ = time.perf_counter()
+                fn()
+                if r_ >= warm:
+                    ts.append((time.perf_counter() - t_) * 1e3)
+            return float(np.median(ts)), float(np.percentile(ts, 10)), float(np.percentile(ts, 90))
+
+        m_, p10_, p90_ = med_ms(lambda: c1.collect(c1.submit(x1, args.top_k, 0.1)))
+        out["latency_b1_ms"] = round(m_, 4)
+        d1 = bufs[0][:1].contiguous()
+        md_, pd10_, pd90_ = med_ms(lambda: c1.step_device(d1.data_ptr(), 1, args.top_k, 0.1, sync=True))
+        out["latency_b1"] = {"host_to_host_ms": {"median": round(m_, 4), "p10": round(p10_, 4), "p90": round(p90_, 4)},
+                             "device_resident_ms": {"median": round(md_, 4), "p10": round(pd10_, 4), "p90": round(pd90_, 4)},
+                             "launches": int(model.cost().n_launches), "capture_fallbacks": c1.stats()["capture_fallbacks"],
+                             "what": "one segment: Classifier::predict's path (configs[0]) -- wall clock of one synchronous call, batch-1 context"}
+        del c1
+        # ---- the other single-GPU configs of BASELINE.json in the same line: configs[2] BirdNET v3.0 batch 64 (logits + 1024-d
+        # embeddings) and configs[3] Perch v2 batch 128, device-resident steps on the same number of contexts
+        if args.model == "v24":
+            extra = {}
+            for key, bsz in (("v30", 64), ("perch", 128)):
+                S2, SR2, SEC2, mk2, name2, seg2 = MODELS[key]
+                with tempfile.NamedTemporaryFile(suffix=".onnx", delete=False) as f2:
+                    f2.write(mk2())
+                m2 = bn.Model(f2.name, device=local_rank)
+                os.unlink(f2.name)
+                cs2 = [bn.Context(m2, bsz) for _ in range(S_)]
+                xb = [torch.from_numpy(synth.synthetic_segments(bsz, S2, SR2, first_index=q * bsz)).cuda() for q in range(2)]
+                nst, nwu = max(24, min(args.steps, 60)), 8
+
+                def run2(n):
+                    for i in range(n):
+                        if i >= S_:
+                            cs2[(i - S_) % S_].synchronize()
+                        cs2[i % S_].step_device(xb[i % 2].data_ptr(), bsz, args.top_k, 0.1, sync=False)
+                    for c_ in cs2:
+                        c_.synchronize()
+
+                run2(nwu)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                run2(nst)
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t2
+                lg2 = cs2[(nst - 1) % S_].step_results(bsz)[0]
+                assert np.isfinite(lg2).all()
+                c2 = m2.cost()
+                extra[key] = {"workload": f"{name2}, batch={bsz} synthetic {SR2 // 1000} kHz {SEC2:g} s segments, inputs resident in HBM",
+                              "value": round(nst * bsz / d2, 1), "unit": "segments/s", "ms_per_step": round(d2 / nst * 1e3, 4), "steps": nst,
+                              "flops_performed_per_segment": round(2.0 * (c2.macs_mfma + c2.macs_valu)),
+                              "frac_mfma_f32_whole_path": round(2.0 * (c2.macs_mfma + c2.macs_valu) * nst * bsz / d2 / 1e12 / MFMA_F32_PEAK_TF, 4),
+                              "capture_fallbacks": sum(c_.stats()["capture_fallbacks"] for c_ in cs2)}
+                del cs2, m2, xb
+            out["extra"] = extra
     if rank == 0:
+        out["capture_fallbacks"] = sum(c.stats()["capture_fallbacks"] for c in ctxs)
+        out["whole_path_frac_mfma_f32"] = None  # filled below from the plan's flop count
         # ---- per-kernel device times (HIP events on the context's stream), roofline of the dominant kernel
         ctxs[0].infer(bufs[0].cpu().numpy())  # puts a real batch into the context's own input buffer
         rows = ctxs[0].time_kernels(B)
@@ -333,10 +420,24 @@ def main():
             roof = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(frac_mfma, 4)}
         # HBM bytes per launch from the committed PMC passes (tools/profile_round.sh + profile_summary.py:
         # FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes, gfx950 read correction applied)
+        # A committed PMC summary is only quoted while it belongs to the newest profile set under profiles/ (tag rNN_vM of
+        # the newest rNN_vM_kernel_stats_*.csv): a summary older than the kernels it is quoted for is refused.
+        import glob
+        import re
+
+        def tag_key(t):
+            m_ = re.match(r"r(\d+)_v(\d+)", t or "")
+            return (int(m_.group(1)), int(m_.group(2))) if m_ else (-1, -1)
+
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        newest = max([tag_key(os.path.basename(f_)) for f_ in glob.glob(os.path.join(prof_dir, "r*_kernel_stats_*.csv"))] or [(-1, -1)])
+        stale = []
         traffic, traffic_src = None, None
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")))
-            if tj.get("batch") == B and dname in tj.get("families", {}):
+            tj = json.load(open(os.path.join(prof_dir, "pmc_traffic.json")))
+            if tag_key(tj.get("tag")) < newest:
+                stale.append(f"profiles/pmc_traffic.json (tag {tj.get('tag')}) is older than the newest kernel stats r{newest[0]:02d}_v{newest[1]}")
+            elif tj.get("batch") == B and dname in tj.get("families", {}):
                 traffic = tj["families"][dname]["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{tj['tag']}_pmc_traffic.json"
         except (OSError, ValueError, KeyError):
@@ -344,13 +445,17 @@ def main():
         # matrix-pipe utilisation of the same family from the committed SQ counter pass (profiles/pmc_mfma.json)
         mfma_busy, mfma_src = None, None
         try:
-            mj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_mfma.json")))
-            if mj.get("batch") == B and dname in mj.get("families", {}):
+            mj = json.load(open(os.path.join(prof_dir, "pmc_mfma.json")))
+            if tag_key(mj.get("tag")) < newest:
+                stale.append(f"profiles/pmc_mfma.json (tag {mj.get('tag')}) is older than the newest kernel stats r{newest[0]:02d}_v{newest[1]}")
+            elif mj.get("batch") == B and dname in mj.get("families", {}):
                 mfma_busy = mj["families"][dname]["mfma_busy"]
                 mfma_src = f"profiles/{mj['tag']}_pmc_mfma.json"
         except (OSError, ValueError, KeyError):
             pass
         roof.update({"mfma_busy": mfma_busy, "mfma_busy_source": mfma_src})
+        if stale:
+            roof["pmc_refused"] = stale
         roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                      "kernel": dname, "launches_per_step": d["launches"],
                      "avg_launch_us": round(d["us"] / d["launches"], 2), "share_of_step": round(d["us"] / total_us, 3),
@@ -362,6 +467,7 @@ def main():
                      "flops_counted": "multiply-adds the launches perform (planner's walk after its rewrites: mel-dead DFT bins pruned, "
                                       "mirror-symmetric DFT bases folded to half their taps) -- not the exporter graph's nominal count"})
         out["roofline"] = roof
+        out["whole_path_frac_mfma_f32"] = round(roof["flops_performed_per_segment"] * value / world / 1e12 / MFMA_F32_PEAK_TF, 4)
         # the three longest single launches, each against its own bound (the family number above averages
         # 33 launches, most of them latency-bound 6x32 / 3x16 feature maps at batch 32)
         tops = []

@@ -47,15 +47,23 @@ impl crate::Classifier {
         if unsafe { bn_topk(context.ctx, n, self.inner.top_k, has_min, min, k.max(1), idx.as_mut_ptr(), conf.as_mut_ptr(), cnt.as_mut_ptr()) } != BN_OK {
             return Err(Error::Inference(last_error()));
         }
-        Ok((0..n)
+        Ok(self.assemble_results(n, k.max(1), &logits, &emb, &idx, &conf, &cnt))
+    }
+
+    /// `process_batch_outputs_from_flat` of the reference (src/classifier.rs:872-911): flat logits / embeddings and the
+    /// device-side top-K rows (index, confidence, count per segment; row stride `k`) -> one `PredictionResult` per segment.
+    fn assemble_results(&self, n: usize, k: usize, logits: &[f32], emb: &[f32], idx: &[u32], conf: &[f32], cnt: &[u32]) -> Vec<PredictionResult> {
+        let cfg = &self.inner.config;
+        let nsp = cfg.num_species;
+        (0..n)
             .map(|i| PredictionResult {
                 model_type: cfg.model_type,
                 predictions: (0..cnt[i] as usize)
                     .map(|j| {
-                        let index = idx[i * k.max(1) + j] as usize;
+                        let index = idx[i * k + j] as usize;
                         Prediction {
                             species: self.inner.labels.get(index).cloned().unwrap_or_else(|| format!("unknown_{index}")),
-                            confidence: conf[i * k.max(1) + j],
+                            confidence: conf[i * k + j],
                             index,
                         }
                     })
@@ -63,7 +71,7 @@ impl crate::Classifier {
                 embeddings: cfg.embedding_dim.map(|d| emb[i * d..(i + 1) * d].to_vec()),
                 raw_scores: logits[i * nsp..(i + 1) * nsp].to_vec(),
             })
-            .collect())
+            .collect()
     }
 }
 
@@ -90,8 +98,9 @@ impl crate::Classifier {
         }
     }
 
+    /// Results of a submitted batch of `n` segments, as `predict_batch_with_context` returns them (classifier.rs:826-867).
     pub fn collect_batch(&self, context: &mut BatchInferenceContext, ticket: u64, n: usize, options: &InferenceOptions)
-        -> Result<(Vec<f32>, Vec<f32>, Vec<u32>, Vec<f32>, Vec<u32>)> {
+        -> Result<Vec<PredictionResult>> {
         let cfg = &self.inner.config;
         let (nsp, emb_dim, k) = (cfg.num_species, cfg.embedding_dim.unwrap_or(0), self.inner.top_k.min(cfg.num_species).max(1));
         let (mut logits, mut emb) = (vec![0f32; n * nsp], vec![0f32; n * emb_dim]);
@@ -102,7 +111,7 @@ impl crate::Classifier {
             bn_infer_collect(context.ctx, ticket, logits.as_mut_ptr(), if emb_dim > 0 { emb.as_mut_ptr() } else { std::ptr::null_mut() },
                              k, idx.as_mut_ptr(), conf.as_mut_ptr(), cnt.as_mut_ptr(), cancel, timeout_ns)
         } {
-            BN_OK => Ok((logits, emb, idx, conf, cnt)), // assembled into PredictionResult exactly as above
+            BN_OK => Ok(self.assemble_results(n, k, &logits, &emb, &idx, &conf, &cnt)),
             BN_ERR_TIMEOUT => Err(Error::Timeout { duration: options.timeout.unwrap_or_default() }),
             BN_ERR_CANCELLED => Err(Error::Cancelled),
             _ => Err(Error::Inference(last_error())),
@@ -122,6 +131,7 @@ fn last_error() -> String {
 /// session becomes a `bn_model`, the model type / shapes come from `bn_model_get_config` (same rules as detection.rs).
 impl crate::ClassifierBuilder {
     pub fn build_hip(self, device: i32) -> Result<crate::Classifier> {
+        crate::ffi::assert_abi();
         let model_path = self.model_path.ok_or(Error::ModelPathRequired)?;
         if self.labels.is_none() && self.labels_path.is_none() {
             return Err(Error::LabelsRequired);
@@ -182,7 +192,10 @@ impl crate::Classifier {
     /// does this shim; `create_native_batch_context` lifts the refusal (the native context runs Perch).
     pub fn create_batch_context(&self, max_batch_size: usize) -> Result<BatchInferenceContext> {
         if self.inner.config.model_type == crate::ModelType::PerchV2 {
-            return Err(Error::Inference("BatchInferenceContext is not supported for PerchV2 models".into()));
+            // the reference's text, src/batch_context.rs:110-113
+            return Err(Error::Inference(
+                "BatchInferenceContext does not yet support PerchV2 models. Use predict_batch() instead.".into(),
+            ));
         }
         self.create_native_batch_context(max_batch_size)
     }

@@ -1,4 +1,4 @@
-//! Raw bindings of include/birdnet_hip.h (BN_ABI_VERSION 1).  Source only -- see ../README.md.
+//! Raw bindings of include/birdnet_hip.h (BN_ABI_VERSION 2: checked by `assert_abi`).  Source only -- see ../README.md.
 #![allow(non_camel_case_types)]
 use std::os::raw::c_char;
 
@@ -25,6 +25,27 @@ pub struct bn_model_config {
     pub embedding_output: i32,
 }
 
+/// `bn_ctx_get_stats`: captures / replays / capture fallbacks (must be 0) of one context.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct bn_ctx_stats {
+    pub captures: u64,
+    pub instantiates: u64,
+    pub replays: u64,
+    pub eager_runs: u64,
+    pub capture_fallbacks: u64,
+    pub evictions: u64,
+    pub cached_graphs: u64,
+    pub last_fallback: [c_char; 192],
+}
+
+pub const BN_ABI_VERSION: i32 = 2;
+/// Call once before anything else: a library built from another header revision is refused instead of misread.
+pub fn assert_abi() {
+    let got = unsafe { bn_abi_version() };
+    assert_eq!(got, BN_ABI_VERSION, "libbirdnet_hip speaks ABI {got}, this crate was written for ABI {BN_ABI_VERSION}");
+}
+
 pub const BN_OK: i32 = 0;
 pub const BN_ERR_TIMEOUT: i32 = 3;
 pub const BN_ERR_CANCELLED: i32 = 4;
@@ -39,6 +60,7 @@ extern "C" {
     pub fn bn_model_get_config(m: *const bn_model, out: *mut bn_model_config) -> i32;
     pub fn bn_ctx_create(m: *mut bn_model, max_batch: usize, flags: u32, out: *mut *mut bn_ctx) -> i32;
     pub fn bn_ctx_destroy(c: *mut bn_ctx);
+    pub fn bn_ctx_get_stats(c: *const bn_ctx, out: *mut bn_ctx_stats, struct_size: usize) -> i32;
     pub fn bn_infer(c: *mut bn_ctx, segs: *const *const f32, batch: usize, logits_out: *mut f32, emb_out: *mut f32,
                     cancel: *const i32, timeout_ns: u64) -> i32;
     pub fn bn_topk(c: *mut bn_ctx, batch: usize, top_k: usize, has_min: i32, min_conf: f32, k_stride: usize,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define BN_ABI_VERSION 1
+#define BN_ABI_VERSION 2 /* 2: bn_model_get_cost / bn_ctx_get_stats take the caller's struct size; bn_ctx_get_stats, bn_group_get_stats */
 #define BN_MAX_OUTPUTS 8
 #define BN_MAX_RANK 6
 #define BN_NAME_LEN 64
@@ -127,7 +127,9 @@ int32_t bn_model_device(const bn_model *m);
 bn_status bn_model_io_info(const bn_model *m, bn_io_info *out);
 /* detect_model_type() result for the loaded graph (detection.rs:15-145) */
 bn_status bn_model_get_config(const bn_model *m, bn_model_config *out);
-bn_status bn_model_get_cost(const bn_model *m, bn_model_cost *out);
+/* struct_size = sizeof(bn_model_cost) as the CALLER was compiled: at most that many bytes are written, so a caller
+ * built against a shorter struct keeps working when fields are appended. */
+bn_status bn_model_get_cost(const bn_model *m, bn_model_cost *out, size_t struct_size);
 
 /* The same detection rules exposed on raw shapes, for shims that keep
  * detection on their side (detection.rs:15-80; override < 0 means None).
@@ -143,6 +145,23 @@ bn_status bn_detect_model_type(const int64_t *in_shape, size_t in_rank, const in
 bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **out);
 void bn_ctx_destroy(bn_ctx *c);
 size_t bn_ctx_max_batch(const bn_ctx *c);
+/* How the context's plans reached the stream so far.  A plan is captured into a hipGraph once per (batch size, input
+ * buffer) and replayed; every LDS opt-in and allocation the launches need happens at bn_ctx_create, so a capture holds
+ * kernel launches only.  Should a capture still fail, that batch runs launch by launch, the event is COUNTED here
+ * (capture_fallbacks, with the runtime's message in last_fallback) and printed to stderr once per context;
+ * BN_STRICT_GRAPH=1 in the environment makes it BN_ERR_BACKEND instead.  capture_fallbacks must read 0 in a
+ * healthy process. */
+typedef struct bn_ctx_stats {
+    uint64_t captures;          /* hipStreamBeginCapture..EndCapture runs */
+    uint64_t instantiates;      /* hipGraphInstantiate calls */
+    uint64_t replays;           /* hipGraphLaunch calls */
+    uint64_t eager_runs;        /* plans launched kernel by kernel (BN_CTX_NO_GRAPH, or a failed capture) */
+    uint64_t capture_fallbacks; /* captures that did not become a graph */
+    uint64_t evictions;         /* instantiated graphs dropped from the 16-entry cache */
+    uint64_t cached_graphs;
+    char last_fallback[192];
+} bn_ctx_stats;
+bn_status bn_ctx_get_stats(const bn_ctx *c, bn_ctx_stats *out, size_t struct_size);
 /* Bytes of device memory held by the context (activations arena + I/O buffers). */
 size_t bn_ctx_device_bytes(const bn_ctx *c);
 
@@ -186,7 +205,9 @@ bn_status bn_infer(bn_ctx *c, const float *const *segs, size_t batch_size, float
  * batches complete in submission order.  More batches in flight = more contexts, each on its own stream.
  * A batch that timed out or was cancelled in bn_infer_collect is abandoned: its ticket is gone and the context
  * drains before its next use.  batch_size == 0 yields ticket 0, which collects to nothing.  Same threading rule
- * as every context call: one thread at a time per context.
+ * as every context call: one thread at a time per context.  Tickets share nothing with the synchronous entry points
+ * (bn_infer_windows, bn_step_device, bn_step_windows) but the context's stream: each of the two slots owns its device
+ * input and pinned staging, so those calls may be mixed with tickets in flight; they run in call order.
  */
 bn_status bn_infer_submit(bn_ctx *c, const float *const *segs, size_t batch_size, size_t top_k,
                           int32_t has_min, float min_conf, uint64_t *ticket);
@@ -336,6 +357,8 @@ bn_status bn_group_create(bn_model *const *models, const int32_t *devices, int32
 void bn_group_destroy(bn_group *g);
 int32_t bn_group_size(const bn_group *g);
 int32_t bn_group_uses_rccl(const bn_group *g);
+/* bn_ctx_get_stats summed over every context of the group (last_fallback: the most recent one); capture_fallbacks must be 0. */
+bn_status bn_group_get_stats(const bn_group *g, bn_ctx_stats *out, size_t struct_size);
 void bn_shard_range(size_t n_windows, int32_t rank, int32_t world, size_t *lo, size_t *hi);
 bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samples, int32_t format,
                                      size_t step_samples, size_t top_k, int32_t has_min, float min_conf,

@@ -41,13 +41,13 @@ BN_CTX_DEFAULT, BN_CTX_ALL_OUTPUTS, BN_CTX_NO_GRAPH = 0, 1, 2
 # every symbol include/birdnet_hip.h and include/birdnet_host.h declare
 ENGINE_SYMBOLS = [
     "bn_abi_version", "bn_device_count", "bn_model_load", "bn_model_load_buffer", "bn_model_free",
-    "bn_model_device", "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create",
+    "bn_model_device", "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create", "bn_ctx_get_stats",
     "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_submit", "bn_infer_collect", "bn_infer_device",
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
     "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
     "bn_recording_create", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
     "bn_infer_windows", "bn_step_windows", "bn_ctx_step_device_rows", "bn_group_create", "bn_group_destroy", "bn_group_size",
-    "bn_group_uses_rccl", "bn_shard_range", "bn_group_analyze_recording", "bn_group_last_error", "bn_recording_create_resampled", "bn_resample_table", "bn_recording_read_f32", "bn_last_error",
+    "bn_group_uses_rccl", "bn_group_get_stats", "bn_shard_range", "bn_group_analyze_recording", "bn_group_last_error", "bn_recording_create_resampled", "bn_resample_table", "bn_recording_read_f32", "bn_last_error",
 ]
 HOST_SYMBOLS = [
     "bnh_classifier_build", "bnh_classifier_free", "bnh_classifier_config", "bnh_classifier_provider",
@@ -82,6 +82,14 @@ class BnModelCost(C.Structure):
                 ("dft_performed_macs", C.c_double), ("dft_fft_equiv_flops", C.c_double)]
 
 
+class BnCtxStats(C.Structure):
+    _fields_ = [("captures", C.c_uint64), ("instantiates", C.c_uint64), ("replays", C.c_uint64), ("eager_runs", C.c_uint64),
+                ("capture_fallbacks", C.c_uint64), ("evictions", C.c_uint64), ("cached_graphs", C.c_uint64), ("last_fallback", C.c_char * 192)]
+
+
+BN_ABI_VERSION = 2  # include/birdnet_hip.h
+
+
 class BnhError(C.Structure):
     _fields_ = [("kind", C.c_int32), ("index", C.c_uint64), ("expected", C.c_uint64), ("got", C.c_uint64),
                 ("duration_ns", C.c_uint64), ("message", C.c_char * 512), ("latitude", C.c_float), ("longitude", C.c_float),
@@ -105,7 +113,8 @@ def _load() -> C.CDLL:
         "bn_model_device": (i32, [vp]),
         "bn_model_io_info": (i32, [vp, C.POINTER(BnIoInfo)]),
         "bn_model_get_config": (i32, [vp, C.POINTER(BnModelConfig)]),
-        "bn_model_get_cost": (i32, [vp, C.POINTER(BnModelCost)]),
+        "bn_model_get_cost": (i32, [vp, C.POINTER(BnModelCost), sz]),
+        "bn_ctx_get_stats": (i32, [vp, C.POINTER(BnCtxStats), sz]),
         "bn_detect_model_type": (i32, [i64p, sz, i64p, C.POINTER(sz), sz, i32, C.POINTER(BnModelConfig)]),
         "bn_ctx_create": (i32, [vp, sz, C.c_uint32, C.POINTER(vp)]),
         "bn_ctx_destroy": (None, [vp]),
@@ -142,6 +151,7 @@ def _load() -> C.CDLL:
         "bn_group_destroy": (None, [vp]),
         "bn_group_size": (i32, [vp]),
         "bn_group_uses_rccl": (i32, [vp]),
+        "bn_group_get_stats": (i32, [vp, C.POINTER(BnCtxStats), sz]),
         "bn_shard_range": (None, [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]),
         "bn_group_analyze_recording": (i32, [vp, vp, sz, i32, sz, sz, i32, C.c_float, f32p, sz, u32p, f32p, u32p, C.POINTER(sz)]),
         "bn_group_last_error": (sz, [C.c_char_p, sz]),
@@ -194,6 +204,8 @@ def _load() -> C.CDLL:
         fn = getattr(L, name)  # AttributeError => the library does not export what the headers declare
         fn.restype = res
         fn.argtypes = args
+    if L.bn_abi_version() != BN_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} speaks ABI {L.bn_abi_version()}, this harness was written for ABI {BN_ABI_VERSION}: rebuild (make)")
     return L
 
 
@@ -571,7 +583,7 @@ class Model:
 
     def cost(self) -> BnModelCost:
         c = BnModelCost()
-        lib.bn_model_get_cost(self._h, C.byref(c))
+        lib.bn_model_get_cost(self._h, C.byref(c), C.sizeof(c))
         return c
 
 
@@ -589,6 +601,16 @@ class Context:
         if getattr(self, "_h", None) and lib is not None:
             lib.bn_ctx_destroy(self._h)
             self._h = None
+
+    def stats(self) -> dict:
+        """bn_ctx_get_stats: captures / instantiates / replays / eager runs / capture fallbacks (must be 0) of this context."""
+        st = BnCtxStats()
+        r = lib.bn_ctx_get_stats(self._h, C.byref(st), C.sizeof(st))
+        if r:
+            raise EngineError(r)
+        d = {k: int(getattr(st, k)) for k, _ in BnCtxStats._fields_ if k != "last_fallback"}
+        d["last_fallback"] = st.last_fallback.decode(errors="replace")
+        return d
 
     def infer(self, segments: np.ndarray, want_embeddings: bool = True, timeout_ns: int = 0, cancel=None):
         x = np.ascontiguousarray(segments, dtype=np.float32)
@@ -959,9 +981,19 @@ class Group:
     def uses_rccl(self) -> bool:
         return bool(lib.bn_group_uses_rccl(self._h))
 
+    def stats(self) -> dict:
+        """bn_group_get_stats: the contexts' counters summed (capture_fallbacks must be 0)."""
+        st = BnCtxStats()
+        if lib.bn_group_get_stats(self._h, C.byref(st), C.sizeof(st)):
+            raise RuntimeError(group_last_error())
+        d = {k: int(getattr(st, k)) for k, _ in BnCtxStats._fields_ if k != "last_fallback"}
+        d["last_fallback"] = st.last_fallback.decode(errors="replace")
+        return d
+
     def analyze_recording(self, samples: np.ndarray, step_samples: int, top_k: int = 10, min_confidence: Optional[float] = None,
-                          want_logits: bool = True):
-        """(logits or None, idx, conf, count) for every window of the recording, in time order."""
+                          want_logits: bool = False):
+        """(logits or None, idx, conf, count) for every window of the recording, in time order.  The default gathers the
+        packed top-K rows only; want_logits=True also allocates and gathers the [G, N] logits (`raw_scores`)."""
         x = np.ascontiguousarray(samples)
         fmt = {np.dtype(np.int16): 0, np.dtype(np.float32): 1}[x.dtype]
         cfg = self.models[0].config

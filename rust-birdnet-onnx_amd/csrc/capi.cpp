@@ -157,7 +157,6 @@ struct bn_ctx {
     hipStream_t stream = nullptr;
     float *d_arena = nullptr;
     float *d_input = nullptr;
-    float *h_input = nullptr;  // pinned
     float *h_out = nullptr;    // pinned staging for logits + embeddings
     size_t h_out_elems = 0;
     size_t device_bytes = 0;
@@ -177,7 +176,9 @@ struct bn_ctx {
     float *h_tk_conf = nullptr;
     size_t step_k = 0;
     // ---- asynchronous host-slice path (bn_infer_submit / bn_infer_collect): a ring of two batches per context.
-    // Slot 0 is the context's own staging (d_input / h_input / h_out), slot 1 is allocated on first use.
+    // Both slots own their device input, pinned input and pinned output buffers (allocated on first use), so a ticket
+    // in flight shares nothing with the synchronous entry points (bn_infer_windows / bn_step_*) but the arena and the
+    // top-K block, and those are ordered by the context's stream.
     struct HostSlot {
         float *d_input = nullptr, *h_input = nullptr, *h_out = nullptr;
         uint32_t *h_tk = nullptr;  // pinned [idx: batch*k][conf: batch*k][count: batch]
@@ -198,6 +199,9 @@ struct bn_ctx {
     std::map<GraphKey, hipGraphExec_t> graphs;
     std::map<GraphKey, uint64_t> graph_used;  // replay counter value at each graph's last launch (least recently used goes first)
     uint64_t graph_tick = 0;
+    // bn_ctx_get_stats: how the plan reached the stream
+    uint64_t n_captures = 0, n_instantiates = 0, n_replays = 0, n_eager_runs = 0, n_capture_fallbacks = 0, n_evictions = 0;
+    std::string last_fallback;  // why the most recent capture did not become a graph
 };
 
 namespace {
@@ -291,15 +295,18 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
-            // Relaxed mode + one capture at a time per process: with thread-local mode a capture was intermittently
-            // invalidated ("operation failed due to a previous error during capture") by what OTHER threads did meanwhile
-            // -- the ranks of a bn_group sharing a device allocate, upload and capture concurrently (1 run in 6 failed).
-            // Only this stream's kernel launches sit between Begin and End, so nothing needs the stricter modes; a
-            // capture happens once per (context, batch size, input pointer), so the mutex costs nothing in steady state.
+            // What sits between Begin and End is kernel launches on this stream and nothing else: the LDS opt-ins and
+            // device queries the launchers used to make on first use (hipFuncSetAttribute on the first > 64 KB launch of
+            // a plan -- the op the one-in-six invalidated capture of round 2 named) happen in prepare_device() at
+            // context creation.  Captures of one process are still serialised (they are rare -- one per context and
+            // batch size -- and a capture is not the place to find out what two of them do to each other), in the
+            // thread-local mode so that what OTHER threads do to the device meanwhile (uploads, allocations of sibling
+            // ranks) is none of this capture's business.
             static std::mutex capture_mu;
             std::lock_guard<std::mutex> capture_lock(capture_mu);
             (void)hipGetLastError();  // drop stale sticky errors of unrelated earlier calls
-            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            c->n_captures++;
             hipError_t le = hipSuccess;
             std::string bad;
             (void)take_launch_error();
@@ -316,16 +323,27 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
                 return fail(BN_ERR_INVALID_ARG, refused);
             }
             hipGraphExec_t ge = nullptr;
+            hipError_t ie = hipSuccess;
             if (le == hipSuccess && e == hipSuccess) {
-                e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-                if (e != hipSuccess) ge = nullptr;
+                ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                c->n_instantiates++;
+                if (ie != hipSuccess) ge = nullptr;
             }
             if (g) (void)hipGraphDestroy(g);
             if (!ge) {
-                // The capture did not survive (the runtime invalidates one now and then when other threads drive the
-                // same device, whatever the capture mode): nothing was enqueued, so this batch simply runs launch by
-                // launch below and the next call captures again.  A launch that is really wrong fails there too.
+                // The capture did not become a graph.  Nothing was enqueued, so the batch can still run launch by launch
+                // below -- but never silently: the event is counted (bn_ctx_get_stats.capture_fallbacks), its cause kept
+                // (.last_fallback) and reported on stderr once per context; BN_STRICT_GRAPH=1 turns it into an error.
                 (void)hipGetLastError();
+                c->n_capture_fallbacks++;
+                c->last_fallback = le != hipSuccess ? "launch of '" + bad + "' failed during capture: " + hipGetErrorString(le)
+                                   : e != hipSuccess ? std::string("hipStreamEndCapture: ") + hipGetErrorString(e)
+                                                     : std::string("hipGraphInstantiate: ") + hipGetErrorString(ie);
+                if (c->n_capture_fallbacks == 1)
+                    fprintf(stderr, "libbirdnet_hip: graph capture for batch %zu failed (%s); running the plan launch by launch\n", batch,
+                            c->last_fallback.c_str());
+                static const bool strict = getenv("BN_STRICT_GRAPH") && atoi(getenv("BN_STRICT_GRAPH")) != 0;
+                if (strict) return fail(BN_ERR_BACKEND, "graph capture failed: " + c->last_fallback);
                 use_graph = false;
             } else {
                 if (c->graphs.size() >= 16) {
@@ -342,6 +360,7 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
                         c->graphs.erase(g_old);
                     }
                     c->graph_used.erase(victim);
+                    c->n_evictions++;
                 }
                 it = c->graphs.emplace(key, ge).first;
             }
@@ -349,11 +368,13 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
         if (use_graph) {
             c->graph_used[it->first] = ++c->graph_tick;
             HIP_TRY(hipGraphLaunch(it->second, c->stream));
+            c->n_replays++;
         }
     }
     if (!use_graph) {
         (void)hipGetLastError();  // drop stale sticky errors of unrelated earlier calls
         (void)take_launch_error();
+        c->n_eager_runs++;
         for (auto &op : p.ops) {
             if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
             launch_op(c, op, d_in, (int64_t)batch);
@@ -412,6 +433,7 @@ bn_status make_plan(bn_model *m, const std::vector<int> &wanted, std::unique_ptr
         return fail(BN_ERR_MODEL_LOAD, e.what());
     }
     HIP_TRY(hipSetDevice(m->device));
+    if (!prepare_device(m->device)) return fail(BN_ERR_BACKEND, "device " + std::to_string(m->device) + " refused the kernels' dynamic-LDS opt-in");
     const Plan &p = *pd->plan;
     HIP_TRY(hipMalloc(&pd->d_consts, (size_t)p.consts_elems * sizeof(float)));
     for (size_t k = 0; k < p.consts.size(); k++)
@@ -545,18 +567,20 @@ bn_status bn_model_get_config(const bn_model *m, bn_model_config *out) {
     return BN_OK;
 }
 
-bn_status bn_model_get_cost(const bn_model *m, bn_model_cost *out) {
+bn_status bn_model_get_cost(const bn_model *m, bn_model_cost *out, size_t struct_size) {
     if (!m || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
     const Plan &p = *m->main_plan->plan;
-    out->macs_mfma = p.macs_mfma;
-    out->macs_valu = p.macs_valu;
-    out->weight_bytes = p.weight_bytes;
-    out->activation_bytes = p.act_bytes;
-    out->n_launches = (int32_t)p.ops.size();
-    out->dft_gemm_macs = p.dft_gemm_macs;
-    out->fft_flops = p.fft_flops;
-    out->dft_performed_macs = p.dft_performed_macs;
-    out->dft_fft_equiv_flops = p.dft_fft_equiv_flops;
+    bn_model_cost c{};
+    c.macs_mfma = p.macs_mfma;
+    c.macs_valu = p.macs_valu;
+    c.weight_bytes = p.weight_bytes;
+    c.activation_bytes = p.act_bytes;
+    c.n_launches = (int32_t)p.ops.size();
+    c.dft_gemm_macs = p.dft_gemm_macs;
+    c.fft_flops = p.fft_flops;
+    c.dft_performed_macs = p.dft_performed_macs;
+    c.dft_fft_equiv_flops = p.dft_fft_equiv_flops;
+    memcpy(out, &c, std::min(struct_size, sizeof(c)));  // never writes past the caller's struct (ABI 2: the struct grew in ABI 1 without a version bump)
     return BN_OK;
 }
 
@@ -574,6 +598,8 @@ bn_status bn_detect_model_type(const int64_t *in_shape, size_t in_rank, const in
     if (!detect_model_type(in, outs, model_type_override, *out, reason)) return fail(BN_ERR_MODEL_DETECTION, reason);
     return BN_OK;
 }
+
+static bn_status ensure_step_block(bn_ctx *c, size_t k);
 
 bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **out) {
     if (!m || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
@@ -598,13 +624,15 @@ bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **
     c->flags = flags;
     const Plan &p = *pd->plan;
     HIP_TRY(hipSetDevice(m->device));
+    if (!prepare_device(m->device)) return fail(BN_ERR_BACKEND, "device " + std::to_string(m->device) + " refused the kernels' dynamic-LDS opt-in");
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t arena_b = (size_t)p.arena_elems * max_batch * sizeof(float);
     const size_t in_b = (size_t)p.sample_count * max_batch * sizeof(float);
     HIP_TRY(hipMalloc(&c->d_arena, arena_b));
-    HIP_TRY(hipMemset(c->d_arena, 0, arena_b));  // the squeeze-excite ticket counters live here and must start at zero
+    // the squeeze-excite ticket counters live here and must start at zero; on the context's OWN stream (a legacy-stream
+    // hipMemset would serialise against -- and be seen by -- whatever sibling contexts are capturing or running)
+    HIP_TRY(hipMemsetAsync(c->d_arena, 0, arena_b, c->stream));
     HIP_TRY(hipMalloc(&c->d_input, in_b));
-    HIP_TRY(hipHostMalloc(&c->h_input, in_b, hipHostMallocDefault));
     {
         size_t row = (size_t)p.outputs[m->cfg.logits_output].row_elems;
         if (m->cfg.embedding_output >= 0) row += (size_t)p.outputs[m->cfg.embedding_output].row_elems;
@@ -614,6 +642,17 @@ bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **
     c->device_bytes = arena_b + in_b;
     m->refs.fetch_add(1, std::memory_order_relaxed);
     c->holds_model = true;
+    // top-K / step buffers for the usual k (<= 32) are part of the context from the start: the step path allocates
+    // nothing (a larger top_k still grows them on first use, behind a stream drain)
+    if (m->cfg.model_type != BN_MODEL_GENERIC) {
+        const size_t n = (size_t)p.outputs[m->cfg.logits_output].row_elems;
+        bn_status st = ensure_step_block(c.get(), std::min<size_t>(32, n));
+        if (st != BN_OK) {
+            bn_ctx_destroy(c.release());
+            return st;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));  // arena zeroed before anyone captures or launches
     *out = c.release();
     return BN_OK;
 }
@@ -625,7 +664,6 @@ void bn_ctx_destroy(bn_ctx *c) {
     for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->d_input) (void)hipFree(c->d_input);
-    if (c->h_input) (void)hipHostFree(c->h_input);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->d_tk_idx) (void)hipFree(c->d_tk_idx);
     if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
@@ -655,6 +693,21 @@ void bn_ctx_destroy(bn_ctx *c) {
 }
 
 size_t bn_ctx_max_batch(const bn_ctx *c) { return c ? c->max_batch : 0; }
+
+bn_status bn_ctx_get_stats(const bn_ctx *c, bn_ctx_stats *out, size_t struct_size) {
+    if (!c || !out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    bn_ctx_stats st{};
+    st.captures = c->n_captures;
+    st.instantiates = c->n_instantiates;
+    st.replays = c->n_replays;
+    st.eager_runs = c->n_eager_runs;
+    st.capture_fallbacks = c->n_capture_fallbacks;
+    st.evictions = c->n_evictions;
+    st.cached_graphs = c->graphs.size();
+    snprintf(st.last_fallback, sizeof(st.last_fallback), "%s", c->last_fallback.c_str());
+    memcpy(out, &st, std::min(struct_size, sizeof(st)));  // a caller built against an older, shorter struct gets its prefix
+    return BN_OK;
+}
 size_t bn_ctx_device_bytes(const bn_ctx *c) { return c ? c->device_bytes : 0; }
 void *bn_ctx_stream(const bn_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
@@ -756,12 +809,7 @@ static bn_status ensure_slot(bn_ctx *c, bn_ctx::HostSlot &sl, int index) {
         HIP_TRY(hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming));
     }
     if (sl.d_input) return BN_OK;
-    if (index == 0) {
-        sl.d_input = c->d_input;
-        sl.h_input = c->h_input;
-        sl.h_out = c->h_out;
-        return BN_OK;
-    }
+    (void)index;
     const size_t in_b = (size_t)p.sample_count * c->max_batch * sizeof(float);
     sl.owned = true;
     HIP_TRY(hipMalloc(&sl.d_input, in_b));
@@ -1213,6 +1261,7 @@ bn_status bn_topk_device(int32_t device, const float *d_logits, size_t rows, siz
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BN_ERR_NO_DEVICE, "no HIP device is visible; this path has no CPU fallback");
     HIP_TRY(hipSetDevice(device));
+    if (!prepare_device(device)) return fail(BN_ERR_BACKEND, "device refused the kernels' dynamic-LDS opt-in");
     uint32_t *d_idx = nullptr, *d_cnt = nullptr, *d_flags = nullptr;
     float *d_conf = nullptr;
     HIP_TRY(hipMalloc(&d_idx, rows * k * sizeof(uint32_t)));

@@ -74,7 +74,7 @@ struct bn_group {
         hipStream_t stream = nullptr;  // staging copies + the collective
         float *d_logits = nullptr;     // [world * per_rank, N]: this rank's slab is filled locally, the rest by the gather
         uint32_t *d_topk = nullptr;    // [world * per_rank, 2k + 1] packed rows: idx[k] | conf[k] | count
-        size_t cap_rows = 0, cap_k = 0;
+        size_t cap_rows = 0, cap_k = 0, cap_rows_logits = 0;
         void *comm = nullptr;
         std::string error;
         bn_status status = BN_OK;
@@ -99,7 +99,7 @@ void free_rank_buffers(bn_group::Rank &r) {
     if (r.d_topk) (void)hipFree(r.d_topk);
     r.d_logits = nullptr;
     r.d_topk = nullptr;
-    r.cap_rows = r.cap_k = 0;
+    r.cap_rows = r.cap_k = r.cap_rows_logits = 0;
 }
 
 }  // namespace
@@ -199,6 +199,26 @@ void bn_group_destroy(bn_group *g) {
 int32_t bn_group_size(const bn_group *g) { return g ? (int32_t)g->ranks.size() : 0; }
 int32_t bn_group_uses_rccl(const bn_group *g) { return g && g->use_rccl ? 1 : 0; }
 
+bn_status bn_group_get_stats(const bn_group *g, bn_ctx_stats *out, size_t struct_size) {
+    if (!g || !out) return gfail(BN_ERR_INVALID_ARG, "null argument");
+    bn_ctx_stats sum{};
+    for (const auto &rk : g->ranks)
+        for (const bn_ctx *c : rk.ctxs) {
+            bn_ctx_stats s{};
+            if (bn_ctx_get_stats(c, &s, sizeof(s)) != BN_OK) continue;
+            sum.captures += s.captures;
+            sum.instantiates += s.instantiates;
+            sum.replays += s.replays;
+            sum.eager_runs += s.eager_runs;
+            sum.capture_fallbacks += s.capture_fallbacks;
+            sum.evictions += s.evictions;
+            sum.cached_graphs += s.cached_graphs;
+            if (s.last_fallback[0]) memcpy(sum.last_fallback, s.last_fallback, sizeof(sum.last_fallback));
+        }
+    memcpy(out, &sum, std::min(struct_size, sizeof(sum)));
+    return BN_OK;
+}
+
 bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samples, int32_t format, size_t step_samples, size_t top_k, int32_t has_min,
                                      float min_conf, float *logits_out, size_t k_stride, uint32_t *idx_out, float *conf_out, uint32_t *count_out,
                                      size_t *n_windows_out) {
@@ -222,9 +242,14 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
         auto fail = [&](bn_status st, const std::string &m) { rk.status = st; rk.error = "rank " + std::to_string(r) + ": " + m; };
         rk.status = BN_OK;
         if (hipSetDevice(rk.device) != hipSuccess) return fail(BN_ERR_NO_DEVICE, "hipSetDevice failed");
-        if (per > rk.cap_rows || k > rk.cap_k) {
+        // the [R * per, N] logits slab (751 MB for the 24 h recording of BASELINE configs[4]) exists only on request;
+        // the default gather moves the packed top-K rows alone (2k + 1 words per window)
+        if (per > rk.cap_rows || k > rk.cap_k || (logits_out && per > rk.cap_rows_logits)) {
+            const bool had_logits = rk.cap_rows_logits > 0;
             free_rank_buffers(rk);
-            if (hipMalloc(&rk.d_logits, R * per * N * sizeof(float)) != hipSuccess) return fail(BN_ERR_BACKEND, "out of device memory for the gathered logits");
+            if ((logits_out || had_logits) && hipMalloc(&rk.d_logits, R * per * N * sizeof(float)) != hipSuccess)
+                return fail(BN_ERR_BACKEND, "out of device memory for the gathered logits");
+            if (rk.d_logits) rk.cap_rows_logits = per;
             if (k && hipMalloc(&rk.d_topk, R * per * tkw * sizeof(uint32_t)) != hipSuccess) return fail(BN_ERR_BACKEND, "out of device memory for the gathered top-K rows");
             rk.cap_rows = per;
             rk.cap_k = k;
@@ -234,7 +259,7 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
         const size_t n_local = hi - lo;
         // padding rows of this rank's slab are defined (zero): they travel through the collective
         if (n_local < per) {
-            (void)hipMemsetAsync(rk.d_logits + (r * per + n_local) * N, 0, (per - n_local) * N * sizeof(float), rk.stream);
+            if (logits_out) (void)hipMemsetAsync(rk.d_logits + (r * per + n_local) * N, 0, (per - n_local) * N * sizeof(float), rk.stream);
             if (k) (void)hipMemsetAsync(rk.d_topk + (r * per + n_local) * tkw, 0, (per - n_local) * tkw * sizeof(uint32_t), rk.stream);
         }
         if (n_local == 0) {

@@ -309,9 +309,14 @@ void launch_null(hipStream_t s);  // empty kernel (timing calibration)
 void launch_error(const char *msg);
 // message of the first launch_error since the last call on this thread (NULL if none); clears it
 const char *take_launch_error();
-// hipFuncAttributeMaxDynamicSharedMemorySize applies to the CURRENT device's function object: the opt-in is cached
-// per (kernel, device) and is safe to call from several threads.  Returns false if the runtime refuses.
+// Per-device preparation (kernels.hip): opts every kernel that may use more than 64 KB of dynamic LDS in on `dev`
+// and caches the device's CU count, ONCE, outside any stream capture.  The C ABI calls it wherever a device is first
+// used (bn_model_load, bn_ctx_create, the stand-alone top-K entry points); launchers never call the runtime for it.
+bool prepare_device(int dev);
+void register_dynamic_lds_kernel(const void *kernel);  // used by each .hip file's register_*_kernels()
+// launch-time check only (no runtime call): true when `bytes` fits and some device was prepared
 bool ensure_dynamic_lds(const void *kernel, size_t bytes);
+int device_cu_count();
 size_t topk_lds_bytes(int64_t n, int64_t k);
 
 // device -> pinned host memory by a kernel's own stores (topk.hip): up to three regions of 32-bit words per launch;

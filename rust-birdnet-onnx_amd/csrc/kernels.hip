@@ -21,6 +21,8 @@
 #include <mutex>
 #include <string>
 #include <utility>
+#include <vector>
+#include <atomic>
 
 #include "kernels.h"
 #include "device_common.h"
@@ -44,21 +46,66 @@ const char *take_launch_error() {
     g_launch_error_out = g_launch_error;
     return g_launch_error_out.c_str();
 }
-bool ensure_dynamic_lds(const void *kernel, size_t bytes) {
-    if (bytes <= 64 * 1024) return true;  // within the default limit
-    static std::mutex mu;
-    static std::map<std::pair<const void *, int>, size_t> done;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return false;
-    std::lock_guard<std::mutex> lk(mu);
-    size_t &have = done[{kernel, dev}];
-    if (bytes <= have) return true;
-    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
+// ---- per-device preparation -----------------------------------------------------------------------------------
+// Everything a launcher would otherwise have to ask the runtime for on its first launch -- the opt-in to more than
+// 64 KB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize, per function AND device) and the device's CU
+// count -- is done ONCE per device by prepare_device(), which bn_model_load / bn_ctx_create / the stand-alone top-K
+// entry points call before anything is launched.  Nothing but kernel launches is then issued between
+// hipStreamBeginCapture and hipStreamEndCapture: a hipFuncSetAttribute inside a capture (the first launch of the
+// 80 KB frame_fold_kernel of a plan) is what invalidated one graph capture in six when several ranks shared a device.
+namespace {
+std::mutex g_prep_mu;
+std::atomic<uint64_t> g_prepared_mask{0};  // device ordinals < 64 that prepare_device() has completed on
+std::atomic<int> g_cu_count[64];
+std::vector<const void *> &dyn_lds_kernels() {
+    static std::vector<const void *> v;
+    return v;
+}
+}  // namespace
+void register_dynamic_lds_kernel(const void *kernel) { dyn_lds_kernels().push_back(kernel); }
+void register_kernels_hip();   // kernels.hip (below)
+void register_stft_kernels();  // stft.hip
+void register_topk_kernels();  // topk.hip
+
+bool prepare_device(int dev) {
+    if (dev < 0 || dev >= 64) return false;
+    if (g_prepared_mask.load(std::memory_order_acquire) & (1ull << dev)) return true;
+    std::lock_guard<std::mutex> lk(g_prep_mu);
+    if (g_prepared_mask.load(std::memory_order_acquire) & (1ull << dev)) return true;
+    if (dyn_lds_kernels().empty()) {
+        register_kernels_hip();
+        register_stft_kernels();
+        register_topk_kernels();
     }
-    have = bytes;
-    return true;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return false;
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) return false;
+    bool ok = true;
+    for (const void *k : dyn_lds_kernels())
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+        }
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    g_cu_count[dev].store(v, std::memory_order_relaxed);
+    if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
+    if (ok) g_prepared_mask.fetch_or(1ull << dev, std::memory_order_release);
+    return ok;
+}
+// the launch-time side: no runtime call at all.  A launcher that needs the opt-in on a device nobody prepared
+// (a programming error in the C ABI layer) refuses the launch instead of asking the runtime mid-capture.
+bool ensure_dynamic_lds(const void *kernel, size_t bytes) {
+    (void)kernel;
+    if (bytes <= 64 * 1024) return true;  // within the default limit
+    return bytes <= 160 * 1024 && g_prepared_mask.load(std::memory_order_acquire) != 0;
+}
+int device_cu_count() {
+    // every device of a process is the same part (gfx950 only, capi.cpp): the first prepared device answers
+    const uint64_t m = g_prepared_mask.load(std::memory_order_acquire);
+    for (int d = 0; d < 64; d++)
+        if (m & (1ull << d)) return g_cu_count[d].load(std::memory_order_relaxed);
+    return 256;
 }
 
 namespace {
@@ -2114,6 +2161,31 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 inline unsigned cap_blocks(int64_t want, int64_t cap) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(want, cap)); }
 
 }  // namespace
+
+// every kernel of this file that may be launched with more than 64 KB of dynamic LDS (prepare_device opts them in)
+void register_kernels_hip() {
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold_kernel));
+#define BN_REG_KS(KERNEL)                                                     \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 1>)); \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 2>)); \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<5, 1>)); \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<5, 2>));
+#define BN_REG_KSI(KERNEL)                                                           \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 1, false>)); \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 2, false>)); \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<5, 1, false>)); \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<5, 2, false>)); \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 1, true>));  \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 2, true>));  \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<5, 1, true>));  \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<5, 2, true>));
+    BN_REG_KS(mbconv_map_kernel)
+    BN_REG_KS(dwconv_map_kernel)
+    BN_REG_KSI(mbconv_pipe_kernel)
+    BN_REG_KSI(mbconv_expand_dw_kernel)
+#undef BN_REG_KS
+#undef BN_REG_KSI
+}
 
 void launch_eltwise(hipStream_t s, const EltDesc &d, float *out, const float *a, const float *const (&b)[ELT_MAX_STAGES], int64_t batch) {
     if (batch <= 0 || d.per_sample <= 0) return;

@@ -484,6 +484,8 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
 
 size_t stft_lds_bytes(const FftDesc &d, int nwaves) { return (size_t)stft_layout(d, nwaves).total * sizeof(float); }
 
+void register_stft_kernels() { register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<8>)); }
+
 void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t batch) {
     if (batch <= 0) return;
     constexpr int NW = 8;
@@ -501,19 +503,7 @@ void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t bat
                 (int64_t)(d.frames - 1) * d.hop + d.L + 3 <= d.a_bs;
     const int tps = (d.frames + d.tpb - 1) / d.tpb;
     const int64_t total = (int64_t)tps * batch;
-    int ncu = 256;
-    {
-        static std::atomic<int> cached[64];  // compute units per device ordinal (0 = not asked yet)
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
-            int v = cached[dev].load(std::memory_order_relaxed);
-            if (v == 0) {
-                if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-                cached[dev].store(v, std::memory_order_relaxed);
-            }
-            ncu = v;
-        }
-    }
+    const int ncu = device_cu_count();  // asked once per device by prepare_device(), never inside a stream capture
     const unsigned grid = (unsigned)std::min<int64_t>(total, ncu);  // one block per CU (LDS-bound), persistent over its tiles
     hipLaunchKernelGGL(stft_kernel<NW>, dim3(grid), dim3(NW * 64), lds, s, dd, p, (int)total, tps);
 }

@@ -497,6 +497,8 @@ size_t topk_lds_bytes(int64_t n, int64_t k) {
     return b <= 150 * 1024 ? b : 0;
 }
 
+void register_topk_kernels() { register_dynamic_lds_kernel(reinterpret_cast<const void *>(topk_kernel)); }
+
 void launch_topk(hipStream_t s, const float *logits, int64_t rows, int64_t n, int64_t k,
                  int has_min, float min_conf, int64_t k_stride, uint32_t *idx, float *conf,
                  uint32_t *count, uint32_t *flags) {

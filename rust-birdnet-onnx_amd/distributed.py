@@ -121,11 +121,12 @@ def chunk_step(segment_samples: int, overlap_secs: float, sample_rate: int) -> i
 
 
 def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: float, batch: int = 32, streams: int = 4, top_k: int = 10,
-                              min_confidence: Optional[float] = None, dist=None, gather: str = "logits", ctxs=None):
+                              min_confidence: Optional[float] = None, dist=None, gather: str = "topk", ctxs=None):
     """BASELINE.json configs[4]: a long mono recording (int16 or float32), sharded by window across the
     ranks of one node.  Every rank uploads its slice once (bn_recording_create), cuts windows on the
     device and keeps `streams` contexts in flight (bn_step_windows); ONE collective at the end
-    assembles the [G, N] logits (gather="logits") or only the [G, k] top-K rows (gather="topk").
+    assembles only the [G, k] top-K rows (gather="topk", the default: 80 B per window at k = 10) or also the [G, N]
+    logits (gather="logits": 26 KB per window for BirdNET v2.4 -- what the reference's `raw_scores` need).
 
     Returns (logits or None, topk_idx, topk_conf, topk_count) for all G windows, in time order."""
     import torch
@@ -162,8 +163,15 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
                 self.__cuda_array_interface__ = {"data": (ptr, False), "shape": shape, "typestr": "<f4", "version": 2}
 
         torch.cuda.set_device(model.device)
-        full = torch.zeros((world * cap, N), dtype=torch.float32, device=torch.device("cuda", model.device))
+        # torch.empty + zeroing only this rank's padding rows: a whole-buffer zero fill would run on torch's current
+        # stream, which the contexts' non-blocking streams never synchronise with -- a late fill could wipe rows a
+        # context had already copied in.  The padding fill is followed by a device-wide synchronize, so it is complete
+        # before the first step is enqueued on any context stream.
+        full = torch.empty((world * cap, N), dtype=torch.float32, device=torch.device("cuda", model.device))
         slab = full[rank * cap:(rank + 1) * cap]
+        if n_local < cap:
+            slab[n_local:].zero_()
+        torch.cuda.synchronize(model.device)
         views = [torch.as_tensor(_DevView(c.output_device(cfg.logits_output)[0], (batch, N)), device=slab.device) for c in ctxs]
         streams = [torch.cuda.ExternalStream(c.stream()) for c in ctxs]
     logits = np.empty((n_local, N), dtype=np.float32) if gather == "logits" and not on_gpu else None
@@ -188,6 +196,7 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
         if on_gpu:  # the step's rows -> this rank's slab, ordered behind the step on the context's own stream
             with torch.cuda.stream(streams[j % len(ctxs)]):
                 slab[f:f + m].copy_(views[j % len(ctxs)][:m], non_blocking=True)
+                full.record_stream(streams[j % len(ctxs)])  # the caching allocator must not recycle it under a foreign stream
     for j in range(max(0, len(jobs) - len(ctxs)), len(jobs)):
         collect(j)
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(bn):
 
 
 def test_abi_version(bn):
-    assert bn.lib.bn_abi_version() == 1
+    assert bn.lib.bn_abi_version() == 2 == bn.BN_ABI_VERSION
 
 
 def test_no_device_means_loud_failure_not_cpu_fallback(bn, tmp_path):

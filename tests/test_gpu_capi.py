@@ -34,7 +34,7 @@ def test_load_buffer_io_info_config_cost(bn, small):
     assert (cfg.model_type, cfg.sample_count, cfg.num_species, cfg.embedding_dim, cfg.logits_output, cfg.embedding_output) == \
            (1, 160000, 200, 1024, 1, 0)
     cost = bn.BnModelCost()
-    assert bn.lib.bn_model_get_cost(h, C.byref(cost)) == 0
+    assert bn.lib.bn_model_get_cost(h, C.byref(cost), C.sizeof(cost)) == 0
     assert cost.macs_mfma > 1e7 and cost.weight_bytes > 1e5 and cost.n_launches > 10
     bn.lib.bn_model_free(h)
     # garbage buffer -> BN_ERR_MODEL_LOAD with a message

@@ -1,0 +1,130 @@
+"""BASELINE.json configs[4] at its size: BirdNET v2.4 over a 24 h continuous 48 kHz recording (28 800 windows of 3 s,
+reference unit of work: chunk_audio, src/bin/birdnet-analyze.rs:707-743), sharded through the C ABI's group API
+(bn_group_analyze_recording), and the RCCL branch of the group on a box that has two or more GPUs.
+
+The oracle cannot run 28 800 full-size segments in seconds, so the full-size checks are the size-independent ones:
+window counts and shard tiling, and bit-identity of chosen windows (first, shard seams, middle, last full, the
+zero-padded tail) with a single context stepping over exactly those windows of the same samples."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from gpu_helpers import write_model
+
+synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+pytestmark = pytest.mark.gpu
+
+SR, S = 48000, 144000
+
+
+@pytest.fixture(scope="module")
+def v24_small():
+    data = synth.birdnet_v24(num_species=500, width=0.5, depth=0.5, head=256)
+    return data, write_model(data)
+
+
+def recording_i16(n_samples: int, seed: int = 2024) -> np.ndarray:
+    """A 291 s period (97 windows -- 97 is prime, so neither a batch of 32 nor a shard of 3 600 windows ever sees the
+    same window at the same position twice in a row): tones cycling over five frequencies with a slow amplitude ramp,
+    plus uniform noise; window 96 of every period is silent (the reference's all-zero segment, integration_test.rs:52-54)."""
+    period = 97 * S
+    rng = np.random.default_rng(seed)
+    t = np.arange(period, dtype=np.float64) / SR
+    w = np.arange(period) // S
+    f = np.array([440.0, 1000.0, 2500.0, 6000.0, 9000.0])[w % 5]
+    x = (0.2 + 0.3 * (w / 97.0)) * np.sin(2 * np.pi * f * t) + 0.05 * rng.uniform(-1, 1, period)
+    x[w == 96] = 0.0
+    block = np.round(x * 32767.0).astype(np.int16)
+    return np.tile(block, (n_samples + period - 1) // period)[:n_samples]
+
+
+def single_context_rows(bn, model, pcm, windows, k, min_conf):
+    """Each window of `windows` through ONE context by bn_step_windows on a recording that holds just its samples
+    (window g of the recording = samples [g*S, min(n, (g+1)*S)), zero-padded by the device like chunk_audio does)."""
+    ctx = bn.Context(model, 1)
+    rows = {}
+    for g in windows:
+        rec = bn.Recording(np.ascontiguousarray(pcm[g * S:min(pcm.shape[0], (g + 1) * S)]))
+        assert rec.n_windows(S) == 1
+        ctx.step_windows(rec, S, 0, 1, k, min_conf)
+        ctx.synchronize()
+        lg, ix, cf, ct = ctx.step_results(1)
+        rows[g] = (lg[0].copy(), ix[0].copy(), cf[0].copy(), int(ct[0]))
+    st = ctx.stats()
+    assert st["capture_fallbacks"] == 0 and st["instantiates"] == 1, st
+    return rows
+
+
+def test_24h_recording_through_the_group_api_on_one_gpu(bn):
+    """28 800 windows (24 h minus 50 000 samples, so the last window is zero-padded) through bn_group_analyze_recording."""
+    path = write_model(synth.birdnet_v24())
+    n = 28800 * S - 50000
+    pcm = recording_i16(n)
+    assert bn.lib.bn_chunk_count(n, S) == 28800
+    # the partition BASELINE configs[4] runs with: 8 contiguous ranges of 3 600 windows tiling [0, 28 800)
+    lo, hi = C.c_size_t(), C.c_size_t()
+    edges = []
+    for r in range(8):
+        bn.lib.bn_shard_range(28800, r, 8, C.byref(lo), C.byref(hi))
+        edges.append((lo.value, hi.value))
+    assert edges == [(3600 * r, 3600 * (r + 1)) for r in range(8)]
+    model = bn.Model(path)
+    grp = bn.Group([model], max_batch=32, contexts_per_device=4)
+    k, min_conf = 10, 0.02
+    logits, idx, conf, cnt = grp.analyze_recording(pcm, S, top_k=k, min_confidence=min_conf)  # default: top-K rows only
+    assert logits is None and idx.shape == (28800, k) and conf.shape == (28800, k) and cnt.shape == (28800,)
+    gst = grp.stats()
+    assert gst["capture_fallbacks"] == 0 and gst["eager_runs"] == 0 and gst["replays"] == 900, gst
+    # first window, both sides of every shard seam of the 8-rank partition, a middle window, the last full window and
+    # the zero-padded tail -- each bit for bit what a single context computes for those samples
+    probe = sorted({0, 1, 31, 32, 14399, 14400, 28798, 28799} | {e for lo_, hi_ in edges[1:] for e in (lo_ - 1, lo_)})
+    want = single_context_rows(bn, model, pcm, probe, k, min_conf)
+    for g in probe:
+        _, ix, cf, ct = want[g]
+        assert cnt[g] == ct, g
+        assert np.array_equal(idx[g, :ct], ix[:ct]) and conf[g, :ct].tobytes() == cf[:ct].tobytes(), g
+    # periodicity of the synthetic recording is a property the whole result must have: window g and g + 97 hold the same
+    # samples (except across the truncated tail), so their rows are bit-identical wherever they were batched or sharded
+    a, b = slice(0, 28800 - 97 - 1), slice(97, 28800 - 1)
+    assert np.array_equal(cnt[a], cnt[b])
+    live = np.arange(k)[None, :] < cnt[a][:, None]
+    assert np.array_equal(np.where(live, idx[a], 0), np.where(live, idx[b], 0))
+    assert np.where(live, conf[a], 0).tobytes() == np.where(live, conf[b], 0).tobytes()
+    assert (cnt > 0).any(), "no window produced a detection: the probe thresholds are too high for this synthetic model"
+    # with the logits requested the same call also returns the [G, N] matrix; checked on a two-hour prefix (600 MB of logits)
+    n2 = 2400 * S
+    lg2, ix2, cf2, ct2 = grp.analyze_recording(pcm[:n2], S, top_k=k, min_confidence=min_conf, want_logits=True)
+    assert lg2.shape == (2400, 6522) and np.array_equal(ct2, cnt[:2400]) and ix2.tobytes() == idx[:2400].tobytes()
+    for g in (0, 1, 31, 32):
+        assert lg2[g].tobytes() == want[g][0].tobytes(), g
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs: exercises ncclCommInitAll + ncclAllGather of csrc/group.cpp")
+def test_group_on_distinct_devices_gathers_over_rccl(bn, v24_small):
+    """Runs the day a multi-GPU box is leased: a group on pairwise distinct devices must take the RCCL branch, and what
+    the last rank holds after the all-gather must equal a single pass bit for bit (logits and top-K rows)."""
+    import torch
+
+    data, path = v24_small
+    ndev = min(torch.cuda.device_count(), 8)
+    rng = np.random.default_rng(7)
+    pcm = np.round(np.clip(synth.synthetic_segments(1, S * (3 * ndev + 1) + 4321, SR)[0] + 0.01 * rng.standard_normal(S * (3 * ndev + 1) + 4321), -1, 1) * 32767).astype(np.int16)
+    step = S - SR  # 1 s overlap: neighbouring shards share samples
+    single = bn.Group([bn.Model(path, device=0)], max_batch=4, contexts_per_device=2)
+    want = single.analyze_recording(pcm, step, top_k=5, min_confidence=0.02, want_logits=True)
+    models = [bn.Model(path, device=d) for d in range(ndev)]
+    grp = bn.Group(models, max_batch=4, contexts_per_device=2)
+    assert grp.size() == ndev and grp.uses_rccl()
+    for want_logits in (True, False):
+        got = grp.analyze_recording(pcm, step, top_k=5, min_confidence=0.02, want_logits=want_logits)
+        if want_logits:
+            assert got[0].tobytes() == want[0].tobytes()
+        else:
+            assert got[0] is None
+        assert np.array_equal(got[3], want[3])
+        for r in range(len(got[3])):
+            c = got[3][r]
+            assert np.array_equal(got[1][r, :c], want[1][r, :c]) and got[2][r, :c].tobytes() == want[2][r, :c].tobytes()
+    assert grp.stats()["capture_fallbacks"] == 0
