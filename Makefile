@@ -7,7 +7,7 @@ SRC := $(PKG)/csrc
 OUT := $(PKG)/libbirdnet_hip.so
 CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Iinclude
 HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH) -ffp-contract=off
-OBJS := $(SRC)/onnx_proto.o $(SRC)/engine.o $(SRC)/detect.o $(SRC)/capi.o $(SRC)/group.o $(SRC)/host_classifier.o $(SRC)/host_capi.o $(SRC)/host_rangefilter.o $(SRC)/kernels.o $(SRC)/topk.o $(SRC)/stft.o $(SRC)/mbrow.o
+OBJS := $(SRC)/onnx_proto.o $(SRC)/engine.o $(SRC)/detect.o $(SRC)/capi.o $(SRC)/group.o $(SRC)/host_classifier.o $(SRC)/host_capi.o $(SRC)/host_rangefilter.o $(SRC)/kernels.o $(SRC)/topk.o $(SRC)/stft.o $(SRC)/mbrow.o $(SRC)/gemm_dma.o $(SRC)/mbmap.o
 
 all: $(OUT) oracle
 

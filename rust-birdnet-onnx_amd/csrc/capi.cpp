@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "hip_gate.h"
+
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -44,7 +46,7 @@ struct PlanDev {
     std::unique_ptr<Plan> plan;
     float *d_consts = nullptr;
     ~PlanDev() {
-        if (d_consts) (void)hipFree(d_consts);
+        if (d_consts) (void)gated::Free(d_consts);
     }
 };
 
@@ -302,8 +304,7 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
             // batch size -- and a capture is not the place to find out what two of them do to each other), in the
             // thread-local mode so that what OTHER threads do to the device meanwhile (uploads, allocations of sibling
             // ranks) is none of this capture's business.
-            static std::mutex capture_mu;
-            std::lock_guard<std::mutex> capture_lock(capture_mu);
+            std::unique_lock<std::shared_mutex> capture_lock(capture_gate());  // hip_gate.h: no allocation / free / synchronous copy of the library overlaps a capture
             (void)hipGetLastError();  // drop stale sticky errors of unrelated earlier calls
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             c->n_captures++;
@@ -356,7 +357,7 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
                     (void)hipStreamSynchronize(c->stream);
                     auto g_old = c->graphs.find(victim->first);
                     if (g_old != c->graphs.end()) {
-                        (void)hipGraphExecDestroy(g_old->second);
+                        (void)hipGraphExecDestroy(g_old->second);  // (the gate is held exclusively here)
                         c->graphs.erase(g_old);
                     }
                     c->graph_used.erase(victim);
@@ -435,10 +436,10 @@ bn_status make_plan(bn_model *m, const std::vector<int> &wanted, std::unique_ptr
     HIP_TRY(hipSetDevice(m->device));
     if (!prepare_device(m->device)) return fail(BN_ERR_BACKEND, "device " + std::to_string(m->device) + " refused the kernels' dynamic-LDS opt-in");
     const Plan &p = *pd->plan;
-    HIP_TRY(hipMalloc(&pd->d_consts, (size_t)p.consts_elems * sizeof(float)));
+    HIP_TRY(gated::Malloc(&pd->d_consts, (size_t)p.consts_elems * sizeof(float)));
     for (size_t k = 0; k < p.consts.size(); k++)
         if (!p.consts[k].empty())
-            HIP_TRY(hipMemcpy(pd->d_consts + p.const_off[k], p.consts[k].data(), p.consts[k].size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(gated::Memcpy(pd->d_consts + p.const_off[k], p.consts[k].data(), p.consts[k].size() * sizeof(float), hipMemcpyHostToDevice));
     out = std::move(pd);
     return BN_OK;
 }
@@ -625,20 +626,20 @@ bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **
     const Plan &p = *pd->plan;
     HIP_TRY(hipSetDevice(m->device));
     if (!prepare_device(m->device)) return fail(BN_ERR_BACKEND, "device " + std::to_string(m->device) + " refused the kernels' dynamic-LDS opt-in");
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(gated::StreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t arena_b = (size_t)p.arena_elems * max_batch * sizeof(float);
     const size_t in_b = (size_t)p.sample_count * max_batch * sizeof(float);
-    HIP_TRY(hipMalloc(&c->d_arena, arena_b));
+    HIP_TRY(gated::Malloc(&c->d_arena, arena_b));
     // the squeeze-excite ticket counters live here and must start at zero; on the context's OWN stream (a legacy-stream
     // hipMemset would serialise against -- and be seen by -- whatever sibling contexts are capturing or running)
     HIP_TRY(hipMemsetAsync(c->d_arena, 0, arena_b, c->stream));
-    HIP_TRY(hipMalloc(&c->d_input, in_b));
+    HIP_TRY(gated::Malloc(&c->d_input, in_b));
     {
         size_t row = (size_t)p.outputs[m->cfg.logits_output].row_elems;
         if (m->cfg.embedding_output >= 0) row += (size_t)p.outputs[m->cfg.embedding_output].row_elems;
         c->h_out_elems = row * max_batch;
     }
-    HIP_TRY(hipHostMalloc(&c->h_out, c->h_out_elems * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(gated::HostMalloc(&c->h_out, c->h_out_elems * sizeof(float), hipHostMallocDefault));
     c->device_bytes = arena_b + in_b;
     m->refs.fetch_add(1, std::memory_order_relaxed);
     c->holds_model = true;
@@ -661,32 +662,32 @@ void bn_ctx_destroy(bn_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->model->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto &kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
-    if (c->d_arena) (void)hipFree(c->d_arena);
-    if (c->d_input) (void)hipFree(c->d_input);
-    if (c->h_out) (void)hipHostFree(c->h_out);
-    if (c->d_tk_idx) (void)hipFree(c->d_tk_idx);
-    if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
-    if (c->d_tk_cnt) (void)hipFree(c->d_tk_cnt);
-    if (c->d_tk_flags) (void)hipFree(c->d_tk_flags);
-    if (c->d_step) (void)hipFree(c->d_step);
-    if (c->h_step) (void)hipHostFree(c->h_step);
+    for (auto &kv : c->graphs) (void)gated::GraphExecDestroy(kv.second);
+    if (c->d_arena) (void)gated::Free(c->d_arena);
+    if (c->d_input) (void)gated::Free(c->d_input);
+    if (c->h_out) (void)gated::HostFree(c->h_out);
+    if (c->d_tk_idx) (void)gated::Free(c->d_tk_idx);
+    if (c->d_tk_conf) (void)gated::Free(c->d_tk_conf);
+    if (c->d_tk_cnt) (void)gated::Free(c->d_tk_cnt);
+    if (c->d_tk_flags) (void)gated::Free(c->d_tk_flags);
+    if (c->d_step) (void)gated::Free(c->d_step);
+    if (c->h_step) (void)gated::HostFree(c->h_step);
     if (c->copy_stream) {
         (void)hipStreamSynchronize(c->copy_stream);
-        (void)hipStreamDestroy(c->copy_stream);
+        (void)gated::StreamDestroy(c->copy_stream);
     }
     for (auto &sl : c->slots) {
         if (sl.owned) {
-            if (sl.d_input) (void)hipFree(sl.d_input);
-            if (sl.h_input) (void)hipHostFree(sl.h_input);
-            if (sl.h_out) (void)hipHostFree(sl.h_out);
+            if (sl.d_input) (void)gated::Free(sl.d_input);
+            if (sl.h_input) (void)gated::HostFree(sl.h_input);
+            if (sl.h_out) (void)gated::HostFree(sl.h_out);
         }
-        if (sl.h_tk) (void)hipHostFree(sl.h_tk);
-        if (sl.h2d_done) (void)hipEventDestroy(sl.h2d_done);
-        if (sl.plan_done) (void)hipEventDestroy(sl.plan_done);
-        if (sl.out_done) (void)hipEventDestroy(sl.out_done);
+        if (sl.h_tk) (void)gated::HostFree(sl.h_tk);
+        if (sl.h2d_done) (void)gated::EventDestroy(sl.h2d_done);
+        if (sl.plan_done) (void)gated::EventDestroy(sl.plan_done);
+        if (sl.out_done) (void)gated::EventDestroy(sl.out_done);
     }
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)gated::StreamDestroy(c->stream);
     bn_model *m = c->holds_model ? c->model : nullptr;
     delete c;
     model_unref(m);
@@ -802,19 +803,19 @@ static bn_status ensure_step_block(bn_ctx *c, size_t k);
 
 static bn_status ensure_slot(bn_ctx *c, bn_ctx::HostSlot &sl, int index) {
     const Plan &p = *c->pd->plan;
-    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->copy_stream) HIP_TRY(gated::StreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!sl.h2d_done) {
-        HIP_TRY(hipEventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sl.plan_done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming));
+        HIP_TRY(gated::EventCreateWithFlags(&sl.h2d_done, hipEventDisableTiming));
+        HIP_TRY(gated::EventCreateWithFlags(&sl.plan_done, hipEventDisableTiming));
+        HIP_TRY(gated::EventCreateWithFlags(&sl.out_done, hipEventDisableTiming));
     }
     if (sl.d_input) return BN_OK;
     (void)index;
     const size_t in_b = (size_t)p.sample_count * c->max_batch * sizeof(float);
     sl.owned = true;
-    HIP_TRY(hipMalloc(&sl.d_input, in_b));
-    HIP_TRY(hipHostMalloc(&sl.h_input, in_b, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(&sl.h_out, c->h_out_elems * sizeof(float), hipHostMallocDefault));
+    HIP_TRY(gated::Malloc(&sl.d_input, in_b));
+    HIP_TRY(gated::HostMalloc(&sl.h_input, in_b, hipHostMallocDefault));
+    HIP_TRY(gated::HostMalloc(&sl.h_out, c->h_out_elems * sizeof(float), hipHostMallocDefault));
     c->device_bytes += in_b;
     return BN_OK;
 }
@@ -854,10 +855,10 @@ bn_status bn_infer_submit(bn_ctx *c, const float *const *segs, size_t batch, siz
         if (st != BN_OK) return st;
         const size_t need = c->max_batch * (2 * k + 1);
         if (need > sl.tk_cap) {
-            if (sl.h_tk) (void)hipHostFree(sl.h_tk);
+            if (sl.h_tk) (void)gated::HostFree(sl.h_tk);
             sl.h_tk = nullptr;
             sl.tk_cap = 0;
-            HIP_TRY(hipHostMalloc(&sl.h_tk, need * sizeof(uint32_t), hipHostMallocDefault));
+            HIP_TRY(gated::HostMalloc(&sl.h_tk, need * sizeof(uint32_t), hipHostMallocDefault));
             sl.tk_cap = need;
         }
     }
@@ -1048,7 +1049,7 @@ bn_status bn_ctx_read_output(bn_ctx *c, int32_t index, size_t batch, float *host
     HIP_TRY(hipSetDevice(c->model->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->in_flight = false;
-    HIP_TRY(hipMemcpy(host_out, d, batch * row * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(gated::Memcpy(host_out, d, batch * row * sizeof(float), hipMemcpyDeviceToHost));
     return BN_OK;
 }
 
@@ -1058,7 +1059,7 @@ size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch, char (*names)[BN_NAME_LEN], 
     if (hipSetDevice(c->model->device) != hipSuccess) return 0;
     (void)hipStreamSynchronize(c->stream);
     std::vector<hipEvent_t> ev(p.ops.size() + 1);
-    for (auto &e : ev) (void)hipEventCreate(&e);
+    for (auto &e : ev) (void)gated::EventCreate(&e);
     // warm (instruction caches, clocks) then measure
     for (auto &op : p.ops) launch_op(c, op, c->d_input, (int64_t)batch);
     (void)hipEventRecord(ev[0], c->stream);
@@ -1075,7 +1076,7 @@ size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch, char (*names)[BN_NAME_LEN], 
     {
         constexpr int NCAL = 16;
         hipEvent_t ce[NCAL + 1];
-        for (auto &e : ce) (void)hipEventCreate(&e);
+        for (auto &e : ce) (void)gated::EventCreate(&e);
         launch_null(c->stream);
         (void)hipEventRecord(ce[0], c->stream);
         for (int k = 0; k < NCAL; k++) {
@@ -1091,7 +1092,7 @@ size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch, char (*names)[BN_NAME_LEN], 
         }
         std::sort(iv.begin(), iv.end());
         overhead_us = std::max(0.0f, iv[NCAL / 2] - 3.6f);
-        for (auto &e : ce) (void)hipEventDestroy(e);
+        for (auto &e : ce) (void)gated::EventDestroy(e);
     }
     (void)hipStreamSynchronize(c->stream);
     for (size_t k = 0; k < p.ops.size() && k < cap; k++) {
@@ -1102,7 +1103,7 @@ size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch, char (*names)[BN_NAME_LEN], 
         if (macs) macs[k] = p.ops[k].macs * (double)batch;
         if (bytes) bytes[k] = p.ops[k].bytes * (double)batch + p.ops[k].weight_bytes;
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
+    for (auto &e : ev) (void)gated::EventDestroy(e);
     return p.ops.size();
 }
 
@@ -1160,16 +1161,16 @@ bn_status bn_topk(bn_ctx *c, size_t batch, size_t top_k, int32_t has_min, float 
 static bn_status ensure_topk_buffers(bn_ctx *c, size_t k) {
     const size_t need = c->max_batch * k;
     if (need > c->tk_cap) {
-        if (c->d_tk_idx) (void)hipFree(c->d_tk_idx);
-        if (c->d_tk_conf) (void)hipFree(c->d_tk_conf);
+        if (c->d_tk_idx) (void)gated::Free(c->d_tk_idx);
+        if (c->d_tk_conf) (void)gated::Free(c->d_tk_conf);
         c->d_tk_idx = nullptr;
         c->d_tk_conf = nullptr;
-        HIP_TRY(hipMalloc(&c->d_tk_idx, need * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&c->d_tk_conf, need * sizeof(float)));
+        HIP_TRY(gated::Malloc(&c->d_tk_idx, need * sizeof(uint32_t)));
+        HIP_TRY(gated::Malloc(&c->d_tk_conf, need * sizeof(float)));
         c->tk_cap = need;
     }
-    if (!c->d_tk_cnt) HIP_TRY(hipMalloc(&c->d_tk_cnt, c->max_batch * sizeof(uint32_t)));
-    if (!c->d_tk_flags) HIP_TRY(hipMalloc(&c->d_tk_flags, c->max_batch * sizeof(uint32_t)));
+    if (!c->d_tk_cnt) HIP_TRY(gated::Malloc(&c->d_tk_cnt, c->max_batch * sizeof(uint32_t)));
+    if (!c->d_tk_flags) HIP_TRY(gated::Malloc(&c->d_tk_flags, c->max_batch * sizeof(uint32_t)));
     return BN_OK;
 }
 
@@ -1181,14 +1182,14 @@ static bn_status ensure_step_block(bn_ctx *c, size_t k) {
     const size_t need = c->max_batch * (2 * k + 1);
     if (need > c->step_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->d_step) (void)hipFree(c->d_step);
-        if (c->h_step) (void)hipHostFree(c->h_step);
+        if (c->d_step) (void)gated::Free(c->d_step);
+        if (c->h_step) (void)gated::HostFree(c->h_step);
         c->d_step = c->h_step = nullptr;
         c->h_tk_idx = c->h_tk_cnt = nullptr;
         c->h_tk_conf = nullptr;
         c->step_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_step, need * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(&c->h_step, need * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(gated::Malloc(&c->d_step, need * sizeof(uint32_t)));
+        HIP_TRY(gated::HostMalloc(&c->h_step, need * sizeof(uint32_t), hipHostMallocDefault));
         c->step_cap = need;
     }
     return BN_OK;
@@ -1264,16 +1265,16 @@ bn_status bn_topk_device(int32_t device, const float *d_logits, size_t rows, siz
     if (!prepare_device(device)) return fail(BN_ERR_BACKEND, "device refused the kernels' dynamic-LDS opt-in");
     uint32_t *d_idx = nullptr, *d_cnt = nullptr, *d_flags = nullptr;
     float *d_conf = nullptr;
-    HIP_TRY(hipMalloc(&d_idx, rows * k * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_conf, rows * k * sizeof(float)));
-    HIP_TRY(hipMalloc(&d_cnt, rows * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&d_flags, rows * sizeof(uint32_t)));
+    HIP_TRY(gated::Malloc(&d_idx, rows * k * sizeof(uint32_t)));
+    HIP_TRY(gated::Malloc(&d_conf, rows * k * sizeof(float)));
+    HIP_TRY(gated::Malloc(&d_cnt, rows * sizeof(uint32_t)));
+    HIP_TRY(gated::Malloc(&d_flags, rows * sizeof(uint32_t)));
     bn_status st = topk_run(device, nullptr, d_logits, rows, n, top_k, has_min, min_conf, k_stride, d_idx, d_conf, d_cnt, d_flags, idx_out, conf_out,
                             count_out);
-    (void)hipFree(d_idx);
-    (void)hipFree(d_conf);
-    (void)hipFree(d_cnt);
-    (void)hipFree(d_flags);
+    (void)gated::Free(d_idx);
+    (void)gated::Free(d_conf);
+    (void)gated::Free(d_cnt);
+    (void)gated::Free(d_flags);
     return st;
 }
 
@@ -1290,14 +1291,14 @@ bn_status bn_topk_host(int32_t device, const float *logits, size_t rows, size_t 
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BN_ERR_NO_DEVICE, "no HIP device is visible; this path has no CPU fallback");
     HIP_TRY(hipSetDevice(device));
     float *d = nullptr;
-    HIP_TRY(hipMalloc(&d, rows * n * sizeof(float)));
-    hipError_t e = hipMemcpy(d, logits, rows * n * sizeof(float), hipMemcpyHostToDevice);
+    HIP_TRY(gated::Malloc(&d, rows * n * sizeof(float)));
+    hipError_t e = gated::Memcpy(d, logits, rows * n * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        (void)hipFree(d);
+        (void)gated::Free(d);
         return fail(BN_ERR_BACKEND, std::string("hipMemcpy: ") + hipGetErrorString(e));
     }
     bn_status st = bn_topk_device(device, d, rows, n, top_k, has_min, min_conf, k_stride, idx_out, conf_out, count_out);
-    (void)hipFree(d);
+    (void)gated::Free(d);
     return st;
 }
 
@@ -1321,11 +1322,11 @@ bn_status bn_recording_create(int32_t device, const void *pcm, size_t n_samples,
     r->format = format;
     r->n_samples = n_samples;
     const size_t bytes = n_samples * (format == BN_PCM_I16 ? sizeof(int16_t) : sizeof(float));
-    HIP_TRY(hipMalloc(&r->d_pcm, std::max<size_t>(bytes, 16)));
+    HIP_TRY(gated::Malloc(&r->d_pcm, std::max<size_t>(bytes, 16)));
     if (bytes) {
-        hipError_t e = hipMemcpy(r->d_pcm, pcm, bytes, hipMemcpyHostToDevice);
+        hipError_t e = gated::Memcpy(r->d_pcm, pcm, bytes, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
-            (void)hipFree(r->d_pcm);
+            (void)gated::Free(r->d_pcm);
             return fail(BN_ERR_BACKEND, std::string("recording upload failed: ") + hipGetErrorString(e));
         }
     }
@@ -1409,19 +1410,19 @@ bn_status bn_recording_create_resampled(int32_t device, const void *pcm, size_t 
     r->format = BN_PCM_F32;
     r->n_samples = n_dst;
     float *d_table = nullptr;
-    hipError_t e = hipMalloc(&r->d_pcm, std::max<size_t>(n_dst * sizeof(float), 16));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_table), t.coef.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(d_table, t.coef.data(), t.coef.size() * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t e = gated::Malloc(&r->d_pcm, std::max<size_t>(n_dst * sizeof(float), 16));
+    if (e == hipSuccess) e = gated::Malloc(reinterpret_cast<void **>(&d_table), t.coef.size() * sizeof(float));
+    if (e == hipSuccess) e = gated::Memcpy(d_table, t.coef.data(), t.coef.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         (void)hipGetLastError();
         launch_resample(nullptr, static_cast<float *>(r->d_pcm), src->d_pcm, format == BN_PCM_I16, d_table, n_samples, n_dst, t.L, t.M, t.T);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (d_table) (void)hipFree(d_table);
+    if (e == hipSuccess) e = gated::DeviceSynchronize();
+    if (d_table) (void)gated::Free(d_table);
     bn_recording_free(src);
     if (e != hipSuccess) {
-        if (r->d_pcm) (void)hipFree(r->d_pcm);
+        if (r->d_pcm) (void)gated::Free(r->d_pcm);
         return fail(BN_ERR_BACKEND, std::string("resampling failed: ") + hipGetErrorString(e));
     }
     *out = r.release();
@@ -1434,14 +1435,14 @@ bn_status bn_recording_read_f32(const bn_recording *r, size_t first, size_t coun
     if (first > r->n_samples || count > r->n_samples - first) return fail(BN_ERR_INVALID_ARG, "sample range exceeds the recording");
     if (count == 0) return BN_OK;
     HIP_TRY(hipSetDevice(r->device));
-    HIP_TRY(hipMemcpy(host_out, static_cast<const float *>(r->d_pcm) + first, count * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(gated::Memcpy(host_out, static_cast<const float *>(r->d_pcm) + first, count * sizeof(float), hipMemcpyDeviceToHost));
     return BN_OK;
 }
 
 void bn_recording_free(bn_recording *r) {
     if (!r) return;
     (void)hipSetDevice(r->device);
-    if (r->d_pcm) (void)hipFree(r->d_pcm);
+    if (r->d_pcm) (void)gated::Free(r->d_pcm);
     delete r;
 }
 
@@ -1468,13 +1469,13 @@ bn_status bn_recording_windows(const bn_recording *r, size_t segment_samples, si
     if (!host_out) return fail(BN_ERR_INVALID_ARG, "null host buffer");
     HIP_TRY(hipSetDevice(r->device));
     float *d = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), count * segment_samples * sizeof(float)));
+    HIP_TRY(gated::Malloc(reinterpret_cast<void **>(&d), count * segment_samples * sizeof(float)));
     (void)hipGetLastError();
     launch_windows(nullptr, d, r->d_pcm, r->format == BN_PCM_I16, r->n_samples, (uint64_t)first_window * step_samples, step_samples, (uint32_t)segment_samples,
                    (uint32_t)count);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpy(host_out, d, count * segment_samples * sizeof(float), hipMemcpyDeviceToHost);
-    (void)hipFree(d);
+    if (e == hipSuccess) e = gated::Memcpy(host_out, d, count * segment_samples * sizeof(float), hipMemcpyDeviceToHost);
+    (void)gated::Free(d);
     if (e != hipSuccess) return fail(BN_ERR_BACKEND, std::string("window kernel failed: ") + hipGetErrorString(e));
     return BN_OK;
 }
@@ -1559,7 +1560,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 if (op.gemm.fold) { snprintf(line, sizeof(line), " fold=%d/%d", op.gemm.fold, op.gemm.fold_n); extra += line; }
                 // which of the three matrix kernels the launcher picks (the LDS-resident framing kernel may still fall back to
                 // the generic one at launch: BN_FRAMELDS=0 or a span that does not fit)
-                extra += op.gemm.fold ? " kernel=frame_fold" : (!(op.gemm.npost || op.gemm.out_strided) && gemm_use_splitk(op.gemm) ? " kernel=splitk" : " kernel=tiled");
+                extra += op.gemm.fold ? " kernel=frame_fold" : gemm_dma_shape(op.gemm) ? " kernel=dma" : (!(op.gemm.npost || op.gemm.out_strided) && gemm_use_splitk(op.gemm) ? " kernel=splitk" : " kernel=tiled");
                 if (op.gemm.npost || op.gemm.out_strided) {
                     snprintf(line, sizeof(line), " post=%d out_rs=%lld out_cs=%lld", op.gemm.npost, (long long)op.gemm.out_rs, (long long)op.gemm.out_cs);
                     extra += line;

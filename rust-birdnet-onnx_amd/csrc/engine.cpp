@@ -2549,11 +2549,23 @@ class Builder {
                 // context throughput drops from 34.2k to 33.1k seg/s.
                 const bool map_off = !(getenv("BN_MBMAP") && std::string(getenv("BN_MBMAP")) == "1");
                 const int64_t map_maxhw = getenv("BN_MBMAP_MAXHW") ? atoll(getenv("BN_MBMAP_MAXHW")) : 512;
-                const bool whole_map = !map_off && H * W <= map_maxhw;
-                const bool producer = pe.kind == OpKind::GEMM && pe.out.space == Space::ARENA && pe.out.id == x.storage && pe.out.offset == 0 &&
-                                      x.offset == 0 && !pe.gemm.has_scale && !pe.gemm.has_res && pe.gemm.rows == H * W && pe.gemm.N == Cin &&
-                                      pe.gemm.lda == pe.gemm.K && pe.gemm.K % 4 == 0 && pe.gemm.K <= (whole_map ? 256 : maxk) && pe.a.offset % 4 == 0 &&
-                                      (pe.a.space != Space::ARENA || plan_.storages[pe.a.id].elems % 4 == 0);
+                const bool producer0 = pe.kind == OpKind::GEMM && pe.out.space == Space::ARENA && pe.out.id == x.storage && pe.out.offset == 0 &&
+                                       x.offset == 0 && !pe.gemm.has_scale && !pe.gemm.has_res && pe.gemm.rows == H * W && pe.gemm.N == Cin &&
+                                       pe.gemm.lda == pe.gemm.K && pe.gemm.K % 4 == 0 && pe.a.offset % 4 == 0 && !pe.gemm.fold && !pe.gemm.npost &&
+                                       (pe.a.space != Space::ARENA || plan_.storages[pe.a.id].elems % 4 == 0);
+                // Whole-map form with the INPUT resident in LDS (mbmap.hip, round 3): one block = one sample's map x a group of
+                // mid channels, input fetched once per block by LDS-DMA, no staging on the vector ALU.  Default wherever a
+                // configuration fits (192- and 48-pixel maps); BN_MBMAP2=0 disables.
+                int map2 = 0;
+                if (producer0) {
+                    MbDesc q{};
+                    q.H = (int32_t)H; q.W = (int32_t)W; q.Cin = pe.gemm.K; q.C = (int32_t)Cin; q.OH = (int32_t)OH; q.OW = (int32_t)OW;
+                    q.k = (int32_t)kw; q.s = (int32_t)strides[1]; q.pt = (int32_t)pt; q.pl = (int32_t)pl;
+                    q.act1 = pe.gemm.act; q.act2 = act.act; q.in_bs = pe.gemm.a_bs;
+                    map2 = mbmap_config(q);
+                }
+                const bool whole_map = map2 != 0 || (!map_off && H * W <= map_maxhw);
+                const bool producer = producer0 && (map2 != 0 || pe.gemm.K <= (whole_map ? 256 : maxk));
                 // halo recompute factor of the expand conv: staged halo pixels / image pixels
                 const int toh0 = strides[1] == 1 ? 8 : 4, tow0 = strides[1] == 1 ? 16 : 8;
                 const int64_t hp = ((toh0 - 1) * strides[1] + kw) * ((tow0 - 1) * strides[1] + kw);
@@ -2563,7 +2575,7 @@ class Builder {
                 MbDesc probe{};
                 probe.k = (int32_t)kw; probe.s = (int32_t)strides[1]; probe.Cin = producer ? pe.gemm.K : 4; probe.C = (int32_t)Cin;
                 probe.H = (int32_t)H; probe.W = (int32_t)W; probe.whole_map = whole_map ? 1 : 0;
-                const bool fits = mbconv_lds_bytes(probe) <= 150 * 1024;
+                const bool fits = map2 != 0 || mbconv_lds_bytes(probe) <= 150 * 1024;
                 const bool tiled_ok = act_zero && ((halo_factor <= maxhalo && big_enough) || force);
                 if (producer && fits && (whole_map || tiled_ok) && sole_consumer(n.inputs[0]) == cur_) {
                     PlanOp mb;
@@ -2595,7 +2607,7 @@ class Builder {
                     m.tiles_x = (int32_t)((OW + tow - 1) / tow); m.tiles_y = (int32_t)((OH + toh - 1) / toh);
                     double halo = (double)((toh - 1) * m.s + m.k) * ((tow - 1) * m.s + m.k) * m.tiles_x * m.tiles_y;
                     if (whole_map) {
-                        m.whole_map = 1;
+                        m.whole_map = map2 ? 2 : 1;
                         m.tiles_x = m.tiles_y = 1;  // one squeeze partial per sample
                         halo = (double)H * W;
                     } else {

@@ -1,0 +1,363 @@
+// 1x1-conv / MatMul GEMM with direct-to-LDS operand staging (gfx950 only).
+//
+// Why a second GEMM kernel.  On this part the exact-f32 matrix instructions and the f32 vector ALU are ONE resource:
+// tools/mfma_valu_probe.cpp times a wave of v_mfma_f32_* and a wave of v_fma_f32 on the same SIMD at the SUM of their
+// solo times, in one instruction stream and in two.  Every vector instruction of a GEMM kernel is therefore paid in
+// full out of the matrix pipe's time, and gemm_mfma_kernel / gemm_splitk_kernel (kernels.hip) spend 9 of them per
+// matrix instruction on global -> VGPR -> LDS staging, address arithmetic and a 16-store-per-tile epilogue (PMC,
+// profiles/r02_v4_pmc_mfma.json).  This kernel has no staging instruction at all:
+//
+//   * both operands arrive by global_load_lds_dwordx4 (LDS-DMA): a wave instruction moves 8 rows x 128 B straight
+//     into a [rows][32 floats] stage image; the per-lane SOURCE address carries the XOR swizzle
+//     (16-byte chunk c of row r lands in slot c ^ ((r >> 1) & 7)) that makes the ds_read_b128 fragment reads
+//     conflict free, the per-stage advance is a scalar add on the uniform base;
+//   * a 3-deep ring of stages, one raw s_barrier and one counted s_waitcnt vmcnt per 32-deep K step, the next two
+//     stages in flight across the barrier;
+//   * v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand: lane (c, q) then holds four CONSECUTIVE output channels
+//     4q..4q+3 of row c, so bias, residual and result move as one dwordx4 per 16x16 tile instead of four dwords;
+//   * a block owns TR rows of ONE sample (TR divides the rows of a sample) x up to 128 output channels: the
+//     squeeze-excite gate of the sample sits in LDS and multiplies the activation fragment (4 v_mul per 16 k);
+//     tiles are 64 x N (N <= 128) or 48 x 64: 16-24 flop per byte fetched from L2 instead of 8 for the 32 x 32
+//     tiles of the split-K kernel, whose time followed its staged bytes.
+//
+// Arithmetic: every output element is one accumulation chain over k in a fixed order (k-slot j of a 16-wide group
+// takes k = 16g + 4q + j), bias added after the sum, activation, then the residual -- independent of the batch size,
+// so a segment's bits do not depend on what shares its batch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+
+#include "device_common.h"
+#include "kernels.h"
+
+namespace bn {
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// epilogue activations this kernel carries (one dispatch on the launch-uniform code); other codes keep the older kernels
+inline __host__ __device__ bool gd_act_ok(int act) {
+    return act == ACT_NONE || act == ACT_RELU || act == ACT_CLIP || act == ACT_SILU || act == ACT_HSWISH || act == ACT_SIGMOID || act == ACT_HSIGMOID;
+}
+template <int N>
+__device__ __forceinline__ void gd_act(int act, float p0, float p1, float (&v)[N]) {
+    if (act == ACT_RELU) map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); });
+    else if (act == ACT_CLIP) map_array<N>(v, [=](float x) { return fminf(fmaxf(x, p0), p1); });
+    else if (act == ACT_SILU) map_array<N>(v, [](float x) { return x * net_sigmoid(x); });
+    else if (act == ACT_HSWISH) map_array<N>(v, [](float x) { return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f); });
+    else if (act == ACT_SIGMOID) map_array<N>(v, [](float x) { return net_sigmoid(x); });
+    else if (act == ACT_HSIGMOID) map_array<N>(v, [=](float x) { return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f); });
+}
+
+#define GD_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+#define GD_GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
+
+// MTW x NTW 16x16 tiles per wave, WM x WN waves per K slice (2 or 4), KS K slices (slice ks takes the 32-deep K
+// steps ks, ks + KS, ... through a ring of D stages of its own; the slices' partial tiles are summed through LDS in
+// slice order at the end): block = 64 WM WN KS threads, tile = (16 MTW WM) rows x (16 NTW WN) channels.  The tile shape
+// does not enter any output element's arithmetic (only KS does), so the launcher may pick it by the batch size.
+template <int MTW, int NTW, int WM, int WN, int KS, int D, bool GATED>
+__global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d, float *__restrict__ C, const float *__restrict__ A, const float *__restrict__ W,
+                                                            const float *__restrict__ bias, const float *__restrict__ res,
+                                                            const float *__restrict__ scale, int tiles_per_sample, int gate_floats) {
+    constexpr int WPS = WM * WN;  // waves per K slice
+    static_assert(WPS == 2 || WPS == 4, "two or four waves per K slice");
+    constexpr int TR = 16 * MTW * WM, BN = 16 * NTW * WN;
+    constexpr int XP = TR / 8, WP = BN / 8, PIECES = XP + WP;  // 1-KiB pieces (8 rows x 128 B) of one stage
+    constexpr int NP = (PIECES + WPS - 1) / WPS;               // pieces every wave issues per stage
+    constexpr int STAGE_FLOATS = (TR + BN) * 32;
+    extern __shared__ __align__(1024) float gd_lds[];
+    float *gate = gd_lds + KS * D * STAGE_FLOATS;  // [gate_floats] (GATED)
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ks = wave / WPS, w4 = wave % WPS;
+    const int lc = lane & 15, lq = lane >> 4;
+    const int wm = w4 % WM, wn = w4 / WM;
+    const int b = blockIdx.x / tiles_per_sample, rt = blockIdx.x - b * tiles_per_sample;
+    const int n0 = blockIdx.y * BN;
+    const int K = d.K;
+    const float *Xb = A + (int64_t)b * d.a_bs + (int64_t)rt * TR * d.lda;  // this tile's rows (lda == K: checked by the launcher)
+    float *ring = gd_lds + ks * D * STAGE_FLOATS;
+
+    // ---- per-lane source offsets of this wave's pieces (elements, relative to Xb / W), swizzle on the source side
+    const int prow = lane >> 3, pslot = lane & 7;
+    uint32_t off[NP], off_tail[NP];
+    bool is_w[NP];
+    uint32_t dst[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        int p = w4 + WPS * j;
+        if (p >= PIECES) p = w4 % PIECES;  // a wave without a piece of its own repeats one (same bytes, same place)
+        const bool w_img = p >= XP;
+        const int row = 8 * (w_img ? p - XP : p) + prow;  // row inside its image
+        const int chunk = pslot ^ ((row >> 1) & 7);       // source chunk that belongs in this slot
+        int grow = row;
+        if (w_img) {
+            grow = n0 + row;
+            grow = grow < d.N ? grow : d.N - 1;
+        }
+        is_w[j] = w_img;
+        off[j] = (uint32_t)grow * (uint32_t)K + 4u * (uint32_t)chunk;
+        off_tail[j] = (uint32_t)grow * (uint32_t)K + 4u * (uint32_t)(chunk & 3);  // half stage: columns 16..31 re-read 0..15
+        dst[j] = (uint32_t)(p * 256);                      // floats from the stage base
+    }
+    const int nst = (K + 31) >> 5;                 // 32-deep K steps of the whole product
+    const int nmine = (nst - ks + KS - 1) / KS;    // ... of this slice: steps ks, ks + KS, ...
+    const int niter = (nst + KS - 1) / KS;         // block-uniform loop count (the barriers)
+    const bool half_tail = (K & 31) != 0;          // K % 32 == 16
+    auto issue = [&](int i) {                      // this slice's i-th step into ring slot i % D
+        const int s = ks + i * KS;
+        float *sb = ring + (i % D) * STAGE_FLOATS;
+        const float *xk = Xb + 32 * s, *wk = W + 32 * s;
+        const bool tail = half_tail && s == nst - 1;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const float *src = (is_w[j] ? wk : xk) + (tail ? off_tail[j] : off[j]);
+            __builtin_amdgcn_global_load_lds(GD_GLB_PTR(src), GD_LDS_PTR(sb + dst[j]), 16, 0, 0);
+        }
+    };
+
+    // ---- prologue: the sample's gate (older than every stage piece, so the first counted wait covers it), D - 1 steps
+    if constexpr (GATED) {
+        const float *gsrc = scale + (int64_t)b * d.s_bs;
+        const int n16 = K >> 2;
+        for (int c0 = wave * 64; c0 < gate_floats / 4; c0 += 64 * WPS * KS) {
+            int c = c0 + lane;
+            c = c < n16 ? c : n16 - 1;
+            __builtin_amdgcn_global_load_lds(GD_GLB_PTR(gsrc + 4 * c), GD_LDS_PTR(gate + 4 * c0), 16, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D - 1; i++)
+        if (i < nmine) issue(i);
+
+    floatx4 acc[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (floats inside a stage): activation rows of this wave's m-tiles, weight rows of its n-tiles
+    int xoff[MTW][2], woff[NTW][2];
+#pragma unroll
+    for (int mt = 0; mt < MTW; mt++) {
+        const int r = (wm * MTW + mt) * 16 + lc;
+#pragma unroll
+        for (int g = 0; g < 2; g++) xoff[mt][g] = r * 32 + 4 * ((4 * g + lq) ^ ((r >> 1) & 7));
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+        const int r = (wn * NTW + nt) * 16 + lc;
+#pragma unroll
+        for (int g = 0; g < 2; g++) woff[nt][g] = TR * 32 + r * 32 + 4 * ((4 * g + lq) ^ ((r >> 1) & 7));
+    }
+
+    for (int i = 0; i < niter; i++) {
+        // This slice's step i has landed once all but the pieces of its YOUNGER steps in flight are done (in-order
+        // completion): min(D - 2, steps left) x NP of them.  lgkmcnt(0): this wave's fragment reads of step i - 1 are done
+        // before anyone refills that slot.
+        const int younger = nmine - 1 - i;  // steps of this slice after i
+        if (D >= 3 && younger >= D - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 2) * NP) : "memory");
+        else if (D >= 4 && younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (i + D - 1 < nmine) issue(i + D - 1);  // into the slot every wave finished reading before the barrier above
+        if (i < nmine) {
+            const int s = ks + i * KS;
+            const float *sb = ring + (i % D) * STAGE_FLOATS;
+            const bool two = !(half_tail && s == nst - 1);
+            // both 16-wide k groups of the step are read up front: the second group's reads are in flight while the first
+            // group's matrix instructions issue, so a wave alone on its SIMD has no read latency between them
+            floatx4 xf[2][MTW], wf[2][NTW], gf[2];
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+#pragma unroll
+                for (int mt = 0; mt < MTW; mt++) xf[g][mt] = *reinterpret_cast<const floatx4 *>(sb + xoff[mt][g]);
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt++) wf[g][nt] = *reinterpret_cast<const floatx4 *>(sb + woff[nt][g]);
+                if constexpr (GATED) gf[g] = *reinterpret_cast<const floatx4 *>(gate + 32 * s + 16 * g + 4 * lq);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                if (g == 0 || two) {
+                    if constexpr (GATED) {
+#pragma unroll
+                        for (int mt = 0; mt < MTW; mt++) xf[g][mt] *= gf[g];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+                            for (int mt = 0; mt < MTW; mt++)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][nt][j], xf[g][mt][j], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- the slices' partial tiles, summed in slice order (fixed: slice 0 + slice 1 (+ slice 2 + slice 3))
+    if constexpr (KS > 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every fragment read of the rings is done: they become the exchange buffer
+        asm volatile("" ::: "memory");
+        floatx4 *xch = reinterpret_cast<floatx4 *>(gd_lds);  // [KS - 1][WPS waves][MTW * NTW][64 lanes]
+        if (ks > 0) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt++) xch[(((ks - 1) * WPS + w4) * (MTW * NTW) + mt * NTW + nt) * 64 + lane] = acc[mt][nt];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ks > 0) return;
+#pragma unroll
+        for (int q = 1; q < KS; q++)
+#pragma unroll
+            for (int mt = 0; mt < MTW; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt++) acc[mt][nt] += xch[(((q - 1) * WPS + w4) * (MTW * NTW) + mt * NTW + nt) * 64 + lane];
+    }
+
+    // ---- epilogue: lane (lc, lq) holds channels nb + 4 lq .. + 3 of row lc of each tile
+    float v[MTW * NTW * 4];
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+        const int n = n0 + (wn * NTW + nt) * 16 + 4 * lq;
+        floatx4 bv = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (d.has_bias && n < d.N) bv = *reinterpret_cast<const floatx4 *>(bias + n);
+#pragma unroll
+        for (int mt = 0; mt < MTW; mt++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[(mt * NTW + nt) * 4 + i] = acc[mt][nt][i] + bv[i];
+    }
+    gd_act<MTW * NTW * 4>(d.act, d.p0, d.p1, v);
+#pragma unroll
+    for (int mt = 0; mt < MTW; mt++) {
+        const int64_t m = (int64_t)rt * TR + (wm * MTW + mt) * 16 + lc;
+        float *crow = C + (int64_t)b * d.c_bs + m * d.ldc;
+        const float *rrow = d.has_res ? res + (int64_t)b * d.r_bs + m * d.ldr : nullptr;
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) {
+            const int n = n0 + (wn * NTW + nt) * 16 + 4 * lq;
+            if (n < d.N) {
+                floatx4 o = floatx4{v[(mt * NTW + nt) * 4], v[(mt * NTW + nt) * 4 + 1], v[(mt * NTW + nt) * 4 + 2], v[(mt * NTW + nt) * 4 + 3]};
+                if (d.has_res) o += *reinterpret_cast<const floatx4 *>(rrow + n);
+                *reinterpret_cast<floatx4 *>(crow + n) = o;
+            }
+        }
+    }
+}
+
+inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int MTW, int NTW, int WM, int WN, int KS, int D>
+size_t cfg_lds(const GemmDesc &d) {
+    constexpr int TR = 16 * MTW * WM, BN = 16 * NTW * WN;
+    const int gate_floats = d.has_scale ? (d.K + 1023) / 1024 * 1024 : 0;  // whole 1-KiB pieces
+    return std::max((size_t)(KS * D * (TR + BN) * 32 + gate_floats), (size_t)((KS - 1) * WM * WN * MTW * NTW * 256)) * sizeof(float);
+}
+
+template <int MTW, int NTW, int WM, int WN, int KS, int D>
+void launch_cfg(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res, const float *scale,
+                int64_t batch) {
+    constexpr int TR = 16 * MTW * WM, BN = 16 * NTW * WN;
+    const int tps = (int)(d.rows / TR);
+    const int gate_floats = d.has_scale ? (d.K + 1023) / 1024 * 1024 : 0;
+    const size_t lds = cfg_lds<MTW, NTW, WM, WN, KS, D>(d);
+    dim3 grid((unsigned)(batch * tps), (unsigned)((d.N + BN - 1) / BN));
+    if (d.has_scale)
+        hipLaunchKernelGGL((gemm_dma_kernel<MTW, NTW, WM, WN, KS, D, true>), grid, dim3(64 * WM * WN * KS), lds, s, d, C, A, W, bias, res, scale, tps, gate_floats);
+    else
+        hipLaunchKernelGGL((gemm_dma_kernel<MTW, NTW, WM, WN, KS, D, false>), grid, dim3(64 * WM * WN * KS), lds, s, d, C, A, W, bias, res, scale, tps, gate_floats);
+}
+
+// K slices per block: a property of the layer's SHAPE (it enters the summation order), deep products (project convs:
+// K 240 .. 1152, head conv) run as two interleaved slices
+inline int gd_kslices(const GemmDesc &d) {
+    static const int force = getenv("BN_GEMMDMA_KS") ? atoi(getenv("BN_GEMMDMA_KS")) : 0;
+    if (force == 1 || force == 2) return force;
+    return d.K >= 192 ? 2 : 1;
+}
+
+}  // namespace
+
+// which block family the LDS-DMA kernel would take for this GEMM (0 = not eligible): per-sample quantities only
+int gemm_dma_shape(const GemmDesc &d) {
+    static const int mode = getenv("BN_GEMMDMA") ? atoi(getenv("BN_GEMMDMA")) : 1;
+    if (mode == 0) return 0;
+    if (d.fold || d.npost || d.out_strided || d.lda != d.K || d.K % 16 || d.K < 32 || d.N % 4 || d.N < 32 || !gd_act_ok(d.act)) return 0;
+    if (d.ldc % 4 || d.c_bs % 4 || d.a_bs % 4 || (d.has_res && (d.ldr % 4 || d.r_bs % 4)) || (d.has_scale && d.s_bs % 4)) return 0;
+    if ((int64_t)d.rows * d.K >= ((int64_t)1 << 30) || (int64_t)d.N * d.K >= ((int64_t)1 << 30)) return 0;  // 32-bit lane offsets
+    if (d.has_scale && d.K > 8192) return 0;
+    // Where it pays (measured, batch 32 and 128, tools/kernel_table.py): deep products with few output channels -- the
+    // project convs and the head conv.  Short-K, wide-N expands are bound by their output stores and their launch, not by
+    // staging: the tiled kernel keeps them (mode 2 sends every eligible shape here, for tests).
+    if (mode != 2 && d.K < 128) return 0;
+    if (d.rows % 32 == 0) return 1;  // 64- or 32-row tiles x up to 128 channels, waves along the rows
+    if (d.rows % 48 == 0) return 2;  // 48-row tiles x 32 / 64 / 128 channels, waves along the channels
+    return 0;
+}
+
+void register_gemm_dma_kernels() {
+#define GD_REG1(MTW, NTW, WM, WN, KS)                                                                               \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_kernel<MTW, NTW, WM, WN, KS, 3, true>));    \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_kernel<MTW, NTW, WM, WN, KS, 3, false>));
+#define GD_REG(MTW, NTW, WM, WN) GD_REG1(MTW, NTW, WM, WN, 1) GD_REG1(MTW, NTW, WM, WN, 2)
+    GD_REG(1, 2, 4, 1) GD_REG(1, 3, 4, 1) GD_REG(1, 4, 4, 1) GD_REG(1, 5, 4, 1) GD_REG(1, 6, 4, 1) GD_REG(1, 7, 4, 1) GD_REG(1, 8, 4, 1)
+    GD_REG(1, 2, 2, 1) GD_REG(1, 3, 2, 1) GD_REG(1, 4, 2, 1) GD_REG(1, 5, 2, 1) GD_REG(1, 6, 2, 1) GD_REG(1, 7, 2, 1) GD_REG(1, 8, 2, 1)
+    GD_REG(3, 1, 1, 2) GD_REG(3, 1, 1, 4) GD_REG(3, 2, 1, 4)
+#undef GD_REG
+#undef GD_REG1
+}
+
+bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res, const float *scale,
+                     int64_t batch) {
+    const int shape = gemm_dma_shape(d);
+    if (!shape || !al16(A) || !al16(W) || !al16(C) || (d.has_res && !al16(res)) || (d.has_bias && !al16(bias)) || (d.has_scale && !al16(scale))) return false;
+    const int ks = gd_kslices(d);
+    // Tile shape by the size of the launch: big tiles (16 - 24 flop per byte staged from L2) once they still give every CU
+    // a block, smaller ones below that so that a batch of 32 spreads over the chip.  BN_GEMMDMA_MINBLOCKS moves the line.
+    static const int64_t min_blocks = getenv("BN_GEMMDMA_MINBLOCKS") ? atoll(getenv("BN_GEMMDMA_MINBLOCKS")) : 192;
+#define GD_GO(MTW, NTW, WM, WN)                                                                  \
+    do {                                                                                         \
+        if (ks == 2 && cfg_lds<MTW, NTW, WM, WN, 2, 3>(d) <= 156 * 1024)                         \
+            launch_cfg<MTW, NTW, WM, WN, 2, 3>(s, d, C, A, W, bias, res, scale, batch);          \
+        else                                                                                     \
+            launch_cfg<MTW, NTW, WM, WN, 1, 3>(s, d, C, A, W, bias, res, scale, batch);          \
+    } while (0)
+#define GD_GO_N(WM)                                 \
+    do {                                            \
+        switch (ntw) {                              \
+            case 2: GD_GO(1, 2, WM, 1); break;      \
+            case 3: GD_GO(1, 3, WM, 1); break;      \
+            case 4: GD_GO(1, 4, WM, 1); break;      \
+            case 5: GD_GO(1, 5, WM, 1); break;      \
+            case 6: GD_GO(1, 6, WM, 1); break;      \
+            case 7: GD_GO(1, 7, WM, 1); break;      \
+            default: GD_GO(1, 8, WM, 1); break;     \
+        }                                           \
+    } while (0)
+    if (shape == 1) {
+        // the fewest channel blocks of at most 128, evenly sized, whole 16-channel tiles
+        const int nb = (d.N + 127) / 128;
+        const int ntw = std::max(2, ((d.N + nb - 1) / nb + 15) / 16);
+        const bool big = d.rows % 64 == 0 && batch * (d.rows / 64) * nb >= min_blocks;
+        if (big) GD_GO_N(4);
+        else GD_GO_N(2);
+    } else {
+        const int64_t tiles = batch * (d.rows / 48);
+        if (d.N > 512 && tiles * ((d.N + 127) / 128) >= min_blocks) GD_GO(3, 2, 1, 4);
+        else if (tiles * ((d.N + 63) / 64) >= min_blocks) GD_GO(3, 1, 1, 4);
+        else GD_GO(3, 1, 1, 2);
+    }
+#undef GD_GO_N
+#undef GD_GO
+    return true;
+}
+
+}  // namespace bn

@@ -14,6 +14,8 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include "hip_gate.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -27,6 +29,8 @@
 #include <vector>
 
 #include "../../include/birdnet_hip.h"
+
+using namespace bn;
 
 namespace {
 
@@ -95,8 +99,8 @@ bn_status gfail(bn_status st, const std::string &msg) {
 
 void free_rank_buffers(bn_group::Rank &r) {
     (void)hipSetDevice(r.device);
-    if (r.d_logits) (void)hipFree(r.d_logits);
-    if (r.d_topk) (void)hipFree(r.d_topk);
+    if (r.d_logits) (void)gated::Free(r.d_logits);
+    if (r.d_topk) (void)gated::Free(r.d_topk);
     r.d_logits = nullptr;
     r.d_topk = nullptr;
     r.cap_rows = r.cap_k = r.cap_rows_logits = 0;
@@ -144,14 +148,14 @@ bn_status bn_group_create(bn_model *const *models, const int32_t *devices, int32
     auto cleanup = [&](bn_status st, const std::string &msg) {
         for (auto &rk : g->ranks) {
             for (bn_ctx *c : rk.ctxs) bn_ctx_destroy(c);
-            if (rk.stream) { (void)hipSetDevice(rk.device); (void)hipStreamDestroy(rk.stream); }
+            if (rk.stream) { (void)hipSetDevice(rk.device); (void)gated::StreamDestroy(rk.stream); }
             if (rk.comm && rccl().ok()) (void)rccl().CommDestroy(rk.comm);
         }
         return gfail(st, msg);
     };
     for (auto &rk : g->ranks) {
         if (hipSetDevice(rk.device) != hipSuccess) return cleanup(BN_ERR_NO_DEVICE, "device " + std::to_string(rk.device) + " is not usable");
-        if (hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess) return cleanup(BN_ERR_BACKEND, "hipStreamCreate failed");
+        if (gated::StreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess) return cleanup(BN_ERR_BACKEND, "hipStreamCreate failed");
         for (int k = 0; k < contexts_per_device; k++) {
             bn_ctx *c = nullptr;
             bn_status st = bn_ctx_create(rk.model, max_batch, BN_CTX_DEFAULT, &c);
@@ -191,7 +195,7 @@ void bn_group_destroy(bn_group *g) {
         for (bn_ctx *c : rk.ctxs) bn_ctx_destroy(c);
         free_rank_buffers(rk);
         if (rk.comm && rccl().ok()) (void)rccl().CommDestroy(rk.comm);
-        if (rk.stream) { (void)hipSetDevice(rk.device); (void)hipStreamDestroy(rk.stream); }
+        if (rk.stream) { (void)hipSetDevice(rk.device); (void)gated::StreamDestroy(rk.stream); }
     }
     delete g;
 }
@@ -247,10 +251,10 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
         if (per > rk.cap_rows || k > rk.cap_k || (logits_out && per > rk.cap_rows_logits)) {
             const bool had_logits = rk.cap_rows_logits > 0;
             free_rank_buffers(rk);
-            if ((logits_out || had_logits) && hipMalloc(&rk.d_logits, R * per * N * sizeof(float)) != hipSuccess)
+            if ((logits_out || had_logits) && gated::Malloc(&rk.d_logits, R * per * N * sizeof(float)) != hipSuccess)
                 return fail(BN_ERR_BACKEND, "out of device memory for the gathered logits");
             if (rk.d_logits) rk.cap_rows_logits = per;
-            if (k && hipMalloc(&rk.d_topk, R * per * tkw * sizeof(uint32_t)) != hipSuccess) return fail(BN_ERR_BACKEND, "out of device memory for the gathered top-K rows");
+            if (k && gated::Malloc(&rk.d_topk, R * per * tkw * sizeof(uint32_t)) != hipSuccess) return fail(BN_ERR_BACKEND, "out of device memory for the gathered top-K rows");
             rk.cap_rows = per;
             rk.cap_k = k;
         }
@@ -378,11 +382,11 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
             size_t lo, hi;
             bn_shard_range(G, (int32_t)r, (int32_t)R, &lo, &hi);
             if (hi == lo) continue;
-            if (logits_out && hipMemcpy(logits_out + lo * N, rk.d_logits + r * per * N, (hi - lo) * N * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            if (logits_out && gated::Memcpy(logits_out + lo * N, rk.d_logits + r * per * N, (hi - lo) * N * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
                 return gfail(BN_ERR_BACKEND, "download of the gathered logits failed");
             if (k && count_out) {
                 std::vector<uint32_t> rows((hi - lo) * tkw);
-                if (hipMemcpy(rows.data(), rk.d_topk + r * per * tkw, rows.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+                if (gated::Memcpy(rows.data(), rk.d_topk + r * per * tkw, rows.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
                     return gfail(BN_ERR_BACKEND, "download of the gathered top-K rows failed");
                 for (size_t i = 0; i < hi - lo; i++) {
                     const uint32_t *row = &rows[i * tkw];

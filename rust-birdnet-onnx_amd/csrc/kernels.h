@@ -144,7 +144,7 @@ struct MbDesc {
     int32_t has_bias1, has_bias2;
     int64_t in_bs, out_bs;
     int32_t tiles_x, tiles_y;  // output tiles of (8x16 at stride 1, 4x8 at stride 2)
-    int32_t whole_map;         // 1: small feature map, one block = (32 mid channels, whole map); w1 is [C][Cin]
+    int32_t whole_map;         // 1: small feature map, one block = (32 mid channels, whole map); w1 is [C][Cin]; 2: mbmap.hip (input resident in LDS)
     // first conv is a k1 x k1 convolution with few input channels (stem) instead of a 1x1 expand: the halo tile is
     // staged as im2col rows, Cin = k1*k1*Cin1 (column order (ky, kx, c)); H, W are its OUTPUT map (what the
     // depthwise conv reads), H1 x W1 x Cin1 the image it reads with stride s1 and padding (pt1, pl1).  k1 == 0: 1x1.
@@ -179,6 +179,11 @@ inline bool mbconv_row_supported(const MbDesc &d) {
 inline int mbconv_row_outw(int k, int s) { return (32 - k) / s + 1; }
 void launch_mbconv_row(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
                        const float *b2, float *gap, int64_t batch);
+// whole-map form with the input resident in LDS (mbmap.hip): configuration this block takes (0 = none; per-sample
+// quantities only), and the launch (false = not eligible, nothing launched)
+int mbmap_config(const MbDesc &d);
+bool launch_mbmap(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
+                  float *gap, int64_t batch);
 struct SeTail;
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1,
                    const float *b1, const float *w2, const float *b2, float *gap, int64_t batch, const SeTail *tail = nullptr);
@@ -242,6 +247,11 @@ inline bool gemm_use_splitk(const GemmDesc &d) {
 inline bool gemm_accepts_post(const GemmDesc &d) { return !d.fold && !d.has_scale && !d.has_res && !gemm_use_splitk(d); }
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W,
                  const float *bias, const float *res, const float *scale, int64_t batch);
+// LDS-DMA GEMM (gemm_dma.hip): 0 = not eligible, 1 = 64-row tiles, 2 = 48-row tiles (per-sample quantities only);
+// launch_gemm_dma returns false (nothing launched) when the shape or a pointer's alignment rules it out.  BN_GEMMDMA=0 disables.
+int gemm_dma_shape(const GemmDesc &d);
+bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res,
+                     const float *scale, int64_t batch);
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w,
                  const float *bias, const float *res, int64_t batch);
 void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w,

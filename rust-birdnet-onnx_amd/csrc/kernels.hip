@@ -66,6 +66,8 @@ void register_dynamic_lds_kernel(const void *kernel) { dyn_lds_kernels().push_ba
 void register_kernels_hip();   // kernels.hip (below)
 void register_stft_kernels();  // stft.hip
 void register_topk_kernels();  // topk.hip
+void register_gemm_dma_kernels();  // gemm_dma.hip
+void register_mbmap_kernels();     // mbmap.hip
 
 bool prepare_device(int dev) {
     if (dev < 0 || dev >= 64) return false;
@@ -76,16 +78,25 @@ bool prepare_device(int dev) {
         register_kernels_hip();
         register_stft_kernels();
         register_topk_kernels();
+        register_gemm_dma_kernels();
+        register_mbmap_kernels();
     }
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) return false;
     if (cur != dev && hipSetDevice(dev) != hipSuccess) return false;
     bool ok = true;
-    for (const void *k : dyn_lds_kernels())
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    for (const void *k : dyn_lds_kernels()) {
+        // the limit is on static + dynamic LDS together: a kernel with static __shared__ arrays gets the remainder
+        hipFuncAttributes fa{};
+        size_t stat = 0;
+        if (hipFuncGetAttributes(&fa, k) == hipSuccess) stat = fa.sharedSizeBytes;
+        else (void)hipGetLastError();
+        const int dyn = (int)(160 * 1024 - std::min<size_t>(stat, 96 * 1024));
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) {
             (void)hipGetLastError();
             ok = false;
         }
+    }
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     g_cu_count[dev].store(v, std::memory_order_relaxed);
@@ -2456,6 +2467,7 @@ void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, con
     const int64_t total_rows = batch * d.rows;
     if (d.npost || d.out_strided) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
     if (d.fold && launch_frame_fold(s, d, C, A, W, bias, batch)) return;
+    if (launch_gemm_dma(s, d, C, A, W, bias, res, scale, batch)) return;  // LDS-DMA kernel (gemm_dma.hip) where its tiles fit the shape
     if (gemm_use_splitk(d)) launch_gemm_splitk(s, d, C, A, W, bias, res, scale, total_rows);
     else launch_gemm_tiled(s, d, C, A, W, bias, res, scale, total_rows);
 }
@@ -2531,6 +2543,10 @@ void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, 
     tail.nblocks = d.tiles_x * d.tiles_y;
     size_t lds = mbconv_lds_bytes(d);
     if (tail.on) lds = std::max(lds, se_tail_lds_bytes(tail.se));
+    if (d.whole_map == 2) {
+        if (!launch_mbmap(s, d, out, in, w1, b1, w2, b2, gap, batch)) launch_error("whole-map MBConv: operands are not 16-byte aligned");
+        return;
+    }
     if (d.whole_map) {
         dim3 gridm((unsigned)((d.C + 31) / 32), (unsigned)batch);
 #define MBM_LAUNCH(K, S)                                                                                                                           \

@@ -196,7 +196,6 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
         if on_gpu:  # the step's rows -> this rank's slab, ordered behind the step on the context's own stream
             with torch.cuda.stream(streams[j % len(ctxs)]):
                 slab[f:f + m].copy_(views[j % len(ctxs)][:m], non_blocking=True)
-                full.record_stream(streams[j % len(ctxs)])  # the caching allocator must not recycle it under a foreign stream
     for j in range(max(0, len(jobs) - len(ctxs)), len(jobs)):
         collect(j)
 
@@ -212,7 +211,7 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
     g_cnt = gather_np(cnt.view(np.int32).reshape(-1, 1), np.int32).view(np.uint32).reshape(-1)
     if on_gpu:
         for c in ctxs:
-            c.synchronize()  # every slab copy has landed
+            c.synchronize()  # every slab copy has landed (`full` stays referenced here until the gather has read it)
         dist.all_gather_into_tensor(full, slab)
         g_logits = full[:G].cpu().numpy()
         # (rows of rank r sit at [r * cap, r * cap + n_r): with equal capacities the first G rows are exactly the windows in

@@ -122,7 +122,7 @@ def _sharded_worker(rank, world, port, model_path, pcm_path, out_dir, overlap):
     d = _il.import_module("rust-birdnet-onnx_amd.distributed")
     model = bn_.Model(model_path, device=0)
     pcm = np.load(pcm_path)
-    logits, idx, conf, cnt = d.analyze_recording_sharded(bn_, model, pcm, overlap, batch=4, streams=2, top_k=5, dist=dist)
+    logits, idx, conf, cnt = d.analyze_recording_sharded(bn_, model, pcm, overlap, batch=4, streams=2, top_k=5, dist=dist, gather="logits")
     np.savez(_os.path.join(out_dir, f"rank{rank}.npz"), logits=logits, idx=idx, conf=conf, cnt=cnt)
     dist.destroy_process_group()
 
@@ -143,7 +143,7 @@ def test_sharded_recording_ingest_two_ranks_equal_single_pass(bn, tmp_path, over
     pcm = np.clip(7000 * np.sin(2 * np.pi * 2200 * t) + rng.normal(0, 700, t.shape), -32768, 32767).astype(np.int16)
     path = write_model(synth.birdnet_v24(num_species=300, width=0.5))
     model = bn.Model(path)
-    want_logits, want_idx, want_conf, want_cnt = dmod.analyze_recording_sharded(bn, model, pcm, overlap, batch=4, streams=2, top_k=5)
+    want_logits, want_idx, want_conf, want_cnt = dmod.analyze_recording_sharded(bn, model, pcm, overlap, batch=4, streams=2, top_k=5, gather="logits")
     windows, starts = reference_windows(pcm, S, overlap, sr)
     ctx = bn.Context(model, 4)
     ref = np.concatenate([ctx.infer(windows[f:f + 4])[0].copy() for f in range(0, len(starts), 4)])
@@ -181,7 +181,7 @@ def _rccl_rehearsal_worker(rank, port, model_path, pcm_path, out_dir):
     dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
     try:
         model = bn.Model(model_path)
-        lg, ix, cf, ct = dmod.analyze_recording_sharded(bn, model, np.load(pcm_path), 1.0, batch=4, streams=2, top_k=5, dist=dist)
+        lg, ix, cf, ct = dmod.analyze_recording_sharded(bn, model, np.load(pcm_path), 1.0, batch=4, streams=2, top_k=5, dist=dist, gather="logits")
         np.savez(os.path.join(out_dir, "rccl.npz"), logits=lg, idx=ix, conf=cf, cnt=ct)
     finally:
         dist.destroy_process_group()
@@ -200,7 +200,7 @@ def test_sharded_recording_device_resident_gather_over_rccl(bn, tmp_path):
     rng = np.random.default_rng(5)
     pcm = np.clip(rng.normal(0, 3000, S * 5 + 999), -32768, 32767).astype(np.int16)
     path = write_model(synth.birdnet_v24(num_species=300, width=0.5))
-    want = dmod.analyze_recording_sharded(bn, bn.Model(path), pcm, 1.0, batch=4, streams=2, top_k=5)
+    want = dmod.analyze_recording_sharded(bn, bn.Model(path), pcm, 1.0, batch=4, streams=2, top_k=5, gather="logits")
     np.save(tmp_path / "pcm.npy", pcm)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -664,16 +664,27 @@ def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride):
         return g.node("Conv", [zz, g.const(wp)], kernel_shape=[1, 1])
     data = op_graph(build, [24, oh, ow])
     import os
-    os.environ["BN_MBMAP"] = "1"  # the whole-map fusion is opt-in (read by the planner at model load)
+    # (a) the round-1 whole-map kernel (opt-in BN_MBMAP=1; the LDS-resident form of round 3 switched off)
+    os.environ["BN_MBMAP"], os.environ["BN_MBMAP2"] = "1", "0"
     try:
         desc = bn.plan_describe(write_model(data))
         assert "MBCONV" in desc and "tiles=1x1" in desc, desc
         got, ref = run_both(bn, data, batch=3)
     finally:
-        del os.environ["BN_MBMAP"]
+        del os.environ["BN_MBMAP"], os.environ["BN_MBMAP2"]
     assert_close(got, ref, f"mbconv map {cin}->{cmid} k{k} s{stride}")
-    # and the default plan (GEMM + whole-map depthwise + excite) on the same graph
-    assert "MBCONV" not in bn.plan_describe(write_model(data))
+    # (b) GEMM + whole-map depthwise + excite on the same graph
+    os.environ["BN_MBMAP2"] = "0"
+    try:
+        assert "MBCONV" not in bn.plan_describe(write_model(data))
+        got3, _ = run_both(bn, data, batch=3)
+    finally:
+        del os.environ["BN_MBMAP2"]
+    assert_close(got3, ref, f"unfused {cin}->{cmid} k{k} s{stride}")
+    # (c) the default plan: the LDS-resident whole-map kernel (mbmap.hip) wherever a configuration fits (192- and
+    # 48-pixel maps with Cin % 16 == 0), the unfused launches elsewhere
+    desc = bn.plan_describe(write_model(data))
+    assert ("MBCONV" in desc) == (h * w in (192, 48) and cin % 16 == 0), desc
     got2, _ = run_both(bn, data, batch=3)
     assert_close(got2, ref, f"gemm + dw map {cin}->{cmid} k{k} s{stride}")
 
