@@ -71,7 +71,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
     extern __shared__ __align__(1024) float gd_lds[];
     float *gate = gd_lds + KS * D * STAGE_FLOATS;  // [gate_floats] (GATED)
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // everything derived from the wave index is wave-uniform: said so (readfirstlane), it lives in scalar registers and the
+    // per-slice branches below are scalar branches (left to itself the compiler carries them per lane: exec-mask
+    // branches, a copy of every accumulator per K step)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ks = wave / WPS, w4 = wave % WPS;
     const int lc = lane & 15, lq = lane >> 4;
     const int wm = w4 % WM, wn = w4 / WM;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
 
     // ---- per-lane source offsets of this wave's pieces (elements, relative to Xb / W), swizzle on the source side
     const int prow = lane >> 3, pslot = lane & 7;
-    uint32_t off[NP], off_tail[NP];
+    uint32_t off[NP];
     bool is_w[NP];
     uint32_t dst[NP];
 #pragma unroll
@@ -100,23 +104,25 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
         }
         is_w[j] = w_img;
         off[j] = (uint32_t)grow * (uint32_t)K + 4u * (uint32_t)chunk;
-        off_tail[j] = (uint32_t)grow * (uint32_t)K + 4u * (uint32_t)(chunk & 3);  // half stage: columns 16..31 re-read 0..15
-        dst[j] = (uint32_t)(p * 256);                      // floats from the stage base
+        dst[j] = (uint32_t)(p * 256);  // floats from the stage base
     }
-    const int nst = (K + 31) >> 5;                 // 32-deep K steps of the whole product
-    const int nmine = (nst - ks + KS - 1) / KS;    // ... of this slice: steps ks, ks + KS, ...
-    const int niter = (nst + KS - 1) / KS;         // block-uniform loop count (the barriers)
-    const bool half_tail = (K & 31) != 0;          // K % 32 == 16
-    auto issue = [&](int i) {                      // this slice's i-th step into ring slot i % D
+    // K steps: nfs full 32-deep ones, then (K % 32 == 16) one HALF step whose stage covers columns K-32 .. K-1 -- memory
+    // that exists, same lane offsets -- and whose second 16-wide group alone is multiplied.  Step s belongs to slice
+    // s % KS; a slice's i-th step is ks + i KS.
+    const int nfs = K >> 5;
+    const bool half_tail = (K & 31) != 0;
+    const int nst = nfs + (half_tail ? 1 : 0);
+    const int nmine = (nst - ks + KS - 1) / KS;
+    const int niter = (nst + KS - 1) / KS;  // block-uniform loop count (the barriers)
+    const int nmain = nfs / KS;             // leading iterations in which EVERY slice has a full step
+    auto issue = [&](int i) {               // this slice's i-th step into ring slot i % D
         const int s = ks + i * KS;
         float *sb = ring + (i % D) * STAGE_FLOATS;
-        const float *xk = Xb + 32 * s, *wk = W + 32 * s;
-        const bool tail = half_tail && s == nst - 1;
+        const int k0 = (half_tail && s == nst - 1) ? K - 32 : 32 * s;
+        const float *xk = Xb + k0, *wk = W + k0;  // uniform bases; the lane offsets are 32-bit
 #pragma unroll
-        for (int j = 0; j < NP; j++) {
-            const float *src = (is_w[j] ? wk : xk) + (tail ? off_tail[j] : off[j]);
-            __builtin_amdgcn_global_load_lds(GD_GLB_PTR(src), GD_LDS_PTR(sb + dst[j]), 16, 0, 0);
-        }
+        for (int j = 0; j < NP; j++)
+            __builtin_amdgcn_global_load_lds(GD_GLB_PTR((is_w[j] ? wk : xk) + off[j]), GD_LDS_PTR(sb + dst[j]), 16, 0, 0);
     };
 
     // ---- prologue: the sample's gate (older than every stage piece, so the first counted wait covers it), D - 1 steps
@@ -154,47 +160,63 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
         for (int g = 0; g < 2; g++) woff[nt][g] = TR * 32 + r * 32 + 4 * ((4 * g + lq) ^ ((r >> 1) & 7));
     }
 
-    for (int i = 0; i < niter; i++) {
-        // This slice's step i has landed once all but the pieces of its YOUNGER steps in flight are done (in-order
-        // completion): min(D - 2, steps left) x NP of them.  lgkmcnt(0): this wave's fragment reads of step i - 1 are done
-        // before anyone refills that slot.
-        const int younger = nmine - 1 - i;  // steps of this slice after i
-        if (D >= 3 && younger >= D - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 2) * NP) : "memory");
-        else if (D >= 4 && younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP) : "memory");
+    // one 16-wide k group of the stage at sb: fragments, gate, matrix instructions
+    auto group = [&](const float *sb, int g, int kcol) {
+        floatx4 xf[MTW], wf[NTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; mt++) xf[mt] = *reinterpret_cast<const floatx4 *>(sb + xoff[mt][g]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) wf[nt] = *reinterpret_cast<const floatx4 *>(sb + woff[nt][g]);
+        if constexpr (GATED) {  // the gate runs along k: either operand carries it -- the one with fewer fragments
+            const floatx4 gf = *reinterpret_cast<const floatx4 *>(gate + kcol + 4 * lq);
+            if constexpr (NTW < MTW) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt++) wf[nt] *= gf;
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MTW; mt++) xf[mt] *= gf;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+                for (int mt = 0; mt < MTW; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][j], xf[mt][j], acc[mt][nt], 0, 0, 0);
+    };
+    // the wait + barrier that make this slice's step i readable, then the refill of the slot read in iteration i - 1.
+    // Step i has landed once all but the pieces of this slice's YOUNGER steps in flight are done (in-order completion):
+    // min(D - 2, steps left) x NP of them.  lgkmcnt(0): this wave's fragment reads of step i - 1 are done before any
+    // wave refills that slot.
+    auto turn = [&](int i) {
+        if (nmine - 1 - i >= D - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 2) * NP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (i + D - 1 < nmine) issue(i + D - 1);  // into the slot every wave finished reading before the barrier above
+        if (i + D - 1 < nmine) issue(i + D - 1);
+    };
+    static_assert(D == 3, "the counted waits above are written for a ring of three");
+
+    // main loop: every slice multiplies a full step, nothing conditional around the matrix instructions (a branch there
+    // makes the compiler copy all accumulators through VGPRs every iteration)
+    for (int i = 0; i < nmain; i++) {
+        turn(i);
+        const float *sb = ring + (i % D) * STAGE_FLOATS;
+        const int kcol = 32 * (ks + i * KS);
+        group(sb, 0, kcol);
+        group(sb, 1, kcol + 16);
+    }
+    // ragged end: at most two more iterations in which some slices have a full step, one the half step, some none
+    for (int i = nmain; i < niter; i++) {
+        turn(i);
         if (i < nmine) {
             const int s = ks + i * KS;
             const float *sb = ring + (i % D) * STAGE_FLOATS;
-            const bool two = !(half_tail && s == nst - 1);
-            // both 16-wide k groups of the step are read up front: the second group's reads are in flight while the first
-            // group's matrix instructions issue, so a wave alone on its SIMD has no read latency between them
-            floatx4 xf[2][MTW], wf[2][NTW], gf[2];
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-#pragma unroll
-                for (int mt = 0; mt < MTW; mt++) xf[g][mt] = *reinterpret_cast<const floatx4 *>(sb + xoff[mt][g]);
-#pragma unroll
-                for (int nt = 0; nt < NTW; nt++) wf[g][nt] = *reinterpret_cast<const floatx4 *>(sb + woff[nt][g]);
-                if constexpr (GATED) gf[g] = *reinterpret_cast<const floatx4 *>(gate + 32 * s + 16 * g + 4 * lq);
-            }
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-                if (g == 0 || two) {
-                    if constexpr (GATED) {
-#pragma unroll
-                        for (int mt = 0; mt < MTW; mt++) xf[g][mt] *= gf[g];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-#pragma unroll
-                        for (int nt = 0; nt < NTW; nt++)
-#pragma unroll
-                            for (int mt = 0; mt < MTW; mt++)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[g][nt][j], xf[g][mt][j], acc[mt][nt], 0, 0, 0);
-                }
+            if (half_tail && s == nst - 1) {
+                group(sb, 1, K - 16);
+            } else {
+                group(sb, 0, 32 * s);
+                group(sb, 1, 32 * s + 16);
             }
         }
     }
@@ -279,7 +301,7 @@ void launch_cfg(hipStream_t s, const GemmDesc &d, float *C, const float *A, cons
 // K slices per block: a property of the layer's SHAPE (it enters the summation order), deep products (project convs:
 // K 240 .. 1152, head conv) run as two interleaved slices
 inline int gd_kslices(const GemmDesc &d) {
-    static const int force = getenv("BN_GEMMDMA_KS") ? atoi(getenv("BN_GEMMDMA_KS")) : 0;
+    const int force = getenv("BN_GEMMDMA_KS") ? atoi(getenv("BN_GEMMDMA_KS")) : 0;
     if (force == 1 || force == 2) return force;
     return d.K >= 192 ? 2 : 1;
 }
@@ -288,7 +310,7 @@ inline int gd_kslices(const GemmDesc &d) {
 
 // which block family the LDS-DMA kernel would take for this GEMM (0 = not eligible): per-sample quantities only
 int gemm_dma_shape(const GemmDesc &d) {
-    static const int mode = getenv("BN_GEMMDMA") ? atoi(getenv("BN_GEMMDMA")) : 1;
+    const int mode = getenv("BN_GEMMDMA") ? atoi(getenv("BN_GEMMDMA")) : 1;  // read per call (tests switch it at run time)
     if (mode == 0) return 0;
     if (d.fold || d.npost || d.out_strided || d.lda != d.K || d.K % 16 || d.K < 32 || d.N % 4 || d.N < 32 || !gd_act_ok(d.act)) return 0;
     if (d.ldc % 4 || d.c_bs % 4 || d.a_bs % 4 || (d.has_res && (d.ldr % 4 || d.r_bs % 4)) || (d.has_scale && d.s_bs % 4)) return 0;
@@ -322,7 +344,7 @@ bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A,
     const int ks = gd_kslices(d);
     // Tile shape by the size of the launch: big tiles (16 - 24 flop per byte staged from L2) once they still give every CU
     // a block, smaller ones below that so that a batch of 32 spreads over the chip.  BN_GEMMDMA_MINBLOCKS moves the line.
-    static const int64_t min_blocks = getenv("BN_GEMMDMA_MINBLOCKS") ? atoll(getenv("BN_GEMMDMA_MINBLOCKS")) : 192;
+    const int64_t min_blocks = getenv("BN_GEMMDMA_MINBLOCKS") ? atoll(getenv("BN_GEMMDMA_MINBLOCKS")) : 192;
 #define GD_GO(MTW, NTW, WM, WN)                                                                  \
     do {                                                                                         \
         if (ks == 2 && cfg_lds<MTW, NTW, WM, WN, 2, 3>(d) <= 156 * 1024)                         \

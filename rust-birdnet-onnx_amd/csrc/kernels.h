@@ -154,6 +154,7 @@ struct MbDesc {
     // row-streaming form (mbrow.hip): tiles_x = strips of mbconv_row_outw(k, s) output columns, tiles_y = bands of
     // toh output rows; 0 = the tiled kernels above
     int32_t row_mode, toh;
+    int32_t dbg;  // mbmap.hip experiments (BN_MM_DBG bit mask, set by the launcher): skip phases to time the rest
 };
 // MaxPool / AveragePool over an NHWC tensor (1-D pooling = H == 1).
 struct PoolDesc {

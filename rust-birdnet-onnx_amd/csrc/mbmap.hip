@@ -12,9 +12,13 @@
 //   * expand: v_mfma_f32_16x16x4_f32 with the FILTERS as the A operand, so a lane ends up with four consecutive
 //     channels of one pixel and writes its activated tile into the chunk image Es with one ds_write_b128 per tile; the
 //     accumulators start at the expand bias; fragments of the next 16-wide k group are read while this group multiplies;
-//   * Es is [H][W + K - 1][NC] with zero columns left and right: the depthwise window needs no horizontal bound
-//     checks (vertical ones are wave-uniform branches); lane = channel (conflict-free LDS reads, 256 / 128 contiguous
-//     bytes per stored pixel), every lane group slides the window along PPG consecutive outputs of a row;
+//   * Es is [H][W + K - 1][NC + 4] with zero columns left and right (no horizontal bound checks; the 4 floats of
+//     padding per pixel make the tile stores conflict free); depthwise: lane = channel (conflict-free LDS reads, 256 /
+//     128 contiguous bytes per stored pixel), lane group = a strip of PPG output columns over ALL rows: every input
+//     row of the strip is read from LDS once and feeds the accumulators of the <= K output rows it touches.  The map
+//     size and the padding are template parameters, so the whole phase is straight-line code -- no division, no
+//     branch, every (input row, tap) -> output row relation resolved at compile time (the first version walked
+//     row segments with run-time bounds: 5 - 7 us per chunk against 3 us for the expand it follows);
 //   * the squeeze sums are complete per (sample, channel): the excite kernel adds nothing up (splits = 1).
 //
 // Arithmetic order per output: expand = bias + k ascending in 16-wide groups (k-slot j of a group: k = 16 g + 4 q + j),
@@ -38,15 +42,30 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int mm_kib(int floats) { return (floats + 255) & ~255; }  // LDS-DMA writes whole 1-KiB pieces
 
-// dense global -> LDS copy of `floats` floats (a multiple of 4) in 1-KiB pieces, piece p by wave p % NWAVES; lanes past
-// the end re-read the last 16 bytes into the region's padding (every region is padded to whole pieces)
-template <int NWAVES>
-__device__ __forceinline__ void mm_copy(float *lds_dst, const float *gsrc, int floats, int wave, int lane) {
-    const int n16 = floats >> 2;
+// Row swizzle of the [rows][Cin] LDS images (input map, filter chunk).  A ds_read_b128 fragment read touches 16 rows at
+// one k position; with a row stride of Cin floats they fall on 64 / gcd(64, Cin mod 64) ... banks: 2-way conflicts for
+// Cin = 80 / 112, 8-way for Cin = 192 (measured: 45 - 83 % of the LDS cycles of the first version were conflicts).  The
+// LDS-DMA destination is lane-linear, so the permutation goes on the SOURCE address (16-byte chunk c of row r is
+// stored in slot c ^ swz(r)) and on the read:
+//   SWZ16 = false (Cin mod 64 in {16, 48}):  swz(r) = 3 ((r >> 3) & 1)      -- inside each 64-byte k group
+//   SWZ16 = true  (Cin mod 64 == 0):         swz(r) = r & 15                 -- inside each 256-byte block of 4 k groups
+// both conflict free for the lane groups of ds_read_b128 (MI355X guide, LDS table).
+template <bool SWZ16>
+__device__ __forceinline__ int mm_swz(int r) { return SWZ16 ? (r & 15) : 3 * ((r >> 3) & 1); }
+
+// dense global -> LDS copy of `rows` rows of CH 16-byte chunks in 1-KiB pieces, piece p by wave p % NWAVES, with the
+// row swizzle; inv_ch = floor(2^32 / CH) + 1 (slot -> row by one multiply-high); lanes past the end re-read the last
+// chunk into the region's padding (every region is padded to whole pieces)
+template <int NWAVES, bool SWZ16>
+__device__ __forceinline__ void mm_copy(float *lds_dst, const float *gsrc, int rows, int CH, uint32_t inv_ch, int wave, int lane) {
+    const int n16 = rows * CH;
     for (int c0 = wave * 64; c0 < n16; c0 += NWAVES * 64) {
-        int c = c0 + lane;
-        c = c < n16 ? c : n16 - 1;
-        __builtin_amdgcn_global_load_lds(MM_GLB_PTR(gsrc + 4 * c), MM_LDS_PTR(lds_dst + 4 * c0), 16, 0, 0);
+        int sl = c0 + lane;
+        sl = sl < n16 ? sl : n16 - 1;
+        const int r = (int)__umulhi((uint32_t)sl, inv_ch);
+        const int c = sl - r * CH;
+        const int src = r * CH + (c ^ mm_swz<SWZ16>(r));
+        __builtin_amdgcn_global_load_lds(MM_GLB_PTR(gsrc + 4 * src), MM_LDS_PTR(lds_dst + 4 * c0), 16, 0, 0);
     }
 }
 
@@ -60,21 +79,27 @@ __device__ __forceinline__ void mm_act(int act, float p0, float p1, float (&v)[N
 
 // K x K depthwise, stride S; MW x NW 16x16 tiles per wave, WM x WN waves: the map has exactly 16 MW WM pixels, a chunk
 // 16 NW WN channels; PPG outputs per window slide
-template <int K, int S, int MW, int NW, int WM, int WN, int PPG>
+template <int K, int S, int MW, int NW, int WM, int WN, int H, int W, bool SWZ16>
 __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                              const float *__restrict__ w1, const float *__restrict__ b1,
                                                              const float *__restrict__ w2, const float *__restrict__ b2,
-                                                             float *__restrict__ gap, int nch) {
+                                                             float *__restrict__ gap, int nch, uint32_t inv_ch) {
     constexpr int NWAVES = WM * WN, T = 64 * NWAVES, HW = 16 * MW * WM, NC = 16 * NW * WN, NG = T / NC;
-    constexpr int IWS = (PPG - 1) * S + K;
+    static_assert(H * W == HW, "the map is exactly the pixels of the wave tiles");
+    constexpr int PT = (K - 1) / 2;  // padding on every side (checked by mbmap_config)
+    constexpr int OH = (H + 2 * PT - K) / S + 1, OW = (W + 2 * PT - K) / S + 1;
+    static_assert(OW % NG == 0, "one strip of output columns per lane group");
+    constexpr int PPG = OW / NG, IWS = (PPG - 1) * S + K, WP = W + K - 1;
+    constexpr int EP = NC + 4;  // floats per pixel of the chunk image: 4 of padding make the tile stores conflict free
     extern __shared__ __align__(1024) float mm_lds[];
-    const int Cin = d.Cin, WP = d.W + K - 1;
+    const int Cin = d.Cin, CH = Cin >> 2;
     float *Xs = mm_lds;                                   // [HW][Cin]
     float *Ws = Xs + mm_kib(HW * Cin);                    // [2][NC][Cin]
     const int wsz = mm_kib(NC * Cin);
-    float *Es = Ws + 2 * wsz;                             // [H][WP][NC], columns < pl and >= pl + W stay zero
-    float *red = Es + mm_kib(d.H * WP * NC);              // [NG][NC]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float *Es = Ws + 2 * wsz;                             // [H][WP][EP], columns < pl and >= pl + W stay zero
+    float *red = Es + mm_kib(H * WP * EP);                // [NG][NC]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar registers, scalar branches
     const int lc = lane & 15, lq = lane >> 4;
     const int wm = wave % WM, wn = wave / WM;
     const int64_t b = blockIdx.y;
@@ -82,26 +107,41 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
     const int nchunks = min(nch, (d.C - cbase + NC - 1) / NC);
 
     // ---- prologue: the sample's input and the first filter chunk on their way, the chunk image zeroed meanwhile
-    mm_copy<NWAVES>(Xs, in + b * d.in_bs, HW * Cin, wave, lane);
-    mm_copy<NWAVES>(Ws, w1 + (int64_t)cbase * Cin, min(NC, d.C - cbase) * Cin, wave, lane);
-    for (int i = tid * 4; i < d.H * WP * NC; i += T * 4) *reinterpret_cast<floatx4 *>(Es + i) = floatx4{0.f, 0.f, 0.f, 0.f};
+    mm_copy<NWAVES, SWZ16>(Xs, in + b * d.in_bs, HW, CH, inv_ch, wave, lane);
+    mm_copy<NWAVES, SWZ16>(Ws, w1 + (int64_t)cbase * Cin, min(NC, d.C - cbase), CH, inv_ch, wave, lane);
+    // the K - 1 padding columns of every row of the chunk image are zero and stay zero (the expand writes the interior)
+    for (int i = tid; i < H * (K - 1) * (EP / 4); i += T) {
+        const int q4 = i % (EP / 4), pc = (i / (EP / 4)) % (K - 1), y = i / ((EP / 4) * (K - 1));
+        const int xcol = pc < PT ? pc : W + pc;
+        *reinterpret_cast<floatx4 *>(Es + (y * WP + xcol) * EP + 4 * q4) = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
 
-    // fragment offsets: this wave's pixels (B operand rows of Xs) and channels (A operand rows of the filter chunk)
-    int xrow[MW], epix[MW], wrow[NW];
+    // fragment offsets: this wave's pixels (B operand rows of Xs) and channels (A operand rows of the filter chunk).
+    // SWZ16: four offsets per row, one per k group of a 256-byte block (group gg of the block sits in chunk slots
+    // 4 (gg ^ (swz >> 2)) + (lq ^ (swz & 3))); else one offset, the k group adds 16 floats
+    constexpr int NOFF = SWZ16 ? 4 : 1;
+    int xrow[MW][NOFF], epix[MW], wrow[NW][NOFF];
 #pragma unroll
     for (int mt = 0; mt < MW; mt++) {
         const int m = (wm * MW + mt) * 16 + lc;
-        xrow[mt] = m * Cin + 4 * lq;
-        const int y = m / d.W, x = m - y * d.W;
-        epix[mt] = (y * WP + x + d.pl) * NC;
+        const int sw = mm_swz<SWZ16>(m);
+#pragma unroll
+        for (int gg = 0; gg < NOFF; gg++) xrow[mt][gg] = m * Cin + 16 * (gg ^ (sw >> 2)) + 4 * (lq ^ (sw & 3));
+        const int y = m / W, x = m - y * W;
+        epix[mt] = (y * WP + x + PT) * EP;
     }
 #pragma unroll
-    for (int nt = 0; nt < NW; nt++) wrow[nt] = ((wn * NW + nt) * 16 + lc) * Cin + 4 * lq;
-    const int G = Cin >> 4;  // 16-wide k groups (Cin % 16 == 0: checked by the planner)
+    for (int nt = 0; nt < NW; nt++) {
+        const int r = (wn * NW + nt) * 16 + lc;
+        const int sw = mm_swz<SWZ16>(r);
+#pragma unroll
+        for (int gg = 0; gg < NOFF; gg++) wrow[nt][gg] = r * Cin + 16 * (gg ^ (sw >> 2)) + 4 * (lq ^ (sw & 3));
+    }
+    const int G = Cin >> 4;  // 16-wide k groups (Cin % 16 == 0; SWZ16: Cin % 64 == 0, so G % 4 == 0)
 
-    // depthwise mapping: lane = channel, NG lane groups over the output segments
+    // depthwise mapping: lane = channel, lane group = strip of PPG output columns
     const int c = tid % NC, grp = tid / NC;
-    const int nsx = (d.OW + PPG - 1) / PPG, nseg = d.OH * nsx;
+    const int ox0 = grp * PPG;
 
     for (int ch = 0; ch < nchunks; ch++) {
         const int c0 = cbase + ch * NC;
@@ -130,40 +170,49 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
 #pragma unroll
             for (int nt = 0; nt < NW; nt++) acc[mt][nt] = bias4[nt];
         // the next chunk's filters start moving now (their buffer was last read two barriers ago)
-        if (ch + 1 < nchunks) mm_copy<NWAVES>(Ws + ((ch + 1) & 1) * wsz, w1 + (int64_t)(c0 + NC) * Cin, min(NC, d.C - c0 - NC) * Cin, wave, lane);
+        if (ch + 1 < nchunks) mm_copy<NWAVES, SWZ16>(Ws + ((ch + 1) & 1) * wsz, w1 + (int64_t)(c0 + NC) * Cin, min(NC, d.C - c0 - NC), CH, inv_ch, wave, lane);
 
-        // ---- expand: D[channel][pixel] += W[channel][k] X[pixel][k]
+        // ---- expand: D[channel][pixel] += W[channel][k] X[pixel][k]; the fragments of group g + 1 are read while group g
+        // multiplies (two register sets, the loop walks two groups per trip; G is even in every supported shape but 5, 7:
+        // the odd tail is one more group)
         floatx4 xa[MW], wa[NW], xb[MW], wb[NW];
+        auto rd = [&](floatx4 (&xf)[MW], floatx4 (&wf)[NW], int blk, int gg) {  // gg: compile-time at every call site
 #pragma unroll
-        for (int mt = 0; mt < MW; mt++) xa[mt] = *reinterpret_cast<const floatx4 *>(Xs + xrow[mt]);
+            for (int mt = 0; mt < MW; mt++) xf[mt] = *reinterpret_cast<const floatx4 *>(Xs + xrow[mt][gg] + blk);
 #pragma unroll
-        for (int nt = 0; nt < NW; nt++) wa[nt] = *reinterpret_cast<const floatx4 *>(Wc + wrow[nt]);
-        for (int g = 0; g < G; g += 2) {
-            if (g + 1 < G) {
-#pragma unroll
-                for (int mt = 0; mt < MW; mt++) xb[mt] = *reinterpret_cast<const floatx4 *>(Xs + xrow[mt] + 16 * (g + 1));
-#pragma unroll
-                for (int nt = 0; nt < NW; nt++) wb[nt] = *reinterpret_cast<const floatx4 *>(Wc + wrow[nt] + 16 * (g + 1));
-            }
+            for (int nt = 0; nt < NW; nt++) wf[nt] = *reinterpret_cast<const floatx4 *>(Wc + wrow[nt][gg] + blk);
+        };
+        auto mm = [&](const floatx4 (&xf)[MW], const floatx4 (&wf)[NW]) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int nt = 0; nt < NW; nt++)
 #pragma unroll
-                    for (int mt = 0; mt < MW; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][j], xa[mt][j], acc[mt][nt], 0, 0, 0);
-            if (g + 1 < G) {
-                if (g + 2 < G) {
+                    for (int mt = 0; mt < MW; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][j], xf[mt][j], acc[mt][nt], 0, 0, 0);
+        };
+        if (d.dbg & 1) {
+        } else if constexpr (SWZ16) {
+            // G % 4 == 0: four groups per trip, the per-row slot of each group precomputed (xrow / wrow [gg])
+            for (int g = 0; g < G; g += 4) {
 #pragma unroll
-                    for (int mt = 0; mt < MW; mt++) xa[mt] = *reinterpret_cast<const floatx4 *>(Xs + xrow[mt] + 16 * (g + 2));
-#pragma unroll
-                    for (int nt = 0; nt < NW; nt++) wa[nt] = *reinterpret_cast<const floatx4 *>(Wc + wrow[nt] + 16 * (g + 2));
+                for (int gg = 0; gg < 4; gg += 2) {
+                    rd(xa, wa, 16 * g, gg);
+                    rd(xb, wb, 16 * g, gg + 1);
+                    mm(xa, wa);
+                    mm(xb, wb);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int nt = 0; nt < NW; nt++)
-#pragma unroll
-                        for (int mt = 0; mt < MW; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[nt][j], xb[mt][j], acc[mt][nt], 0, 0, 0);
+            }
+        } else {
+            int g = 0;
+            for (; g + 1 < G; g += 2) {
+                rd(xa, wa, 16 * g, 0);
+                rd(xb, wb, 16 * g + 16, 0);
+                mm(xa, wa);
+                mm(xb, wb);
+            }
+            if (g < G) {
+                rd(xa, wa, 16 * g, 0);
+                mm(xa, wa);
             }
         }
         {
@@ -186,37 +235,48 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
         __builtin_amdgcn_s_barrier();  // the chunk image is complete
         asm volatile("" ::: "memory");
 
-        // ---- depthwise + squeeze
+        // ---- depthwise + squeeze: all OH x PPG outputs of the strip in registers, input rows read once each
         float sum = 0.0f;
-        float *ob = out + b * d.out_bs + cg;
-        for (int seg = grp; seg < nseg; seg += NG) {
-            const int oy = seg / nsx, ox0 = (seg - oy * nsx) * PPG;
-            float ov[PPG];
+        if (!(d.dbg & 2)) {
+            float ov[OH][PPG];
 #pragma unroll
-            for (int q = 0; q < PPG; q++) ov[q] = bz;
+            for (int oy = 0; oy < OH; oy++)
 #pragma unroll
-            for (int ky = 0; ky < K; ky++) {
-                const int iy = oy * S - d.pt + ky;
-                if (iy >= 0 && iy < d.H) {  // uniform over the lane group's wave (a wave holds whole groups)
-                    const float *rp = Es + (iy * WP + ox0 * S) * NC + c;
+                for (int q = 0; q < PPG; q++) ov[oy][q] = bz;
+            const float *rp0 = Es + (ox0 * S) * EP + c;
 #pragma unroll
-                    for (int ix = 0; ix < IWS; ix++) {
-                        const float val = rp[ix * NC];
+            for (int iy = 0; iy < H; iy++) {
+                float val[IWS];
 #pragma unroll
-                        for (int kx = 0; kx < K; kx++)
-                            if (ix - kx >= 0 && (ix - kx) % S == 0 && (ix - kx) / S < PPG) ov[(ix - kx) / S] = fmaf(val, wd[ky * K + kx], ov[(ix - kx) / S]);
+                for (int ix = 0; ix < IWS; ix++) val[ix] = rp0[(iy * WP + ix) * EP];
+#pragma unroll
+                for (int ky = 0; ky < K; ky++) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int t = iy + PT - ky;  // = oy * S for the output row this (input row, tap row) pair feeds
+                    if (t >= 0 && t % S == 0 && t / S < OH) {  // compile time after unrolling
+#pragma unroll
+                        for (int q = 0; q < PPG; q++)
+#pragma unroll
+                            for (int kx = 0; kx < K; kx++) ov[t / S][q] = fmaf(val[q * S + kx], wd[ky * K + kx], ov[t / S][q]);
                     }
                 }
             }
-            mm_act<PPG>(d.act2, d.p0_2, d.p1_2, ov);
-            if (cact) {
-                float *op = ob + (int64_t)(oy * d.OW + ox0) * d.C;
+            float *ob = out + b * d.out_bs + cg;
 #pragma unroll
-                for (int q = 0; q < PPG; q++)
-                    if (ox0 + q < d.OW) {
-                        op[(int64_t)q * d.C] = ov[q];
-                        sum += ov[q];
+            for (int oy = 0; oy < OH; oy++) {
+                float r[PPG];
+#pragma unroll
+                for (int q = 0; q < PPG; q++) r[q] = ov[oy][q];
+                mm_act<PPG>(d.act2, d.p0_2, d.p1_2, r);
+                if (cact) {
+                    float *op = ob + (int64_t)(oy * OW + ox0) * d.C;
+#pragma unroll
+                    for (int q = 0; q < PPG; q++) {
+                        if (!(d.dbg & 4)) op[(int64_t)q * d.C] = r[q];
+                        sum += r[q];
                     }
+                }
             }
         }
         if (d.has_gap) {
@@ -237,7 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
 template <int MW, int NW, int WM, int WN>
 size_t cfg_lds(const MbDesc &d) {
     constexpr int HW = 16 * MW * WM, NC = 16 * NW * WN, NG = 64 * WM * WN / NC;
-    return (size_t)(mm_kib(HW * d.Cin) + 2 * mm_kib(NC * d.Cin) + mm_kib(d.H * (d.W + d.k - 1) * NC) + NG * NC) * sizeof(float);
+    return (size_t)(mm_kib(HW * d.Cin) + 2 * mm_kib(NC * d.Cin) + mm_kib(d.H * (d.W + d.k - 1) * (NC + 4)) + NG * NC) * sizeof(float);
 }
 
 inline bool mm_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -248,42 +308,45 @@ inline bool mm_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15
 //   1: 192-pixel map, chunks of 64 channels, 8 waves      2: 192-pixel map, chunks of 32, 8 waves (wider inputs)
 //   3: 48-pixel map, chunks of 64 channels, 4 waves
 int mbmap_config(const MbDesc &d) {
-    static const int mode = getenv("BN_MBMAP2") ? atoi(getenv("BN_MBMAP2")) : 1;
+    const int mode = getenv("BN_MBMAP2") ? atoi(getenv("BN_MBMAP2")) : 1;  // read per call: plans are built (and tests switch it) at run time
     if (mode == 0) return 0;
     if (d.k1 > 0 || !((d.k == 3 || d.k == 5) && (d.s == 1 || d.s == 2))) return 0;
     if (d.Cin % 16 || d.Cin < 16 || d.C % 4 || d.in_bs % 4 || d.W % 4) return 0;
-    if (d.pl < 0 || d.pl > d.k - 1 || d.pt < 0) return 0;
-    if (d.OH != (d.H + 2 * d.pt - d.k) / d.s + 1 && d.OH != (d.H + d.s - 1) / d.s) return 0;  // "same" or symmetric padding
-    if ((d.OW - 1) * d.s + d.k > d.W + d.k - 1) return 0;                                      // the padded row holds every tap
+    const int pad = (d.k - 1) / 2;  // the kernels are compiled for symmetric "same" padding
+    if (d.pt != pad || d.pl != pad || d.OH != (d.H + 2 * pad - d.k) / d.s + 1 || d.OW != (d.W + 2 * pad - d.k) / d.s + 1) return 0;
     if (!mbconv_row_act_supported(d.act1) || !mbconv_row_act_supported(d.act2)) return 0;
     const size_t cap = 160 * 1024;
-    const int hw = d.H * d.W;
-    if (hw == 192) {
+    const int cls = d.Cin % 64;
+    // (the row swizzle each configuration is compiled with: see mm_swz)
+    if (d.H == 6 && d.W == 32 && (cls == 16 || cls == 48)) {
         if (cfg_lds<3, 2, 4, 2>(d) <= cap) return 1;
         if (cfg_lds<3, 1, 4, 2>(d) <= cap) return 2;
-    } else if (hw == 48) {
+    } else if (d.H == 3 && d.W == 16 && cls == 0) {
         if (cfg_lds<3, 1, 1, 4>(d) <= cap) return 3;
     }
     return 0;
 }
 
-// chunks of channels one block walks (the input is fetched once per block): enough blocks per sample to fill the chip
-// at batch 32 with four contexts, few enough that the input fetch is amortised over at least two chunks
-int mbmap_chunks_per_block(const MbDesc &d, int cfg) {
-    static const int force = getenv("BN_MBMAP2_NCH") ? atoi(getenv("BN_MBMAP2_NCH")) : 0;
-    if (force > 0) return force;
+// chunks of channels one block walks (the input is fetched once per block): the fewest blocks that still give every CU
+// one -- the blocks are LDS-bound to one per CU, so more blocks than CUs means a second round (measured, batch 32:
+// 1152 channels as 288 blocks 32 us, as 192 blocks 25 us) and fewer blocks amortise the input fetch better.  The
+// grouping does not enter the arithmetic (squeeze sums are complete per channel inside a block).
+int mbmap_chunks_per_block(const MbDesc &d, int cfg, int64_t batch) {
+    const int force = getenv("BN_MBMAP2_NCH") ? atoi(getenv("BN_MBMAP2_NCH")) : 0;
     const int nc = cfg == 2 ? 32 : 64;
     const int chunks = (d.C + nc - 1) / nc;
-    return cfg == 2 ? (chunks >= 12 ? 3 : 2) : 2;
+    if (force > 0) return std::min(force, chunks);
+    const int64_t ncu = device_cu_count();
+    return (int)std::max<int64_t>(1, std::min<int64_t>(chunks, (chunks * batch + ncu - 1) / ncu));
 }
 
 void register_mbmap_kernels() {
-#define MM_REG(K, S, MW, NW, WM, WN, PPG) register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_kernel<K, S, MW, NW, WM, WN, PPG>));
-#define MM_REG_KS(MW, NW, WM, WN, P1, P2) \
-    MM_REG(3, 1, MW, NW, WM, WN, P1) MM_REG(5, 1, MW, NW, WM, WN, P1) MM_REG(3, 2, MW, NW, WM, WN, P2) MM_REG(5, 2, MW, NW, WM, WN, P2)
-    MM_REG_KS(3, 2, 4, 2, 8, 4)
-    MM_REG_KS(3, 1, 4, 2, 4, 4)
-    MM_REG_KS(3, 1, 1, 4, 4, 4)
+#define MM_REG(K, S, MW, NW, WM, WN, H, W, SW) register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_kernel<K, S, MW, NW, WM, WN, H, W, SW>));
+#define MM_REG_KS(MW, NW, WM, WN, H, W, SW) \
+    MM_REG(3, 1, MW, NW, WM, WN, H, W, SW) MM_REG(5, 1, MW, NW, WM, WN, H, W, SW) MM_REG(3, 2, MW, NW, WM, WN, H, W, SW) MM_REG(5, 2, MW, NW, WM, WN, H, W, SW)
+    MM_REG_KS(3, 2, 4, 2, 6, 32, false)
+    MM_REG_KS(3, 1, 4, 2, 6, 32, false)
+    MM_REG_KS(3, 1, 1, 4, 3, 16, true)
 #undef MM_REG_KS
 #undef MM_REG
 }
@@ -292,24 +355,28 @@ bool launch_mbmap(hipStream_t s, const MbDesc &d, float *out, const float *in, c
                   float *gap, int64_t batch) {
     const int cfg = mbmap_config(d);
     if (!cfg || !mm_al16(in) || !mm_al16(w1) || !mm_al16(b1)) return false;
-    const int nch = mbmap_chunks_per_block(d, cfg);
-#define MM_GO(K, S, MW, NW, WM, WN, PPG)                                                                                              \
+    MbDesc dd = d;
+    dd.dbg = getenv("BN_MM_DBG") ? atoi(getenv("BN_MM_DBG")) : 0;
+    const int nch = mbmap_chunks_per_block(d, cfg, batch);
+    const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(d.Cin / 4)) + 1u;  // slot -> row of the swizzled copies
+#define MM_GO(K, S, MW, NW, WM, WN, H, W, SW)                                                                                          \
     do {                                                                                                                              \
         constexpr int NC = 16 * NW * WN;                                                                                              \
         dim3 grid((unsigned)((d.C + nch * NC - 1) / (nch * NC)), (unsigned)batch);                                                    \
         const size_t lds_ = cfg_lds<MW, NW, WM, WN>(d);                                                                               \
-        hipLaunchKernelGGL((mbmap_kernel<K, S, MW, NW, WM, WN, PPG>), grid, dim3(64 * WM * WN), lds_, s, d, out, in, w1, b1, w2, b2, gap, nch); \
+        hipLaunchKernelGGL((mbmap_kernel<K, S, MW, NW, WM, WN, H, W, SW>), grid, dim3(64 * WM * WN), lds_, s, dd, out, in, w1, b1, w2, b2, gap, nch, \
+                           inv_ch);                                                                                                   \
     } while (0)
-#define MM_GO_KS(MW, NW, WM, WN, P1, P2)                         \
-    do {                                                         \
-        if (d.k == 3 && d.s == 1) MM_GO(3, 1, MW, NW, WM, WN, P1);      \
-        else if (d.k == 5 && d.s == 1) MM_GO(5, 1, MW, NW, WM, WN, P1); \
-        else if (d.k == 3) MM_GO(3, 2, MW, NW, WM, WN, P2);             \
-        else MM_GO(5, 2, MW, NW, WM, WN, P2);                           \
+#define MM_GO_KS(MW, NW, WM, WN, H, W, SW)                                   \
+    do {                                                                     \
+        if (d.k == 3 && d.s == 1) MM_GO(3, 1, MW, NW, WM, WN, H, W, SW);      \
+        else if (d.k == 5 && d.s == 1) MM_GO(5, 1, MW, NW, WM, WN, H, W, SW); \
+        else if (d.k == 3) MM_GO(3, 2, MW, NW, WM, WN, H, W, SW);             \
+        else MM_GO(5, 2, MW, NW, WM, WN, H, W, SW);                           \
     } while (0)
-    if (cfg == 1) MM_GO_KS(3, 2, 4, 2, 8, 4);
-    else if (cfg == 2) MM_GO_KS(3, 1, 4, 2, 4, 4);
-    else MM_GO_KS(3, 1, 1, 4, 4, 4);
+    if (cfg == 1) MM_GO_KS(3, 2, 4, 2, 6, 32, false);
+    else if (cfg == 2) MM_GO_KS(3, 1, 4, 2, 6, 32, false);
+    else MM_GO_KS(3, 1, 1, 4, 3, 16, true);
 #undef MM_GO_KS
 #undef MM_GO
     return true;
