@@ -245,6 +245,19 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
         }
         case OpKind::REDUCE: launch_reduce(c->stream, op.red, out, a, batch, op.red.pair ? resolve(c, op.b, d_in) : nullptr); break;
         case OpKind::GEMM:
+            if (op.se_fused) {  // squeeze-excite in the GEMM's prologue: only the LDS-DMA kernel carries it (planner rule I)
+                SeInline si{};
+                si.se = op.se;
+                si.partial = resolve(c, op.b, d_in);
+                si.w1 = resolve(c, op.x[0], d_in);
+                si.b1 = resolve(c, op.x[1], d_in);
+                si.w2t = resolve(c, op.x[2], d_in);
+                si.b2 = resolve(c, op.x[3], d_in);
+                if (!launch_gemm_dma(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in),
+                                     resolve(c, op.scale, d_in), batch, &si))
+                    launch_error("GEMM with inline squeeze-excite: operands are not 16-byte aligned");
+                break;
+            }
             launch_gemm(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in),
                         resolve(c, op.scale, d_in), batch);
             break;
@@ -1558,6 +1571,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 snprintf(line, sizeof(line), " rows=%lld K=%d N=%d lda=%lld act=%d bias=%d res=%d gate=%d", (long long)op.gemm.rows, op.gemm.K, op.gemm.N, (long long)op.gemm.lda, op.gemm.act, op.gemm.has_bias, op.gemm.has_res, op.gemm.has_scale);
                 extra = line;
                 if (op.gemm.fold) { snprintf(line, sizeof(line), " fold=%d/%d", op.gemm.fold, op.gemm.fold_n); extra += line; }
+                if (op.gemm.se_inline) { snprintf(line, sizeof(line), " se_inline=%d/%d", op.se.C, op.se.Cr); extra += line; }
                 // which of the three matrix kernels the launcher picks (the LDS-resident framing kernel may still fall back to
                 // the generic one at launch: BN_FRAMELDS=0 or a span that does not fit)
                 extra += op.gemm.fold ? " kernel=frame_fold" : gemm_dma_shape(op.gemm) ? " kernel=dma" : (!(op.gemm.npost || op.gemm.out_strided) && gemm_use_splitk(op.gemm) ? " kernel=splitk" : " kernel=tiled");

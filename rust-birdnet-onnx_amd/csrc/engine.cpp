@@ -185,6 +185,7 @@ class Builder {
         for (auto &op : plan_.ops) {
             (op.mfma ? plan_.macs_mfma : plan_.macs_valu) += op.macs;
             plan_.macs_mfma += op.macs_mfma_extra;
+            plan_.macs_valu += op.macs_valu_extra;
             plan_.act_bytes += op.bytes;
             plan_.weight_bytes += op.weight_bytes;
             plan_.fft_flops += op.flops_fft;
@@ -2855,7 +2856,54 @@ class Builder {
         absorb_chains_into_gemms();
         absorb_into_stft();
         pair_minmax_reductions();
+        absorb_se_into_gemms();
         recompute_liveness();
+    }
+
+    // (I) The two small squeeze-excite products move into the prologue of the GEMM that consumes their gate, when that GEMM
+    // runs on the LDS-DMA kernel (gemm_dma.hip): every block of a sample recomputes the gate from the squeeze partial sums
+    // while its first K steps are in flight.  One launch less per MBConv block -- 7 - 8 us of the serial chain of a step,
+    // of which 3.6 us are the launch itself -- for C x Cr x 8 bytes of L2 reads per block; only up to BN_SEGEMM_MAXC
+    // channels (default 768: at C = 1152 the 442 KB of excite weights per block cost more than the launch they save).
+    // MEASURED (batch 32, v2.4): slower.  A block has 2 - 8 waves for two products the stand-alone excite kernel spreads
+    // over 80 per sample; the prologue is a chain of load latencies (K = 672: project conv 20 -> 52 us against 20 + 8 for
+    // the two launches), four contexts 52.7 k -> 47.2 k segments/s.  Opt-in (BN_SEGEMM=1), kept under test.
+    void absorb_se_into_gemms() {
+        if (!(getenv("BN_SEGEMM") && atoi(getenv("BN_SEGEMM")) == 1)) return;
+        const int max_c = gemm_dma_se_max_channels();
+        std::vector<Ref *> refs;
+        for (size_t j = 0; j < plan_.ops.size(); j++) {
+            if (plan_.ops[j].kind != OpKind::SEFC || plan_.ops[j].out.space != Space::ARENA) continue;
+            const int gate_id = plan_.ops[j].out.id;
+            if (plan_.storages[gate_id].pinned) continue;
+            int cons = -1, users = 0;
+            for (size_t k = 0; k < plan_.ops.size(); k++) {
+                if (k == j) continue;
+                all_refs(plan_.ops[k], refs);
+                bool uses = false;
+                for (Ref *r : refs) uses = uses || (r->space == Space::ARENA && r->id == gate_id);
+                if (uses) { users++; cons = (int)k; }
+            }
+            if (users != 1 || cons < (int)j) continue;
+            PlanOp &g = plan_.ops[cons];
+            const PlanOp &se = plan_.ops[j];
+            if (g.kind != OpKind::GEMM || !g.gemm.has_scale || g.scale.space != Space::ARENA || g.scale.id != gate_id || g.scale.offset != 0 || g.se_fused) continue;
+            if (se.se.C != g.gemm.K || se.se.C > max_c || se.se.C % 4 || !gemm_dma_shape(g.gemm)) continue;
+            g.se_fused = 1;
+            g.se = se.se;
+            g.gemm.se_inline = 1;
+            g.b = se.a;       // squeeze partial sums
+            g.x[0] = se.w;    // W1 [Cr][C]
+            g.x[1] = se.bias;
+            g.x[2] = se.w2;   // W2 transposed [Cr][C]
+            g.x[3] = se.bias2;
+            g.name = se.name + "+" + g.name;
+            g.macs_valu_extra += se.macs;
+            g.weight_bytes += se.weight_bytes;
+            g.bytes += se.bytes;
+            plan_.ops.erase(plan_.ops.begin() + (long)j);
+            j--;
+        }
     }
 
     // (G) Neighbours of an STFT launch move into it:

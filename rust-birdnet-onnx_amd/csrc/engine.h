@@ -46,6 +46,8 @@ struct PlanOp {
     MbDesc mb{};
     PoolDesc pool{};
     FftDesc fft{};
+    // GEMM (gemm.se_inline, planner rule I): the squeeze-excite that PRECEDES it is computed in the GEMM's prologue: `se`
+    // holds its shape, b the squeeze partial sums, x[0..3] its weights (w1, b1, w2 transposed, b2).
     // DWCONV / MBCONV: the squeeze-excite that follows is finished by the launch's last block per sample (kernels.h,
     // SeTail): `se` holds its shape, x[0..3] its weights (w1, b1, w2 transposed, b2), res the gate, scale the
     // per-sample ticket counters (a pinned arena storage of one word per sample, zero between launches)
@@ -53,6 +55,7 @@ struct PlanOp {
     double flops_fft = 0;   // FFT: algorithmic flops per sample counted as an FFT (2.5 L log2 L per real frame) + sparse mel
     double macs = 0;        // per sample
     double macs_mfma_extra = 0;  // MBCONV: the expand part runs on the matrix cores
+    double macs_valu_extra = 0;  // GEMM with the squeeze-excite products in its prologue: those run on the vector ALU
     double bytes = 0;       // algorithmic bytes read+written per sample (weights excluded)
     double weight_bytes = 0;
     bool mfma = false;

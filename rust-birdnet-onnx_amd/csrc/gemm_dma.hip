@@ -58,10 +58,14 @@ __device__ __forceinline__ void gd_act(int act, float p0, float p1, float (&v)[N
 // steps ks, ks + KS, ... through a ring of D stages of its own; the slices' partial tiles are summed through LDS in
 // slice order at the end): block = 64 WM WN KS threads, tile = (16 MTW WM) rows x (16 NTW WN) channels.  The tile shape
 // does not enter any output element's arithmetic (only KS does), so the launcher may pick it by the batch size.
-template <int MTW, int NTW, int WM, int WN, int KS, int D, bool GATED>
+// GATE: 0 = plain, 1 = the squeeze-excite gate of the sample is read from memory, 2 = ... is computed in the prologue from
+// the squeeze partial sums (every block of a sample redoes the two small excite products: one launch less per block,
+// 7 - 8 us of the step's serial chain each; the order of every sum in it is fixed and does not depend on the block shape)
+template <int MTW, int NTW, int WM, int WN, int KS, int D, int GATE>
 __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d, float *__restrict__ C, const float *__restrict__ A, const float *__restrict__ W,
                                                             const float *__restrict__ bias, const float *__restrict__ res,
-                                                            const float *__restrict__ scale, int tiles_per_sample, int gate_floats) {
+                                                            const float *__restrict__ scale, int tiles_per_sample, int gate_floats, SeInline sei) {
+    constexpr bool GATED = GATE != 0;
     constexpr int WPS = WM * WN;  // waves per K slice
     static_assert(WPS == 2 || WPS == 4, "two or four waves per K slice");
     constexpr int TR = 16 * MTW * WM, BN = 16 * NTW * WN;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
     };
 
     // ---- prologue: the sample's gate (older than every stage piece, so the first counted wait covers it), D - 1 steps
-    if constexpr (GATED) {
+    if constexpr (GATE == 1) {
         const float *gsrc = scale + (int64_t)b * d.s_bs;
         const int n16 = K >> 2;
         for (int c0 = wave * 64; c0 < gate_floats / 4; c0 += 64 * WPS * KS) {
@@ -138,6 +142,47 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
 #pragma unroll
     for (int i = 0; i < D - 1; i++)
         if (i < nmine) issue(i);
+
+    if constexpr (GATE == 2) {
+        // the excite products of this block's sample, while the first K steps are on their way.  Fixed orders: squeeze =
+        // splits ascending; hidden unit j = one wave, lane l sums c = l, l + 64, ... then a 6-step butterfly; gate c = one
+        // lane, j ascending.  None of it depends on how many waves the block has.
+        constexpr int T = 64 * WPS * KS, NWV = WPS * KS;
+        const SeFcDesc &se = sei.se;
+        float *sbuf = gate + gate_floats, *hbuf = sbuf + ((se.C + 3) & ~3);
+        const float *pp = sei.partial + (int64_t)b * se.in_bs;
+        for (int c = tid; c < se.C; c += T) {
+            float a = 0.0f;
+            for (int sp = 0; sp < se.splits; sp++) a += pp[(int64_t)sp * se.C + c];
+            sbuf[c] = a * se.inv_hw;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int j = wave; j < se.Cr; j += NWV) {
+            const float *wr = sei.w1 + (int64_t)j * se.C;
+            float a = 0.0f;
+            for (int c = lane; c < se.C; c += 64) a = fmaf(wr[c], sbuf[c], a);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0) {
+                float hv[1] = {a + (sei.b1 ? sei.b1[j] : 0.0f)};
+                gd_act<1>(se.act1, se.p0_1, se.p1_1, hv);
+                hbuf[j] = hv[0];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int c = tid; c < se.C; c += T) {
+            float a = 0.0f;
+            for (int j = 0; j < se.Cr; j++) a = fmaf(sei.w2t[(int64_t)j * se.C + c], hbuf[j], a);
+            float gv[1] = {a + (sei.b2 ? sei.b2[c] : 0.0f)};
+            gd_act<1>(se.act2, se.p0_2, se.p1_2, gv);
+            gate[c] = gv[0];
+        }
+        // (visible to every wave behind the barrier of the first turn() below, which also waits lgkmcnt(0))
+    }
 
     floatx4 acc[MTW][NTW];
 #pragma unroll
@@ -278,24 +323,28 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int MTW, int NTW, int WM, int WN, int KS, int D>
-size_t cfg_lds(const GemmDesc &d) {
+size_t cfg_lds(const GemmDesc &d, int se_cr = 0) {
     constexpr int TR = 16 * MTW * WM, BN = 16 * NTW * WN;
     const int gate_floats = d.has_scale ? (d.K + 1023) / 1024 * 1024 : 0;  // whole 1-KiB pieces
-    return std::max((size_t)(KS * D * (TR + BN) * 32 + gate_floats), (size_t)((KS - 1) * WM * WN * MTW * NTW * 256)) * sizeof(float);
+    const int se_floats = d.se_inline ? ((d.K + 3) & ~3) + ((se_cr + 3) & ~3) : 0;  // squeeze means + hidden units
+    return std::max((size_t)(KS * D * (TR + BN) * 32 + gate_floats + se_floats), (size_t)((KS - 1) * WM * WN * MTW * NTW * 256)) * sizeof(float);
 }
 
 template <int MTW, int NTW, int WM, int WN, int KS, int D>
 void launch_cfg(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res, const float *scale,
-                int64_t batch) {
+                int64_t batch, const SeInline *se) {
     constexpr int TR = 16 * MTW * WM, BN = 16 * NTW * WN;
     const int tps = (int)(d.rows / TR);
     const int gate_floats = d.has_scale ? (d.K + 1023) / 1024 * 1024 : 0;
-    const size_t lds = cfg_lds<MTW, NTW, WM, WN, KS, D>(d);
+    const size_t lds = cfg_lds<MTW, NTW, WM, WN, KS, D>(d, se ? se->se.Cr : 0);
     dim3 grid((unsigned)(batch * tps), (unsigned)((d.N + BN - 1) / BN));
-    if (d.has_scale)
-        hipLaunchKernelGGL((gemm_dma_kernel<MTW, NTW, WM, WN, KS, D, true>), grid, dim3(64 * WM * WN * KS), lds, s, d, C, A, W, bias, res, scale, tps, gate_floats);
+    SeInline none{};
+    if (d.se_inline && se)
+        hipLaunchKernelGGL((gemm_dma_kernel<MTW, NTW, WM, WN, KS, D, 2>), grid, dim3(64 * WM * WN * KS), lds, s, d, C, A, W, bias, res, scale, tps, gate_floats, *se);
+    else if (d.has_scale)
+        hipLaunchKernelGGL((gemm_dma_kernel<MTW, NTW, WM, WN, KS, D, 1>), grid, dim3(64 * WM * WN * KS), lds, s, d, C, A, W, bias, res, scale, tps, gate_floats, none);
     else
-        hipLaunchKernelGGL((gemm_dma_kernel<MTW, NTW, WM, WN, KS, D, false>), grid, dim3(64 * WM * WN * KS), lds, s, d, C, A, W, bias, res, scale, tps, gate_floats);
+        hipLaunchKernelGGL((gemm_dma_kernel<MTW, NTW, WM, WN, KS, D, 0>), grid, dim3(64 * WM * WN * KS), lds, s, d, C, A, W, bias, res, scale, tps, gate_floats, none);
 }
 
 // K slices per block: a property of the layer's SHAPE (it enters the summation order), deep products (project convs:
@@ -327,8 +376,9 @@ int gemm_dma_shape(const GemmDesc &d) {
 
 void register_gemm_dma_kernels() {
 #define GD_REG1(MTW, NTW, WM, WN, KS)                                                                               \
-    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_kernel<MTW, NTW, WM, WN, KS, 3, true>));    \
-    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_kernel<MTW, NTW, WM, WN, KS, 3, false>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_kernel<MTW, NTW, WM, WN, KS, 3, 0>));       \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_kernel<MTW, NTW, WM, WN, KS, 3, 1>));       \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_kernel<MTW, NTW, WM, WN, KS, 3, 2>));
 #define GD_REG(MTW, NTW, WM, WN) GD_REG1(MTW, NTW, WM, WN, 1) GD_REG1(MTW, NTW, WM, WN, 2)
     GD_REG(1, 2, 4, 1) GD_REG(1, 3, 4, 1) GD_REG(1, 4, 4, 1) GD_REG(1, 5, 4, 1) GD_REG(1, 6, 4, 1) GD_REG(1, 7, 4, 1) GD_REG(1, 8, 4, 1)
     GD_REG(1, 2, 2, 1) GD_REG(1, 3, 2, 1) GD_REG(1, 4, 2, 1) GD_REG(1, 5, 2, 1) GD_REG(1, 6, 2, 1) GD_REG(1, 7, 2, 1) GD_REG(1, 8, 2, 1)
@@ -337,20 +387,25 @@ void register_gemm_dma_kernels() {
 #undef GD_REG1
 }
 
+int gemm_dma_se_max_channels() { return getenv("BN_SEGEMM_MAXC") ? atoi(getenv("BN_SEGEMM_MAXC")) : 768; }
+
 bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res, const float *scale,
-                     int64_t batch) {
+                     int64_t batch, const SeInline *se) {
     const int shape = gemm_dma_shape(d);
-    if (!shape || !al16(A) || !al16(W) || !al16(C) || (d.has_res && !al16(res)) || (d.has_bias && !al16(bias)) || (d.has_scale && !al16(scale))) return false;
+    if (!shape || !al16(A) || !al16(W) || !al16(C) || (d.has_res && !al16(res)) || (d.has_bias && !al16(bias)) ||
+        (d.has_scale && !d.se_inline && !al16(scale)))
+        return false;
+    if (d.se_inline && !se) return false;
     const int ks = gd_kslices(d);
     // Tile shape by the size of the launch: big tiles (16 - 24 flop per byte staged from L2) once they still give every CU
     // a block, smaller ones below that so that a batch of 32 spreads over the chip.  BN_GEMMDMA_MINBLOCKS moves the line.
     const int64_t min_blocks = getenv("BN_GEMMDMA_MINBLOCKS") ? atoll(getenv("BN_GEMMDMA_MINBLOCKS")) : 192;
 #define GD_GO(MTW, NTW, WM, WN)                                                                  \
     do {                                                                                         \
-        if (ks == 2 && cfg_lds<MTW, NTW, WM, WN, 2, 3>(d) <= 156 * 1024)                         \
-            launch_cfg<MTW, NTW, WM, WN, 2, 3>(s, d, C, A, W, bias, res, scale, batch);          \
+        if (ks == 2 && cfg_lds<MTW, NTW, WM, WN, 2, 3>(d, se ? se->se.Cr : 0) <= 156 * 1024)     \
+            launch_cfg<MTW, NTW, WM, WN, 2, 3>(s, d, C, A, W, bias, res, scale, batch, se);      \
         else                                                                                     \
-            launch_cfg<MTW, NTW, WM, WN, 1, 3>(s, d, C, A, W, bias, res, scale, batch);          \
+            launch_cfg<MTW, NTW, WM, WN, 1, 3>(s, d, C, A, W, bias, res, scale, batch, se);      \
     } while (0)
 #define GD_GO_N(WM)                                 \
     do {                                            \

@@ -104,6 +104,9 @@ struct GemmDesc {
     int32_t post_act[4];
     float post_p0[4], post_p1[4];
     int64_t out_rs, out_cs;  // element (m, n) of sample b is stored at C + b*c_bs + m*out_rs + n*out_cs
+    // squeeze-excite computed in the GEMM's own prologue (planner rule I, gemm_dma.hip): the gate is not read from
+    // memory, every block derives it from the squeeze partial sums of its sample
+    int32_t se_inline;
 };
 
 // Direct NHWC convolution, weights [kh][kw][cin/groups][cout].
@@ -207,6 +210,12 @@ struct SeFcDesc {
     int64_t in_bs, out_bs;
 };
 
+// Squeeze-excite inside the consuming GEMM (GemmDesc::se_inline): the excite shapes and operands
+struct SeInline {
+    SeFcDesc se;
+    const float *partial, *w1, *b1, *w2t, *b2;  // squeeze partial sums [batch][splits][C]; W1 [Cr][C]; W2 transposed [Cr][C]
+};
+
 // Squeeze-excite finished INSIDE the kernel that produced the squeeze sums (depthwise / fused MBConv launches): every
 // block publishes its partial sums write-through, takes a ticket on a per-sample counter, and the block that draws
 // the last ticket of its sample reduces the partials and runs both excite products -- no separate launch, no
@@ -252,7 +261,9 @@ void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, con
 // launch_gemm_dma returns false (nothing launched) when the shape or a pointer's alignment rules it out.  BN_GEMMDMA=0 disables.
 int gemm_dma_shape(const GemmDesc &d);
 bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res,
-                     const float *scale, int64_t batch);
+                     const float *scale, int64_t batch, const SeInline *se = nullptr);
+// the largest channel count whose excite products a GEMM block computes for itself (BN_SEGEMM_MAXC; 0 = never)
+int gemm_dma_se_max_channels();
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w,
                  const float *bias, const float *res, int64_t batch);
 void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w,

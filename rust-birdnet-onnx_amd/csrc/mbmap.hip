@@ -77,15 +77,18 @@ __device__ __forceinline__ void mm_act(int act, float p0, float p1, float (&v)[N
     else if (act == ACT_HSWISH) map_array<N>(v, [](float x) { return x * fminf(fmaxf(x * (1.0f / 6.0f) + 0.5f, 0.0f), 1.0f); });
 }
 
-// K x K depthwise, stride S; MW x NW 16x16 tiles per wave, WM x WN waves: the map has exactly 16 MW WM pixels, a chunk
-// 16 NW WN channels; PPG outputs per window slide
-template <int K, int S, int MW, int NW, int WM, int WN, int H, int W, bool SWZ16>
-__global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
-                                                             const float *__restrict__ w1, const float *__restrict__ b1,
-                                                             const float *__restrict__ w2, const float *__restrict__ b2,
-                                                             float *__restrict__ gap, int nch, uint32_t inv_ch) {
-    constexpr int NWAVES = WM * WN, T = 64 * NWAVES, HW = 16 * MW * WM, NC = 16 * NW * WN, NG = T / NC;
+// K x K depthwise, stride S; MW x NW 16x16 tiles per wave, WM x WN waves per K slice, KSP K slices (KSP = 2: the k groups of
+// the expand are split between two sets of waves whose partial tiles are added through the chunk image -- twice the
+// waves for the same LDS, used where a map of 48 pixels gives four waves too little to hide anything); the map has
+// exactly H W = 16 MW WM pixels, a chunk 16 NW WN channels
+template <int K, int S, int MW, int NW, int WM, int WN, int KSP, int H, int W, bool SWZ16>
+__global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
+                                                                   const float *__restrict__ w1, const float *__restrict__ b1,
+                                                                   const float *__restrict__ w2, const float *__restrict__ b2,
+                                                                   float *__restrict__ gap, int nch, uint32_t inv_ch) {
+    constexpr int WPS = WM * WN, NWAVES = WPS * KSP, T = 64 * NWAVES, HW = 16 * MW * WM, NC = 16 * NW * WN, NG = T / NC;
     static_assert(H * W == HW, "the map is exactly the pixels of the wave tiles");
+    static_assert(KSP == 1 || (KSP == 2 && SWZ16), "the K split walks the 4-group blocks of the SWZ16 layout");
     constexpr int PT = (K - 1) / 2;  // padding on every side (checked by mbmap_config)
     constexpr int OH = (H + 2 * PT - K) / S + 1, OW = (W + 2 * PT - K) / S + 1;
     static_assert(OW % NG == 0, "one strip of output columns per lane group");
@@ -96,17 +99,18 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
     float *Xs = mm_lds;                                   // [HW][Cin]
     float *Ws = Xs + mm_kib(HW * Cin);                    // [2][NC][Cin]
     const int wsz = mm_kib(NC * Cin);
-    float *Es = Ws + 2 * wsz;                             // [H][WP][EP], columns < pl and >= pl + W stay zero
+    float *Es = Ws + 2 * wsz;                             // [H][WP][EP], columns < PT and >= PT + W stay zero
     float *red = Es + mm_kib(H * WP * EP);                // [NG][NC]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: scalar registers, scalar branches
     const int lc = lane & 15, lq = lane >> 4;
-    const int wm = wave % WM, wn = wave / WM;
+    const int kh = wave / WPS, w4 = wave % WPS;           // K slice, wave inside the slice
+    const int wm = w4 % WM, wn = w4 / WM;
     const int64_t b = blockIdx.y;
     const int cbase = blockIdx.x * nch * NC;              // first mid channel of this block
     const int nchunks = min(nch, (d.C - cbase + NC - 1) / NC);
 
-    // ---- prologue: the sample's input and the first filter chunk on their way, the chunk image zeroed meanwhile
+    // ---- prologue: the sample's input and the first filter chunk on their way, the padding of the chunk image zeroed
     mm_copy<NWAVES, SWZ16>(Xs, in + b * d.in_bs, HW, CH, inv_ch, wave, lane);
     mm_copy<NWAVES, SWZ16>(Ws, w1 + (int64_t)cbase * Cin, min(NC, d.C - cbase), CH, inv_ch, wave, lane);
     // the K - 1 padding columns of every row of the chunk image are zero and stay zero (the expand writes the interior)
@@ -117,16 +121,16 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
     }
 
     // fragment offsets: this wave's pixels (B operand rows of Xs) and channels (A operand rows of the filter chunk).
-    // SWZ16: four offsets per row, one per k group of a 256-byte block (group gg of the block sits in chunk slots
-    // 4 (gg ^ (swz >> 2)) + (lq ^ (swz & 3))); else one offset, the k group adds 16 floats
-    constexpr int NOFF = SWZ16 ? 4 : 1;
-    int xrow[MW][NOFF], epix[MW], wrow[NW][NOFF];
+    // SWZ16: group gg of a 256-byte block sits in chunk slots 4 (gg ^ (swz >> 2)) + (lq ^ (swz & 3)); a wave reads NGG
+    // groups per block (all four, or its slice's two); else one offset, the k group adds 16 floats
+    constexpr int NGG = SWZ16 ? 4 / KSP : 1;
+    int xrow[MW][NGG], epix[MW], wrow[NW][NGG];
 #pragma unroll
     for (int mt = 0; mt < MW; mt++) {
         const int m = (wm * MW + mt) * 16 + lc;
         const int sw = mm_swz<SWZ16>(m);
 #pragma unroll
-        for (int gg = 0; gg < NOFF; gg++) xrow[mt][gg] = m * Cin + 16 * (gg ^ (sw >> 2)) + 4 * (lq ^ (sw & 3));
+        for (int gi = 0; gi < NGG; gi++) xrow[mt][gi] = m * Cin + 16 * ((NGG * kh + gi) ^ (sw >> 2)) + 4 * (lq ^ (sw & 3));
         const int y = m / W, x = m - y * W;
         epix[mt] = (y * WP + x + PT) * EP;
     }
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
         const int r = (wn * NW + nt) * 16 + lc;
         const int sw = mm_swz<SWZ16>(r);
 #pragma unroll
-        for (int gg = 0; gg < NOFF; gg++) wrow[nt][gg] = r * Cin + 16 * (gg ^ (sw >> 2)) + 4 * (lq ^ (sw & 3));
+        for (int gi = 0; gi < NGG; gi++) wrow[nt][gi] = r * Cin + 16 * ((NGG * kh + gi) ^ (sw >> 2)) + 4 * (lq ^ (sw & 3));
     }
     const int G = Cin >> 4;  // 16-wide k groups (Cin % 16 == 0; SWZ16: Cin % 64 == 0, so G % 4 == 0)
 
@@ -143,44 +147,55 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
     const int c = tid % NC, grp = tid / NC;
     const int ox0 = grp * PPG;
 
-    for (int ch = 0; ch < nchunks; ch++) {
-        const int c0 = cbase + ch * NC;
-        float *Wc = Ws + (ch & 1) * wsz;
-        // filters of this chunk (and, first time, the input) have landed; every wave is done with the previous chunk
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // per-lane constants of the chunk: expand bias of the lane's four channels per n-tile, depthwise filter of channel c
+    // per-lane constants of a chunk (expand bias of the lane's four channels per n-tile, depthwise filter and bias of
+    // channel c), fetched one chunk AHEAD: their load latency is hidden behind the previous chunk
+    struct ChunkConst {
         floatx4 bias4[NW];
+        float wd[K * K], bz;
+    };
+    auto fetch = [&](ChunkConst &cc_, int c0) {
 #pragma unroll
         for (int nt = 0; nt < NW; nt++) {
             const int n = c0 + (wn * NW + nt) * 16 + 4 * lq;
-            bias4[nt] = (d.has_bias1 && n < d.C) ? *reinterpret_cast<const floatx4 *>(b1 + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+            cc_.bias4[nt] = (d.has_bias1 && kh == 0 && n < d.C) ? *reinterpret_cast<const floatx4 *>(b1 + n) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
+        const int cl = min(c0 + c, d.C - 1);
+#pragma unroll
+        for (int q = 0; q < K * K; q++) cc_.wd[q] = w2[q * d.C + cl];
+        cc_.bz = d.has_bias2 ? b2[cl] : 0.0f;
+    };
+    ChunkConst nxt;
+    fetch(nxt, cbase);
+    // the first filter chunk and the input have landed, the padding is written
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int c0 = cbase + ch * NC;
+        float *Wc = Ws + (ch & 1) * wsz;
+        const ChunkConst cur = nxt;
         const int cg = c0 + c;
         const bool cact = cg < d.C;
-        const int cc = cact ? cg : d.C - 1;
-        float wd[K * K];
-#pragma unroll
-        for (int q = 0; q < K * K; q++) wd[q] = w2[q * d.C + cc];
-        const float bz = d.has_bias2 ? b2[cc] : 0.0f;
+        // the next chunk's filters and constants start moving now (that filter buffer was last read two barriers ago)
+        if (ch + 1 < nchunks) {
+            mm_copy<NWAVES, SWZ16>(Ws + ((ch + 1) & 1) * wsz, w1 + (int64_t)(c0 + NC) * Cin, min(NC, d.C - c0 - NC), CH, inv_ch, wave, lane);
+            fetch(nxt, c0 + NC);
+        }
         floatx4 acc[MW][NW];
 #pragma unroll
         for (int mt = 0; mt < MW; mt++)
 #pragma unroll
-            for (int nt = 0; nt < NW; nt++) acc[mt][nt] = bias4[nt];
-        // the next chunk's filters start moving now (their buffer was last read two barriers ago)
-        if (ch + 1 < nchunks) mm_copy<NWAVES, SWZ16>(Ws + ((ch + 1) & 1) * wsz, w1 + (int64_t)(c0 + NC) * Cin, min(NC, d.C - c0 - NC), CH, inv_ch, wave, lane);
+            for (int nt = 0; nt < NW; nt++) acc[mt][nt] = cur.bias4[nt];  // (slices past the first start at zero: fetch)
 
-        // ---- expand: D[channel][pixel] += W[channel][k] X[pixel][k]; the fragments of group g + 1 are read while group g
-        // multiplies (two register sets, the loop walks two groups per trip; G is even in every supported shape but 5, 7:
-        // the odd tail is one more group)
+        // ---- expand: D[channel][pixel] += W[channel][k] X[pixel][k]; the fragments of the next group are read while this
+        // group multiplies (two register sets)
         floatx4 xa[MW], wa[NW], xb[MW], wb[NW];
-        auto rd = [&](floatx4 (&xf)[MW], floatx4 (&wf)[NW], int blk, int gg) {  // gg: compile-time at every call site
+        auto rd = [&](floatx4 (&xf)[MW], floatx4 (&wf)[NW], int blk, int gi) {  // gi: compile-time at every call site
 #pragma unroll
-            for (int mt = 0; mt < MW; mt++) xf[mt] = *reinterpret_cast<const floatx4 *>(Xs + xrow[mt][gg] + blk);
+            for (int mt = 0; mt < MW; mt++) xf[mt] = *reinterpret_cast<const floatx4 *>(Xs + xrow[mt][gi] + blk);
 #pragma unroll
-            for (int nt = 0; nt < NW; nt++) wf[nt] = *reinterpret_cast<const floatx4 *>(Wc + wrow[nt][gg] + blk);
+            for (int nt = 0; nt < NW; nt++) wf[nt] = *reinterpret_cast<const floatx4 *>(Wc + wrow[nt][gi] + blk);
         };
         auto mm = [&](const floatx4 (&xf)[MW], const floatx4 (&wf)[NW]) {
 #pragma unroll
@@ -192,12 +207,12 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
         };
         if (d.dbg & 1) {
         } else if constexpr (SWZ16) {
-            // G % 4 == 0: four groups per trip, the per-row slot of each group precomputed (xrow / wrow [gg])
+            // G % 4 == 0: one 256-byte block of four groups per trip; this slice takes NGG of them, two at a time
             for (int g = 0; g < G; g += 4) {
 #pragma unroll
-                for (int gg = 0; gg < 4; gg += 2) {
-                    rd(xa, wa, 16 * g, gg);
-                    rd(xb, wb, 16 * g, gg + 1);
+                for (int gi = 0; gi < NGG; gi += 2) {
+                    rd(xa, wa, 16 * g, gi);
+                    rd(xb, wb, 16 * g, gi + 1);
                     mm(xa, wa);
                     mm(xb, wb);
                 }
@@ -215,7 +230,25 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
                 mm(xa, wa);
             }
         }
-        {
+        if constexpr (KSP == 2) {
+            // the second slice parks its partial tile in the chunk image, the first adds it (slice 0 + slice 1) and goes on
+            if (kh == 1) {
+#pragma unroll
+                for (int mt = 0; mt < MW; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NW; nt++) *reinterpret_cast<floatx4 *>(Es + epix[mt] + (wn * NW + nt) * 16 + 4 * lq) = acc[mt][nt];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kh == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MW; mt++)
+#pragma unroll
+                    for (int nt = 0; nt < NW; nt++) acc[mt][nt] += *reinterpret_cast<const floatx4 *>(Es + epix[mt] + (wn * NW + nt) * 16 + 4 * lq);
+            }
+        }
+        if (kh == 0) {
             float v[MW * NW * 4];
 #pragma unroll
             for (int mt = 0; mt < MW; mt++)
@@ -242,7 +275,7 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
 #pragma unroll
             for (int oy = 0; oy < OH; oy++)
 #pragma unroll
-                for (int q = 0; q < PPG; q++) ov[oy][q] = bz;
+                for (int q = 0; q < PPG; q++) ov[oy][q] = cur.bz;
             const float *rp0 = Es + (ox0 * S) * EP + c;
 #pragma unroll
             for (int iy = 0; iy < H; iy++) {
@@ -251,14 +284,12 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
                 for (int ix = 0; ix < IWS; ix++) val[ix] = rp0[(iy * WP + ix) * EP];
 #pragma unroll
                 for (int ky = 0; ky < K; ky++) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
                     const int t = iy + PT - ky;  // = oy * S for the output row this (input row, tap row) pair feeds
                     if (t >= 0 && t % S == 0 && t / S < OH) {  // compile time after unrolling
 #pragma unroll
                         for (int q = 0; q < PPG; q++)
 #pragma unroll
-                            for (int kx = 0; kx < K; kx++) ov[t / S][q] = fmaf(val[q * S + kx], wd[ky * K + kx], ov[t / S][q]);
+                            for (int kx = 0; kx < K; kx++) ov[t / S][q] = fmaf(val[q * S + kx], cur.wd[ky * K + kx], ov[t / S][q]);
                     }
                 }
             }
@@ -279,24 +310,24 @@ __global__ __launch_bounds__(64 * WM * WN) void mbmap_kernel(MbDesc d, float *__
                 }
             }
         }
-        if (d.has_gap) {
-            red[grp * NC + c] = sum;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (grp == 0 && cact) {
-                float t = red[c];
+        if (d.has_gap) red[grp * NC + c] = sum;
+        // ONE barrier ends the chunk: the squeeze partials are written, every wave is done reading the chunk image, and the
+        // next chunk's filters (issued a whole chunk ago) have landed for every wave
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (d.has_gap && grp == 0 && cact) {
+            float t = red[c];
 #pragma unroll
-                for (int y = 1; y < NG; y++) t += red[y * NC + c];
-                gap[b * d.gap_bs + cg] = t;
-            }
+            for (int y = 1; y < NG; y++) t += red[y * NC + c];
+            gap[b * d.gap_bs + cg] = t;  // (read before the next chunk writes `red`: that happens behind its own barrier)
         }
     }
 }
 
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, int KSP = 1>
 size_t cfg_lds(const MbDesc &d) {
-    constexpr int HW = 16 * MW * WM, NC = 16 * NW * WN, NG = 64 * WM * WN / NC;
+    constexpr int HW = 16 * MW * WM, NC = 16 * NW * WN, NG = 64 * WM * WN * KSP / NC;
     return (size_t)(mm_kib(HW * d.Cin) + 2 * mm_kib(NC * d.Cin) + mm_kib(d.H * (d.W + d.k - 1) * (NC + 4)) + NG * NC) * sizeof(float);
 }
 
@@ -306,7 +337,7 @@ inline bool mm_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15
 
 // Which configuration takes this block (0 = none).  Per-sample quantities only.
 //   1: 192-pixel map, chunks of 64 channels, 8 waves      2: 192-pixel map, chunks of 32, 8 waves (wider inputs)
-//   3: 48-pixel map, chunks of 64 channels, 4 waves
+//   3: 48-pixel map, chunks of 64 channels, 8 waves (two K slices)
 int mbmap_config(const MbDesc &d) {
     const int mode = getenv("BN_MBMAP2") ? atoi(getenv("BN_MBMAP2")) : 1;  // read per call: plans are built (and tests switch it) at run time
     if (mode == 0) return 0;
@@ -322,7 +353,7 @@ int mbmap_config(const MbDesc &d) {
         if (cfg_lds<3, 2, 4, 2>(d) <= cap) return 1;
         if (cfg_lds<3, 1, 4, 2>(d) <= cap) return 2;
     } else if (d.H == 3 && d.W == 16 && cls == 0) {
-        if (cfg_lds<3, 1, 1, 4>(d) <= cap) return 3;
+        if (cfg_lds<3, 1, 1, 4, 2>(d) <= cap) return 3;
     }
     return 0;
 }
@@ -341,12 +372,14 @@ int mbmap_chunks_per_block(const MbDesc &d, int cfg, int64_t batch) {
 }
 
 void register_mbmap_kernels() {
-#define MM_REG(K, S, MW, NW, WM, WN, H, W, SW) register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_kernel<K, S, MW, NW, WM, WN, H, W, SW>));
-#define MM_REG_KS(MW, NW, WM, WN, H, W, SW) \
-    MM_REG(3, 1, MW, NW, WM, WN, H, W, SW) MM_REG(5, 1, MW, NW, WM, WN, H, W, SW) MM_REG(3, 2, MW, NW, WM, WN, H, W, SW) MM_REG(5, 2, MW, NW, WM, WN, H, W, SW)
-    MM_REG_KS(3, 2, 4, 2, 6, 32, false)
-    MM_REG_KS(3, 1, 4, 2, 6, 32, false)
-    MM_REG_KS(3, 1, 1, 4, 3, 16, true)
+#define MM_REG(K, S, MW, NW, WM, WN, KSP, H, W, SW) \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW>));
+#define MM_REG_KS(MW, NW, WM, WN, KSP, H, W, SW)                                                 \
+    MM_REG(3, 1, MW, NW, WM, WN, KSP, H, W, SW) MM_REG(5, 1, MW, NW, WM, WN, KSP, H, W, SW) \
+    MM_REG(3, 2, MW, NW, WM, WN, KSP, H, W, SW) MM_REG(5, 2, MW, NW, WM, WN, KSP, H, W, SW)
+    MM_REG_KS(3, 2, 4, 2, 1, 6, 32, false)
+    MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false)
+    MM_REG_KS(3, 1, 1, 4, 2, 3, 16, true)
 #undef MM_REG_KS
 #undef MM_REG
 }
@@ -359,24 +392,24 @@ bool launch_mbmap(hipStream_t s, const MbDesc &d, float *out, const float *in, c
     dd.dbg = getenv("BN_MM_DBG") ? atoi(getenv("BN_MM_DBG")) : 0;
     const int nch = mbmap_chunks_per_block(d, cfg, batch);
     const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(d.Cin / 4)) + 1u;  // slot -> row of the swizzled copies
-#define MM_GO(K, S, MW, NW, WM, WN, H, W, SW)                                                                                          \
+#define MM_GO(K, S, MW, NW, WM, WN, KSP, H, W, SW)                                                                                          \
     do {                                                                                                                              \
         constexpr int NC = 16 * NW * WN;                                                                                              \
         dim3 grid((unsigned)((d.C + nch * NC - 1) / (nch * NC)), (unsigned)batch);                                                    \
-        const size_t lds_ = cfg_lds<MW, NW, WM, WN>(d);                                                                               \
-        hipLaunchKernelGGL((mbmap_kernel<K, S, MW, NW, WM, WN, H, W, SW>), grid, dim3(64 * WM * WN), lds_, s, dd, out, in, w1, b1, w2, b2, gap, nch, \
+        const size_t lds_ = cfg_lds<MW, NW, WM, WN, KSP>(d);                                                                               \
+        hipLaunchKernelGGL((mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW>), grid, dim3(64 * WM * WN * KSP), lds_, s, dd, out, in, w1, b1, w2, b2, gap, nch, \
                            inv_ch);                                                                                                   \
     } while (0)
-#define MM_GO_KS(MW, NW, WM, WN, H, W, SW)                                   \
-    do {                                                                     \
-        if (d.k == 3 && d.s == 1) MM_GO(3, 1, MW, NW, WM, WN, H, W, SW);      \
-        else if (d.k == 5 && d.s == 1) MM_GO(5, 1, MW, NW, WM, WN, H, W, SW); \
-        else if (d.k == 3) MM_GO(3, 2, MW, NW, WM, WN, H, W, SW);             \
-        else MM_GO(5, 2, MW, NW, WM, WN, H, W, SW);                           \
+#define MM_GO_KS(MW, NW, WM, WN, KSP, H, W, SW)                                    \
+    do {                                                                          \
+        if (d.k == 3 && d.s == 1) MM_GO(3, 1, MW, NW, WM, WN, KSP, H, W, SW);      \
+        else if (d.k == 5 && d.s == 1) MM_GO(5, 1, MW, NW, WM, WN, KSP, H, W, SW); \
+        else if (d.k == 3) MM_GO(3, 2, MW, NW, WM, WN, KSP, H, W, SW);             \
+        else MM_GO(5, 2, MW, NW, WM, WN, KSP, H, W, SW);                           \
     } while (0)
-    if (cfg == 1) MM_GO_KS(3, 2, 4, 2, 6, 32, false);
-    else if (cfg == 2) MM_GO_KS(3, 1, 4, 2, 6, 32, false);
-    else MM_GO_KS(3, 1, 1, 4, 3, 16, true);
+    if (cfg == 1) MM_GO_KS(3, 2, 4, 2, 1, 6, 32, false);
+    else if (cfg == 2) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false);
+    else MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true);
 #undef MM_GO_KS
 #undef MM_GO
     return true;
