@@ -423,3 +423,49 @@ def _range(bn, G, r, world):
     lo, hi = C.c_size_t(), C.c_size_t()
     bn.lib.bn_shard_range(G, r, world, C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+def test_round3_kernels_tile_shape_and_grouping_do_not_enter_the_arithmetic(bn, v24_full, monkeypatch):
+    """The LDS-DMA GEMM picks its block tile by the size of the launch and the whole-map MBConv kernel its channel
+    grouping by the batch: neither may change a single bit (a shard's short last batch must equal the single pass).
+    Forced extremes of both knobs, batch 5, full-size v2.4: logits bit-identical to the default plan's."""
+    data, path = v24_full
+    x = synth.synthetic_segments(5, 144000, 48000)
+    base, _ = bn.Context(bn.Model(path), 5).infer(x)
+    base = base.copy()
+    for env in ({"BN_GEMMDMA_MINBLOCKS": "1"}, {"BN_GEMMDMA_MINBLOCKS": "100000000"}, {"BN_MBMAP2_NCH": "1"}, {"BN_MBMAP2_NCH": "7"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got, _ = bn.Context(bn.Model(path), 5).infer(x)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert got.tobytes() == base.tobytes(), env
+    # ... and batch 1 / 32 of the same segments (different tile shapes by the default rule) repeat the bits
+    one = np.concatenate([bn.Context(bn.Model(path), 1).infer(x[i:i + 1])[0] for i in range(5)])
+    assert one.tobytes() == base.tobytes()
+    big = synth.synthetic_segments(32, 144000, 48000)
+    big[:5] = x
+    many, _ = bn.Context(bn.Model(path), 32).infer(big)
+    assert many[:5].tobytes() == base.tobytes()
+
+
+@pytest.mark.parametrize("env", [{"BN_GEMMDMA": "0"}, {"BN_GEMMDMA": "2"}, {"BN_MBMAP2": "0"}, {"BN_SEGEMM": "1"}, {"BN_GEMMDMA_KS": "1"}])
+def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, monkeypatch, env):
+    """Every round-3 rewrite has an off switch (and two opt-ins): the older kernels (BN_GEMMDMA=0, BN_MBMAP2=0), the
+    LDS-DMA GEMM on every eligible shape (BN_GEMMDMA=2), the squeeze-excite products in the GEMM prologue (BN_SEGEMM=1),
+    one K slice per block (BN_GEMMDMA_KS=1) -- each within the network tolerance of the oracle, same top-1."""
+    data, path = v24_full
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    desc = bn.plan_describe(path)
+    if env.get("BN_GEMMDMA") == "0":
+        assert "kernel=dma" not in desc
+    if env.get("BN_MBMAP2") == "0":
+        assert "tiles=1x1" not in desc
+    if env.get("BN_SEGEMM") == "1":
+        assert "se_inline=" in desc
+    x = synth.synthetic_segments(3, 144000, 48000)
+    got, _ = bn.Context(bn.Model(path), 3).infer(x)
+    ref = onnx_ref.run_model(data, x)["output"]
+    assert_close(got, ref, str(env))
+    assert np.array_equal(got.argmax(1), ref.argmax(1))
