@@ -18,5 +18,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3
 # matrix-pipe utilisation, LDS conflicts, wait breakdown and the clock (SQ: 8 slots per pass, GRBM: its own 2)
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq -o run -- python3 $R/tools/pmc_run.py 32 3 > $O/pmc_sq.log 2>&1 &&
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_inst -o run -- python3 $R/tools/pmc_run.py 32 3 > $O/pmc_inst.log 2>&1 &&
+# the same two SQ passes per kernel NAME (template arguments kept): profiles/<tag>_pmc_by_kernel.txt
+(python3 $R/tools/pmc_kernels.py $O/pmc_sq > $O/pmc_by_kernel_sq.txt; python3 $R/tools/pmc_kernels.py $O/pmc_inst > $O/pmc_by_kernel_inst.txt; true) &&
 # BASELINE configs[4] on ONE GPU: the 24 h recording (28 800 windows), log kept
-python3 $R/tools/analyze_recording.py --hours 24 > $O/recording_24h.log 2>&1
+python3 $R/tools/analyze_recording.py --hours 24 --gather topk > $O/recording_24h.log 2>&1

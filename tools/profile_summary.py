@@ -23,7 +23,8 @@ from collections import defaultdict
 
 def family(name):
     n = name.replace("bn::(anonymous namespace)::", "")
-    for key, fam in (("gemm_mfma_kernel", "gemm_mfma_kernel"), ("gemm_splitk_kernel", "gemm_mfma_kernel"), ("frame_fold_kernel", "gemm_mfma_kernel"), ("mbconv_", "mbconv_row_kernel"),
+    for key, fam in (("gemm_mfma_kernel", "gemm_mfma_kernel"), ("gemm_splitk_kernel", "gemm_mfma_kernel"), ("gemm_dma_kernel", "gemm_mfma_kernel"), ("frame_fold_kernel", "gemm_mfma_kernel"),
+                     ("mbconv_", "mbconv_row_kernel"), ("mbmap_kernel", "mbconv_row_kernel"),
                      ("dwconv_", "dwconv_kernel"), ("conv_small", "conv_direct_kernel"), ("conv_direct", "conv_direct_kernel"),
                      ("stft_kernel", "stft_kernel"), ("se_fc", "se_fc_kernel"), ("gap_partial", "gap_partial_kernel"), ("elt_", "elt_kernel"), ("reduce_", "reduce_kernel"), ("minmax_chunks", "reduce_kernel"),
                      ("topk", "topk_kernel")):
@@ -89,7 +90,7 @@ def mfma_summary(src, tag):
         fams[fam] = e
     doc = {"tag": tag, "batch": 32,
            "command": "rocprofv3 --pmc <SQ counters + GRBM_GUI_ACTIVE> (separate passes, no trace domains) -- python3 tools/pmc_run.py 32 3",
-           "definitions": {"mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES (= 64 per v_mfma_f32_32x32x2_f32, per SIMD) / (1024 SIMDs x launch duration x 2.4 GHz): "
+           "definitions": {"mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES (= 64 per v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_16x16x4_f32, per SIMD) / (1024 SIMDs x launch duration x 2.4 GHz): "
                                         "the fraction of the matrix pipes' peak-clock cycles the launch kept busy",
                            "mfma_busy_grbm": "the same over GRBM_GUI_ACTIVE / 8; that quotient reads high on dispatches under ~0.3 ms "
                                              "(MI355X_MICROARCH.md, DVFS give-back), so this one reads LOW here -- kept for reference",
@@ -141,6 +142,10 @@ def main():
     print(json.dumps(doc["kernel_stats_1stream"], indent=1))
     if os.path.isdir(os.path.join(src, "pmc_sq")):
         print(json.dumps(mfma_summary(src, tag)["families"], indent=1))
+    for part in ("sq", "inst"):
+        f = os.path.join(src, f"pmc_by_kernel_{part}.txt")
+        if os.path.exists(f):
+            shutil.copy(f, f"profiles/{tag}_pmc_by_kernel_{part}.txt")
     rec = os.path.join(src, "recording_24h.log")
     if os.path.exists(rec):
         shutil.copy(rec, f"profiles/{tag}_recording_24h.log")
