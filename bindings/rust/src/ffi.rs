@@ -37,6 +37,7 @@ pub struct bn_ctx_stats {
     pub evictions: u64,
     pub cached_graphs: u64,
     pub last_fallback: [c_char; 192],
+    pub input_copies: u64,
 }
 
 pub const BN_ABI_VERSION: i32 = 2;
@@ -61,6 +62,7 @@ extern "C" {
     pub fn bn_ctx_create(m: *mut bn_model, max_batch: usize, flags: u32, out: *mut *mut bn_ctx) -> i32;
     pub fn bn_ctx_destroy(c: *mut bn_ctx);
     pub fn bn_ctx_get_stats(c: *const bn_ctx, out: *mut bn_ctx_stats, struct_size: usize) -> i32;
+    pub fn bn_ctx_input_device(c: *const bn_ctx, d_ptr: *mut *mut f32, capacity_floats: *mut usize) -> i32;
     pub fn bn_infer(c: *mut bn_ctx, segs: *const *const f32, batch: usize, logits_out: *mut f32, emb_out: *mut f32,
                     cancel: *const i32, timeout_ns: u64) -> i32;
     pub fn bn_topk(c: *mut bn_ctx, batch: usize, top_k: usize, has_min: i32, min_conf: f32, k_stride: usize,

@@ -160,6 +160,7 @@ typedef struct bn_ctx_stats {
     uint64_t evictions;         /* instantiated graphs dropped from the 16-entry cache */
     uint64_t cached_graphs;
     char last_fallback[192];
+    uint64_t input_copies;      /* device-to-device copies of a caller's batch into the context's own input buffer */
 } bn_ctx_stats;
 bn_status bn_ctx_get_stats(const bn_ctx *c, bn_ctx_stats *out, size_t struct_size);
 /* Bytes of device memory held by the context (activations arena + I/O buffers). */
@@ -221,6 +222,12 @@ bn_status bn_infer_collect(bn_ctx *c, uint64_t ticket, float *logits_out, float 
  * not is refused with BN_ERR_INVALID_ARG, nothing is launched.
  * Asynchronous on the context's stream unless `sync` is non-zero. */
 bn_status bn_infer_device(bn_ctx *c, const float *d_pcm, size_t batch_size, int32_t sync);
+/* The context's OWN device input buffer ([max_batch, sample_count] f32, 256-byte aligned).  The plan always reads its batch
+ * from here: one hipGraph per batch size, however many buffers a caller cycles through.  bn_infer_device /
+ * bn_step_device copy a batch that lives elsewhere in on the context's stream (device to device, ~10 us for 32 x 3 s);
+ * a caller that produces its batch directly in this buffer and passes this pointer pays no copy.  The buffer is also
+ * what bn_infer_windows / bn_step_windows fill: do not write it while such a call is in flight. */
+bn_status bn_ctx_input_device(const bn_ctx *c, float **d_ptr, size_t *capacity_floats);
 /* Device pointer and row length of graph output `index` after the last run
  * (row-major [batch, row_elems] f32). */
 bn_status bn_ctx_output_device(const bn_ctx *c, int32_t index, const float **d_ptr,

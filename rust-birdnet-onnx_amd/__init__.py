@@ -41,7 +41,7 @@ BN_CTX_DEFAULT, BN_CTX_ALL_OUTPUTS, BN_CTX_NO_GRAPH = 0, 1, 2
 # every symbol include/birdnet_hip.h and include/birdnet_host.h declare
 ENGINE_SYMBOLS = [
     "bn_abi_version", "bn_device_count", "bn_model_load", "bn_model_load_buffer", "bn_model_free",
-    "bn_model_device", "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create", "bn_ctx_get_stats",
+    "bn_model_device", "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create", "bn_ctx_get_stats", "bn_ctx_input_device",
     "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_submit", "bn_infer_collect", "bn_infer_device",
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
     "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
@@ -84,7 +84,8 @@ class BnModelCost(C.Structure):
 
 class BnCtxStats(C.Structure):
     _fields_ = [("captures", C.c_uint64), ("instantiates", C.c_uint64), ("replays", C.c_uint64), ("eager_runs", C.c_uint64),
-                ("capture_fallbacks", C.c_uint64), ("evictions", C.c_uint64), ("cached_graphs", C.c_uint64), ("last_fallback", C.c_char * 192)]
+                ("capture_fallbacks", C.c_uint64), ("evictions", C.c_uint64), ("cached_graphs", C.c_uint64), ("last_fallback", C.c_char * 192),
+                ("input_copies", C.c_uint64)]
 
 
 BN_ABI_VERSION = 2  # include/birdnet_hip.h
@@ -115,6 +116,7 @@ def _load() -> C.CDLL:
         "bn_model_get_config": (i32, [vp, C.POINTER(BnModelConfig)]),
         "bn_model_get_cost": (i32, [vp, C.POINTER(BnModelCost), sz]),
         "bn_ctx_get_stats": (i32, [vp, C.POINTER(BnCtxStats), sz]),
+        "bn_ctx_input_device": (i32, [vp, C.POINTER(vp), C.POINTER(sz)]),
         "bn_detect_model_type": (i32, [i64p, sz, i64p, C.POINTER(sz), sz, i32, C.POINTER(BnModelConfig)]),
         "bn_ctx_create": (i32, [vp, sz, C.c_uint32, C.POINTER(vp)]),
         "bn_ctx_destroy": (None, [vp]),
@@ -601,6 +603,14 @@ class Context:
         if getattr(self, "_h", None) and lib is not None:
             lib.bn_ctx_destroy(self._h)
             self._h = None
+
+    def input_device(self):
+        """(device pointer, capacity in floats) of the context's own input buffer: a batch written here runs without a copy."""
+        p, n = C.c_void_p(), C.c_size_t()
+        st = lib.bn_ctx_input_device(self._h, C.byref(p), C.byref(n))
+        if st:
+            raise EngineError(st)
+        return p.value, n.value
 
     def stats(self) -> dict:
         """bn_ctx_get_stats: captures / instantiates / replays / eager runs / capture fallbacks (must be 0) of this context."""

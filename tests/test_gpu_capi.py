@@ -187,18 +187,37 @@ def test_misaligned_device_input_is_refused_not_fatal(bn):
 
 
 def test_many_input_buffers_through_one_context(bn, small):
-    """The per-context hipGraph cache is keyed by (batch, input pointer) and bounded at 16 graphs with least-recently-used
-    eviction: a caller cycling through more device buffers and batch sizes than that keeps getting the right answer (and the
-    buffers it comes back to first are still cached)."""
+    """The plan always reads its batch from the context's own input buffer (a foreign device pointer is copied in on the
+    stream), so the hipGraph cache is keyed by the batch size alone: a caller cycling through 64 device buffers and two
+    batch sizes gets ONE capture + instantiate per batch size and the right answer every time; a batch written straight
+    into bn_ctx_input_device runs without the copy."""
     import torch
     data, path = small
     m = bn.Model(path)
     ctx = bn.Context(m, 4)
     xs = [synth.synthetic_segments(4, 160000, 32000, first_index=10 * i) for i in range(6)]
     want = [ctx.infer(x)[0] for x in xs]
-    bufs = [torch.from_numpy(xs[i % 6]).cuda() for i in range(22)]
+    base = ctx.stats()
+    bufs = [torch.from_numpy(xs[i % 6]).cuda() for i in range(64)]
     for rnd in range(2):
         for i, d in enumerate(bufs):
-            n = 4 if (i + rnd) % 3 else 3           # two batch sizes per buffer over the rounds: > 16 distinct keys
+            n = 4 if (i + rnd) % 3 else 3           # two batch sizes per buffer over the rounds
             ctx.infer_device(d.data_ptr(), n, sync=True)
             assert ctx.read_output(1, n).tobytes() == want[i % 6][:n].tobytes(), (rnd, i)
+    st = ctx.stats()
+    assert st["capture_fallbacks"] == 0 and st["evictions"] == 0
+    assert st["instantiates"] - base["instantiates"] <= 2 and st["cached_graphs"] <= 3, st   # batch 4 (maybe cached by infer) and 3
+    assert st["replays"] - base["replays"] == 128 and st["input_copies"] - base["input_copies"] == 128, st
+    # zero-copy: the batch produced directly in the context's buffer
+    ptr, cap = ctx.input_device()
+    assert cap == 4 * 160000 and ptr % 256 == 0
+    class _View:
+        def __init__(self, p, shape):
+            self.__cuda_array_interface__ = {"data": (p, False), "shape": shape, "typestr": "<f4", "version": 2}
+    own = torch.as_tensor(_View(ptr, (4, 160000)), device="cuda")
+    own.copy_(torch.from_numpy(xs[5]).cuda())
+    torch.cuda.synchronize()
+    before = ctx.stats()["input_copies"]
+    ctx.infer_device(ptr, 4, sync=True)
+    assert ctx.stats()["input_copies"] == before
+    assert ctx.read_output(1, 4).tobytes() == want[5].tobytes()
