@@ -419,18 +419,36 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
             }
             if (dbg & 2) continue;
             // the kept bins: out[c] = alpha Re Z[k] + beta Im Z[k] + gamma Re Z[M-k] + delta Im Z[M-k]
+            // (four bins per lane in flight: the table entry, then the two transform slots it names, are dependent LDS reads
+            // -- one bin at a time this loop was five round trips of ~250 cycles per frame, 8 of the kernel's 67 us)
             for (int rep = 0; rep < ((dbg & 64) ? 4 : 1); rep++)
             for (int fi = 0; fi < F; fi++) {
                 const int t = g * F + fi;
                 const float2 *zf = wbuf + fi * fstride;
-                for (int c = lane; c < nout; c += 64) {
-                    const float4 e0 = *reinterpret_cast<const float4 *>(otab + 8 * c);
-                    const float2 e1 = *reinterpret_cast<const float2 *>(otab + 8 * c + 4);
-                    const float2 za = zf[(int)e0.x], zb = zf[(int)e0.y];
-                    float v = e0.z * za.x + e0.w * za.y + e1.x * zb.x + e1.y * zb.y;
-                    if (d.has_bias) v += p.bias[c];
-                    if (nmel) spec[t * nout + c] = v;
-                    else if (t < rows_here) p.out[b * d.c_bs + (int64_t)(t0 + t) * d.ldc + c] = v;
+                for (int c0 = lane; c0 < nout; c0 += 256) {
+                    float4 e0[4];
+                    float2 e1[4], za[4], zb[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int c = min(c0 + 64 * k, nout - 1);
+                        e0[k] = *reinterpret_cast<const float4 *>(otab + 8 * c);
+                        e1[k] = *reinterpret_cast<const float2 *>(otab + 8 * c + 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        za[k] = zf[(int)e0[k].x];
+                        zb[k] = zf[(int)e0[k].y];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int c = c0 + 64 * k;
+                        if (c < nout) {
+                            float v = e0[k].z * za[k].x + e0[k].w * za[k].y + e1[k].x * zb[k].x + e1[k].y * zb[k].y;
+                            if (d.has_bias) v += p.bias[c];
+                            if (nmel) spec[t * nout + c] = v;
+                            else if (t < rows_here) p.out[b * d.c_bs + (int64_t)(t0 + t) * d.ldc + c] = v;
+                        }
+                    }
                 }
             }
             wave_sync();  // the transform buffer is rewritten by this wave's next group
@@ -450,24 +468,33 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
                 const bool live = m < nmel && t < rows_here;
                 const int e0 = live ? (int)mstart[m] : 0, e1 = live ? (int)mstart[m + 1] : 0;
                 const float *sp = spec + (live ? t : 0) * nout;
+                // Eight entries of the band in flight: an entry (column, weight) and the spectrum value it names are two
+                // dependent LDS reads, and a band has up to ~30 entries -- two at a time the phase was a chain of ~15 round
+                // trips per work item, 30 of the kernel's 67 us for 10 000 multiply-adds per tile.  Same sums as before:
+                // entries at even offsets from the band's first feed a0, odd ones a1, combined once at the end.
                 float a0 = 0.0f, a1 = 0.0f;
-                int e = e0;
-                for (; e + 1 < e1; e += 2) {  // two entries in flight; combined in a fixed order below
-                    const float2 c0 = ment[e], c1 = ment[e + 1];
-                    a0 = fmaf(sp[(int)c0.x], c0.y, a0);
-                    a1 = fmaf(sp[(int)c1.x], c1.y, a1);
-                }
-                if (e < e1) {
-                    const float2 c0 = ment[e];
-                    a0 = fmaf(sp[(int)c0.x], c0.y, a0);
+                for (int e = e0; e < ((dbg & 512) ? e0 : e1); e += 8) {
+                    float2 cc[8];
+                    float sv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) cc[k] = ment[e + k < e1 ? e + k : e0];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) sv[k] = sp[(int)cc[k].x];
+#pragma unroll
+                    for (int k = 0; k < 8; k += 2) {
+                        if (e + k < e1) a0 = fmaf(sv[k], cc[k].y, a0);
+                        if (e + k + 1 < e1) a1 = fmaf(sv[k + 1], cc[k + 1].y, a1);
+                    }
                 }
                 float acc[1] = {(a0 + a1) + ((live && d.mel_has_bias) ? p.mel_bias[m] : 0.0f)};
+                if (!(dbg & 128)) {
                 act_small<1>(d.mel_act, d.mel_p0, d.mel_p1, acc);
                 if (0 < npost) act_small<1>(po_a0, po_p00, po_p10, acc);
                 if (1 < npost) act_small<1>(po_a1, po_p01, po_p11, acc);
                 if (2 < npost) act_small<1>(po_a2, po_p02, po_p12, acc);
                 if (3 < npost) act_small<1>(po_a3, po_p03, po_p13, acc);
-                if (live) ob[(int64_t)(t0 + t) * d.out_rs + (int64_t)m * d.out_cs] = acc[0];
+                }
+                if (live && !(dbg & 256)) ob[(int64_t)(t0 + t) * d.out_rs + (int64_t)m * d.out_cs] = acc[0];
             }
         }
         if (next < total_tiles) BN_WRITE_SPAN(next);
