@@ -361,14 +361,19 @@ inline int gd_kslices(const GemmDesc &d) {
 int gemm_dma_shape(const GemmDesc &d) {
     const int mode = getenv("BN_GEMMDMA") ? atoi(getenv("BN_GEMMDMA")) : 1;  // read per call (tests switch it at run time)
     if (mode == 0) return 0;
-    if (d.fold || d.npost || d.out_strided || d.lda != d.K || d.K % 16 || d.K < 32 || d.N % 4 || d.N < 32 || !gd_act_ok(d.act)) return 0;
+    if (d.fold || d.npost || d.out_strided || d.lda != d.K || d.K % 16 || d.K < 32 || d.N % 4 || d.N < 16 || !gd_act_ok(d.act)) return 0;
     if (d.ldc % 4 || d.c_bs % 4 || d.a_bs % 4 || (d.has_res && (d.ldr % 4 || d.r_bs % 4)) || (d.has_scale && d.s_bs % 4)) return 0;
     if ((int64_t)d.rows * d.K >= ((int64_t)1 << 30) || (int64_t)d.N * d.K >= ((int64_t)1 << 30)) return 0;  // 32-bit lane offsets
     if (d.has_scale && d.K > 8192) return 0;
     // Where it pays (measured, batch 32 and 128, tools/kernel_table.py): deep products with few output channels -- the
     // project convs and the head conv.  Short-K, wide-N expands are bound by their output stores and their launch, not by
     // staging: the tiled kernel keeps them (mode 2 sends every eligible shape here, for tests).
-    if (mode != 2 && d.K < 128) return 0;
+    // ... and the project convs of the big feature maps (few output channels, K 32 .. 144): memory-bound either way, but
+    // the tiled kernel spends 17 - 27 vector instructions per matrix instruction on them, and at four contexts every
+    // vector instruction is taken from the budget the other contexts' matrix work needs (BN_GEMMDMA_SMALLN=0 keeps
+    // them on the tiled kernel)
+    const bool small_n = d.N <= 32 && d.has_scale && !(getenv("BN_GEMMDMA_SMALLN") && atoi(getenv("BN_GEMMDMA_SMALLN")) == 0);
+    if (mode != 2 && d.K < 128 && !small_n) return 0;
     if (d.rows % 32 == 0) return 1;  // 64- or 32-row tiles x up to 128 channels, waves along the rows
     if (d.rows % 48 == 0) return 2;  // 48-row tiles x 32 / 64 / 128 channels, waves along the channels
     return 0;
@@ -380,7 +385,7 @@ void register_gemm_dma_kernels() {
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_kernel<MTW, NTW, WM, WN, KS, 3, 1>));       \
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_kernel<MTW, NTW, WM, WN, KS, 3, 2>));
 #define GD_REG(MTW, NTW, WM, WN) GD_REG1(MTW, NTW, WM, WN, 1) GD_REG1(MTW, NTW, WM, WN, 2)
-    GD_REG(1, 2, 4, 1) GD_REG(1, 3, 4, 1) GD_REG(1, 4, 4, 1) GD_REG(1, 5, 4, 1) GD_REG(1, 6, 4, 1) GD_REG(1, 7, 4, 1) GD_REG(1, 8, 4, 1)
+    GD_REG(1, 1, 4, 1) GD_REG(1, 1, 2, 1) GD_REG(1, 2, 4, 1) GD_REG(1, 3, 4, 1) GD_REG(1, 4, 4, 1) GD_REG(1, 5, 4, 1) GD_REG(1, 6, 4, 1) GD_REG(1, 7, 4, 1) GD_REG(1, 8, 4, 1)
     GD_REG(1, 2, 2, 1) GD_REG(1, 3, 2, 1) GD_REG(1, 4, 2, 1) GD_REG(1, 5, 2, 1) GD_REG(1, 6, 2, 1) GD_REG(1, 7, 2, 1) GD_REG(1, 8, 2, 1)
     GD_REG(3, 1, 1, 2) GD_REG(3, 1, 1, 4) GD_REG(3, 2, 1, 4)
 #undef GD_REG
@@ -413,6 +418,7 @@ bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A,
 #define GD_GO_N(WM)                                 \
     do {                                            \
         switch (ntw) {                              \
+            case 1: GD_GO(1, 1, WM, 1); break;      \
             case 2: GD_GO(1, 2, WM, 1); break;      \
             case 3: GD_GO(1, 3, WM, 1); break;      \
             case 4: GD_GO(1, 4, WM, 1); break;      \
@@ -425,7 +431,7 @@ bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A,
     if (shape == 1) {
         // the fewest channel blocks of at most 128, evenly sized, whole 16-channel tiles
         const int nb = (d.N + 127) / 128;
-        const int ntw = std::max(2, ((d.N + nb - 1) / nb + 15) / 16);
+        const int ntw = ((d.N + nb - 1) / nb + 15) / 16;
         const bool big = d.rows % 64 == 0 && batch * (d.rows / 64) * nb >= min_blocks;
         if (big) GD_GO_N(4);
         else GD_GO_N(2);
