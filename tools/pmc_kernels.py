@@ -44,6 +44,8 @@ def main():
             line += f" mfma_busy={c['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * us * 2400):.3f}"
         if wc:
             line += f" issue={c.get('SQ_ACTIVE_INST_ANY', 0) / wc:.2f} stall={c.get('SQ_WAIT_INST_ANY', 0) / wc:.2f} wait={c.get('SQ_WAIT_ANY', 0) / wc:.2f}"
+        if "SQ_INSTS_VALU" in c:
+            line += f" valu={c['SQ_INSTS_VALU']:.0f} salu={c.get('SQ_INSTS_SALU', 0):.0f} lds={c.get('SQ_INSTS_LDS', 0):.0f} vmem_rd={c.get('SQ_INSTS_VMEM_RD', 0):.0f} vmem_wr={c.get('SQ_INSTS_VMEM_WR', 0):.0f} waves={c.get('SQ_WAVES', 0):.0f}"
         if c.get("SQ_INSTS_MFMA"):
             line += f" valu/mfma={c.get('SQ_INSTS_VALU', 0) / c['SQ_INSTS_MFMA']:.1f} mfma={c['SQ_INSTS_MFMA']:.0f}"
         if c.get("SQ_LDS_IDX_ACTIVE"):
