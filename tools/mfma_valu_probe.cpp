@@ -14,6 +14,53 @@
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// E  every wave: NV independent v_pk_fma_f32 (two f32 FMAs per lane per instruction) -- does the packed form really retire
+//    twice the FMAs per issue slot, alone and beside exact-f32 MFMAs?   F = E's loop on waves 4-7, A's loop on waves 0-3.
+template <int MODE>
+__global__ __launch_bounds__(512) void probe_pk(float *out, int iters, int nv_per_m) {
+    const int wave = threadIdx.x >> 6;
+    floatx16 acc0 = {0}, acc1 = {0};
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    floatx2 a2 = {a, a + 1}, b2 = {b, b + 1};
+    floatx2 v0 = a2, v1 = b2, v2 = a2 + b2, v3 = a2 - b2, v4 = a2 * 2, v5 = b2 * 2, v6 = a2 + 1, v7 = b2 + 1;
+    const bool do_m = MODE == 1 && wave < 4;
+    const bool do_v = MODE == 0 || (MODE == 1 && wave >= 4);
+    for (int i = 0; i < iters; i++) {
+        if (do_m) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
+        }
+        if (do_v) {
+            for (int j = 0; j < nv_per_m; j++) {
+                v0 = __builtin_elementwise_fma(v0, b2, a2); v1 = __builtin_elementwise_fma(v1, b2, a2);
+                v2 = __builtin_elementwise_fma(v2, b2, a2); v3 = __builtin_elementwise_fma(v3, b2, a2);
+                v4 = __builtin_elementwise_fma(v4, b2, a2); v5 = __builtin_elementwise_fma(v5, b2, a2);
+                v6 = __builtin_elementwise_fma(v6, b2, a2); v7 = __builtin_elementwise_fma(v7, b2, a2);
+            }
+        }
+    }
+    floatx2 s2 = v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
+    float s = s2.x + s2.y;
+    for (int r = 0; r < 16; r++) s += acc0[r] + acc1[r];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+template <int MODE>
+float run_pk(int threads, int iters, int nv, float *d) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe_pk<MODE>), dim3(256), dim3(threads), 0, 0, d, iters, nv);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((probe_pk<MODE>), dim3(256), dim3(threads), 0, 0, d, iters, nv);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1000.0f;
+}
 
 template <int MODE, int SHAPE>
 __global__ __launch_bounds__(512) void probe(float *out, int iters, int nv_per_m) {
@@ -82,6 +129,8 @@ int main() {
             }
             printf("\n");
         }
+        printf("  packed: E(v_pk_fma_f32 alone) 256 thr=%.1f us  512 thr=%.1f us   F(MFMA waves 0-3 + pk waves 4-7)=%.1f us\n", run_pk<0>(256, iters, nv, d),
+               run_pk<0>(512, iters, nv, d), run_pk<1>(512, iters, nv, d));
     }
     return 0;
 }
