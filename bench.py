@@ -324,6 +324,7 @@ def main():
         "p10_ms": step_stats["p10_ms"],
         "p90_ms": step_stats["p90_ms"],
         "step_interval_stats": step_stats,
+        "step_done_ms": [round(float(v), 3) for v in done_ms] if len(done_ms) <= 64 else None,  # completion time of every timed step since the start of the timed region (short runs only)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -1026,117 +1026,219 @@ __global__ void gap_partial_kernel(GapDesc d, float *__restrict__ partial, const
 }
 
 // stage 2 (squeeze finish + reduce FC + excite FC + gate activation) in ONE launch:
-// grid (ceil(C/256), batch), 1024 threads.  Every block of a sample redoes the cheap first half
-// (the C-vector sum and the Cr hidden units, 16 waves in parallel) and then produces its own
-// 256-channel slice of the gate; the work is spread over several CUs per sample because one CU
-// streams weights at only ~10 B/clk.  W1 is [Cr][C]; W2T is [Cr][C] (transposed at plan time).
+// grid (blocks per sample group, ceil(batch / G)), 1024 threads.  A block serves G samples (round 3): the two weight
+// matrices are the same for every sample, so each weight a block loads feeds G multiply-adds -- at batch 128 the launch
+// moved 150 MB of weights from L2 to redo, per 256-channel slice of every sample, a 221 KB product; a quarter of that with
+// G = 4.  Every block of a group redoes the cheap first half (the C-vector sums and the Cr hidden units, 16 waves in
+// parallel) and then produces its own 256-channel slices of the gate; the work is spread over several CUs per group
+// because one CU streams weights at only ~10 B/clk.  W1 is [Cr][C]; W2T is [Cr][C] (transposed at plan time).
+// Weights do not depend on the data: the first W1 chunk of every wave and the W2T column of the block's first slice are
+// requested BEFORE the squeeze sums are read, so their round trips overlap instead of following one another (the
+// launch is a chain of dependent loads: 7.8 us for 0.6 MFLOP).
+// Every sample's arithmetic (which partial sums meet in which order, the lane-strided dot products, the shuffle trees,
+// the four-way split of the excite sum) is the one of the G = 1 kernel: a gate's bits do not depend on G or the batch.
+template <int G>
 __global__ __launch_bounds__(1024) void se_fc_kernel(SeFcDesc d, float *__restrict__ gate, const float *__restrict__ partial,
                                                      const float *__restrict__ w1, const float *__restrict__ b1,
-                                                     const float *__restrict__ w2t, const float *__restrict__ b2) {
-    extern __shared__ __align__(16) float ssm[];  // s[C] | h[Cr] | red[P*C <= 1024]
-    float *hid = ssm + d.C;
-    float *red = hid + d.Cr;
-    const int64_t b = blockIdx.y;
-    const float *pp = partial + b * d.in_bs;
-    // squeeze finish: P = 1024 / C thread groups share the splits (group p takes p, p+P, ...),
+                                                     const float *__restrict__ w2t, const float *__restrict__ b2, int batch) {
+    constexpr int SE_NPRE = G == 1 ? 8 : 6;  // W2T values of a slice requested ahead, per thread (the rest of a column is loaded in the loop)
+    extern __shared__ __align__(16) float ssm[];  // s[G][C] | h[G][Cr] | red[G * 1024]
+    float *hid = ssm + G * d.C;
+    float *red = hid + G * d.Cr;
+    const int64_t bq = (int64_t)blockIdx.y * G;
+    const int ng = (int)min((int64_t)G, (int64_t)batch - bq);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cl = threadIdx.x & 255, q = threadIdx.x >> 8;
+    const int nslices = (d.C + 255) / 256;
+    const bool vec = (d.C & 3) == 0;
+    const int CV = d.C >> 2;
+
+    // ---- requests that do not depend on the data
+    // (clamped addresses, not predicated loads: a select on a loaded value pins an s_waitcnt behind the load)
+    float wpre[SE_NPRE];
+    {
+        const int c = min((int)blockIdx.x * 256 + cl, d.C - 1);
+#pragma unroll
+        for (int i = 0; i < SE_NPRE; i++) wpre[i] = w2t[(int64_t)min(q + 4 * i, d.Cr - 1) * d.C + c];
+    }
+    constexpr bool W1PRE = G == 1;  // (with four samples' accumulators the sixteen extra registers spill)
+    float4 w1pre[4];
+    if constexpr (W1PRE) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = wave + 16 * r < d.Cr ? wave + 16 * r : d.Cr - 1;
+            w1pre[r] = reinterpret_cast<const float4 *>(w1 + (int64_t)j * d.C)[vec ? min(lane, CV - 1) : 0];  // (C >= 4 floats: in bounds either way)
+        }
+    }
+
+    // ---- squeeze finish: P = 1024 / C thread groups share the splits (group p takes p, p+P, ...),
     // the P results are added in a fixed order (deterministic)
     const int P = d.C >= 1024 ? 1 : 1024 / d.C;
-    if (P == 1) {
-        for (int c = threadIdx.x; c < d.C; c += 1024) {
-            // four partials in flight (independent accumulators, combined in a fixed order)
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int sp = 0;
-            for (; sp + 3 < d.splits; sp += 4) {
-                a0 += pp[(int64_t)sp * d.C + c];
-                a1 += pp[(int64_t)(sp + 1) * d.C + c];
-                a2 += pp[(int64_t)(sp + 2) * d.C + c];
-                a3 += pp[(int64_t)(sp + 3) * d.C + c];
-            }
-            for (; sp < d.splits; sp++) a0 += pp[(int64_t)sp * d.C + c];
-            ssm[c] = ((a0 + a1) + (a2 + a3)) * d.inv_hw;
+    if (d.splits == 1) {
+        for (int i = threadIdx.x; i < ng * d.C; i += 1024) {
+            const int g = i / d.C, c = i - g * d.C;
+            ssm[i] = ((partial[(bq + g) * d.in_bs + c] + 0.f) + (0.f + 0.f)) * d.inv_hw;  // the P == 1 expression with one split
         }
     } else {
-        const int p = threadIdx.x / d.C, c = threadIdx.x - p * d.C;
-        if (p < P) {
-            float a0 = 0.f, a1 = 0.f;
-            int sp = p;
-            for (; sp + P < d.splits; sp += 2 * P) {
-                a0 += pp[(int64_t)sp * d.C + c];
-                a1 += pp[(int64_t)(sp + P) * d.C + c];
+        for (int g = 0; g < ng; g++) {
+            const float *pp = partial + (bq + g) * d.in_bs;
+            float *sg = ssm + g * d.C;
+            if (P == 1) {
+                for (int c = threadIdx.x; c < d.C; c += 1024) {
+                    // four partials in flight (independent accumulators, combined in a fixed order)
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    int sp = 0;
+                    for (; sp + 3 < d.splits; sp += 4) {
+                        a0 += pp[(int64_t)sp * d.C + c];
+                        a1 += pp[(int64_t)(sp + 1) * d.C + c];
+                        a2 += pp[(int64_t)(sp + 2) * d.C + c];
+                        a3 += pp[(int64_t)(sp + 3) * d.C + c];
+                    }
+                    for (; sp < d.splits; sp++) a0 += pp[(int64_t)sp * d.C + c];
+                    sg[c] = ((a0 + a1) + (a2 + a3)) * d.inv_hw;
+                }
+            } else {
+                const int p = threadIdx.x / d.C, c = threadIdx.x - p * d.C;
+                if (p < P) {
+                    float a0 = 0.f, a1 = 0.f;
+                    int sp = p;
+                    for (; sp + P < d.splits; sp += 2 * P) {
+                        a0 += pp[(int64_t)sp * d.C + c];
+                        a1 += pp[(int64_t)(sp + P) * d.C + c];
+                    }
+                    if (sp < d.splits) a0 += pp[(int64_t)sp * d.C + c];
+                    red[p * d.C + c] = a0 + a1;
+                }
+                __syncthreads();
+                if ((int)threadIdx.x < d.C) {
+                    float acc = red[threadIdx.x];
+                    for (int t = 1; t < P; t++) acc += red[t * d.C + threadIdx.x];
+                    sg[threadIdx.x] = acc * d.inv_hw;
+                }
+                if (g + 1 < ng) __syncthreads();  // red is reused by the next sample
             }
-            if (sp < d.splits) a0 += pp[(int64_t)sp * d.C + c];
-            red[p * d.C + c] = a0 + a1;
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < d.C) {
-            float acc = red[threadIdx.x];
-            for (int q = 1; q < P; q++) acc += red[q * d.C + threadIdx.x];
-            ssm[threadIdx.x] = acc * d.inv_hw;
         }
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // hidden units: wave w owns rows w, w+16, w+32, w+48 (then +64 ...) and streams them TOGETHER, so
+    // ---- hidden units: wave w owns rows w, w+16, w+32, w+48 (then +64 ...) and streams them TOGETHER, so
     // four independent weight loads are in flight per step instead of one dependent chain per row
     // (at C=1152, Cr=48 the row-at-a-time loop cost ~25 us of pure load latency)
-    if ((d.C & 3) == 0) {
-        const int CV = d.C >> 2;
+    if (vec) {
         const float4 *s4 = reinterpret_cast<const float4 *>(ssm);
         for (int j0 = wave; j0 < d.Cr; j0 += 64) {
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            float a[4][G];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int g = 0; g < G; g++) a[r][g] = 0.f;
             const float4 *wr[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int j = j0 + 16 * r < d.Cr ? j0 + 16 * r : d.Cr - 1;
                 wr[r] = reinterpret_cast<const float4 *>(w1 + (int64_t)j * d.C);
             }
-#pragma unroll 2
-            for (int cv = lane; cv < CV; cv += 64) {
-                const float4 sv = s4[cv];
+            int cv = lane;
+            if (W1PRE && j0 == wave && cv < CV) {  // the chunk requested before the squeeze sums
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float4 wv = wr[r][cv];
-                    a[r] = fmaf(sv.x, wv.x, a[r]);
-                    a[r] = fmaf(sv.y, wv.y, a[r]);
-                    a[r] = fmaf(sv.z, wv.z, a[r]);
-                    a[r] = fmaf(sv.w, wv.w, a[r]);
+                for (int g = 0; g < G; g++) {
+                    const float4 sv = s4[g * CV + cv];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        a[r][g] = fmaf(sv.x, w1pre[r].x, a[r][g]);
+                        a[r][g] = fmaf(sv.y, w1pre[r].y, a[r][g]);
+                        a[r][g] = fmaf(sv.z, w1pre[r].z, a[r][g]);
+                        a[r][g] = fmaf(sv.w, w1pre[r].w, a[r][g]);
+                    }
+                }
+                cv += 64;
+            }
+#pragma unroll(G == 1 ? 2 : 1)
+            for (; cv < CV; cv += 64) {
+                float4 wv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) wv[r] = wr[r][cv];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const float4 sv = s4[g * CV + cv];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        a[r][g] = fmaf(sv.x, wv[r].x, a[r][g]);
+                        a[r][g] = fmaf(sv.y, wv[r].y, a[r][g]);
+                        a[r][g] = fmaf(sv.z, wv[r].z, a[r][g]);
+                        a[r][g] = fmaf(sv.w, wv[r].w, a[r][g]);
+                    }
                 }
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float acc = a[r];
-                for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
                 const int j = j0 + 16 * r;
-                if (lane == 0 && j < d.Cr) hid[j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
+                const float bj = (b1 && j < d.Cr) ? b1[j] : 0.f;
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    float acc = a[r][g];
+                    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+                    if (lane == 0 && j < d.Cr) hid[g * d.Cr + j] = act_apply(d.act1, acc + bj, d.p0_1, d.p1_1);
+                }
             }
         }
     } else {
-        for (int j = wave; j < d.Cr; j += 16) {
-            const float *wr = w1 + (int64_t)j * d.C;
-            float acc = 0.f;
-            for (int c = lane; c < d.C; c += 64) acc = fmaf(ssm[c], wr[c], acc);
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-            if (lane == 0) hid[j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
-        }
+        for (int g = 0; g < ng; g++)
+            for (int j = wave; j < d.Cr; j += 16) {
+                const float *wr = w1 + (int64_t)j * d.C;
+                float acc = 0.f;
+                for (int c = lane; c < d.C; c += 64) acc = fmaf(ssm[g * d.C + c], wr[c], acc);
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+                if (lane == 0) hid[g * d.Cr + j] = act_apply(d.act1, acc + (b1 ? b1[j] : 0.f), d.p0_1, d.p1_1);
+            }
     }
     __syncthreads();
-    // excite: 256-channel slices, 4 thread groups split the Cr terms (fixed-order combine).  A block takes the
-    // slices blockIdx.x, blockIdx.x + gridDim.x, ...: the launcher caps the blocks per sample so that a large
+    // ---- excite: 256-channel slices, 4 thread groups split the Cr terms (fixed-order combine).  A block takes the
+    // slices blockIdx.x, blockIdx.x + gridDim.x, ...: the launcher caps the blocks per group so that a large
     // batch does not redo the first half once per slice (the result does not depend on that split)
-    const int cl = threadIdx.x & 255, q = threadIdx.x >> 8;
-    const int nslices = (d.C + 255) / 256;
     for (int slice = blockIdx.x; slice < nslices; slice += gridDim.x) {
         const int c = slice * 256 + cl;
-        float acc = 0.f;
+        float acc[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) acc[g] = 0.f;
         if (c < d.C) {
+#pragma unroll
+            for (int i = 0; i < SE_NPRE; i++) {
+                const int j = q + 4 * i;
+                if (j < d.Cr) {
+#pragma unroll
+                    for (int g = 0; g < G; g++) acc[g] = fmaf(hid[g * d.Cr + j], wpre[i], acc[g]);
+                }
+            }
 #pragma unroll 4
-            for (int j = q; j < d.Cr; j += 4) acc = fmaf(hid[j], w2t[(int64_t)j * d.C + c], acc);
+            for (int j = q + 4 * SE_NPRE; j < d.Cr; j += 4) {
+                const float w = w2t[(int64_t)j * d.C + c];
+#pragma unroll
+                for (int g = 0; g < G; g++) acc[g] = fmaf(hid[g * d.Cr + j], w, acc[g]);
+            }
         }
-        red[q * 256 + cl] = acc;
+#pragma unroll
+        for (int g = 0; g < G; g++) red[(g * 4 + q) * 256 + cl] = acc[g];
+        {   // the next slice's column, requested before the combine
+            const int cn = (slice + (int)gridDim.x) * 256 + cl;
+            if (slice + (int)gridDim.x < nslices) {
+                const int cc = min(cn, d.C - 1);
+#pragma unroll
+                for (int i = 0; i < SE_NPRE; i++) wpre[i] = w2t[(int64_t)min(q + 4 * i, d.Cr - 1) * d.C + cc];
+            }
+        }
         __syncthreads();
-        if (q == 0 && c < d.C) {
-            const float v = ((red[cl] + red[256 + cl]) + red[512 + cl]) + red[768 + cl] + (b2 ? b2[c] : 0.f);
-            gate[b * d.out_bs + c] = act_apply(d.act2, v, d.p0_2, d.p1_2);
+        // thread group q finishes samples q, q + 4, ...
+        if (c < d.C) {
+            const float bc = b2 ? b2[c] : 0.f;
+#pragma unroll
+            for (int g0 = 0; g0 < G; g0 += 4) {
+                const int g = g0 + q;
+                if (g < ng) {
+                    const float *rg = red + g * 1024;
+                    const float v = ((rg[cl] + rg[256 + cl]) + rg[512 + cl]) + rg[768 + cl] + bc;
+                    gate[(bq + g) * d.out_bs + c] = act_apply(d.act2, v, d.p0_2, d.p1_2);
+                }
+            }
         }
         __syncthreads();  // red is reused by the next slice
     }
@@ -2485,11 +2587,21 @@ void launch_se_fc(hipStream_t s, const SeFcDesc &d, float *gate, float *hidden, 
                   const float *b1, const float *w2, const float *b2, int64_t batch) {
     (void)hidden;
     if (batch <= 0) return;
-    // blocks per sample: one per 256-channel slice, capped so that the whole launch stays near two blocks per CU
+    // samples per block: 1 by default.  BN_SEFC_G=4 lets a block serve four samples (a quarter of the weight traffic:
+    // the wide layers at batch 128 take 17 us instead of 21) -- but with four samples' accumulators there is no room to
+    // keep as many weight loads in flight, a launch at batch 32 takes 15 us instead of 9.5, and with four contexts the
+    // two cancel (55.2 - 56.1 k against 55.6 k segments/s, one box): kept as a tested option, not the default
+    const int force_g = getenv("BN_SEFC_G") ? atoi(getenv("BN_SEFC_G")) : 0;  // (read per call: the tests flip it)
+    const int G = force_g == 4 ? 4 : 1;
+    const int64_t groups = (batch + G - 1) / G;
+    // blocks per group: one per 256-channel slice, capped so that the whole launch stays near two blocks per CU
     const int64_t nslices = (d.C + 255) / 256;
-    const int64_t per_sample = std::max<int64_t>(1, std::min<int64_t>(nslices, 512 / std::max<int64_t>(batch, 1)));
-    hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)per_sample, (unsigned)batch), dim3(1024),
-                       (size_t)(d.C + d.Cr + 1024) * sizeof(float), s, d, gate, partial, w1, b1, w2, b2);
+    const int64_t per_group = std::max<int64_t>(1, std::min<int64_t>(nslices, 512 / std::max<int64_t>(groups, 1)));
+    const size_t lds = (size_t)(G * (d.C + d.Cr) + G * 1024) * sizeof(float);
+    if (G == 4)
+        hipLaunchKernelGGL(se_fc_kernel<4>, dim3((unsigned)per_group, (unsigned)groups), dim3(1024), lds, s, d, gate, partial, w1, b1, w2, b2, (int)batch);
+    else
+        hipLaunchKernelGGL(se_fc_kernel<1>, dim3((unsigned)per_group, (unsigned)groups), dim3(1024), lds, s, d, gate, partial, w1, b1, w2, b2, (int)batch);
 }
 
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w, const float *bias,

@@ -433,7 +433,9 @@ def test_round3_kernels_tile_shape_and_grouping_do_not_enter_the_arithmetic(bn, 
     x = synth.synthetic_segments(5, 144000, 48000)
     base, _ = bn.Context(bn.Model(path), 5).infer(x)
     base = base.copy()
-    for env in ({"BN_GEMMDMA_MINBLOCKS": "1"}, {"BN_GEMMDMA_MINBLOCKS": "100000000"}, {"BN_MBMAP2_NCH": "1"}, {"BN_MBMAP2_NCH": "7"}):
+    # (BN_SEFC_G: samples per block of the squeeze-excite launch -- 1 everywhere, 4 everywhere incl. the ragged last group)
+    for env in ({"BN_GEMMDMA_MINBLOCKS": "1"}, {"BN_GEMMDMA_MINBLOCKS": "100000000"}, {"BN_MBMAP2_NCH": "1"}, {"BN_MBMAP2_NCH": "7"},
+                {"BN_SEFC_G": "1"}, {"BN_SEFC_G": "4"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got, _ = bn.Context(bn.Model(path), 5).infer(x)

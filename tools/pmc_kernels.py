@@ -49,7 +49,7 @@ def main():
         if c.get("SQ_INSTS_MFMA"):
             line += f" valu/mfma={c.get('SQ_INSTS_VALU', 0) / c['SQ_INSTS_MFMA']:.1f} mfma={c['SQ_INSTS_MFMA']:.0f}"
         if c.get("SQ_LDS_IDX_ACTIVE"):
-            line += f" lds_conf={c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.2f}"
+            line += f" lds_conf={c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.2f} lds_idx_cycles={c['SQ_LDS_IDX_ACTIVE']:.0f} lds_conf_cycles={c.get('SQ_LDS_BANK_CONFLICT', 0):.0f}"
         for extra in ("FETCH_SIZE", "WRITE_SIZE"):
             if extra in c:
                 line += f" {extra}={c[extra] / 1024:.1f}MiB"
