@@ -994,7 +994,11 @@ class Builder {
         const int strips = (m.OW + outw - 1) / outw;
         if (!(env && std::string(env) == "force") && (double)m.OW < 0.7 * (double)(strips * outw)) return;
         m.row_mode = 1;
-        m.toh = std::min<int32_t>(m.OH, getenv("BN_MBROW_TOH") ? std::max(1, atoi(getenv("BN_MBROW_TOH"))) : (m.OH <= 12 ? 6 : 8));
+        // band height: a band of toh output rows expands (toh - 1) s + k halo rows, so taller bands recompute less (12 rows of a
+        // 5x5 block: 16 halo rows instead of 2 x 10) -- what several contexts sharing the chip pay for; a block with one or two
+        // 32-channel chunks keeps 8 so that one context alone still has enough waves (stem: 38 us at 8, 48 us at 12)
+        const int toh_default = (m.C + 31) / 32 >= 3 ? 12 : 8;
+        m.toh = std::min<int32_t>(m.OH, getenv("BN_MBROW_TOH") ? std::max(1, atoi(getenv("BN_MBROW_TOH"))) : toh_default);
         m.tiles_x = (m.OW + outw - 1) / outw;
         m.tiles_y = (m.OH + m.toh - 1) / m.toh;
         halo = 32.0 * m.tiles_x * (double)m.tiles_y * ((m.toh - 1) * m.s + m.k);

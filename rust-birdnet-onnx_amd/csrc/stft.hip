@@ -35,7 +35,10 @@
 namespace bn {
 namespace {
 
-constexpr int WBUF = 1024 + 128;  // complex slots of one wave's transform buffer: 64 blocks of 16 + 2 slots of padding each
+// complex slots of one wave's transform buffer: SLOTS / 16 blocks of 16 + 2 slots of padding each.  SLOTS = 1024 with 8 waves per
+// block, or 512 with 16 waves (M <= 512: one frame per wave at a time) -- the same LDS either way, but four waves per SIMD
+// instead of two to cover the LDS round trips and barriers the kernel is bound by
+__host__ __device__ constexpr int wbuf_slots(int slots) { return slots + slots / 8; }
 
 __device__ __forceinline__ int phys(int i) { return i + 2 * (i >> 4); }
 
@@ -60,11 +63,11 @@ __device__ __forceinline__ void bfly4(float2 &u0, float2 &u1, float2 &u2, float2
 
 // one in-place DIF pass over the wave's 1024 slots: sub-problems of size n, radix R, twiddles tw[(p-1)*q + j].
 // Two butterflies per lane are in flight at a time (register budget: 256 per lane at 8 waves per CU).
-template <int R>
+template <int R, int SLOTS>
 __device__ __forceinline__ void strided_pass(float2 *__restrict__ x, const float2 *__restrict__ tw, int logn, int lane) {
     constexpr int LR = R == 4 ? 2 : 1;
     const int lq = logn - LR, q = 1 << lq;
-    constexpr int PER_LANE = 1024 / R / 64, INFL = 4;
+    constexpr int PER_LANE = SLOTS / R / 64, INFL = PER_LANE < 4 ? PER_LANE : 4;
 #pragma unroll 1
     for (int h = 0; h < PER_LANE; h += INFL) {
         float2 u[INFL][R];
@@ -219,11 +222,11 @@ struct StftLds {
     int sig, tw, wbuf, window, otab, mstart, ment, spec, mel, total;
 };
 __host__ __device__ __forceinline__ int kib(int floats) { return (floats + 255) & ~255; }
-__host__ __device__ __forceinline__ StftLds stft_layout(const FftDesc &d, int nw) {
+__host__ __device__ __forceinline__ StftLds stft_layout(const FftDesc &d, int nw, int slots) {
     StftLds l;
     int o = 0;
     l.sig = o; o += ((d.tpb - 1) * d.hop + d.L + 3) & ~3;
-    l.wbuf = o; o += 2 * nw * WBUF;
+    l.wbuf = o; o += 2 * nw * wbuf_slots(slots);
     l.tw = o; o += kib(2 * d.tw_count);
     l.window = o; o += kib(d.L);
     l.otab = o; o += kib(8 * d.nout);
@@ -249,15 +252,15 @@ __device__ __forceinline__ void async_copy(float *lds_dst, const float *gsrc, in
     }
 }
 
-constexpr int SPAN_R = 4;  // float4 per thread of a tile's signal span held in registers (<= 8192 floats per 512 threads)
+constexpr int SPAN_FLOATS = 8192;  // a tile's signal span is staged in registers: SPAN_FLOATS / (4 threads) float4 per thread
 
 // first DIF pass fused with the frame load: element i of frame fi is (w[2i] x[2i], w[2i+1] x[2i+1]) straight from the span
-template <int R>
+template <int R, int SLOTS>
 __device__ __forceinline__ void first_pass(float2 *__restrict__ x, const float2 *__restrict__ tw, const float *__restrict__ sig,
                                            const float2 *__restrict__ wnd, int M, int logM, int hop, int frame0, int rows_here, int lane) {
     constexpr int LR = R == 4 ? 2 : 1;
     const int q = M >> LR;
-    constexpr int PER_LANE = 1024 / R / 64, INFL = 2;
+    constexpr int PER_LANE = SLOTS / R / 64, INFL = 2;
 #pragma unroll 1
     for (int h = 0; h < PER_LANE; h += INFL) {
         float2 u[INFL][R];
@@ -298,20 +301,21 @@ __device__ __forceinline__ void first_pass(float2 *__restrict__ x, const float2 
 
 // Persistent blocks: a block walks the (sample, frame tile) work items blockIdx.x, + gridDim.x, ...; the tables are
 // copied to LDS once, and the NEXT tile's signal span is fetched into registers while the current tile is transformed.
-template <int NW>
+template <int NW, int SLOTS>
 __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, int total_tiles, int tiles_per_sample) {
+    constexpr int SPAN_R = SPAN_FLOATS / (4 * NW * 64);
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const StftLds lay = stft_layout(d, NW);
+    const StftLds lay = stft_layout(d, NW, SLOTS);
     float *sig = lds + lay.sig;
     float2 *tw = reinterpret_cast<float2 *>(lds + lay.tw);
-    float2 *wbuf = reinterpret_cast<float2 *>(lds + lay.wbuf) + wave * WBUF;
+    float2 *wbuf = reinterpret_cast<float2 *>(lds + lay.wbuf) + wave * wbuf_slots(SLOTS);
     float2 *wnd = reinterpret_cast<float2 *>(lds + lay.window);
     float *otab = lds + lay.otab;
     float *mstart = lds + lay.mstart;
     float2 *ment = reinterpret_cast<float2 *>(lds + lay.ment);
     float *spec = lds + lay.spec;
-    const int M = d.M, logM = d.logM, hop = d.hop, nout = d.nout, nmel = d.nmel, F = d.F;
+    const int M = d.M, logM = d.logM, hop = d.hop, nout = d.nout, nmel = d.nmel, F = SLOTS >> d.logM;  // frames per wave pass
     const int dbg = d.dbg;
 
     // ---- tables -> LDS, once per block
@@ -408,13 +412,13 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
         const int groups = (rows_here + F - 1) / F;
         for (int g = wave; g < groups; g += NW) {
             if (!(dbg & 1)) {
-                if (first_radix == 2) first_pass<2>(wbuf, tw + pt0, sig, wnd, M, logM, hop, g * F, rows_here, lane);
-                else first_pass<4>(wbuf, tw + pt0, sig, wnd, M, logM, hop, g * F, rows_here, lane);
+                if (first_radix == 2) first_pass<2, SLOTS>(wbuf, tw + pt0, sig, wnd, M, logM, hop, g * F, rows_here, lane);
+                else first_pass<4, SLOTS>(wbuf, tw + pt0, sig, wnd, M, logM, hop, g * F, rows_here, lane);
                 wave_sync();
-                if (1 < npass) { strided_pass<4>(wbuf, tw + pt1, ln1, lane); wave_sync(); }
-                if (2 < npass) { strided_pass<4>(wbuf, tw + pt2, ln2, lane); wave_sync(); }
-                if (3 < npass) { strided_pass<4>(wbuf, tw + pt3, ln3, lane); wave_sync(); }
-                block16(wbuf + 18 * lane);
+                if (1 < npass) { strided_pass<4, SLOTS>(wbuf, tw + pt1, ln1, lane); wave_sync(); }
+                if (2 < npass) { strided_pass<4, SLOTS>(wbuf, tw + pt2, ln2, lane); wave_sync(); }
+                if (3 < npass) { strided_pass<4, SLOTS>(wbuf, tw + pt3, ln3, lane); wave_sync(); }
+                if (SLOTS == 1024 || lane < SLOTS / 16) block16(wbuf + 18 * lane);
                 wave_sync();
             }
             if (dbg & 2) continue;
@@ -425,22 +429,23 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
             for (int fi = 0; fi < F; fi++) {
                 const int t = g * F + fi;
                 const float2 *zf = wbuf + fi * fstride;
-                for (int c0 = lane; c0 < nout; c0 += 256) {
-                    float4 e0[4];
-                    float2 e1[4], za[4], zb[4];
+                constexpr int BI = SLOTS == 1024 ? 4 : 2;  // bins per lane in flight (twice the waves hold half as many each)
+                for (int c0 = lane; c0 < nout; c0 += 64 * BI) {
+                    float4 e0[BI];
+                    float2 e1[BI], za[BI], zb[BI];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < BI; k++) {
                         const int c = min(c0 + 64 * k, nout - 1);
                         e0[k] = *reinterpret_cast<const float4 *>(otab + 8 * c);
                         e1[k] = *reinterpret_cast<const float2 *>(otab + 8 * c + 4);
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < BI; k++) {
                         za[k] = zf[(int)e0[k].x];
                         zb[k] = zf[(int)e0[k].y];
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
+                    for (int k = 0; k < BI; k++) {
                         const int c = c0 + 64 * k;
                         if (c < nout) {
                             float v = e0[k].z * za[k].x + e0[k].w * za[k].y + e1[k].x * zb[k].x + e1[k].y * zb[k].y;
@@ -473,15 +478,16 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
                 // trips per work item, 30 of the kernel's 67 us for 10 000 multiply-adds per tile.  Same sums as before:
                 // entries at even offsets from the band's first feed a0, odd ones a1, combined once at the end.
                 float a0 = 0.0f, a1 = 0.0f;
-                for (int e = e0; e < ((dbg & 512) ? e0 : e1); e += 8) {
-                    float2 cc[8];
-                    float sv[8];
+                constexpr int MI = SLOTS == 1024 ? 8 : 4;  // entries per lane in flight (even: the a0 / a1 assignment stays)
+                for (int e = e0; e < ((dbg & 512) ? e0 : e1); e += MI) {
+                    float2 cc[MI];
+                    float sv[MI];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) cc[k] = ment[e + k < e1 ? e + k : e0];
+                    for (int k = 0; k < MI; k++) cc[k] = ment[e + k < e1 ? e + k : e0];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) sv[k] = sp[(int)cc[k].x];
+                    for (int k = 0; k < MI; k++) sv[k] = sp[(int)cc[k].x];
 #pragma unroll
-                    for (int k = 0; k < 8; k += 2) {
+                    for (int k = 0; k < MI; k += 2) {
                         if (e + k < e1) a0 = fmaf(sv[k], cc[k].y, a0);
                         if (e + k + 1 < e1) a1 = fmaf(sv[k + 1], cc[k + 1].y, a1);
                     }
@@ -509,16 +515,31 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
 
 }  // namespace
 
-size_t stft_lds_bytes(const FftDesc &d, int nwaves) { return (size_t)stft_layout(d, nwaves).total * sizeof(float); }
+// 16 waves x 512 slots where a frame fits 512 complex points (BN_STFT_NW=8 keeps the 8 x 1024 form), else 8 x 1024
+static bool stft_wide(const FftDesc &d) {
+    const char *e = getenv("BN_STFT_NW");  // (read per call: the tests flip it)
+    if (e && atoi(e) == 8) return false;
+    if (!e || atoi(e) != 16) return false;  // opt-in: measured slower (128-register cap at 16 waves: 156 B of scratch per lane; 74.6 vs 69.1 us)
+    return d.M <= 512 && d.tpb % (512 / d.M) == 0;
+}
 
-void register_stft_kernels() { register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<8>)); }
+size_t stft_lds_bytes(const FftDesc &d, int nwaves) {
+    (void)nwaves;
+    return (size_t)(stft_wide(d) ? stft_layout(d, 16, 512) : stft_layout(d, 8, 1024)).total * sizeof(float);
+}
+
+void register_stft_kernels() {
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<8, 1024>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<16, 512>));
+}
 
 void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t batch) {
     if (batch <= 0) return;
-    constexpr int NW = 8;
-    const size_t lds = stft_lds_bytes(d, NW);
+    const bool wide = stft_wide(d);
+    const size_t lds = stft_lds_bytes(d, 0);
     const int span = (d.tpb - 1) * d.hop + d.L;
-    if (lds > 160 * 1024 || span > SPAN_R * 4 * NW * 64 || !ensure_dynamic_lds(reinterpret_cast<const void *>(stft_kernel<NW>), lds)) {
+    const void *fn = wide ? reinterpret_cast<const void *>(stft_kernel<16, 512>) : reinterpret_cast<const void *>(stft_kernel<8, 1024>);
+    if (lds > 160 * 1024 || span > SPAN_FLOATS || !ensure_dynamic_lds(fn, lds)) {
         launch_error("STFT kernel: the frame span does not fit the LDS / the staging registers");
         return;
     }
@@ -532,7 +553,8 @@ void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t bat
     const int64_t total = (int64_t)tps * batch;
     const int ncu = device_cu_count();  // asked once per device by prepare_device(), never inside a stream capture
     const unsigned grid = (unsigned)std::min<int64_t>(total, ncu);  // one block per CU (LDS-bound), persistent over its tiles
-    hipLaunchKernelGGL(stft_kernel<NW>, dim3(grid), dim3(NW * 64), lds, s, dd, p, (int)total, tps);
+    if (wide) hipLaunchKernelGGL((stft_kernel<16, 512>), dim3(grid), dim3(16 * 64), lds, s, dd, p, (int)total, tps);
+    else hipLaunchKernelGGL((stft_kernel<8, 1024>), dim3(grid), dim3(8 * 64), lds, s, dd, p, (int)total, tps);
 }
 
 }  // namespace bn
