@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--host-steps", type=int, default=120, help="minimum number of steps of the host-to-host leg")
     ap.add_argument("--host-warmup", type=int, default=96, help="minimum number of warm-up steps of the host-to-host leg")
     ap.add_argument("--cpu-sample", type=int, default=512, help="segments the CPU oracle is timed on (about 15-30 s of host work)")
+    ap.add_argument("--no-saturated", action="store_true", help="skip roofline.saturated (the dominant family timed at 4x the batch)")
     ap.add_argument("--no-extras", action="store_true", help="skip latency_b1 (configs[0]) and the v3.0 b64 / Perch b128 lines (configs[2], [3])")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-launch timing table to stderr")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -341,6 +342,76 @@ def main():
         },
     }
 
+    def run_extras():
+        """configs[2] / [3] in the same line.  Each runs as a CHILD process of this script (`--model v30 --batch 64`, `--model perch
+        --batch 128`, 60 timed steps): inside this process, behind the v2.4 run, the same loop reads 10 % lower (39.4 k against
+        44.0 k segments/s for v3.0, whether it runs before or after the timing blocks below) -- the in-process loop is kept as the
+        fallback and says so in "mode"."""
+        import subprocess
+
+        extra = {}
+        for key, bsz in (("v30", 64), ("perch", 128)):
+            try:
+                r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--model", key, "--batch", str(bsz), "--steps", "60", "--warmup", "8",
+                                     "--streams", str(S_), "--no-extras", "--no-cpu-baseline", "--no-host-leg", "--no-saturated"],
+                                    capture_output=True, text=True, timeout=600)
+                line = [l for l in r_.stdout.splitlines() if l.startswith("{")][-1]
+                j_ = json.loads(line)
+                extra[key] = {"workload": j_["config"]["workload"], "value": j_["value"], "unit": j_["unit"], "ms_per_step": j_["ms_per_step"],
+                              "median_ms": j_.get("median_ms"), "p10_ms": j_.get("p10_ms"), "p90_ms": j_.get("p90_ms"), "steps": j_["steps"],
+                              "flops_performed_per_segment": j_["roofline"].get("flops_performed_per_segment"),
+                              "frac_mfma_f32_whole_path": j_.get("whole_path_frac_mfma_f32"), "capture_fallbacks": j_.get("capture_fallbacks"),
+                              "mode": "child process: " + " ".join(r_.args[1:])}
+            except Exception as e_:  # noqa: BLE001 -- fall back to the in-process loop below
+                print(f"bench: child run of {key} failed ({e_}); measuring it in this process", file=sys.stderr)
+                extra = None
+                break
+        if extra is not None:
+            out["extra"] = extra
+            return
+        if args.model == "v24":
+            extra = {}
+            for key, bsz in (("v30", 64), ("perch", 128)):
+                S2, SR2, SEC2, mk2, name2, seg2 = MODELS[key]
+                with tempfile.NamedTemporaryFile(suffix=".onnx", delete=False) as f2:
+                    f2.write(mk2())
+                m2 = bn.Model(f2.name, device=local_rank)
+                os.unlink(f2.name)
+                cs2 = [bn.Context(m2, bsz) for _ in range(S_)]
+                own2 = []
+                for q, c_ in enumerate(cs2):
+                    ptr2, cap2 = c_.input_device()
+                    assert cap2 >= bsz * S2
+                    torch.as_tensor(_DevBuf(ptr2, (bsz, S2)), device="cuda").copy_(torch.from_numpy(synth.synthetic_segments(bsz, S2, SR2, first_index=(q % 2) * bsz)))
+                    own2.append(ptr2)
+                torch.cuda.synchronize()
+                nst, nwu = max(24, min(args.steps, 60)), 8
+
+                def run2(n):
+                    for i in range(n):
+                        if i >= S_:
+                            cs2[(i - S_) % S_].synchronize()
+                        cs2[i % S_].step_device(own2[i % S_], bsz, args.top_k, 0.1, sync=False)
+                    for c_ in cs2:
+                        c_.synchronize()
+
+                run2(nwu)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                run2(nst)
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t2
+                lg2 = cs2[(nst - 1) % S_].step_results(bsz)[0]
+                assert np.isfinite(lg2).all()
+                c2 = m2.cost()
+                extra[key] = {"workload": f"{name2}, batch={bsz} synthetic {SR2 // 1000} kHz {SEC2:g} s segments, inputs resident in HBM",
+                              "value": round(nst * bsz / d2, 1), "unit": "segments/s", "ms_per_step": round(d2 / nst * 1e3, 4), "steps": nst,
+                              "flops_performed_per_segment": round(2.0 * (c2.macs_mfma + c2.macs_valu)),
+                              "frac_mfma_f32_whole_path": round(2.0 * (c2.macs_mfma + c2.macs_valu) * nst * bsz / d2 / 1e12 / MFMA_F32_PEAK_TF, 4),
+                              "capture_fallbacks": sum(c_.stats()["capture_fallbacks"] for c_ in cs2), "mode": "in-process"}
+                del cs2, m2
+            out["extra"] = extra
+
     if host_to_host is not None:
         out["host_to_host"] = host_to_host
     if rank == 0 and world == 1 and not args.no_extras:
@@ -368,44 +439,6 @@ def main():
                              "launches": int(model.cost().n_launches), "capture_fallbacks": c1.stats()["capture_fallbacks"],
                              "what": "one segment: Classifier::predict's path (configs[0]) -- wall clock of one synchronous call, batch-1 context"}
         del c1
-        # ---- the other single-GPU configs of BASELINE.json in the same line: configs[2] BirdNET v3.0 batch 64 (logits + 1024-d
-        # embeddings) and configs[3] Perch v2 batch 128, device-resident steps on the same number of contexts
-        if args.model == "v24":
-            extra = {}
-            for key, bsz in (("v30", 64), ("perch", 128)):
-                S2, SR2, SEC2, mk2, name2, seg2 = MODELS[key]
-                with tempfile.NamedTemporaryFile(suffix=".onnx", delete=False) as f2:
-                    f2.write(mk2())
-                m2 = bn.Model(f2.name, device=local_rank)
-                os.unlink(f2.name)
-                cs2 = [bn.Context(m2, bsz) for _ in range(S_)]
-                xb = [torch.from_numpy(synth.synthetic_segments(bsz, S2, SR2, first_index=q * bsz)).cuda() for q in range(2)]
-                nst, nwu = max(24, min(args.steps, 60)), 8
-
-                def run2(n):
-                    for i in range(n):
-                        if i >= S_:
-                            cs2[(i - S_) % S_].synchronize()
-                        cs2[i % S_].step_device(xb[i % 2].data_ptr(), bsz, args.top_k, 0.1, sync=False)
-                    for c_ in cs2:
-                        c_.synchronize()
-
-                run2(nwu)
-                torch.cuda.synchronize()
-                t2 = time.perf_counter()
-                run2(nst)
-                torch.cuda.synchronize()
-                d2 = time.perf_counter() - t2
-                lg2 = cs2[(nst - 1) % S_].step_results(bsz)[0]
-                assert np.isfinite(lg2).all()
-                c2 = m2.cost()
-                extra[key] = {"workload": f"{name2}, batch={bsz} synthetic {SR2 // 1000} kHz {SEC2:g} s segments, inputs resident in HBM",
-                              "value": round(nst * bsz / d2, 1), "unit": "segments/s", "ms_per_step": round(d2 / nst * 1e3, 4), "steps": nst,
-                              "flops_performed_per_segment": round(2.0 * (c2.macs_mfma + c2.macs_valu)),
-                              "frac_mfma_f32_whole_path": round(2.0 * (c2.macs_mfma + c2.macs_valu) * nst * bsz / d2 / 1e12 / MFMA_F32_PEAK_TF, 4),
-                              "capture_fallbacks": sum(c_.stats()["capture_fallbacks"] for c_ in cs2)}
-                del cs2, m2, xb
-            out["extra"] = extra
     if rank == 0:
         out["capture_fallbacks"] = sum(c.stats()["capture_fallbacks"] for c in ctxs)
         out["whole_path_frac_mfma_f32"] = None  # filled below from the plan's flop count
@@ -493,6 +526,8 @@ def main():
         # the same family where the launches are not latency-bound: one context at 4x the batch, and the MARGINAL cost of a
         # further batch of B, (t(4B) - t(B)) / 3 per launch -- what each of the concurrent contexts pays per step
         try:
+            if args.no_saturated:
+                raise RuntimeError("skipped (--no-saturated)")
             big = bn.Context(model, 4 * B)
             big.infer(np.concatenate([bufs[0].cpu().numpy()] * 4))
             rows4 = big.time_kernels(4 * B)
@@ -611,6 +646,14 @@ def main():
                                              f"(the fastest of the thread counts tried)"}
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_extras and args.model == "v24":
+            ctxs.clear()
+            logit_views.clear()
+            ev_streams.clear()
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            run_extras()
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -840,6 +840,7 @@ class Builder {
         if ((int64_t)(d.tpb - 1) * g.lda + L > 8192 || d.tpb % d.F) return false;
         d.a_bs = g.a_bs; d.ldc = g.ldc; d.c_bs = g.c_bs; d.has_bias = has_bias ? 1 : 0;
         d.out_rs = g.ldc; d.out_cs = 1;
+        d.power = 0; d.otab_stride = 8;
         // pass structure: radix 2 first when log2 M is odd, radix 4 down to 16-point blocks (registers)
         std::vector<int> radix;
         std::vector<float> tw;
@@ -997,7 +998,10 @@ class Builder {
         // band height: a band of toh output rows expands (toh - 1) s + k halo rows, so taller bands recompute less (12 rows of a
         // 5x5 block: 16 halo rows instead of 2 x 10) -- what several contexts sharing the chip pay for; a block with one or two
         // 32-channel chunks keeps 8 so that one context alone still has enough waves (stem: 38 us at 8, 48 us at 12)
-        const int toh_default = (m.C + 31) / 32 >= 3 ? 12 : 8;
+        // (bands balanced: 16 rows are one band of 16, not 12 + 4)
+        const int toh_target = (m.C + 31) / 32 >= 3 ? 12 : 8;
+        const int nbands = std::max(1, (m.OH + toh_target / 2 - 1) / toh_target);
+        const int toh_default = (m.OH + nbands - 1) / nbands;
         m.toh = std::min<int32_t>(m.OH, getenv("BN_MBROW_TOH") ? std::max(1, atoi(getenv("BN_MBROW_TOH"))) : toh_default);
         m.tiles_x = (m.OW + outw - 1) / outw;
         m.tiles_y = (m.OH + m.toh - 1) / m.toh;
@@ -2932,6 +2936,71 @@ class Builder {
             }
             return users;
         };
+        //  * (round 3) the power / magnitude pass behind a cos | sin bank: an elementwise launch  re*re + im*im [-> sqrt]  over
+        //    the two halves of every spectrum row, whose only reader it is -- the launch computes both linear forms of a bin
+        //    in one lane and stores f(u^2 + v^2): half the spectrum bytes written, none read back, one launch less, and the
+        //    mel bank that follows becomes a direct neighbour (next rule).  BN_STFT_POWER=0 disables.
+        if (!(getenv("BN_STFT_POWER") && std::string(getenv("BN_STFT_POWER")) == "0")) {
+            bool again = true;
+            while (again) {
+                again = false;
+                auto users = users_of();
+                for (size_t i = 0; i < plan_.ops.size() && !again; i++) {
+                    PlanOp &f = plan_.ops[i];
+                    FftDesc &d = f.fft;
+                    if (f.kind != OpKind::FFT || d.nmel || d.power || d.has_bias || d.npost || f.out.space != Space::ARENA || plan_.storages[f.out.id].pinned) continue;
+                    if (d.nout % 2 || d.ldc != d.nout || d.out_rs != d.nout || d.out_cs != 1) continue;
+                    const auto &u = users[f.out.id];
+                    if (u.size() != 2 || u[0] != (int)i) continue;
+                    PlanOp &el = plan_.ops[u[1]];
+                    const EltDesc &e = el.elt;
+                    const int64_t nb = d.nout / 2;
+                    if (el.kind != OpKind::ELT || e.nd != 2 || e.size[0] != d.frames || e.size[1] != nb || e.sa[0] != d.nout || e.sa[1] != 1 || e.ba != d.c_bs) continue;
+                    if (el.a.space != Space::ARENA || el.a.id != f.out.id || el.a.offset != f.out.offset) continue;
+                    if (el.out.space != Space::ARENA || e.so[1] != 1 || e.so[0] < nb) continue;
+                    // stage 0: x * x (the operand is the same view); stage 1: + y^2 with y the other half of the row; [stage 2: sqrt]
+                    if (e.nstages < 2 || e.nstages > 3) continue;
+                    const EltStage &s0 = e.st[0], &s1 = e.st[1];
+                    const Ref &r0 = el.eb[0], &r1 = el.eb[1];
+                    if (s0.bin != BIN_MUL || s0.bsq || s0.act != ACT_NONE || r0.space != Space::ARENA || r0.id != f.out.id || r0.offset != f.out.offset ||
+                        s0.sb[0] != d.nout || s0.sb[1] != 1 || s0.bb != d.c_bs)
+                        continue;
+                    if (s1.bin != BIN_ADD || !s1.bsq || s1.act != ACT_NONE || r1.space != Space::ARENA || r1.id != f.out.id || r1.offset != f.out.offset + nb ||
+                        s1.sb[0] != d.nout || s1.sb[1] != 1 || s1.bb != d.c_bs)
+                        continue;
+                    if (e.nstages == 3 && !(e.st[2].bin == BIN_NONE && e.st[2].act == ACT_SQRT)) continue;
+                    // the two halves must be the two forms of the SAME bins in the same order (same buffer positions)
+                    const std::vector<float> &ot = plan_.consts[f.bias2.id];
+                    bool same = (int64_t)ot.size() >= f.bias2.offset + d.nout * 8;
+                    for (int64_t c = 0; c < nb && same; c++) {
+                        const float *u0 = &ot[(size_t)(f.bias2.offset + c * 8)], *v0 = &ot[(size_t)(f.bias2.offset + (c + nb) * 8)];
+                        same = u0[0] == v0[0] && u0[1] == v0[1];
+                    }
+                    if (!same) continue;
+                    std::vector<float> ot2((size_t)nb * 12, 0.0f);
+                    for (int64_t c = 0; c < nb; c++) {
+                        const float *u0 = &ot[(size_t)(f.bias2.offset + c * 8)], *v0 = &ot[(size_t)(f.bias2.offset + (c + nb) * 8)];
+                        float *o = &ot2[(size_t)c * 12];
+                        for (int q = 0; q < 6; q++) o[q] = u0[q];
+                        for (int q = 0; q < 4; q++) o[8 + q] = v0[2 + q];
+                    }
+                    FftDesc probe = d;
+                    probe.nout = (int32_t)nb; probe.otab_stride = 12; probe.power = e.nstages == 3 ? 2 : 1;
+                    if (stft_lds_bytes(probe, 8) > 156 * 1024) continue;
+                    d = probe;
+                    d.ldc = e.so[0]; d.out_rs = e.so[0]; d.out_cs = 1; d.c_bs = e.bo;
+                    f.bias2 = Ref{Space::CONSTS, add_const(ot2), 0};
+                    f.out = el.out;
+                    f.name += "+" + el.name;
+                    f.weight_bytes += 4.0 * (double)ot2.size() - 4.0 * 8.0 * (double)(2 * nb);
+                    f.bytes -= 4.0 * (double)d.frames * (double)nb;  // one value per bin is written instead of two; the cos | sin rows are never read back
+                    f.macs += 2.0 * (double)d.frames * (double)nb;
+                    f.flops_fft += 3.0 * (double)d.frames * (double)nb;
+                    plan_.ops.erase(plan_.ops.begin() + u[1]);
+                    again = true;
+                }
+            }
+        }
         bool changed = mel_on;
         while (changed) {
             changed = false;
@@ -2966,8 +3035,14 @@ class Builder {
                 FftDesc probe = f.fft;
                 probe.nmel = (int32_t)N;
                 probe.mel_nnz = (int32_t)nnz_count;
+                // the tile's spectrum rows join the LDS image.  Where 16 frames per tile no longer fit (v3.0: 513 bins, 128 bands)
+                // tiles of 8 would, but the launch then loses to FFT + dense mel GEMM (200 us against 97 + 66 at batch 64,
+                // 41.5 k against 44.0 k segments/s): BN_STFT_MEL=force takes the smaller tile anyway (tests)
+                if (getenv("BN_STFT_MEL") && std::string(getenv("BN_STFT_MEL")) == "force")
+                    while (stft_lds_bytes(probe, 8) > 156 * 1024 && probe.tpb > 8 && (probe.tpb / 2) % probe.F == 0) probe.tpb /= 2;
                 if (stft_lds_bytes(probe, 8) > 156 * 1024) continue;
                 FftDesc &d = f.fft;
+                d.tpb = probe.tpb;
                 d.nmel = (int32_t)N;
                 d.mel_nnz = (int32_t)nnz_count;
                 if (ment.empty()) { ment.push_back(0.0f); ment.push_back(0.0f); }

@@ -306,13 +306,17 @@ struct FftDesc {
     int32_t npost, post_act[4];
     float post_p0[4], post_p1[4];
     int64_t out_rs, out_cs;  // mel element (t, m) of sample b is stored at out + b*c_bs + t*out_rs + m*out_cs
+    // power spectrum mode (the planner folds  re^2 + im^2 [-> sqrt]  behind a cos | sin bank into the launch): output c is
+    // f(u^2 + v^2) with u, v the two linear forms of bin c (otab row: positions, 4 coefficients of u, 4 of v); 0 = off,
+    // 1 = u^2 + v^2, 2 = sqrt(u^2 + v^2).  otab_stride: floats per otab row (8, or 12 in power mode)
+    int32_t power, otab_stride;
 };
 struct StftPtrs {
     float *out;
     const float *in;
     const float *window;  // [L]
     const float2 *tw;     // [tw_count]
-    const float *otab;    // [nout][8]: position of Z[k], position of Z[M-k] (as floats), 4 coefficients, 2 pad
+    const float *otab;    // [nout][otab_stride]: position of Z[k], position of Z[M-k] (as floats), 4 coefficients, 2 pad (power mode: + 4 coefficients)
     const float *bias;    // [nout] or NULL
     const float *pre[ELT_MAX_STAGES];
     const float *mstart, *mcol, *mval, *mel_bias;  // CSR of the mel filter bank: row starts, (column, value) pairs in mcol (indices stored as floats); mval unused

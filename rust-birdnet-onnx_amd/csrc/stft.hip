@@ -229,7 +229,7 @@ __host__ __device__ __forceinline__ StftLds stft_layout(const FftDesc &d, int nw
     l.wbuf = o; o += 2 * nw * wbuf_slots(slots);
     l.tw = o; o += kib(2 * d.tw_count);
     l.window = o; o += kib(d.L);
-    l.otab = o; o += kib(8 * d.nout);
+    l.otab = o; o += kib((d.otab_stride > 0 ? d.otab_stride : 8) * d.nout);
     l.mstart = o; o += d.nmel ? kib(d.nmel + 1) : 0;
     l.ment = o; o += d.nmel ? kib(2 * d.mel_nnz) : 0;  // (column, value) pairs
     l.spec = o; o += d.nmel ? d.tpb * d.nout : 0;  // the tile's spectrum rows (mel fusion only)
@@ -321,7 +321,8 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     // ---- tables -> LDS, once per block
     async_copy<NW>(lds + lay.tw, reinterpret_cast<const float *>(p.tw), 2 * d.tw_count, wave, lane);
     async_copy<NW>(lds + lay.window, p.window, d.L, wave, lane);
-    async_copy<NW>(otab, p.otab, 8 * nout, wave, lane);
+    const int ostride = d.otab_stride > 0 ? d.otab_stride : 8, power = d.power;
+    async_copy<NW>(otab, p.otab, ostride * nout, wave, lane);
     if (nmel) {
         async_copy<NW>(mstart, p.mstart, nmel + 1, wave, lane);
         async_copy<NW>(lds + lay.ment, p.mcol, 2 * d.mel_nnz, wave, lane);
@@ -436,8 +437,8 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
 #pragma unroll
                     for (int k = 0; k < BI; k++) {
                         const int c = min(c0 + 64 * k, nout - 1);
-                        e0[k] = *reinterpret_cast<const float4 *>(otab + 8 * c);
-                        e1[k] = *reinterpret_cast<const float2 *>(otab + 8 * c + 4);
+                        e0[k] = *reinterpret_cast<const float4 *>(otab + ostride * c);
+                        e1[k] = *reinterpret_cast<const float2 *>(otab + ostride * c + 4);
                     }
 #pragma unroll
                     for (int k = 0; k < BI; k++) {
@@ -449,6 +450,13 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
                         const int c = c0 + 64 * k;
                         if (c < nout) {
                             float v = e0[k].z * za[k].x + e0[k].w * za[k].y + e1[k].x * zb[k].x + e1[k].y * zb[k].y;
+                            if (power) {  // launch-uniform: the second linear form of the bin, then u^2 + v^2 (+ sqrt)
+                                const float4 e2 = *reinterpret_cast<const float4 *>(otab + ostride * c + 8);
+                                const float w = e2.x * za[k].x + e2.y * za[k].y + e2.z * zb[k].x + e2.w * zb[k].y;
+                                const float uu = v * v, ww = w * w;
+                                v = uu + ww;
+                                if (power == 2) v = sqrtf(v);
+                            }
                             if (d.has_bias) v += p.bias[c];
                             if (nmel) spec[t * nout + c] = v;
                             else if (t < rows_here) p.out[b * d.c_bs + (int64_t)(t0 + t) * d.ldc + c] = v;
@@ -465,11 +473,11 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
             // odd: conflict-free), sum the band's entries in index order, run the compression chain on the one value and
             // store it; the 16 frames of a band are neighbours in the target view.  (The first version gave four threads a
             // band and 16 frames each: 650 instructions per thread, a quarter of the lanes idle, as long as the transform.)
-            constexpr int TPB = 16;
+            const int ltpb = 31 - __builtin_clz((unsigned)tpb);  // frames per tile: a power of two (16, or 8 where the LDS is short)
             float *ob = p.out + b * d.c_bs;
-            for (int i0 = 0; i0 < nmel * TPB; i0 += NW * 64) {
+            for (int i0 = 0; i0 < (nmel << ltpb); i0 += NW * 64) {
                 const int i = i0 + tid;
-                const int m = i >> 4, t = i & (TPB - 1);
+                const int m = i >> ltpb, t = i & (tpb - 1);
                 const bool live = m < nmel && t < rows_here;
                 const int e0 = live ? (int)mstart[m] : 0, e1 = live ? (int)mstart[m + 1] : 0;
                 const float *sp = spec + (live ? t : 0) * nout;

@@ -138,6 +138,37 @@ def test_fft_front_end_whole_models(bn, v24_full, v30_small, monkeypatch):
             assert [p.index for p in a.predictions] == [p.index for p in b.predictions]
 
 
+def test_v30_power_spectrum_folded_into_the_fft_launch(bn, v30_small, monkeypatch):
+    """Round 3: behind v3.0's cos | sin bank the planner folds  sqrt(re^2 + im^2)  into the FFT launch (the mel bank stays a
+    dense GEMM by default: with 513 bins its spectrum rows only fit the LDS in tiles of 8 frames, which is slower;
+    BN_STFT_MEL=force takes it in as well -- the whole front end in ONE launch).  With the rule off (BN_STFT_POWER=0) the
+    magnitude is its own elementwise launch again.  All three within the oracle's tolerance, same top-K order."""
+    data, path = v30_small
+    x = synth.synthetic_segments(5, 160000, 32000)
+    out = onnx_ref.run_model(data, x)
+
+    def run():
+        return bn.Classifier.builder().model_path(path).labels(labels(300)).top_k(5).with_rocm().build().predict_batch(list(x))
+
+    first = [l for l in bn.plan_describe(path).splitlines() if " FFT " in l]
+    assert len(first) == 1 and "power=2" in first[0] and "mel=0" in first[0] and "Sqrt" in first[0], first
+    res = run()
+    check_results(res, out["output_1"], out["output_0"], 5, None)
+    monkeypatch.setenv("BN_STFT_MEL", "force")
+    one = [l for l in bn.plan_describe(path).splitlines() if " FFT " in l]
+    assert "power=2" in one[0] and "tpb=8" in one[0] and "MatMul" in one[0] and "mel=0" not in one[0], one
+    res1 = run()
+    check_results(res1, out["output_1"], out["output_0"], 5, None)
+    monkeypatch.delenv("BN_STFT_MEL")
+    monkeypatch.setenv("BN_STFT_POWER", "0")
+    desc0 = bn.plan_describe(path)
+    assert "power=0" in desc0 and any(" ELT " in l and "Sqrt" in l for l in desc0.splitlines())
+    res0 = run()
+    check_results(res0, out["output_1"], out["output_0"], 5, None)
+    for a, b, c in zip(res, res0, res1):
+        assert [p.index for p in a.predictions] == [p.index for p in b.predictions] == [p.index for p in c.predictions]
+
+
 def test_v30_embeddings_and_logits(bn, v30_small):
     data, path = v30_small
     clf = bn.Classifier.builder().model_path(path).labels(labels(300)).top_k(5).with_rocm().build()
