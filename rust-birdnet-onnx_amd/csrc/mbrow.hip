@@ -202,6 +202,21 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
             for (int j = 0; j < 4; j++) mine = mine && (((im_ok >> (g * 4 + j)) & 1u) || 8 * g + 4 * lh + j >= d.Cin);
         im_fast = __all(mine);
     }
+    // ... and with a 2-channel image (the v2.4 spectrogram pair) whose samples are 8-byte aligned, the columns (k, k + 1) of a tap
+    // are one dwordx2: half the load instructions of the launch's busiest path (a dummy column pair reads elements 0, 1)
+    bool im_pair = false;
+    if constexpr (IM2COL) {
+        bool pairs = im_fast && d.Cin1 == 2 && (d.in_bs & 1) == 0 && (reinterpret_cast<uintptr_t>(in) & 7u) == 0;
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const unsigned ok0 = (im_ok >> (g * 4 + j)) & 1u, ok1 = (im_ok >> (g * 4 + j + 1)) & 1u;
+                const bool real = ok0 && ok1 && a_off[g * 4 + j + 1] == a_off[g * 4 + j] + 1u && (a_off[g * 4 + j] & 1u) == 0;
+                pairs = pairs && (real || (!ok0 && !ok1));  // a padding pair (k >= K) reads elements 0, 1 against zero weights
+            }
+        im_pair = __all(pairs);
+    }
 
     const int64_t a_rs = (int64_t)d.W * d.Cin;                        // floats per input row
     const unsigned a_lane4 = 4u * (unsigned)(ixc * d.Cin + 4 * lh);      // byte offset of this lane's pixel + K half within the row
@@ -218,7 +233,13 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
             const int y0_ = iy_ * d.s1 - d.pt1;                                                                                 \
             const int x0_ = ixc * d.s1 - d.pl1;                                                                                 \
             const float *px_ = xin + ((int64_t)y0_ * d.W1 + x0_) * d.Cin1;                                                      \
-            if (im_fast && y0_ >= 0 && y0_ + d.k1 <= d.H1) {                                                                    \
+            if (im_pair && y0_ >= 0 && y0_ + d.k1 <= d.H1) { /* two channels per tap: columns (k, k + 1) are neighbours in memory */ \
+                _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                                \
+                    const float2 lo_ = *reinterpret_cast<const float2 *>(px_ + a_off[g * 4]);                                   \
+                    const float2 hi_ = *reinterpret_cast<const float2 *>(px_ + a_off[g * 4 + 2]);                               \
+                    dst[g] = make_float4(lo_.x, lo_.y, hi_.x, hi_.y);                                                           \
+                }                                                                                                               \
+            } else if (im_fast && y0_ >= 0 && y0_ + d.k1 <= d.H1) {                                                             \
                 _Pragma("unroll") for (int g = 0; g < NG; g++)                                                                  \
                     dst[g] = make_float4(px_[a_off[g * 4]], px_[a_off[g * 4 + 1]], px_[a_off[g * 4 + 2]], px_[a_off[g * 4 + 3]]); \
             } else {                                                                                                            \
