@@ -1622,8 +1622,8 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 snprintf(line, sizeof(line), " C=%d Cr=%d act1=%d act2=%d", op.se.C, op.se.Cr, op.se.act1, op.se.act2);
                 extra = line;
             } else if (op.kind == OpKind::FFT) {
-                snprintf(line, sizeof(line), " frames=%d L=%d hop=%d bins=%d power=%d tpb=%d mel=%d pre=%d post=%d out_rs=%lld out_cs=%lld fft_flops=%.3g", op.fft.frames, op.fft.L,
-                         op.fft.hop, op.fft.nout, op.fft.power, op.fft.tpb, op.fft.nmel, op.fft.npre, op.fft.npost, (long long)op.fft.out_rs, (long long)op.fft.out_cs, op.flops_fft);
+                snprintf(line, sizeof(line), " frames=%d L=%d hop=%d bins=%d power=%d tpb=%d mel=%d%s pre=%d post=%d out_rs=%lld out_cs=%lld fft_flops=%.3g", op.fft.frames, op.fft.L,
+                         op.fft.hop, op.fft.nout, op.fft.power, op.fft.tpb, op.fft.nmel, op.fft.nmel ? (op.fft.mel_mode == 1 ? "(mfma)" : "(csr)") : "", op.fft.npre, op.fft.npost, (long long)op.fft.out_rs, (long long)op.fft.out_cs, op.flops_fft);
                 extra = line;
             } else {
                 snprintf(line, sizeof(line), " kept=%lld red=%lld op=%d inner_kept=%d", (long long)op.red.kept, (long long)op.red.red, op.red.op, op.red.inner_kept);

@@ -3045,6 +3045,41 @@ class Builder {
                 d.tpb = probe.tpb;
                 d.nmel = (int32_t)N;
                 d.mel_nnz = (int32_t)nnz_count;
+                d.mel_mode = 0; d.mel_groups = 0; d.spec_stride = d.nout;
+                // the bank as 16 x 16 tiles for the matrix cores (kernels.h, FftDesc::mel_mode): tile rows of 16 bands, of each
+                // only the 16-bin groups that hold a non-zero; a tile is stored in the lane order of the A fragment (lane (i, q)
+                // holds band i, bins 16 g + 4 q + 0..3).  BN_STFT_MELMFMA=0 keeps the (column, weight) lists on the vector ALU.
+                if (!(getenv("BN_STFT_MELMFMA") && std::string(getenv("BN_STFT_MELMFMA")) == "0") && d.tpb == 16) {
+                    const int64_t ntile = (N + 15) / 16, ngrp = (K + 15) / 16;
+                    std::vector<float> tab((size_t)ntile + 1, 0.0f), glist, pack;
+                    for (int64_t t = 0; t < ntile; t++) {
+                        tab[(size_t)t] = (float)glist.size();
+                        for (int64_t gq = 0; gq < ngrp; gq++) {
+                            bool any = false;
+                            for (int64_t i = 0; i < 16 && !any; i++)
+                                for (int64_t k = 0; k < 16 && !any; k++) {
+                                    const int64_t nn = 16 * t + i, kk = 16 * gq + k;
+                                    any = nn < N && kk < K && W[(size_t)(g.w.offset + nn * K + kk)] != 0.0f;
+                                }
+                            if (!any) continue;
+                            glist.push_back((float)gq);
+                            for (int lane = 0; lane < 64; lane++)
+                                for (int j = 0; j < 4; j++) {
+                                    const int64_t nn = 16 * t + (lane & 15), kk = 16 * gq + 4 * (lane >> 4) + j;
+                                    pack.push_back(nn < N && kk < K ? W[(size_t)(g.w.offset + nn * K + kk)] : 0.0f);
+                                }
+                        }
+                    }
+                    tab[(size_t)ntile] = (float)glist.size();
+                    FftDesc probe2 = d;
+                    probe2.mel_mode = 1; probe2.mel_groups = (int32_t)glist.size(); probe2.spec_stride = (int32_t)(16 * ngrp + 8);
+                    if (!glist.empty() && glist.size() < (1u << 22) && stft_lds_bytes(probe2, 8) <= 156 * 1024) {
+                        d = probe2;
+                        tab.insert(tab.end(), glist.begin(), glist.end());
+                        mstart = tab;
+                        ment = pack;
+                    }
+                }
                 if (ment.empty()) { ment.push_back(0.0f); ment.push_back(0.0f); }
                 d.mel_has_bias = gd.has_bias;
                 d.mel_act = gd.act; d.mel_p0 = gd.p0; d.mel_p1 = gd.p1;
@@ -3058,7 +3093,7 @@ class Builder {
                 f.x[3] = g.bias;
                 f.out = g.out;
                 f.name += "+" + g.name;
-                const double nnz = (double)nnz_count;
+                const double nnz = d.mel_mode == 1 ? 256.0 * (double)d.mel_groups : (double)nnz_count;  // multiply-adds performed per frame
                 f.flops_fft += 2.0 * nnz * (double)d.frames;
                 f.macs += nnz * (double)d.frames;
                 f.weight_bytes += 4.0 * (mstart.size() + ment.size());

@@ -310,6 +310,12 @@ struct FftDesc {
     // f(u^2 + v^2) with u, v the two linear forms of bin c (otab row: positions, 4 coefficients of u, 4 of v); 0 = off,
     // 1 = u^2 + v^2, 2 = sqrt(u^2 + v^2).  otab_stride: floats per otab row (8, or 12 in power mode)
     int32_t power, otab_stride;
+    // mel filter bank on the matrix cores (mel_mode 1, tpb == 16): the bank is cut into tiles of 16 bands x 16 bins, only
+    // the tiles that hold a non-zero are kept (triangular filters: a diagonal stripe), each stored in the fragment order of
+    // v_mfma_f32_16x16x4_f32; mstart = [ceil(nmel/16) + 1 tile-row starts | bin-group index of every kept tile] (as floats),
+    // mcol = the kept tiles, 256 floats each.  spec_stride: floats per spectrum row in LDS (nout in CSR mode; in MFMA mode
+    // 16 ceil(nout/16) + 8: whole bin groups, and = 8 mod 16 makes the ds_read_b128 fragment reads conflict free)
+    int32_t mel_mode, mel_groups, spec_stride;
 };
 struct StftPtrs {
     float *out;

@@ -230,9 +230,10 @@ __host__ __device__ __forceinline__ StftLds stft_layout(const FftDesc &d, int nw
     l.tw = o; o += kib(2 * d.tw_count);
     l.window = o; o += kib(d.L);
     l.otab = o; o += kib((d.otab_stride > 0 ? d.otab_stride : 8) * d.nout);
-    l.mstart = o; o += d.nmel ? kib(d.nmel + 1) : 0;
-    l.ment = o; o += d.nmel ? kib(2 * d.mel_nnz) : 0;  // (column, value) pairs
-    l.spec = o; o += d.nmel ? d.tpb * d.nout : 0;  // the tile's spectrum rows (mel fusion only)
+    const bool csr = d.nmel && d.mel_mode == 0;  // (MFMA mode reads its tiles from global memory / L2: nothing of the bank in LDS)
+    l.mstart = o; o += csr ? kib(d.nmel + 1) : 0;
+    l.ment = o; o += csr ? kib(2 * d.mel_nnz) : 0;  // (column, value) pairs
+    l.spec = o; o += d.nmel ? d.tpb * (d.spec_stride > 0 ? d.spec_stride : d.nout) : 0;  // the tile's spectrum rows (mel fusion only)
     l.mel = o;
     l.total = o;
     return l;
@@ -323,10 +324,13 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     async_copy<NW>(lds + lay.window, p.window, d.L, wave, lane);
     const int ostride = d.otab_stride > 0 ? d.otab_stride : 8, power = d.power;
     async_copy<NW>(otab, p.otab, ostride * nout, wave, lane);
-    if (nmel) {
+    const int mel_mode = d.mel_mode, SS = d.spec_stride > 0 ? d.spec_stride : nout;
+    if (nmel && mel_mode == 0) {
         async_copy<NW>(mstart, p.mstart, nmel + 1, wave, lane);
         async_copy<NW>(lds + lay.ment, p.mcol, 2 * d.mel_nnz, wave, lane);
     }
+    if (nmel && SS > nout)  // the padding columns of the spectrum rows meet zero filter taps: they must hold numbers (written once)
+        for (int i = tid; i < d.tpb * (SS - nout); i += NW * 64) spec[(i / (SS - nout)) * SS + nout + i % (SS - nout)] = 0.0f;
 
     // (literal indices into the descriptor arrays everywhere: a loop the compiler does not unroll would index the
     // kernel argument dynamically and move ALL of it into scratch memory)
@@ -458,7 +462,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
                                 if (power == 2) v = sqrtf(v);
                             }
                             if (d.has_bias) v += p.bias[c];
-                            if (nmel) spec[t * nout + c] = v;
+                            if (nmel) spec[t * SS + c] = v;
                             else if (t < rows_here) p.out[b * d.c_bs + (int64_t)(t0 + t) * d.ldc + c] = v;
                         }
                     }
@@ -467,7 +471,62 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
             wave_sync();  // the transform buffer is rewritten by this wave's next group
         }
         __syncthreads();  // every wave is done with the span; the tile's spectrum rows are complete
-        if (nmel && !(dbg & 4)) {
+        if (nmel && mel_mode == 1 && !(dbg & 4)) {
+            // Mel filter bank on the matrix cores: D[band][frame] = sum over the kept 16-bin tiles of the band tile's row,
+            // A = a filter tile in fragment order straight from global memory (one coalesced dwordx4 per lane), B = the
+            // spectrum rows in LDS (k-slot j of a bin group: bin 16 g + 4 q + j, so one ds_read_b128 per lane feeds four
+            // matrix instructions).  A wave owns a tile of 16 bands x the tile's 16 frames; a lane ends up with 4 bands of one
+            // frame and runs the compression chain on those four values ONCE.  (The sparse (column, weight) walk it replaces
+            // was a chain of dependent LDS reads per (band, frame): 19 of the kernel's 58 us for 10 000 multiply-adds per tile.)
+            typedef float floatx4 __attribute__((ext_vector_type(4)));
+            const int ntile = (nmel + 15) >> 4;
+            const float *mt = p.mstart;
+            const float4 *mp = reinterpret_cast<const float4 *>(p.mcol);
+            const int ln = lane & 15, lq = lane >> 4;
+            float *ob = p.out + b * d.c_bs;
+            for (int tl0 = wave; tl0 < ntile; tl0 += NW) {
+                const int tl = __builtin_amdgcn_readfirstlane(tl0);
+                const int g0 = (int)mt[tl], g1 = (int)mt[tl + 1];
+                floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                const float *srow = spec + ln * SS + 4 * lq;
+                for (int gi = g0; gi < g1; gi += 4) {
+                    float4 av[4], bv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int gg = min(gi + k, g1 - 1);
+                        const int g = (int)mt[ntile + 1 + gg];
+                        av[k] = mp[(int64_t)gg * 64 + lane];
+                        bv[k] = *reinterpret_cast<const float4 *>(srow + 16 * g);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (gi + k < g1) {
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k].x, bv[k].x, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k].y, bv[k].y, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k].z, bv[k].z, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k].w, bv[k].w, acc, 0, 0, 0);
+                        }
+                    }
+                }
+                const int m0 = 16 * tl + 4 * lq;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = acc[j] + ((d.mel_has_bias && m0 + j < nmel) ? p.mel_bias[m0 + j] : 0.0f);
+                if (!(dbg & 128)) {
+                    act_small<4>(d.mel_act, d.mel_p0, d.mel_p1, v);
+                    if (0 < npost) act_small<4>(po_a0, po_p00, po_p10, v);
+                    if (1 < npost) act_small<4>(po_a1, po_p01, po_p11, v);
+                    if (2 < npost) act_small<4>(po_a2, po_p02, po_p12, v);
+                    if (3 < npost) act_small<4>(po_a3, po_p03, po_p13, v);
+                }
+                if (ln < rows_here && !(dbg & 256)) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (m0 + j < nmel) ob[(int64_t)(t0 + ln) * d.out_rs + (int64_t)(m0 + j) * d.out_cs] = v[j];
+                }
+            }
+        }
+        if (nmel && mel_mode == 0 && !(dbg & 4)) {
             // Mel filter bank over the whole tile: one work item per (band, frame), frames fastest -- the 16 lanes of a band
             // read the same (column, weight) entry (an LDS broadcast) and 16 different spectrum rows (row stride nout is
             // odd: conflict-free), sum the band's entries in index order, run the compression chain on the one value and
@@ -480,7 +539,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
                 const int m = i >> ltpb, t = i & (tpb - 1);
                 const bool live = m < nmel && t < rows_here;
                 const int e0 = live ? (int)mstart[m] : 0, e1 = live ? (int)mstart[m + 1] : 0;
-                const float *sp = spec + (live ? t : 0) * nout;
+                const float *sp = spec + (live ? t : 0) * SS;
                 // Eight entries of the band in flight: an entry (column, weight) and the spectrum value it names are two
                 // dependent LDS reads, and a band has up to ~30 entries -- two at a time the phase was a chain of ~15 round
                 // trips per work item, 30 of the kernel's 67 us for 10 000 multiply-adds per tile.  Same sums as before:
