@@ -195,6 +195,15 @@ __device__ __forceinline__ void bin_small(int bin, float b, float (&v)[N]) {
     else if (bin == BIN_MIN) map_array<N>(v, [=](float a) { return fminf(a, b); });
 }
 
+// One shared copy of the stage dispatch for the mel phase's four-value arrays (by value: registers in, registers out).  Inlined
+// at its five call sites the dispatch -- a compare chain over every stage code, each with a four-element body -- made the
+// compression chain of 4 values cost 2.4 us per tile (instruction fetch, not arithmetic: 9.5 of the kernel's 61 us).
+struct Vals4 { float x[4]; };
+__device__ __noinline__ Vals4 act_small4(int act, float p0, float p1, Vals4 v) {
+    act_small<4>(act, p0, p1, v.x);
+    return v;
+}
+
 // The absorbed per-sample chain: up to four stages  v = act(bin(v, scalar)).  All indices are literals so that the
 // fields stay in registers.
 struct PreChain {
@@ -408,6 +417,33 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     __syncthreads();
     if (dbg & 8) return;
 
+    // (the wave <-> band tile assignment is the same for every frame tile: filter tiles, group indices and bias are loaded ONCE per
+    // block and stay in registers -- per tile they were three dependent L2 round trips behind the barrier, 5 - 6 us of a 16 us tile)
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    constexpr int MPRE = 8;
+    const bool mel_mfma = nmel && mel_mode == 1 && !(dbg & 4);
+    const int ntile = (nmel + 15) >> 4;
+    const float *mt = p.mstart;
+    const float4 *mp = reinterpret_cast<const float4 *>(p.mcol);
+    float4 apre[MPRE];
+    int gpre[MPRE];
+    int pg0 = 0, pg1 = 0;
+    float bpre[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // mel bias of this lane's four bands
+    if (mel_mfma && wave < ntile) {
+        const int tl = __builtin_amdgcn_readfirstlane(wave);
+        pg0 = (int)mt[tl];
+        pg1 = (int)mt[tl + 1];
+#pragma unroll
+        for (int k = 0; k < MPRE; k++) {
+            const int gg = min(pg0 + k, pg1 - 1);
+            gpre[k] = (int)mt[ntile + 1 + gg];
+            apre[k] = mp[(int64_t)gg * 64 + lane];
+        }
+        if (d.mel_has_bias) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) bpre[j] = p.mel_bias[min(16 * tl + 4 * (lane >> 4) + j, nmel - 1)];
+        }
+    }
     const int fstride = M + (M >> 3);
     for (; tile < total_tiles;) {
         const int next = tile + gridDim.x;
@@ -470,26 +506,38 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
             }
             wave_sync();  // the transform buffer is rewritten by this wave's next group
         }
+        // Mel filter bank on the matrix cores (mel_mode 1): D[band][frame] = sum over the kept 16-bin tiles of the band tile's
+        // row, A = a filter tile in fragment order straight from global memory (one coalesced dwordx4 per lane), B = the
+        // spectrum rows in LDS (k-slot j of a bin group: bin 16 g + 4 q + j, so one ds_read_b128 per lane feeds four matrix
+        // instructions).  A wave owns a tile of 16 bands x the tile's 16 frames; a lane ends up with 4 bands of one frame and
+        // runs the compression chain on those four values ONCE.  (The sparse (column, weight) walk it replaces was a chain of
+        // dependent LDS reads per (band, frame): 19 of the kernel's 58 us for 10 000 multiply-adds per tile.)  The filter
         __syncthreads();  // every wave is done with the span; the tile's spectrum rows are complete
-        if (nmel && mel_mode == 1 && !(dbg & 4)) {
-            // Mel filter bank on the matrix cores: D[band][frame] = sum over the kept 16-bin tiles of the band tile's row,
-            // A = a filter tile in fragment order straight from global memory (one coalesced dwordx4 per lane), B = the
-            // spectrum rows in LDS (k-slot j of a bin group: bin 16 g + 4 q + j, so one ds_read_b128 per lane feeds four
-            // matrix instructions).  A wave owns a tile of 16 bands x the tile's 16 frames; a lane ends up with 4 bands of one
-            // frame and runs the compression chain on those four values ONCE.  (The sparse (column, weight) walk it replaces
-            // was a chain of dependent LDS reads per (band, frame): 19 of the kernel's 58 us for 10 000 multiply-adds per tile.)
-            typedef float floatx4 __attribute__((ext_vector_type(4)));
-            const int ntile = (nmel + 15) >> 4;
-            const float *mt = p.mstart;
-            const float4 *mp = reinterpret_cast<const float4 *>(p.mcol);
+        if (mel_mfma) {
             const int ln = lane & 15, lq = lane >> 4;
             float *ob = p.out + b * d.c_bs;
+            const float *srow = spec + ln * SS + 4 * lq;
             for (int tl0 = wave; tl0 < ntile; tl0 += NW) {
                 const int tl = __builtin_amdgcn_readfirstlane(tl0);
                 const int g0 = (int)mt[tl], g1 = (int)mt[tl + 1];
                 floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                const float *srow = spec + ln * SS + 4 * lq;
-                for (int gi = g0; gi < g1; gi += 4) {
+                int gi = g0;
+                if (tl0 == wave) {  // the requested tiles
+                    float4 bv[MPRE];
+#pragma unroll
+                    for (int k = 0; k < MPRE; k++) bv[k] = *reinterpret_cast<const float4 *>(srow + 16 * gpre[k]);
+#pragma unroll
+                    for (int k = 0; k < MPRE; k++) {
+                        if (pg0 + k < pg1) {
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[k].x, bv[k].x, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[k].y, bv[k].y, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[k].z, bv[k].z, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(apre[k].w, bv[k].w, acc, 0, 0, 0);
+                        }
+                    }
+                    gi = g0 + MPRE;
+                }
+                for (; gi < g1; gi += 4) {
                     float4 av[4], bv[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -511,13 +559,16 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
                 const int m0 = 16 * tl + 4 * lq;
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = acc[j] + ((d.mel_has_bias && m0 + j < nmel) ? p.mel_bias[m0 + j] : 0.0f);
+                for (int j = 0; j < 4; j++) v[j] = acc[j] + (tl0 == wave ? bpre[j] : ((d.mel_has_bias && m0 + j < nmel) ? p.mel_bias[m0 + j] : 0.0f));
                 if (!(dbg & 128)) {
-                    act_small<4>(d.mel_act, d.mel_p0, d.mel_p1, v);
-                    if (0 < npost) act_small<4>(po_a0, po_p00, po_p10, v);
-                    if (1 < npost) act_small<4>(po_a1, po_p01, po_p11, v);
-                    if (2 < npost) act_small<4>(po_a2, po_p02, po_p12, v);
-                    if (3 < npost) act_small<4>(po_a3, po_p03, po_p13, v);
+                    Vals4 w4 = {{v[0], v[1], v[2], v[3]}};
+                    if (d.mel_act != ACT_NONE) w4 = act_small4(d.mel_act, d.mel_p0, d.mel_p1, w4);
+                    if (0 < npost) w4 = act_small4(po_a0, po_p00, po_p10, w4);
+                    if (1 < npost) w4 = act_small4(po_a1, po_p01, po_p11, w4);
+                    if (2 < npost) w4 = act_small4(po_a2, po_p02, po_p12, w4);
+                    if (3 < npost) w4 = act_small4(po_a3, po_p03, po_p13, w4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = w4.x[j];
                 }
                 if (ln < rows_here && !(dbg & 256)) {
 #pragma unroll
@@ -571,7 +622,10 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
             }
         }
         if (next < total_tiles) BN_WRITE_SPAN(next);
-        __syncthreads();  // next span in place, spectrum rows read
+        // next span in place, spectrum rows read: an LDS-only rendezvous (__syncthreads would also wait for the tile's result
+        // stores to complete -- a full write round trip per tile, 4.4 of the kernel's 58 us)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         tile = next;
     }
 #undef BN_TILE_GEOM
