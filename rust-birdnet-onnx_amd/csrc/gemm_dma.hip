@@ -266,6 +266,22 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
         }
     }
 
+    // ---- bias and residual of the finishing slice are requested BEFORE the slices meet (clamped addresses, no predicates): their
+    // round trip runs under the exchange below instead of behind it
+    floatx4 bpre[NTW], rpre[MTW][NTW];
+    if (ks == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) {
+            const int n = min(n0 + (wn * NTW + nt) * 16 + 4 * lq, d.N - 4);
+            bpre[nt] = d.has_bias ? *reinterpret_cast<const floatx4 *>(bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < MTW; mt++) {
+                const int64_t m = (int64_t)rt * TR + (wm * MTW + mt) * 16 + lc;
+                rpre[mt][nt] = d.has_res ? *reinterpret_cast<const floatx4 *>(res + (int64_t)b * d.r_bs + m * d.ldr + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+
     // ---- the slices' partial tiles, summed in slice order (fixed: slice 0 + slice 1 (+ slice 2 + slice 3))
     if constexpr (KS > 1) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -295,8 +311,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++) {
         const int n = n0 + (wn * NTW + nt) * 16 + 4 * lq;
-        floatx4 bv = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (d.has_bias && n < d.N) bv = *reinterpret_cast<const floatx4 *>(bias + n);
+        (void)n;
+        const floatx4 bv = bpre[nt];  // (columns n >= N are never stored)
 #pragma unroll
         for (int mt = 0; mt < MTW; mt++)
 #pragma unroll
@@ -307,13 +323,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
     for (int mt = 0; mt < MTW; mt++) {
         const int64_t m = (int64_t)rt * TR + (wm * MTW + mt) * 16 + lc;
         float *crow = C + (int64_t)b * d.c_bs + m * d.ldc;
-        const float *rrow = d.has_res ? res + (int64_t)b * d.r_bs + m * d.ldr : nullptr;
 #pragma unroll
         for (int nt = 0; nt < NTW; nt++) {
             const int n = n0 + (wn * NTW + nt) * 16 + 4 * lq;
             if (n < d.N) {
                 floatx4 o = floatx4{v[(mt * NTW + nt) * 4], v[(mt * NTW + nt) * 4 + 1], v[(mt * NTW + nt) * 4 + 2], v[(mt * NTW + nt) * 4 + 3]};
-                if (d.has_res) o += *reinterpret_cast<const floatx4 *>(rrow + n);
+                if (d.has_res) o += rpre[mt][nt];
                 *reinterpret_cast<floatx4 *>(crow + n) = o;
             }
         }
