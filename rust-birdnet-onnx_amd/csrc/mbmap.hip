@@ -354,6 +354,8 @@ int mbmap_config(const MbDesc &d) {
         if (cfg_lds<3, 1, 4, 2>(d) <= cap) return 2;
     } else if (d.H == 3 && d.W == 16 && cls == 0) {
         if (cfg_lds<3, 1, 1, 4, 2>(d) <= cap) return 3;
+    } else if (d.H == 4 && d.W == 16 && cls == 0 && d.s == 1) {  // BirdNET v3.0's last stage (5 s segments: one more row than v2.4's 3 x 16)
+        if (cfg_lds<2, 1, 2, 2, 2>(d) <= cap) return 4;  // 32-channel chunks (Cin = 192: two filter chunks of 64 would not fit), eight waves
     }
     return 0;
 }
@@ -364,7 +366,7 @@ int mbmap_config(const MbDesc &d) {
 // grouping does not enter the arithmetic (squeeze sums are complete per channel inside a block).
 int mbmap_chunks_per_block(const MbDesc &d, int cfg, int64_t batch) {
     const int force = getenv("BN_MBMAP2_NCH") ? atoi(getenv("BN_MBMAP2_NCH")) : 0;
-    const int nc = cfg == 2 ? 32 : 64;
+    const int nc = (cfg == 2 || cfg == 4) ? 32 : 64;
     const int chunks = (d.C + nc - 1) / nc;
     if (force > 0) return std::min(force, chunks);
     const int64_t ncu = device_cu_count();
@@ -380,6 +382,7 @@ void register_mbmap_kernels() {
     MM_REG_KS(3, 2, 4, 2, 1, 6, 32, false)
     MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false)
     MM_REG_KS(3, 1, 1, 4, 2, 3, 16, true)
+    MM_REG(3, 1, 2, 1, 2, 2, 2, 4, 16, true) MM_REG(5, 1, 2, 1, 2, 2, 2, 4, 16, true)
 #undef MM_REG_KS
 #undef MM_REG
 }
@@ -409,7 +412,9 @@ bool launch_mbmap(hipStream_t s, const MbDesc &d, float *out, const float *in, c
     } while (0)
     if (cfg == 1) MM_GO_KS(3, 2, 4, 2, 1, 6, 32, false);
     else if (cfg == 2) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false);
-    else MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true);
+    else if (cfg == 3) MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true);
+    else if (d.k == 3) MM_GO(3, 1, 2, 1, 2, 2, 2, 4, 16, true);
+    else MM_GO(5, 1, 2, 1, 2, 2, 2, 4, 16, true);
 #undef MM_GO_KS
 #undef MM_GO
     return true;

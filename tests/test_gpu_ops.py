@@ -633,6 +633,7 @@ def test_pipelined_mbconv_is_bit_identical_to_the_plain_kernel(bn):
 
 
 @pytest.mark.parametrize("cin,h,w,cmid,k,stride", [(80, 6, 32, 480, 3, 1), (112, 6, 32, 672, 5, 2), (192, 3, 16, 1152, 5, 1),
+                                                  (192, 4, 16, 1152, 5, 1), (192, 4, 16, 1152, 3, 1), (192, 4, 16, 600, 5, 2),
                                                   (20, 5, 7, 72, 3, 1), (40, 12, 40, 100, 3, 2)])
 def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride):
     """The whole-map MBConv kernel at the late-stage shapes (K up to 192, ragged channel counts, K % 8 == 4)
@@ -682,9 +683,9 @@ def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride):
         del os.environ["BN_MBMAP2"]
     assert_close(got3, ref, f"unfused {cin}->{cmid} k{k} s{stride}")
     # (c) the default plan: the LDS-resident whole-map kernel (mbmap.hip) wherever a configuration fits (192- and
-    # 48-pixel maps with Cin % 16 == 0), the unfused launches elsewhere
+    # 48-pixel maps with Cin % 16 == 0; BirdNET v3.0's 4 x 16 map), the unfused launches elsewhere
     desc = bn.plan_describe(write_model(data))
-    assert ("MBCONV" in desc) == (h * w in (192, 48) and cin % 16 == 0), desc
+    assert ("MBCONV" in desc) == ((h * w in (192, 48) or (h * w == 64 and stride == 1)) and cin % 16 == 0), desc
     got2, _ = run_both(bn, data, batch=3)
     assert_close(got2, ref, f"gemm + dw map {cin}->{cmid} k{k} s{stride}")
 
