@@ -879,7 +879,11 @@ __global__ __launch_bounds__(640) void frame_fold_kernel(FrameDesc d, float *__r
         const float *ap = As + cur * FRAME_BM * GEMM_LD + (wm * 32 + lr) * GEMM_LD + 4 * lh;
         const float *wp = Ws + cur * BN * GEMM_LD + (wn * 32 + lr) * GEMM_LD + 4 * lh;
         mfma_ktile_full<1>(ap, wp, acc);
-        __syncthreads();
+        // LDS-only rendezvous: the operand tiles of step ks + 1 are in place.  (__syncthreads would also wait for the filter
+        // rows of step ks + 2, requested a moment ago: they are only needed after the next step's multiplications.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     const int n = n0 + wn * 32 + lr;
     if (n < d.N) {

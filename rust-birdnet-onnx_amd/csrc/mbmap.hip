@@ -264,8 +264,11 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
                     *reinterpret_cast<floatx4 *>(Es + epix[mt] + (wn * NW + nt) * 16 + 4 * lq) =
                         floatx4{v[(mt * NW + nt) * 4], v[(mt * NW + nt) * 4 + 1], v[(mt * NW + nt) * 4 + 2], v[(mt * NW + nt) * 4 + 3]};
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // the chunk image is complete
+        // the chunk image is complete -- and this is where every wave waits for the NEXT chunk's filters (requested a whole
+        // expand phase ago): only loads are outstanding here.  Waiting for them at the end of the chunk, behind the depthwise
+        // phase's result stores, made every chunk wait for a store round trip as well (vmcnt counts both).
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
         // ---- depthwise + squeeze: all OH x PPG outputs of the strip in registers, input rows read once each
@@ -311,9 +314,9 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
             }
         }
         if (d.has_gap) red[grp * NC + c] = sum;
-        // ONE barrier ends the chunk: the squeeze partials are written, every wave is done reading the chunk image, and the
-        // next chunk's filters (issued a whole chunk ago) have landed for every wave
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // ONE barrier ends the chunk: the squeeze partials are written and every wave is done reading the chunk image (LDS
+        // only: the result stores stay in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (d.has_gap && grp == 0 && cact) {
