@@ -482,11 +482,14 @@ def test_round3_kernels_tile_shape_and_grouping_do_not_enter_the_arithmetic(bn, 
     assert many[:5].tobytes() == base.tobytes()
 
 
-@pytest.mark.parametrize("env", [{"BN_GEMMDMA": "0"}, {"BN_GEMMDMA": "2"}, {"BN_MBMAP2": "0"}, {"BN_SEGEMM": "1"}, {"BN_GEMMDMA_KS": "1"}])
+@pytest.mark.parametrize("env", [{"BN_GEMMDMA": "0"}, {"BN_GEMMDMA": "2"}, {"BN_MBMAP2": "0"}, {"BN_SEGEMM": "1"}, {"BN_GEMMDMA_KS": "1"},
+                                 {"BN_STFT_MELMFMA": "0"}, {"BN_STFT_NW": "16"}, {"BN_MBROW_TOH": "8"}])
 def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, monkeypatch, env):
     """Every round-3 rewrite has an off switch (and two opt-ins): the older kernels (BN_GEMMDMA=0, BN_MBMAP2=0), the
     LDS-DMA GEMM on every eligible shape (BN_GEMMDMA=2), the squeeze-excite products in the GEMM prologue (BN_SEGEMM=1),
-    one K slice per block (BN_GEMMDMA_KS=1) -- each within the network tolerance of the oracle, same top-1."""
+    one K slice per block (BN_GEMMDMA_KS=1), the mel bank as a sparse walk on the vector ALU instead of 16 x 16 tiles on the
+    matrix cores (BN_STFT_MELMFMA=0), the FFT kernel as 16 waves x 512 slots (BN_STFT_NW=16), the round-2 band height of the
+    row-streaming MBConv (BN_MBROW_TOH=8) -- each within the network tolerance of the oracle, same top-1."""
     data, path = v24_full
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -497,6 +500,10 @@ def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, mon
         assert "tiles=1x1" not in desc
     if env.get("BN_SEGEMM") == "1":
         assert "se_inline=" in desc
+    if env.get("BN_STFT_MELMFMA") == "0":
+        assert "(csr)" in desc and "(mfma)" not in desc
+    else:
+        assert "(mfma)" in desc
     x = synth.synthetic_segments(3, 144000, 48000)
     got, _ = bn.Context(bn.Model(path), 3).infer(x)
     ref = onnx_ref.run_model(data, x)["output"]
