@@ -147,6 +147,40 @@ def test_stft_absorption_switches(bn, tmp_path, monkeypatch):
     assert sum(" FFT " in l and "pre=0" in l for l in lines) == 2 and sum(" ELT " in l and "Sub:Sub_2" in l for l in lines) == 1
 
 
+def test_round3_planner_rules(bn, tmp_path, monkeypatch):
+    """Planner rules of round 3, on the CPU (plan_describe needs no device): the mel bank of the FFT launch as 16 x 16 tiles for
+    the matrix cores; the magnitude pass behind v3.0's cos | sin bank folded into the FFT launch (and the dense-ish mel bank
+    left a GEMM unless forced); v3.0's 4 x 16 late stage through the LDS-resident whole-map MBConv kernel; balanced bands of the
+    row-streaming MBConv; every rule with its switch."""
+    p24 = tmp_path / "v24.onnx"
+    p24.write_bytes(synth.birdnet_v24())
+    d24 = bn.plan_describe(str(p24))
+    fft = [l for l in d24.splitlines() if " FFT " in l]
+    assert len(fft) == 1 and "mel=96(mfma)" in fft[0] and "power=0" in fft[0] and "tpb=16" in fft[0], fft
+    rows = {l.split()[2]: int(l.split("rows=")[1].split()[0]) for l in d24.splitlines() if " MBCONV " in l and "rows=" in l}
+    assert rows["stem:Conv_28+Conv_31"] == 8 and rows["mbconv:Conv_42+Conv_45"] == 12 and rows["mbconv:Conv_85+Conv_88"] == 12, rows
+    monkeypatch.setenv("BN_STFT_MELMFMA", "0")
+    assert "mel=96(csr)" in bn.plan_describe(str(p24))
+    monkeypatch.delenv("BN_STFT_MELMFMA")
+    p30 = tmp_path / "v30.onnx"
+    p30.write_bytes(synth.birdnet_v30())
+    d30 = bn.plan_describe(str(p30))
+    fft = [l for l in d30.splitlines() if " FFT " in l]
+    assert len(fft) == 1 and "bins=513" in fft[0] and "power=2" in fft[0] and "mel=0" in fft[0] and "Sqrt:" in fft[0], fft
+    assert not any(" ELT " in l and "Sqrt:" in l for l in d30.splitlines())
+    assert sum(" MBCONV " in l and "4x16x192->(1152)->4x16x1152" in l and "tiles=1x1" in l for l in d30.splitlines()) == 4, d30
+    monkeypatch.setenv("BN_STFT_POWER", "0")
+    d30b = bn.plan_describe(str(p30))
+    assert "bins=1026" in d30b and any(" ELT " in l and "Sqrt:" in l for l in d30b.splitlines())
+    monkeypatch.delenv("BN_STFT_POWER")
+    monkeypatch.setenv("BN_STFT_MEL", "force")
+    one = [l for l in bn.plan_describe(str(p30)).splitlines() if " FFT " in l]
+    assert "power=2" in one[0] and "tpb=8" in one[0] and "mel=128(csr)" in one[0] and "MatMul:" in one[0], one
+    monkeypatch.delenv("BN_STFT_MEL")
+    monkeypatch.setenv("BN_MBMAP2", "0")
+    assert not any(" MBCONV " in l and "4x16x192" in l for l in bn.plan_describe(str(p30)).splitlines())
+
+
 def test_plan_without_folding(bn, tmp_path, monkeypatch):
     monkeypatch.setenv("BN_CONVFOLD", "0")
     p = tmp_path / "m.onnx"
