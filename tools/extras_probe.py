@@ -40,3 +40,14 @@ print("C v30 after host leg:", round(run(m30, 64, 160000, 32000)))
 big = bn.Context(m24, 128); big.infer(np.concatenate([x] * 4)); big.time_kernels(128); del big
 print("D v30 after time_kernels:", round(run(m30, 64, 160000, 32000)))
 print("E v30 foreign ptr:", round(run(m30, 64, 160000, 32000, own=False)))
+
+# ---- idle contexts kept alive: do they slow the active ones?
+keep = [bn.Context(m24, 32) for _ in range(4)]
+xk = synth.synthetic_segments(32, 144000, 48000)
+for c_ in keep:
+    c_.infer(xk)
+print("F v30 with 4 idle v24 contexts alive:", round(run(m30, 64, 160000, 32000)))
+print("F2 v24 with 4 idle v24 contexts alive:", round(run(m24, 32, 144000, 48000, nst=200, nwu=20)))
+del keep
+import gc; gc.collect()
+print("G v30 after freeing them:", round(run(m30, 64, 160000, 32000)))
