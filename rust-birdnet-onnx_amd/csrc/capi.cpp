@@ -1608,8 +1608,8 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                     w += snprintf(line + w, sizeof(line) - w, "%s%lld/%lld/%lld", q ? "," : "", (long long)op.elt.size[q], (long long)op.elt.so[q], (long long)op.elt.sa[q]);
                 extra = line;
             } else if (op.kind == OpKind::MBCONV) {
-                snprintf(line, sizeof(line), " %dx%dx%d->(%d)->%dx%dx%d k=%d s=%d tiles=%dx%d squeeze=%d se=%d rows=%d", op.mb.H, op.mb.W, op.mb.Cin, op.mb.C, op.mb.OH, op.mb.OW, op.mb.C, op.mb.k, op.mb.s, op.mb.tiles_y, op.mb.tiles_x, op.mb.has_gap, op.se_fused,
-                         op.mb.row_mode ? op.mb.toh : 0);
+                snprintf(line, sizeof(line), " %dx%dx%d->(%d)->%dx%dx%d k=%d s=%d tiles=%dx%d squeeze=%d se=%d rows=%d%s", op.mb.H, op.mb.W, op.mb.Cin, op.mb.C, op.mb.OH, op.mb.OW, op.mb.C, op.mb.k, op.mb.s, op.mb.tiles_y, op.mb.tiles_x, op.mb.has_gap, op.se_fused,
+                         op.mb.row_mode ? op.mb.toh : 0, op.mb.row_mode && op.mb.row_tr ? "(columns)" : "");
                 extra = line;
             } else if (op.kind == OpKind::POOL) {
                 snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%dx%d max=%d", op.pool.H, op.pool.W, op.pool.C, op.pool.OH, op.pool.OW, op.pool.kh, op.pool.kw,

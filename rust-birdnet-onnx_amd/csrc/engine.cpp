@@ -991,20 +991,36 @@ class Builder {
         const int outw = mbconv_row_outw(m.k, m.s);
         // a strip expands 32 halo columns for `outw` outputs whatever the map's width: on narrow maps (Perch: 32 or 16
         // columns against strips of 30 / 28 / 14) half of every strip is idle and the tiled kernel wins (measured: 0.53-0.57
-        // utilisation -> 1.2-2.5x slower, 0.71 and above -> faster); BN_MBROW=force takes it regardless (tests)
-        const int strips = (m.OW + outw - 1) / outw;
-        if (!(env && std::string(env) == "force") && (double)m.OW < 0.7 * (double)(strips * outw)) return;
+        // utilisation -> 1.2-2.5x slower, 0.71 and above -> faster).  Round 3: such maps are usually TALL (Perch: 125 x 32,
+        // 63 x 16) -- the kernel then streams along the map's rows' direction instead (MbDesc::row_tr: strips across the
+        // height), if that fills its strips.  BN_MBROW=force takes the row kernel regardless (tests), BN_MBROW_TR=0 never
+        // transposes, =1 always does where the kernel supports it
+        const bool force = env && std::string(env) == "force";
+        const char *tre = getenv("BN_MBROW_TR");
+        const int strips = (m.OW + outw - 1) / outw, strips_t = (m.OH + outw - 1) / outw;
+        const double util = (double)m.OW / (double)(strips * outw), util_t = (double)m.OH / (double)(strips_t * outw);
+        bool tr = m.k1 == 0 && m.k == 3 && util_t >= 0.7 && util_t > util + 0.08;  // (5 x 5 instances: no register to spare for the second addressing form)
+        if (tre && std::string(tre) == "0") tr = false;
+        if (tre && std::string(tre) == "1") tr = m.k1 == 0 && m.k == 3;
+        if (tr) {
+            MbDesc probe = m;
+            probe.row_tr = 1;
+            if (!mbconv_row_supported(probe)) tr = false;
+        }
+        if (!force && !tr && util < 0.7) return;
         m.row_mode = 1;
+        m.row_tr = tr ? 1 : 0;
+        const int rows_k = tr ? m.OW : m.OH, cols_k = tr ? m.OH : m.OW;  // the kernel's output rows / columns
         // band height: a band of toh output rows expands (toh - 1) s + k halo rows, so taller bands recompute less (12 rows of a
         // 5x5 block: 16 halo rows instead of 2 x 10) -- what several contexts sharing the chip pay for; a block with one or two
         // 32-channel chunks keeps 8 so that one context alone still has enough waves (stem: 38 us at 8, 48 us at 12)
         // (bands balanced: 16 rows are one band of 16, not 12 + 4)
         const int toh_target = (m.C + 31) / 32 >= 3 ? 12 : 8;
-        const int nbands = std::max(1, (m.OH + toh_target / 2 - 1) / toh_target);
-        const int toh_default = (m.OH + nbands - 1) / nbands;
-        m.toh = std::min<int32_t>(m.OH, getenv("BN_MBROW_TOH") ? std::max(1, atoi(getenv("BN_MBROW_TOH"))) : toh_default);
-        m.tiles_x = (m.OW + outw - 1) / outw;
-        m.tiles_y = (m.OH + m.toh - 1) / m.toh;
+        const int nbands = std::max(1, (rows_k + toh_target / 2 - 1) / toh_target);
+        const int toh_default = (rows_k + nbands - 1) / nbands;
+        m.toh = std::min<int32_t>(rows_k, getenv("BN_MBROW_TOH") ? std::max(1, atoi(getenv("BN_MBROW_TOH"))) : toh_default);
+        m.tiles_x = (cols_k + outw - 1) / outw;
+        m.tiles_y = (rows_k + m.toh - 1) / m.toh;
         halo = 32.0 * m.tiles_x * (double)m.tiles_y * ((m.toh - 1) * m.s + m.k);
     }
 

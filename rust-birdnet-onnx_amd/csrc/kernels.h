@@ -157,6 +157,10 @@ struct MbDesc {
     // row-streaming form (mbrow.hip): tiles_x = strips of mbconv_row_outw(k, s) output columns, tiles_y = bands of
     // toh output rows; 0 = the tiled kernels above
     int32_t row_mode, toh;
+    // row-streaming form, transposed: the kernel's rows are the map's COLUMNS (strips then run across the map's height).  For
+    // maps that are tall and narrow (Perch: 125 x 32, 63 x 16) a 30-column strip is half empty while the height fills
+    // several; H/W, OH/OW, pt/pl, tiles_x/tiles_y and toh stay in MAP terms in the plan, the launcher swaps them for the kernel
+    int32_t row_tr;
     int32_t dbg;  // mbmap.hip experiments (BN_MM_DBG bit mask, set by the launcher): skip phases to time the rest
 };
 // MaxPool / AveragePool over an NHWC tensor (1-D pooling = H == 1).
@@ -177,6 +181,7 @@ inline bool mbconv_row_supported(const MbDesc &d) {
     if (!((d.k == 3 || d.k == 5) && (d.s == 1 || d.s == 2))) return false;
     if (!mbconv_row_act_supported(d.act1) || !mbconv_row_act_supported(d.act2)) return false;
     if ((int64_t)d.OH * d.OW * d.C >= ((int64_t)1 << 31) || (int64_t)d.W * d.Cin >= ((int64_t)1 << 30)) return false;  // 32-bit lane offsets
+    if (d.row_tr && ((int64_t)d.H * d.W * d.Cin >= ((int64_t)1 << 30) || d.k1 > 0 || d.k != 3)) return false;  // transposed: a column step is a map row; 3 x 3 instances only
     if (d.k1 > 0) return ng >= 2 && ng <= 4 && d.k == 3 && d.k1 <= 4 && d.Cin1 >= 1;
     return d.Cin % 4 == 0 && ng >= 2 && ng <= 6;
 }

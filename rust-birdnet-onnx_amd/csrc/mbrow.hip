@@ -108,8 +108,8 @@ __device__ __forceinline__ void row_act_t(int act, float p0, float p1, float (&v
 //   main      J = K .. nrows      unrolled 2K times: slot = i % K, operand buffer = (K + i) & 1, stride-2 blocks emit on
 //                                 even i; J = nrows is the drain step (its expansion is discarded)
 // Row and column masks (halo outside the image) are applied by rarely taken uniform branches AFTER the block.
-template <int K, int S, int NG, bool IM2COL, int ACT>
-__global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
+template <int K, int S, int NG, bool IM2COL, int ACT, bool TR = false>
+__global__ __launch_bounds__(256, (K == 5 && ACT != ACT_RELU) ? 1 : 2) void mbconv_row_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                             const float *__restrict__ w1, const float *__restrict__ b1,
                                                             const float *__restrict__ w2, const float *__restrict__ b2,
                                                             float *__restrict__ gap, int total_units) {
@@ -163,9 +163,15 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
     for (int q = 0; q < NOUT; q++) omask |= (cact && NOUT * lh + q < OUTW && ox0 + NOUT * lh + q < d.OW) ? (1u << q) : 0u;
     const float bv = d.has_bias1 ? b1[cgc] : 0.0f;
     const float bias2 = d.has_bias2 ? b2[cgc] : 0.0f;
-    float wd[K * K];
+    float wd[K * K];  // [kernel row tap][kernel column tap]; transposed: the map's (kx, ky)
+    constexpr bool tr = TR;  // compile-time: the second addressing form costs the plain instances nothing (3 x 3, 1x1-expand blocks only)
+    if (tr) {
 #pragma unroll
-    for (int q = 0; q < K * K; q++) wd[q] = w2[q * d.C + cgc];
+        for (int q = 0; q < K * K; q++) wd[q] = w2[((q % K) * K + q / K) * d.C + cgc];
+    } else {
+#pragma unroll
+        for (int q = 0; q < K * K; q++) wd[q] = w2[q * d.C + cgc];
+    }
 
     // ---- A operand addressing.  plain: X[iy][ixc][8g + 4lh .. +3], a group that is channel padding (Cin % 8 == 4, last
     // group, upper half) re-reads group 0 and is zeroed; stem: im2col column k = 8g + 4lh + j -> tap (ky, kx), channel cc
@@ -218,8 +224,11 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
         im_pair = __all(pairs);
     }
 
-    const int64_t a_rs = (int64_t)d.W * d.Cin;                        // floats per input row
-    const unsigned a_lane4 = 4u * (unsigned)(ixc * d.Cin + 4 * lh);      // byte offset of this lane's pixel + K half within the row
+    // (transposed: kernel pixel (r, c) is map pixel (y = c, x = r) of a map that is d.H wide -- a row step is one pixel, a column
+    // step one map row)
+    const int64_t a_rs = tr ? (int64_t)d.Cin : (int64_t)d.W * d.Cin;   // floats per input row
+    const int a_px = tr ? d.H * d.Cin : d.Cin;                          // floats per input column step
+    const unsigned a_lane4 = 4u * (unsigned)(ixc * a_px + 4 * lh);            // byte offset of this lane's pixel + K half within the row
     const unsigned a_last4 = a_lane4 + (pad_lane ? 0u : 32u * (NG - 1));  // channel-padding lanes re-read group 0 (then zeroed)
     float4 abuf[2][NG];
 #pragma unroll
@@ -270,9 +279,10 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
         for (int x = 0; x < XW; x++) rows[s_][x] = 0.0f;
 
     float *obase = out + b * d.out_bs;  // wave-uniform base, lanes add 32-bit offsets
-    const unsigned ocol4 = 4u * (unsigned)((ox0 + NOUT * lh) * d.C + cgc);  // this lane's byte offset within an output row
-    const int64_t o_rs = (int64_t)d.OW * d.C;                              // floats per output row
-    const size_t o_ps = 4 * (size_t)d.C;                                   // bytes per output pixel
+    const int o_px = tr ? d.OH * d.C : d.C;                           // floats per output column step
+    const unsigned ocol4 = 4u * (unsigned)((ox0 + NOUT * lh) * o_px + cgc);  // this lane's byte offset within an output row
+    const int64_t o_rs = tr ? (int64_t)d.C : (int64_t)d.OW * d.C;     // floats per output row
+    const size_t o_ps = 4 * (size_t)o_px;                                   // bytes per output pixel
     int nst = 0;
     (void)nst;
     float2_t sum2 = {0.0f, 0.0f};  // squeeze partial of this lane, even / odd outputs
@@ -409,14 +419,30 @@ __global__ __launch_bounds__(256, 2) void mbconv_row_kernel(MbDesc d, float *__r
 
 }  // namespace
 
+static void launch_mbconv_row_impl(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
+                                   const float *b2, float *gap, int64_t batch);
+
 void launch_mbconv_row(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
                        const float *b2, float *gap, int64_t batch) {
     if (batch <= 0) return;
     const int64_t total = batch * d.tiles_x * d.tiles_y * ((d.C + 31) / 32);
-    if (!mbconv_row_supported(d) || d.toh <= 0 || total > 0x7fffffff) {
+    if (!mbconv_row_supported(d) || d.toh <= 0 || total > 0x7fffffff || (d.row_tr && (d.k1 > 0 || d.k != 3))) {
         launch_error("row-streaming MBConv: shape outside the instantiated set");
         return;
     }
+    if (d.row_tr) {  // the kernel sees the transposed map (plan terms -> kernel terms); tiles_x / tiles_y / toh are kernel terms already
+        MbDesc t = d;
+        std::swap(t.H, t.W);
+        std::swap(t.OH, t.OW);
+        std::swap(t.pt, t.pl);
+        return launch_mbconv_row_impl(s, t, out, in, w1, b1, w2, b2, gap, batch);
+    }
+    launch_mbconv_row_impl(s, d, out, in, w1, b1, w2, b2, gap, batch);
+}
+
+static void launch_mbconv_row_impl(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,
+                                   const float *b2, float *gap, int64_t batch) {
+    const int64_t total = batch * d.tiles_x * d.tiles_y * ((d.C + 31) / 32);
     const dim3 grid((unsigned)((total + 3) / 4));
     const int ng = (d.Cin + 7) / 8;
     const int actc = d.act1 == d.act2 && (d.act1 == ACT_RELU || d.act1 == ACT_SILU) ? d.act1 : -1;
@@ -438,6 +464,26 @@ void launch_mbconv_row(hipStream_t s, const MbDesc &d, float *out, const float *
         else if (ng == 5) ROW_LAUNCH(K, S, 5, false);   \
         else ROW_LAUNCH(K, S, 6, false);                \
     } while (0)
+    // transposed streaming (3 x 3 blocks with a 1x1 expand): the same instances with the second addressing form
+#define ROW_LAUNCH_T(S, NG)                                                                                                                \
+    do {                                                                                                                                   \
+        if (actc == ACT_RELU) hipLaunchKernelGGL((mbconv_row_kernel<3, S, NG, false, ACT_RELU, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
+        else if (actc == ACT_SILU) hipLaunchKernelGGL((mbconv_row_kernel<3, S, NG, false, ACT_SILU, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
+        else hipLaunchKernelGGL((mbconv_row_kernel<3, S, NG, false, -1, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
+    } while (0)
+#define ROW_NG_T(S)                             \
+    do {                                        \
+        if (ng <= 2) ROW_LAUNCH_T(S, 2);        \
+        else if (ng == 3) ROW_LAUNCH_T(S, 3);   \
+        else if (ng == 4) ROW_LAUNCH_T(S, 4);   \
+        else if (ng == 5) ROW_LAUNCH_T(S, 5);   \
+        else ROW_LAUNCH_T(S, 6);                \
+    } while (0)
+    if (d.row_tr) {
+        if (d.s == 1) ROW_NG_T(1);
+        else ROW_NG_T(2);
+        return;
+    }
     if (d.k1 > 0) {
         if (d.s == 1) {
             if (ng <= 2) ROW_LAUNCH(3, 1, 2, true);
@@ -452,6 +498,8 @@ void launch_mbconv_row(hipStream_t s, const MbDesc &d, float *out, const float *
     else if (d.k == 3 && d.s == 2) ROW_NG(3, 2);
     else if (d.k == 5 && d.s == 1) ROW_NG(5, 1);
     else ROW_NG(5, 2);
+#undef ROW_NG_T
+#undef ROW_LAUNCH_T
 #undef ROW_NG
 #undef ROW_LAUNCH
 }

@@ -523,10 +523,11 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
     os.environ["BN_MBPIPE"] = "1" if variant == "pipe" else "0"   # pipelined 512-thread variant of the tiled kernel
     os.environ["BN_MBROW"] = "force" if variant == "row" else "0"   # force: narrow maps too (the planner leaves those to the tiled kernel)
     os.environ["BN_MBROW_TOH"] = "5"                              # several bands, a ragged last one
+    os.environ["BN_MBROW_TR"] = "0"                               # row streaming along the map's rows (the bit-identical form)
     try:
         desc = bn.plan_describe(write_model(data))
         assert "MBCONV" in desc
-        mb_rows = int([l for l in desc.splitlines() if " MBCONV " in l][0].rsplit("rows=", 1)[1])
+        mb_rows = int([l for l in desc.splitlines() if " MBCONV " in l][0].rsplit("rows=", 1)[1].split("(")[0])  # ("(columns)": transposed streaming)
         if variant == "row":
             assert mb_rows == (min(5, oh) if cin >= 12 else 0), desc  # Cin <= 8 (one K group) stays with the tiled kernel
         else:
@@ -537,8 +538,15 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
             os.environ["BN_MBROW"] = "0"
             tiled, _ = run_both(bn, data)
             assert np.array_equal(got.view(np.uint32), tiled.view(np.uint32)), "row-streaming kernel differs from the tiled kernel"
+            if k == 3:
+                # ... and streaming along the map's COLUMNS (round 3: tall narrow maps; the depthwise taps then meet in (kx, ky)
+                # order, so the bits may differ from the tiled kernel's: checked against the oracle)
+                os.environ["BN_MBROW"], os.environ["BN_MBROW_TR"] = "force", "1"
+                assert "(columns)" in bn.plan_describe(write_model(data))
+                got_t, _ = run_both(bn, data)
+                assert_close(got_t, ref, f"mbconv[row, transposed] {cin}->{cmid} k{k} s{stride}")
     finally:
-        for key in ("BN_MBFUSE", "BN_MBMAP", "BN_MBMAP_MAXHW", "BN_MBPIPE", "BN_MBROW", "BN_MBROW_TOH"):
+        for key in ("BN_MBFUSE", "BN_MBMAP", "BN_MBMAP_MAXHW", "BN_MBPIPE", "BN_MBROW", "BN_MBROW_TOH", "BN_MBROW_TR"):
             del os.environ[key]
     assert_close(got, ref, f"mbconv[{variant}] {cin}->{cmid} k{k} s{stride}")
 
