@@ -109,7 +109,7 @@ __device__ __forceinline__ void row_act_t(int act, float p0, float p1, float (&v
 //                                 even i; J = nrows is the drain step (its expansion is discarded)
 // Row and column masks (halo outside the image) are applied by rarely taken uniform branches AFTER the block.
 template <int K, int S, int NG, bool IM2COL, int ACT, bool TR = false>
-__global__ __launch_bounds__(256, (K == 5 && ACT != ACT_RELU) ? 1 : 2) void mbconv_row_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
+__global__ __launch_bounds__(256, (K == 5 && (ACT != ACT_RELU || (S == 1 && NG >= 5))) ? 1 : 2) void mbconv_row_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                             const float *__restrict__ w1, const float *__restrict__ b1,
                                                             const float *__restrict__ w2, const float *__restrict__ b2,
                                                             float *__restrict__ gap, int total_units) {
