@@ -311,7 +311,11 @@ __device__ __forceinline__ void first_pass(float2 *__restrict__ x, const float2 
 
 // Persistent blocks: a block walks the (sample, frame tile) work items blockIdx.x, + gridDim.x, ...; the tables are
 // copied to LDS once, and the NEXT tile's signal span is fetched into registers while the current tile is transformed.
-template <int NW, int SLOTS>
+// PRE: the launch carries an absorbed prologue chain (false: none of its state exists -- the kernel keeps far more launch-uniform
+// values than there are scalar registers, and every one it does not need is one fewer reloaded from a spill lane in the hot loops)
+// MELM: the absorbed mel bank -- 0 none, 1 the sparse walk, 2 16 x 16 tiles on the matrix cores, -1 decided at run time (the instances with
+// a prologue chain, which are big as it is)
+template <int NW, int SLOTS, bool PRE, int MELM>
 __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, int total_tiles, int tiles_per_sample) {
     constexpr int SPAN_R = SPAN_FLOATS / (4 * NW * 64);
     extern __shared__ __align__(16) float lds[];
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     float *mstart = lds + lay.mstart;
     float2 *ment = reinterpret_cast<float2 *>(lds + lay.ment);
     float *spec = lds + lay.spec;
-    const int M = d.M, logM = d.logM, hop = d.hop, nout = d.nout, nmel = d.nmel, F = SLOTS >> d.logM;  // frames per wave pass
+    const int M = d.M, logM = d.logM, hop = d.hop, nout = d.nout, nmel = MELM == 0 ? 0 : d.nmel, F = SLOTS >> d.logM;  // frames per wave pass
     const int dbg = d.dbg;
 
     // ---- tables -> LDS, once per block
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     async_copy<NW>(lds + lay.window, p.window, d.L, wave, lane);
     const int ostride = d.otab_stride > 0 ? d.otab_stride : 8, power = d.power;
     async_copy<NW>(otab, p.otab, ostride * nout, wave, lane);
-    const int mel_mode = d.mel_mode, SS = d.spec_stride > 0 ? d.spec_stride : nout;
+    const int mel_mode = MELM < 0 ? d.mel_mode : (MELM == 2 ? 1 : 0), SS = d.spec_stride > 0 ? d.spec_stride : nout;
     if (nmel && mel_mode == 0) {
         async_copy<NW>(mstart, p.mstart, nmel + 1, wave, lane);
         async_copy<NW>(lds + lay.ment, p.mcol, 2 * d.mel_nnz, wave, lane);
@@ -344,12 +348,12 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     // (literal indices into the descriptor arrays everywhere: a loop the compiler does not unroll would index the
     // kernel argument dynamically and move ALL of it into scratch memory)
     static_assert(ELT_MAX_STAGES == 4, "the stages below are spelled out");
-    PreChain chain{d.npre, {d.pre_bin[0], d.pre_bin[1], d.pre_bin[2], d.pre_bin[3]}, {d.pre_act[0], d.pre_act[1], d.pre_act[2], d.pre_act[3]},
+    PreChain chain{PRE ? d.npre : 0, {d.pre_bin[0], d.pre_bin[1], d.pre_bin[2], d.pre_bin[3]}, {d.pre_act[0], d.pre_act[1], d.pre_act[2], d.pre_act[3]},
                    {0.f, 0.f, 0.f, 0.f}, {d.pre_p0[0], d.pre_p0[1], d.pre_p0[2], d.pre_p0[3]}, {d.pre_p1[0], d.pre_p1[1], d.pre_p1[2], d.pre_p1[3]}};
     const int64_t bb0 = d.pre_bb[0], bb1 = d.pre_bb[1], bb2 = d.pre_bb[2], bb3 = d.pre_bb[3];
     const float *pre0 = p.pre[0], *pre1 = p.pre[1], *pre2 = p.pre[2], *pre3 = p.pre[3];
-    const bool use0 = 0 < chain.n && chain.bin[0] != BIN_NONE, use1 = 1 < chain.n && chain.bin[1] != BIN_NONE;
-    const bool use2 = 2 < chain.n && chain.bin[2] != BIN_NONE, use3 = 3 < chain.n && chain.bin[3] != BIN_NONE;
+    const bool use0 = PRE && 0 < chain.n && chain.bin[0] != BIN_NONE, use1 = PRE && 1 < chain.n && chain.bin[1] != BIN_NONE;
+    const bool use2 = PRE && 2 < chain.n && chain.bin[2] != BIN_NONE, use3 = PRE && 3 < chain.n && chain.bin[3] != BIN_NONE;
     const int npost = d.npost;
     const int po_a0 = d.post_act[0], po_a1 = d.post_act[1], po_a2 = d.post_act[2], po_a3 = d.post_act[3];
     const float po_p00 = d.post_p0[0], po_p01 = d.post_p0[1], po_p02 = d.post_p0[2], po_p03 = d.post_p0[3];
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
         _Pragma("unroll") for (int k = 0; k < SPAN_R; k++) {                                      \
             v[4 * k] = sr[k].x; v[4 * k + 1] = sr[k].y; v[4 * k + 2] = sr[k].z; v[4 * k + 3] = sr[k].w; \
         }                                                                                         \
-        if (!(dbg & 16)) pre_chain<4 * SPAN_R>(chain, v);                                         \
+        if (PRE && !(dbg & 16)) pre_chain<4 * SPAN_R>(chain, v);                                  \
         _Pragma("unroll") for (int k = 0; k < SPAN_R; k++) {                                      \
             const int c = tid + k * NW * 64;                                                      \
             if (c < n4) reinterpret_cast<float4 *>(sig)[c] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]); \
@@ -650,8 +654,11 @@ size_t stft_lds_bytes(const FftDesc &d, int nwaves) {
 }
 
 void register_stft_kernels() {
-    register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<8, 1024>));
-    register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<16, 512>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<8, 1024, false, 0>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<8, 1024, false, 1>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<8, 1024, false, 2>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<8, 1024, true, -1>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<16, 512, true, -1>));
 }
 
 void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t batch) {
@@ -659,7 +666,13 @@ void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t bat
     const bool wide = stft_wide(d);
     const size_t lds = stft_lds_bytes(d, 0);
     const int span = (d.tpb - 1) * d.hop + d.L;
-    const void *fn = wide ? reinterpret_cast<const void *>(stft_kernel<16, 512>) : reinterpret_cast<const void *>(stft_kernel<8, 1024>);
+    const bool pre = d.npre > 0;
+    const int melm = d.nmel == 0 ? 0 : (d.mel_mode == 1 ? 2 : 1);
+    const void *fn = wide  ? reinterpret_cast<const void *>(stft_kernel<16, 512, true, -1>)
+                     : pre ? reinterpret_cast<const void *>(stft_kernel<8, 1024, true, -1>)
+                     : melm == 0 ? reinterpret_cast<const void *>(stft_kernel<8, 1024, false, 0>)
+                     : melm == 1 ? reinterpret_cast<const void *>(stft_kernel<8, 1024, false, 1>)
+                                 : reinterpret_cast<const void *>(stft_kernel<8, 1024, false, 2>);
     if (lds > 160 * 1024 || span > SPAN_FLOATS || !ensure_dynamic_lds(fn, lds)) {
         launch_error("STFT kernel: the frame span does not fit the LDS / the staging registers");
         return;
@@ -674,8 +687,11 @@ void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t bat
     const int64_t total = (int64_t)tps * batch;
     const int ncu = device_cu_count();  // asked once per device by prepare_device(), never inside a stream capture
     const unsigned grid = (unsigned)std::min<int64_t>(total, ncu);  // one block per CU (LDS-bound), persistent over its tiles
-    if (wide) hipLaunchKernelGGL((stft_kernel<16, 512>), dim3(grid), dim3(16 * 64), lds, s, dd, p, (int)total, tps);
-    else hipLaunchKernelGGL((stft_kernel<8, 1024>), dim3(grid), dim3(8 * 64), lds, s, dd, p, (int)total, tps);
+    if (wide) hipLaunchKernelGGL((stft_kernel<16, 512, true, -1>), dim3(grid), dim3(16 * 64), lds, s, dd, p, (int)total, tps);
+    else if (pre) hipLaunchKernelGGL((stft_kernel<8, 1024, true, -1>), dim3(grid), dim3(8 * 64), lds, s, dd, p, (int)total, tps);
+    else if (melm == 0) hipLaunchKernelGGL((stft_kernel<8, 1024, false, 0>), dim3(grid), dim3(8 * 64), lds, s, dd, p, (int)total, tps);
+    else if (melm == 1) hipLaunchKernelGGL((stft_kernel<8, 1024, false, 1>), dim3(grid), dim3(8 * 64), lds, s, dd, p, (int)total, tps);
+    else hipLaunchKernelGGL((stft_kernel<8, 1024, false, 2>), dim3(grid), dim3(8 * 64), lds, s, dd, p, (int)total, tps);
 }
 
 }  // namespace bn
