@@ -108,8 +108,18 @@ __device__ __forceinline__ void row_act_t(int act, float p0, float p1, float (&v
 //   main      J = K .. nrows      unrolled 2K times: slot = i % K, operand buffer = (K + i) & 1, stride-2 blocks emit on
 //                                 even i; J = nrows is the drain step (its expansion is discarded)
 // Row and column masks (halo outside the image) are applied by rarely taken uniform branches AFTER the block.
+// Waves per SIMD the instance is compiled for: two (256 registers each) wherever everything fits; the instances whose live state does not
+// (5 x 5 windows with SiLU / run-time activations or five and more K groups; run-time activations with six K groups or an im2col stem) get
+// one wave's 512 registers instead of spilling to scratch memory -- tests/test_build_hygiene.py keeps the build free of scratch
+template <int K, int NG, int S, bool IM2COL, int ACT>
+constexpr int mbrow_waves_per_simd() {
+    if (K == 5 && (ACT != ACT_RELU || (S == 1 && NG >= 5))) return 1;
+    if (ACT != ACT_RELU && ACT != ACT_SILU && (NG >= 6 || IM2COL)) return 1;
+    if (IM2COL && ACT == ACT_SILU && NG >= 4) return 1;
+    return 2;
+}
 template <int K, int S, int NG, bool IM2COL, int ACT, bool TR = false>
-__global__ __launch_bounds__(256, (K == 5 && (ACT != ACT_RELU || (S == 1 && NG >= 5))) ? 1 : 2) void mbconv_row_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
+__global__ __launch_bounds__(256, (mbrow_waves_per_simd<K, NG, S, IM2COL, ACT>())) void mbconv_row_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                             const float *__restrict__ w1, const float *__restrict__ b1,
                                                             const float *__restrict__ w2, const float *__restrict__ b2,
                                                             float *__restrict__ gap, int total_units) {
