@@ -6,7 +6,10 @@ PKG := rust-birdnet-onnx_amd
 SRC := $(PKG)/csrc
 OUT := $(PKG)/libbirdnet_hip.so
 CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -Iinclude
-HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH) -ffp-contract=off
+# -fno-slp-vectorize: left to itself the compiler packs neighbouring scalar f32 operations into v_pk_fma_f32 / v_pk_mul_f32 and pays
+# for the pairs with register moves (mbmap's depthwise phase: 120 v_pk_fma + 216 v_mov for 240 multiply-adds); on this part a packed
+# f32 instruction costs 1.56x a plain one (tools/mfma_valu_probe.cpp) and every vector instruction is paid out of the MFMA time
+HIPFLAGS := $(CXXFLAGS) --offload-arch=$(ARCH) -ffp-contract=off -fno-slp-vectorize
 OBJS := $(SRC)/onnx_proto.o $(SRC)/engine.o $(SRC)/detect.o $(SRC)/capi.o $(SRC)/group.o $(SRC)/host_classifier.o $(SRC)/host_capi.o $(SRC)/host_rangefilter.o $(SRC)/kernels.o $(SRC)/topk.o $(SRC)/stft.o $(SRC)/mbrow.o $(SRC)/gemm_dma.o $(SRC)/mbmap.o
 
 all: $(OUT) oracle
