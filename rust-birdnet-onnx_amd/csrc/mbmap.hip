@@ -159,9 +159,11 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
             const int n = c0 + (wn * NW + nt) * 16 + 4 * lq;
             cc_.bias4[nt] = (d.has_bias1 && kh == 0 && n < d.C) ? *reinterpret_cast<const floatx4 *>(b1 + n) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
-        const int cl = min(c0 + c, d.C - 1);
+        // (uniform base + unsigned 32-bit lane offset: the form the compiler can issue as a scalar-base load -- with a signed index it
+        // sign-extended and added 64 bits on the vector ALU for every tap, 110 of the chunk's 800 vector instructions)
+        const unsigned cl = (unsigned)min(c0 + c, d.C - 1);
 #pragma unroll
-        for (int q = 0; q < K * K; q++) cc_.wd[q] = w2[q * d.C + cl];
+        for (int q = 0; q < K * K; q++) cc_.wd[q] = (w2 + (size_t)q * (size_t)d.C)[cl];
         cc_.bz = d.has_bias2 ? b2[cl] : 0.0f;
     };
     ChunkConst nxt;
@@ -296,7 +298,8 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
                     }
                 }
             }
-            float *ob = out + b * d.out_bs + cg;
+            float *ob = out + b * d.out_bs;                                  // uniform
+            const unsigned olane = (unsigned)(cg + ox0 * d.C);                // this lane's channel + strip offset
 #pragma unroll
             for (int oy = 0; oy < OH; oy++) {
                 float r[PPG];
@@ -304,10 +307,9 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
                 for (int q = 0; q < PPG; q++) r[q] = ov[oy][q];
                 mm_act<PPG>(d.act2, d.p0_2, d.p1_2, r);
                 if (cact) {
-                    float *op = ob + (int64_t)(oy * OW + ox0) * d.C;
 #pragma unroll
                     for (int q = 0; q < PPG; q++) {
-                        if (!(d.dbg & 4)) op[(int64_t)q * d.C] = r[q];
+                        if (!(d.dbg & 4)) (ob + (size_t)(oy * OW + q) * (size_t)d.C)[olane] = r[q];
                         sum += r[q];
                     }
                 }
