@@ -2881,6 +2881,7 @@ class Builder {
         }
         absorb_chains_into_gemms();
         absorb_into_stft();
+        planar_stft_tables();
         pair_minmax_reductions();
         absorb_se_into_gemms();
         recompute_liveness();
@@ -3161,6 +3162,31 @@ class Builder {
                 plan_.ops.erase(plan_.ops.begin() + (long)e);
                 changed = true;
             }
+        }
+    }
+
+    // The untangle table of every FFT launch goes from rows [nout][8 | 12] to PLANES: [nout][4] (two buffer positions, first two
+    // coefficients), [nout][2] (the other two), [nout][4] (power mode: the second linear form).  The kernel's lanes read consecutive
+    // outputs: 32-byte row strides put the 16-byte reads 2-way and the 8-byte reads 4-way on the LDS banks (53 % of the bin phase's
+    // LDS cycles were conflicts); consecutive 16- and 8-byte elements of a plane do not conflict.
+    void planar_stft_tables() {
+        for (PlanOp &f : plan_.ops) {
+            FftDesc &d = f.fft;
+            if (f.kind != OpKind::FFT || d.otab_planar || f.bias2.space != Space::CONSTS) continue;
+            const int stride = d.otab_stride > 0 ? d.otab_stride : 8;
+            const std::vector<float> &ot = plan_.consts[f.bias2.id];
+            const int64_t n = d.nout;
+            if ((int64_t)ot.size() < f.bias2.offset + n * stride) continue;
+            std::vector<float> pl((size_t)(n * (d.power ? 10 : 6)), 0.0f);
+            for (int64_t c = 0; c < n; c++) {
+                const float *r = &ot[(size_t)(f.bias2.offset + c * stride)];
+                for (int q = 0; q < 4; q++) pl[(size_t)(c * 4 + q)] = r[q];
+                for (int q = 0; q < 2; q++) pl[(size_t)(4 * n + c * 2 + q)] = r[4 + q];
+                if (d.power)
+                    for (int q = 0; q < 4; q++) pl[(size_t)(6 * n + c * 4 + q)] = r[8 + q];
+            }
+            f.bias2 = Ref{Space::CONSTS, add_const(pl), 0};
+            d.otab_planar = 1;
         }
     }
 

@@ -321,6 +321,7 @@ struct FftDesc {
     // mcol = the kept tiles, 256 floats each.  spec_stride: floats per spectrum row in LDS (nout in CSR mode; in MFMA mode
     // 16 ceil(nout/16) + 8: whole bin groups, and = 8 mod 16 makes the ds_read_b128 fragment reads conflict free)
     int32_t mel_mode, mel_groups, spec_stride;
+    int32_t otab_planar;  // 1: the untangle table is stored as planes [nout][4] | [nout][2] | [nout][4 (power mode)] instead of rows
 };
 struct StftPtrs {
     float *out;

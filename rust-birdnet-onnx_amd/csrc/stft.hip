@@ -74,7 +74,10 @@ __device__ __forceinline__ void strided_pass(float2 *__restrict__ x, const float
         int base[INFL], j[INFL];
 #pragma unroll
         for (int t = 0; t < INFL; t++) {
-            const int g = lane + 64 * (h + t);
+            // which butterflies a lane takes is free: with q = 16 a half wave reads two 64-blocks, and under the 2-per-16 padding
+            // neighbouring blocks b, b + 1 overlap on the banks (72 b mod 32) while b, b + 2 do not -- lanes 16-31 take block b + 2
+            const int g0 = lane + 64 * (h + t);
+            const int g = lq == 4 ? ((g0 & ~0x30) | ((g0 & 0x10) << 1) | ((g0 & 0x20) >> 1)) : g0;
             j[t] = g & (q - 1);
             base[t] = ((g >> lq) << logn) + j[t];
 #pragma unroll
@@ -238,7 +241,7 @@ __host__ __device__ __forceinline__ StftLds stft_layout(const FftDesc &d, int nw
     l.wbuf = o; o += 2 * nw * wbuf_slots(slots);
     l.tw = o; o += kib(2 * d.tw_count);
     l.window = o; o += kib(d.L);
-    l.otab = o; o += kib((d.otab_stride > 0 ? d.otab_stride : 8) * d.nout);
+    l.otab = o; o += kib(d.otab_planar ? (d.power ? 10 : 6) * d.nout : (d.otab_stride > 0 ? d.otab_stride : 8) * d.nout);
     const bool csr = d.nmel && d.mel_mode == 0;  // (MFMA mode reads its tiles from global memory / L2: nothing of the bank in LDS)
     l.mstart = o; o += csr ? kib(d.nmel + 1) : 0;
     l.ment = o; o += csr ? kib(2 * d.mel_nnz) : 0;  // (column, value) pairs
@@ -335,8 +338,11 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     // ---- tables -> LDS, once per block
     async_copy<NW>(lds + lay.tw, reinterpret_cast<const float *>(p.tw), 2 * d.tw_count, wave, lane);
     async_copy<NW>(lds + lay.window, p.window, d.L, wave, lane);
-    const int ostride = d.otab_stride > 0 ? d.otab_stride : 8, power = d.power;
-    async_copy<NW>(otab, p.otab, ostride * nout, wave, lane);
+    const int power = d.power, planar = d.otab_planar;
+    // row form: [nout][ostride]; plane form (the planner's default): [nout][4] at 0, [nout][2] at 4 nout, [nout][4] at 6 nout
+    const int ostride = planar ? 4 : (d.otab_stride > 0 ? d.otab_stride : 8);
+    const int o1 = planar ? 4 * nout : 4, os1 = planar ? 2 : ostride, o2 = planar ? 6 * nout : 8;
+    async_copy<NW>(otab, p.otab, planar ? (power ? 10 : 6) * nout : ostride * nout, wave, lane);
     const int mel_mode = MELM < 0 ? d.mel_mode : (MELM == 2 ? 1 : 0), SS = d.spec_stride > 0 ? d.spec_stride : nout;
     if (nmel && mel_mode == 0) {
         async_copy<NW>(mstart, p.mstart, nmel + 1, wave, lane);
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
                     for (int k = 0; k < BI; k++) {
                         const int c = min(c0 + 64 * k, nout - 1);
                         e0[k] = *reinterpret_cast<const float4 *>(otab + ostride * c);
-                        e1[k] = *reinterpret_cast<const float2 *>(otab + ostride * c + 4);
+                        e1[k] = *reinterpret_cast<const float2 *>(otab + o1 + os1 * c);
                     }
 #pragma unroll
                     for (int k = 0; k < BI; k++) {
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
                         if (c < nout) {
                             float v = e0[k].z * za[k].x + e0[k].w * za[k].y + e1[k].x * zb[k].x + e1[k].y * zb[k].y;
                             if (power) {  // launch-uniform: the second linear form of the bin, then u^2 + v^2 (+ sqrt)
-                                const float4 e2 = *reinterpret_cast<const float4 *>(otab + ostride * c + 8);
+                                const float4 e2 = *reinterpret_cast<const float4 *>(otab + o2 + ostride * c);
                                 const float w = e2.x * za[k].x + e2.y * za[k].y + e2.z * zb[k].x + e2.w * zb[k].y;
                                 const float uu = v * v, ww = w * w;
                                 v = uu + ww;
