@@ -258,6 +258,11 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
                     launch_error("GEMM with inline squeeze-excite: operands are not 16-byte aligned");
                 break;
             }
+            if (op.gemm2.N > 0) {  // planner rule J: the product over this GEMM's rows runs behind it in the same launch
+                launch_gemm_fold_pair(c->stream, op.gemm, op.gemm2, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
+                                      resolve(c, op.bias2, d_in), batch);
+                break;
+            }
             launch_gemm(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in),
                         resolve(c, op.scale, d_in), batch);
             break;
@@ -1589,6 +1594,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 extra = line;
                 if (op.gemm.fold) { snprintf(line, sizeof(line), " fold=%d/%d", op.gemm.fold, op.gemm.fold_n); extra += line; }
                 if (op.gemm.se_inline) { snprintf(line, sizeof(line), " se_inline=%d/%d", op.se.C, op.se.Cr); extra += line; }
+                if (op.gemm2.N > 0) { snprintf(line, sizeof(line), " pair=%dx%d post=%d out_rs=%lld out_cs=%lld", op.gemm2.K, op.gemm2.N, op.gemm2.npost, (long long)op.gemm2.out_rs, (long long)op.gemm2.out_cs); extra += line; }
                 // which of the three matrix kernels the launcher picks (the LDS-resident framing kernel may still fall back to
                 // the generic one at launch: BN_FRAMELDS=0 or a span that does not fit)
                 extra += op.gemm.fold ? " kernel=frame_fold" : gemm_dma_shape(op.gemm) ? " kernel=dma" : (!(op.gemm.npost || op.gemm.out_strided) && gemm_use_splitk(op.gemm) ? " kernel=splitk" : " kernel=tiled");

@@ -2882,6 +2882,7 @@ class Builder {
         absorb_chains_into_gemms();
         absorb_into_stft();
         planar_stft_tables();
+        fuse_fold_pairs();
         pair_minmax_reductions();
         absorb_se_into_gemms();
         recompute_liveness();
@@ -3160,6 +3161,45 @@ class Builder {
                     f.name = el.name + "+" + f.name;
                 }
                 plan_.ops.erase(plan_.ops.begin() + (long)e);
+                changed = true;
+            }
+        }
+    }
+
+    // (J) The product that consumes the rows of a folded framing GEMM -- the mel filter bank of a spectrogram branch that stayed on the
+    // matrix path: K2 = the bank's <= 128 live bins, with the compression chain and the layout copy rule E put into its epilogue --
+    // runs behind the K loop of the framing kernel on the block's own spectrum tile (kernels.hip, frame_fold_kernel<true>): the
+    // spectrum rows are neither written nor read back, one launch less.  Measured slower (kernels.hip, frame_fold_pair_ok): opt-in, BN_FRAMEPAIR=1.
+    void fuse_fold_pairs() {
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            std::vector<std::vector<int>> users(plan_.storages.size());
+            std::vector<Ref *> refs;
+            for (size_t k = 0; k < plan_.ops.size(); k++) {
+                all_refs(plan_.ops[k], refs);
+                for (Ref *r : refs)
+                    if (r->space == Space::ARENA && (users[r->id].empty() || users[r->id].back() != (int)k)) users[r->id].push_back((int)k);
+            }
+            for (size_t i = 0; i < plan_.ops.size() && !changed; i++) {
+                PlanOp &f = plan_.ops[i];
+                if (f.kind != OpKind::GEMM || !f.gemm.fold || f.gemm2.N > 0 || f.gemm.npost || f.gemm.out_strided || f.se_fused) continue;
+                if (f.out.space != Space::ARENA || plan_.storages[f.out.id].pinned) continue;
+                const auto &u = users[f.out.id];
+                if (u.size() != 2 || u[0] != (int)i) continue;
+                PlanOp &g = plan_.ops[u[1]];
+                if (g.kind != OpKind::GEMM || g.se_fused || g.gemm2.N > 0 || g.a.space != Space::ARENA || g.a.id != f.out.id || g.a.offset != f.out.offset) continue;
+                if (g.w.space != Space::CONSTS || (g.gemm.has_bias && g.bias.space != Space::CONSTS)) continue;
+                if (!frame_fold_pair_ok(f.gemm, g.gemm)) continue;
+                f.gemm2 = g.gemm;
+                f.w2 = g.w;
+                f.bias2 = g.bias;
+                f.out = g.out;
+                f.name += "+" + g.name;
+                f.macs += g.macs;
+                f.weight_bytes += g.weight_bytes;
+                f.bytes += g.bytes - 8.0 * (double)f.gemm.rows * (double)f.gemm.N;  // the spectrum rows never touch memory
+                plan_.ops.erase(plan_.ops.begin() + u[1]);
                 changed = true;
             }
         }

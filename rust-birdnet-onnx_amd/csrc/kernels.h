@@ -260,6 +260,10 @@ inline bool gemm_use_splitk(const GemmDesc &d) {
 }
 // true when the launch would run a kernel variant that supports npost / out_strided
 inline bool gemm_accepts_post(const GemmDesc &d) { return !d.fold && !d.has_scale && !d.has_res && !gemm_use_splitk(d); }
+// Folded framing GEMM with the product over its rows fused behind it (planner rule J; kernels.hip, frame_fold_kernel<true>)
+bool frame_fold_pair_ok(const GemmDesc &d, const GemmDesc &d2);
+void launch_gemm_fold_pair(hipStream_t s, const GemmDesc &d, const GemmDesc &d2, float *C2, const float *A, const float *W, const float *bias,
+                           const float *W2, const float *bias2, int64_t batch);
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W,
                  const float *bias, const float *res, const float *scale, int64_t batch);
 // LDS-DMA GEMM (gemm_dma.hip): 0 = not eligible, 1 = 64-row tiles, 2 = 48-row tiles (per-sample quantities only);

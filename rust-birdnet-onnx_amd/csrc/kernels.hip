@@ -793,8 +793,25 @@ struct FrameDesc {
     int32_t has_bias;
 };
 constexpr int FRAME_BM = 64;
-__global__ __launch_bounds__(640) void frame_fold_kernel(FrameDesc d, float *__restrict__ C, const float *__restrict__ A,
-                                                         const float *__restrict__ W, const float *__restrict__ bias) {
+// One shared copy of the compact stage dispatch (device_common.h) for a wave's 16 accumulators, by value: registers in, registers out.
+// (The generic gemm_epilogue inlines libm for every stage code: behind this kernel it took 256 registers and scratch.)
+__device__ __noinline__ floatx16 act_small16(int act, float p0, float p1, floatx16 a) {
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = a[r];
+    act_small<16>(act, p0, p1, v);
+#pragma unroll
+    for (int r = 0; r < 16; r++) a[r] = v[r];
+    return a;
+}
+// PAIR (planner rule J): the product that consumes the rows of this one -- the mel filter bank of the spectrogram branch, K2 = N <= 128
+// spectrum bins -> N2 <= 128 bands, with its absorbed epilogue chain and output view -- runs behind the K loop on the block's own 64 x N
+// spectrum tile (accumulators -> LDS as 32-deep K tiles of the second product, filter rows staged step by step, the shared
+// gemm_epilogue): the spectrum rows are neither written nor read back and the launch that did it is gone.
+template <bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 640) void frame_fold_kernel(FrameDesc d, float *__restrict__ C, const float *__restrict__ A,
+                                                         const float *__restrict__ W, const float *__restrict__ bias, GemmDesc d2,
+                                                         float *__restrict__ C2, const float *__restrict__ W2, const float *__restrict__ bias2) {
     extern __shared__ __align__(16) float frame_lds[];
     const int T = blockDim.x, tid = threadIdx.x;
     const int BN = (T >> 7) * 32;  // WN wave columns of 32 outputs
@@ -886,7 +903,63 @@ __global__ __launch_bounds__(640) void frame_fold_kernel(FrameDesc d, float *__r
         asm volatile("" ::: "memory");
     }
     const int n = n0 + wn * 32 + lr;
-    if (n < d.N) {
+    if constexpr (PAIR) {
+        // (one N tile covers the whole spectrum row: the launcher guarantees N <= BN and grid.y == 1)
+        // the spectrum tile (+ bias) as K tiles of the second product: S[ks = wn][row][k = lr]; columns n >= N hold copies of the
+        // last filter row's output and meet zero taps below
+        float *S = As;                                    // [BN / 32][64][GEMM_LD]  (both tile buffers are free: the K loop ended on a barrier)
+        float *W2s = S + (BN >> 5) * FRAME_BM * GEMM_LD;  // [<= 128][GEMM_LD]
+        {
+            const float bv = (d.has_bias && n < d.N) ? bias[n] : 0.0f;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                S[(wn * FRAME_BM + r) * GEMM_LD + lr] = acc[0][reg] + bv;
+            }
+        }
+        const int n2tiles = (d2.N + 31) >> 5, k2steps = (d2.K + 31) >> 5;
+        floatx16 acc2[1];
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc2[0][r] = 0.0f;
+        for (int ks2 = 0; ks2 < k2steps; ks2++) {
+            // filter rows of this step: W2 is [N2][K2], K2 contiguous; rows / taps past the end are zero
+            for (int e = tid; e < n2tiles * 32 * 32; e += T) {
+                const int n2 = e >> 5, kk = e & 31, k = ks2 * 32 + kk;
+                W2s[n2 * GEMM_LD + kk] = (n2 < d2.N && k < d2.K) ? W2[(int64_t)n2 * d2.K + k] : 0.0f;
+            }
+            __syncthreads();  // (first step: the spectrum tile is complete as well)
+            if (wn < n2tiles)
+                mfma_ktile_full<1>(S + (ks2 * FRAME_BM + wm * 32 + lr) * GEMM_LD + 4 * lh, W2s + (wn * 32 + lr) * GEMM_LD + 4 * lh, acc2);
+            __syncthreads();
+        }
+        if (wn < n2tiles) {
+            const int64_t rb = (int64_t)b * d2.rows + row0;
+            // epilogue of the second product: bias, activation, the absorbed chain, the consumer's view (gemm_epilogue's semantics with
+            // the compact stage functions; the planner fuses only chains made of those)
+            const int n2 = wn * 32 + lr;
+            floatx16 a2 = acc2[0];
+            if (d2.has_bias) {
+                const float bv2 = n2 < d2.N ? bias2[n2] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) a2[r] += bv2;
+            }
+            if (d2.act != ACT_NONE) a2 = act_small16(d2.act, d2.p0, d2.p1, a2);
+            if (0 < d2.npost) a2 = act_small16(d2.post_act[0], d2.post_p0[0], d2.post_p1[0], a2);
+            if (1 < d2.npost) a2 = act_small16(d2.post_act[1], d2.post_p0[1], d2.post_p1[1], a2);
+            if (2 < d2.npost) a2 = act_small16(d2.post_act[2], d2.post_p0[2], d2.post_p1[2], a2);
+            if (3 < d2.npost) a2 = act_small16(d2.post_act[3], d2.post_p0[3], d2.post_p1[3], a2);
+            if (n2 < d2.N) {
+                const int64_t rs = d2.out_strided ? d2.out_rs : d2.ldc, cs = d2.out_strided ? d2.out_cs : 1;
+                float *cb2 = C2 + (int64_t)b * d2.c_bs + (int64_t)n2 * cs;
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    if (r < rows_here) cb2[(int64_t)(row0 + r) * rs] = a2[reg];
+                }
+            }
+            (void)rb;
+        }
+    } else if (n < d.N) {
         const float bv = d.has_bias ? bias[n] : 0.0f;
         float *cb = C + (int64_t)b * d.c_bs + (int64_t)row0 * d.ldc + n;
 #pragma unroll
@@ -2281,7 +2354,8 @@ inline unsigned cap_blocks(int64_t want, int64_t cap) { return (unsigned)std::ma
 
 // every kernel of this file that may be launched with more than 64 KB of dynamic LDS (prepare_device opts them in)
 void register_kernels_hip() {
-    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold_kernel));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold_kernel<false>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold_kernel<true>));
 #define BN_REG_KS(KERNEL)                                                     \
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 1>)); \
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 2>)); \
@@ -2537,10 +2611,17 @@ static void launch_gemm_splitk(hipStream_t s, const GemmDesc &d, float *C, const
 
 // Folded framing GEMM from an LDS-resident signal span; false when the shape does not fit (the caller then runs the
 // generic folded GEMM).  Decided from per-sample quantities and pointer alignment only.  BN_FRAMELDS=0 disables.
-static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, int64_t batch) {
+static bool frame_fold_shape_ok(const GemmDesc &d, const float *W) {
     if (getenv("BN_FRAMELDS") && atoi(getenv("BN_FRAMELDS")) == 0) return false;
-    if (d.has_res || d.has_scale || d.act != ACT_NONE || d.K % GEMM_BK || d.fold_n != 2 * d.K || d.K % 4 || !aligned16(W)) return false;
+    if (d.has_res || d.has_scale || d.act != ACT_NONE || d.K % GEMM_BK || d.fold_n != 2 * d.K || d.K % 4 || (W && !aligned16(W))) return false;
     if (d.lda <= 0 || d.lda > 4096 || d.rows < 32 || d.c_bs < 0) return false;
+    return true;
+}
+
+// pair != nullptr: the fused second product (frame_fold_kernel<true>); the caller has checked frame_fold_pair_ok
+static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, int64_t batch,
+                              const GemmDesc *pair = nullptr, float *C2 = nullptr, const float *W2 = nullptr, const float *bias2 = nullptr) {
+    if (!frame_fold_shape_ok(d, W)) return false;
     FrameDesc f{};
     f.rows = (int32_t)d.rows; f.N = d.N; f.K = d.K; f.L = d.fold_n; f.hop = (int32_t)d.lda;
     f.tiles = (int32_t)((d.rows + FRAME_BM - 1) / FRAME_BM);
@@ -2557,17 +2638,50 @@ static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const 
     // enter any output's arithmetic (47 -> 27 us for one segment)
     if ((int64_t)f.tiles * batch <= 32 && d.N > 64) wn = 2;
     if (force_wn >= 2 && force_wn <= 5) wn = force_wn;
+    if (pair) wn = std::max(2, (d.N + 31) / 32);  // one N tile holds the whole spectrum row (N <= 128)
     const int bn = 32 * wn;
     const size_t lds = (size_t)(((f.span + 3) & ~3) + 2 * FRAME_BM * GEMM_LD + 2 * bn * GEMM_LD) * sizeof(float);
     if (lds > 160 * 1024) return false;
-    if (!ensure_dynamic_lds(reinterpret_cast<const void *>(frame_fold_kernel), lds)) return false;
+    const void *fn = pair ? reinterpret_cast<const void *>(frame_fold_kernel<true>) : reinterpret_cast<const void *>(frame_fold_kernel<false>);
+    if (!ensure_dynamic_lds(fn, lds)) return false;
     // enough row tiles to fill the chip: one block walks all N tiles of its rows (span loaded once); else spread them
     const int64_t row_blocks = (int64_t)f.tiles * batch;
     const int walk_env = getenv("BN_FRAME_WALK") ? atoi(getenv("BN_FRAME_WALK")) : -1;  // tests / experiments
     const bool walk = walk_env >= 0 ? walk_env != 0 : row_blocks >= 256;
-    dim3 grid((unsigned)row_blocks, walk ? 1u : (unsigned)((d.N + bn - 1) / bn));
-    hipLaunchKernelGGL(frame_fold_kernel, grid, dim3(128 * wn), lds, s, f, C, A, W, bias);
+    dim3 grid((unsigned)row_blocks, (walk || pair) ? 1u : (unsigned)((d.N + bn - 1) / bn));
+    GemmDesc none{};
+    if (pair) hipLaunchKernelGGL(frame_fold_kernel<true>, grid, dim3(128 * wn), lds, s, f, C, A, W, bias, *pair, C2, W2, bias2);
+    else hipLaunchKernelGGL(frame_fold_kernel<false>, grid, dim3(128 * wn), lds, s, f, C, A, W, bias, none, nullptr, nullptr, nullptr);
     return true;
+}
+
+// Planner rule J and its launcher agree through this: the folded framing GEMM `d` (its LDS-resident kernel) followed by a plain
+// product over its rows
+bool frame_fold_pair_ok(const GemmDesc &d, const GemmDesc &d2) {
+    // opt-in (BN_FRAMEPAIR=1): correct, one launch and the spectrum's round trip less -- and slower: behind the K loop the block's eight
+    // waves stage the second product's filter rows and run its epilogue with the CU to themselves, 68.4 us against 50 + 19 at batch 32 and
+    // 63 against 56 us of marginal cost, where the separate launch spreads the same work over the chip beside the other contexts' kernels
+    if (!(getenv("BN_FRAMEPAIR") && atoi(getenv("BN_FRAMEPAIR")) == 1)) return false;
+    if (!d.fold || !frame_fold_shape_ok(d, nullptr)) return false;
+    if (d.N > 128 || d.ldc != d.N) return false;
+    const int wn = std::max(2, (d.N + 31) / 32);
+    const int64_t span = (int64_t)(FRAME_BM - 1) * d.lda + d.fold_n;
+    if ((size_t)(((span + 3) & ~3) + 2 * FRAME_BM * GEMM_LD + 2 * 32 * wn * GEMM_LD) * sizeof(float) > 160 * 1024) return false;
+    // the second product's tiles must fit the two tile buffers: K tiles of the spectrum + one step of its filter rows
+    const int n2pad = (d2.N + 31) / 32 * 32;
+    if (wn * FRAME_BM * GEMM_LD + n2pad * GEMM_LD > 2 * FRAME_BM * GEMM_LD + 2 * 32 * wn * GEMM_LD) return false;
+    if (d2.N > 32 * wn || d2.N < 1 || d2.K != d.N || d2.lda != d2.K || d2.rows != d.rows || d2.a_bs != d.c_bs) return false;
+    if (d2.fold || d2.has_scale || d2.has_res || d2.se_inline) return false;
+    bool stages = stft_act_supported(d2.act);  // the compact stage functions only
+    for (int q = 0; q < d2.npost && q < 4; q++) stages = stages && stft_act_supported(d2.post_act[q]);
+    return stages && d2.npost <= 4;
+}
+
+void launch_gemm_fold_pair(hipStream_t s, const GemmDesc &d, const GemmDesc &d2, float *C2, const float *A, const float *W, const float *bias,
+                           const float *W2, const float *bias2, int64_t batch) {
+    if (batch <= 0) return;
+    if (!frame_fold_pair_ok(d, d2) || !launch_frame_fold(s, d, nullptr, A, W, bias, batch, &d2, C2, W2, bias2))
+        launch_error("folded framing GEMM + fused product: shape outside what the planner may fuse");
 }
 
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,

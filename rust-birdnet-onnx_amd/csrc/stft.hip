@@ -136,49 +136,7 @@ __device__ __forceinline__ void block16(float2 *__restrict__ blk) {
     for (int i = 0; i < 8; i++) *reinterpret_cast<float4 *>(blk + 2 * i) = make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y);
 }
 
-// Stage functions of the absorbed chains, COMPACT on purpose: the generic act_array_all / bin_array dispatchers inline
-// libm (tanhf, erff, powf, ...) for every instantiation -- with nine stage slots that made this kernel 676 KB of code,
-// and walking through it ran at instruction-fetch speed (a 4-stage chain over 16 floats per thread cost 19 us per
-// tile).  Only codes with a few-instruction body are accepted here (kernels.h, stft_stage_supported: the planner
-// absorbs nothing else), dispatched by compare chains on the launch-uniform code.
-__device__ __forceinline__ float pow_compact(float x, float p) {
-    // x^p without libm: exp2(p log2 |x|) (hardware exp2 / log2, ~1e-6 relative), the sign and the special cases by hand
-    const float ax = fabsf(x);
-    float r = __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(ax));
-    if (x < 0.0f) {
-        const float fl = floorf(p);
-        if (fl != p) r = __builtin_nanf("");                 // negative base, non-integer exponent
-        else if (fl * 0.5f != floorf(fl * 0.5f)) r = -r;     // odd integer exponent keeps the sign
-    }
-    if (p == 0.0f) r = 1.0f;
-    return r;
-}
-// ONE dispatch per stage for a whole register array (the code is launch-uniform): a compare chain per element would
-// be re-evaluated, operands reloaded, for every value.
-template <int N>
-__device__ __forceinline__ void act_small(int act, float p0, float p1, float (&v)[N]) {
-    if (act == ACT_NONE) return;
-    if (act == ACT_AFFINE) map_array<N>(v, [=](float x) { return p0 * x + p1; });
-    else if (act == ACT_SQUARE) map_array<N>(v, [](float x) { return x * x; });
-    else if (act == ACT_POW) map_array<N>(v, [=](float x) { return pow_compact(x, p0); });
-    else if (act == ACT_LOG) map_array<N>(v, [](float x) { return net_log(x); });
-    else if (act == ACT_EXP) map_array<N>(v, [](float x) { return net_exp(x); });
-    else if (act == ACT_SQRT) map_array<N>(v, [](float x) { return sqrtf(x); });
-    else if (act == ACT_ABS) map_array<N>(v, [](float x) { return fabsf(x); });
-    else if (act == ACT_MAXC) map_array<N>(v, [=](float x) { return fmaxf(x, p0); });
-    else if (act == ACT_MINC) map_array<N>(v, [=](float x) { return fminf(x, p0); });
-    else if (act == ACT_RELU) map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); });
-    else if (act == ACT_CLIP) map_array<N>(v, [=](float x) { return fminf(fmaxf(x, p0), p1); });
-    else if (act == ACT_NEG) map_array<N>(v, [](float x) { return -x; });
-    else if (act == ACT_RECIP) map_array<N>(v, [](float x) { return 1.0f / x; });
-    else if (act == ACT_RSUB) map_array<N>(v, [=](float x) { return p0 - x; });
-    else if (act == ACT_RDIV) map_array<N>(v, [=](float x) { return p0 / x; });
-    else if (act == ACT_SIGMOID) map_array<N>(v, [](float x) { return net_sigmoid(x); });
-    else if (act == ACT_SILU) map_array<N>(v, [](float x) { return x * net_sigmoid(x); });
-    else if (act == ACT_LEAKY) map_array<N>(v, [=](float x) { return x >= 0.0f ? x : p0 * x; });
-    else if (act == ACT_FLOOR) map_array<N>(v, [](float x) { return floorf(x); });
-    else if (act == ACT_CEIL) map_array<N>(v, [](float x) { return ceilf(x); });
-}
+// (the compact stage functions pow_compact / act_small live in device_common.h: the folded framing GEMM's fused product uses them too)
 template <int N>
 __device__ __forceinline__ void bin_small(int bin, float b, float (&v)[N]) {
     if (bin == BIN_ADD) map_array<N>(v, [=](float a) { return a + b; });
