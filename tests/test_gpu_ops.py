@@ -197,6 +197,45 @@ def test_stft_every_transform_size(bn, n_fft, hop, monkeypatch):
     assert_close(got, ref, f"stft n_fft={n_fft}", atol=2e-5 * float(np.abs(ref).max()), rtol=0)
 
 
+@pytest.mark.parametrize("n_mels,bias", [(40, True), (96, False), (150, True)])
+def test_stft_with_absorbed_mel_bank_sizes(bn, n_mels, bias, monkeypatch):
+    """The mel filter bank inside the FFT launch on the matrix cores (16 x 16 tiles of the banded matrix) and as the sparse walk on the
+    vector ALU, for band counts that leave a ragged last tile (40 = 2.5 tiles) and that give a wave more than one tile (150 bands = 10
+    tiles over 8 waves), with a bias and a compression chain behind it -- both against the oracle and against each other."""
+    import importlib
+    synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+    n_fft, hop, sr = 1024, 280, 48000
+    frames = (144000 - n_fft) // hop + 1
+    rng = np.random.default_rng(n_mels)
+    mel = synth.mel_filterbank(n_fft // 2 + 1, n_mels, sr, 500.0, 15000.0).astype(np.float32)
+    b = rng.standard_normal(n_mels).astype(np.float32)
+
+    def build(g, x):
+        u = g.node("Unsqueeze", [x, g.const(np.array([1], dtype=np.int64))])
+        c = g.node("Conv", [u, g.const(synth.dft_basis(n_fft, "real"))], kernel_shape=[n_fft], strides=[hop])
+        t = g.node("Transpose", [c], perm=[0, 2, 1])
+        m = g.node("MatMul", [t, g.const(mel)])
+        if bias:
+            m = g.node("Add", [m, g.const(b)])
+        # (a well-conditioned chain: the power-law compression of the models amplifies the f32 noise of near-zero mel values a
+        # thousandfold, which says nothing about the kernel; it is covered at model level)
+        p = g.node("Add", [g.node("Mul", [g.node("Relu", [m]), g.const(np.float32(0.5))]), g.const(np.float32(0.25))])
+        return g.node("Transpose", [p], perm=[0, 2, 1])
+    data = op_graph(build, [n_mels, frames])
+    monkeypatch.setenv("BN_STFT", "1")
+    desc = bn.plan_describe(write_model(data))
+    line = [l for l in desc.splitlines() if " FFT " in l]
+    assert len(line) == 1 and f"mel={n_mels}(mfma)" in line[0] and "MatMul" in line[0], desc
+    got, ref = run_both(bn, data, batch=3)
+    tol = 2e-5 * float(np.abs(ref).max())
+    assert_close(got, ref, f"stft + mel {n_mels} on the matrix cores", atol=tol, rtol=2e-4)
+    monkeypatch.setenv("BN_STFT_MELMFMA", "0")
+    assert f"mel={n_mels}(csr)" in bn.plan_describe(write_model(data))
+    walk, _ = run_both(bn, data, batch=3)
+    assert_close(walk, ref, f"stft + mel {n_mels} sparse walk", atol=tol, rtol=2e-4)
+    assert_close(got, walk, "matrix cores vs sparse walk", atol=tol, rtol=2e-4)
+
+
 def test_conv1d_not_folded_when_not_symmetric(bn):
     """A filter bank that is symmetric except for one tap, or whose tap 0 is not zero, keeps the full-length GEMM."""
     import importlib
