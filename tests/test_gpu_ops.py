@@ -236,6 +236,39 @@ def test_stft_with_absorbed_mel_bank_sizes(bn, n_mels, bias, monkeypatch):
     assert_close(got, walk, "matrix cores vs sparse walk", atol=tol, rtol=2e-4)
 
 
+@pytest.mark.parametrize("n_fft,hop,root", [(1024, 320, True), (512, 160, False), (256, 100, True)])
+def test_stft_power_spectrum_folded_into_the_launch(bn, n_fft, hop, root, monkeypatch):
+    """re^2 + im^2 (-> sqrt) behind a cos | sin bank: the planner folds it into the FFT launch (FftDesc::power 1 / 2), which then
+    writes one value per bin; with the rule off the elementwise launch comes back.  Both against the oracle."""
+    import importlib
+    synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+    nb = n_fft // 2 + 1
+    frames = (144000 - n_fft) // hop + 1
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        u = g.node("Unsqueeze", [x, i64(1)])
+        c = g.node("Conv", [u, g.const(synth.dft_basis(n_fft, "complex"))], kernel_shape=[n_fft], strides=[hop])  # [B, 2 nb, frames]
+        t = g.node("Transpose", [c], perm=[0, 2, 1])
+        re = g.node("Slice", [t, i64(0), i64(nb), i64(2), i64(1)])
+        im = g.node("Slice", [t, i64(nb), i64(2 * nb), i64(2), i64(1)])
+        p = g.node("Add", [g.node("Mul", [re, re]), g.node("Mul", [im, im])])
+        return g.node("Sqrt", [p]) if root else p
+    data = op_graph(build, [frames, nb])
+    monkeypatch.setenv("BN_STFT", "1")
+    desc = bn.plan_describe(write_model(data))
+    line = [l for l in desc.splitlines() if " FFT " in l]
+    assert len(line) == 1 and f"power={2 if root else 1}" in line[0] and f"bins={nb} " in line[0] and " ELT " not in desc, desc
+    got, ref = run_both(bn, data, batch=2)
+    tol = 3e-5 * float(np.abs(ref).max())
+    assert_close(got, ref, f"stft power n_fft={n_fft} root={root}", atol=tol, rtol=2e-4)
+    monkeypatch.setenv("BN_STFT_POWER", "0")
+    desc0 = bn.plan_describe(write_model(data))
+    assert "power=0" in desc0 and " ELT " in desc0
+    got0, _ = run_both(bn, data, batch=2)
+    assert_close(got0, ref, f"stft + elementwise power n_fft={n_fft}", atol=tol, rtol=2e-4)
+
+
 def test_conv1d_not_folded_when_not_symmetric(bn):
     """A filter bank that is symmetric except for one tap, or whose tap 0 is not zero, keeps the full-length GEMM."""
     import importlib
