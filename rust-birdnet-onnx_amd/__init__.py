@@ -1001,9 +1001,10 @@ class Group:
         return d
 
     def analyze_recording(self, samples: np.ndarray, step_samples: int, top_k: int = 10, min_confidence: Optional[float] = None,
-                          want_logits: bool = False):
+                          want_logits: bool = True):
         """(logits or None, idx, conf, count) for every window of the recording, in time order.  The default gathers the
-        packed top-K rows only; want_logits=True also allocates and gathers the [G, N] logits (`raw_scores`)."""
+        [G, N] logits too (the reference's `raw_scores`, classifier.rs:907,948); want_logits=False is the lighter opt-in that
+        gathers the packed top-K rows only (the logits slab is then not even allocated)."""
         x = np.ascontiguousarray(samples)
         fmt = {np.dtype(np.int16): 0, np.dtype(np.float32): 1}[x.dtype]
         cfg = self.models[0].config

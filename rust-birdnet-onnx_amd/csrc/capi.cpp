@@ -24,6 +24,7 @@
 #include "detect.h"
 #include "engine.h"
 #include "kernels.h"
+#include "plan_rules.h"
 
 using namespace bn;
 
@@ -460,7 +461,7 @@ bn_status make_plan(bn_model *m, const std::vector<int> &wanted, std::unique_ptr
     } catch (const std::exception &e) {
         return fail(BN_ERR_MODEL_LOAD, e.what());
     }
-    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(bn::use_device(m->device));
     if (!prepare_device(m->device)) return fail(BN_ERR_BACKEND, "device " + std::to_string(m->device) + " refused the kernels' dynamic-LDS opt-in");
     const Plan &p = *pd->plan;
     HIP_TRY(gated::Malloc(&pd->d_consts, (size_t)p.consts_elems * sizeof(float)));
@@ -566,7 +567,7 @@ bn_status bn_model_load_buffer(const void *bytes, size_t len, int32_t device, in
 
 static void model_unref(bn_model *m) {
     if (m && m->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
-        (void)hipSetDevice(m->device);
+        (void)bn::use_device(m->device);
         delete m;
     }
 }
@@ -651,7 +652,7 @@ bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **
     c->max_batch = max_batch;
     c->flags = flags;
     const Plan &p = *pd->plan;
-    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(bn::use_device(m->device));
     if (!prepare_device(m->device)) return fail(BN_ERR_BACKEND, "device " + std::to_string(m->device) + " refused the kernels' dynamic-LDS opt-in");
     HIP_TRY(gated::StreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     const size_t arena_b = (size_t)p.arena_elems * max_batch * sizeof(float);
@@ -687,7 +688,7 @@ bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **
 
 void bn_ctx_destroy(bn_ctx *c) {
     if (!c) return;
-    (void)hipSetDevice(c->model->device);
+    (void)bn::use_device(c->model->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->graphs) (void)gated::GraphExecDestroy(kv.second);
     if (c->d_arena) (void)gated::Free(c->d_arena);
@@ -749,7 +750,7 @@ bn_status bn_ctx_input_device(const bn_ctx *c, float **d_ptr, size_t *capacity_f
 
 bn_status bn_ctx_synchronize(bn_ctx *c) {
     if (!c) return fail(BN_ERR_INVALID_ARG, "null context");
-    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(bn::use_device(c->model->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->in_flight = false;
     return BN_OK;
@@ -761,7 +762,7 @@ bn_status bn_infer_device(bn_ctx *c, const float *d_pcm, size_t batch, int32_t s
     if (!d_pcm) return fail(BN_ERR_INVALID_ARG, "null input");
     if (reinterpret_cast<uintptr_t>(d_pcm) & 15u) return fail(BN_ERR_INVALID_ARG, "device input must be 16-byte aligned");
     if (batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(batch) + " exceeds context max " + std::to_string(c->max_batch));
-    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(bn::use_device(c->model->device));
     bn_status st = drain_if_needed(c);
     if (st != BN_OK) return st;
     st = enqueue_plan(c, d_pcm, batch, nullptr);
@@ -869,7 +870,7 @@ bn_status bn_infer_submit(bn_ctx *c, const float *const *segs, size_t batch, siz
     const size_t N = (size_t)lo.row_elems;
     const size_t k = std::min(top_k, N);
     if (k && topk_lds_bytes((int64_t)N, (int64_t)k) == 0) return fail(BN_ERR_INVALID_ARG, "top_k too large for the on-chip heap (k <= 9000)");
-    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(bn::use_device(c->model->device));
     bn_ctx::HostSlot *slp = nullptr;
     int index = 0;
     for (int q = 0; q < 2 && !slp; q++) {
@@ -985,7 +986,7 @@ bn_status bn_infer_collect(bn_ctx *c, uint64_t ticket, float *logits_out, float 
     if (!slp) return fail(BN_ERR_INVALID_ARG, "unknown or already collected ticket");
     bn_ctx::HostSlot &sl = *slp;
     // batches complete in submission order: collecting the younger one first simply waits for both
-    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(bn::use_device(c->model->device));
     const auto start = std::chrono::steady_clock::now();
     int spins = 0;
     while (true) {
@@ -1081,7 +1082,7 @@ bn_status bn_ctx_read_output(bn_ctx *c, int32_t index, size_t batch, float *host
     bn_status st = bn_ctx_output_device(c, index, &d, &row);
     if (st != BN_OK) return st;
     if (!host_out || batch > c->max_batch) return fail(BN_ERR_INVALID_ARG, "bad host buffer / batch");
-    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(bn::use_device(c->model->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->in_flight = false;
     HIP_TRY(gated::Memcpy(host_out, d, batch * row * sizeof(float), hipMemcpyDeviceToHost));
@@ -1091,7 +1092,7 @@ bn_status bn_ctx_read_output(bn_ctx *c, int32_t index, size_t batch, float *host
 size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch, char (*names)[BN_NAME_LEN], float *usec, double *macs, double *bytes, size_t cap) {
     if (!c || batch == 0 || batch > c->max_batch) return 0;
     const Plan &p = *c->pd->plan;
-    if (hipSetDevice(c->model->device) != hipSuccess) return 0;
+    if (bn::use_device(c->model->device) != hipSuccess) return 0;
     (void)hipStreamSynchronize(c->stream);
     std::vector<hipEvent_t> ev(p.ops.size() + 1);
     for (auto &e : ev) (void)gated::EventCreate(&e);
@@ -1184,7 +1185,7 @@ bn_status bn_topk(bn_ctx *c, size_t batch, size_t top_k, int32_t has_min, float 
         return BN_OK;
     }
     if (!idx_out || !conf_out) return fail(BN_ERR_INVALID_ARG, "null output");
-    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(bn::use_device(c->model->device));
     {
         bn_status est = ensure_topk_buffers(c, k);
         if (est != BN_OK) return est;
@@ -1240,7 +1241,7 @@ bn_status bn_step_device(bn_ctx *c, const float *d_pcm, size_t batch, size_t top
     const size_t n = (size_t)lo.row_elems;
     const size_t k = std::min(top_k, n);
     if (k == 0 || topk_lds_bytes((int64_t)n, (int64_t)k) == 0) return fail(BN_ERR_INVALID_ARG, "top_k must be in 1..9000");
-    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(bn::use_device(c->model->device));
     bn_status st = drain_if_needed(c);
     if (st != BN_OK) return st;
     st = ensure_step_block(c, k);
@@ -1296,7 +1297,7 @@ bn_status bn_topk_device(int32_t device, const float *d_logits, size_t rows, siz
     if (!d_logits || !idx_out || !conf_out) return fail(BN_ERR_INVALID_ARG, "null argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BN_ERR_NO_DEVICE, "no HIP device is visible; this path has no CPU fallback");
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(bn::use_device(device));
     if (!prepare_device(device)) return fail(BN_ERR_BACKEND, "device refused the kernels' dynamic-LDS opt-in");
     uint32_t *d_idx = nullptr, *d_cnt = nullptr, *d_flags = nullptr;
     float *d_conf = nullptr;
@@ -1324,7 +1325,7 @@ bn_status bn_topk_host(int32_t device, const float *logits, size_t rows, size_t 
     if (!logits) return fail(BN_ERR_INVALID_ARG, "null argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(BN_ERR_NO_DEVICE, "no HIP device is visible; this path has no CPU fallback");
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(bn::use_device(device));
     float *d = nullptr;
     HIP_TRY(gated::Malloc(&d, rows * n * sizeof(float)));
     hipError_t e = gated::Memcpy(d, logits, rows * n * sizeof(float), hipMemcpyHostToDevice);
@@ -1351,7 +1352,7 @@ bn_status bn_recording_create(int32_t device, const void *pcm, size_t n_samples,
     if (format != BN_PCM_I16 && format != BN_PCM_F32) return fail(BN_ERR_INVALID_ARG, "unknown PCM format");
     if (n_samples && !pcm) return fail(BN_ERR_INVALID_ARG, "null PCM buffer");
     if (bn_device_count() <= 0) return fail(BN_ERR_NO_DEVICE, "no gfx950 device visible");
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(bn::use_device(device));
     auto r = std::make_unique<bn_recording>();
     r->device = device;
     r->format = format;
@@ -1469,14 +1470,14 @@ bn_status bn_recording_read_f32(const bn_recording *r, size_t first, size_t coun
     if (r->format != BN_PCM_F32) return fail(BN_ERR_INVALID_ARG, "recording is not f32");
     if (first > r->n_samples || count > r->n_samples - first) return fail(BN_ERR_INVALID_ARG, "sample range exceeds the recording");
     if (count == 0) return BN_OK;
-    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(bn::use_device(r->device));
     HIP_TRY(gated::Memcpy(host_out, static_cast<const float *>(r->d_pcm) + first, count * sizeof(float), hipMemcpyDeviceToHost));
     return BN_OK;
 }
 
 void bn_recording_free(bn_recording *r) {
     if (!r) return;
-    (void)hipSetDevice(r->device);
+    (void)bn::use_device(r->device);
     if (r->d_pcm) (void)gated::Free(r->d_pcm);
     delete r;
 }
@@ -1502,7 +1503,7 @@ bn_status bn_recording_windows(const bn_recording *r, size_t segment_samples, si
     if (st != BN_OK) return st;
     if (count == 0) return BN_OK;
     if (!host_out) return fail(BN_ERR_INVALID_ARG, "null host buffer");
-    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(bn::use_device(r->device));
     float *d = nullptr;
     HIP_TRY(gated::Malloc(reinterpret_cast<void **>(&d), count * segment_samples * sizeof(float)));
     (void)hipGetLastError();
@@ -1525,7 +1526,7 @@ bn_status bn_infer_windows(bn_ctx *c, const bn_recording *r, size_t step_samples
     if (!logits_out) return fail(BN_ERR_INVALID_ARG, "null argument");
     if (count > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(count) + " exceeds context max " + std::to_string(c->max_batch));
     if (r->device != c->model->device) return fail(BN_ERR_INVALID_ARG, "recording and context live on different devices");
-    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(bn::use_device(c->model->device));
     st = drain_if_needed(c);
     if (st != BN_OK) return st;
     if (cancel && *cancel) return fail(BN_ERR_CANCELLED, "inference was cancelled");
@@ -1551,7 +1552,7 @@ bn_status bn_step_windows(bn_ctx *c, const bn_recording *r, size_t step_samples,
     if (count == 0) return BN_OK;
     if (count > c->max_batch) return fail(BN_ERR_INVALID_ARG, "batch size " + std::to_string(count) + " exceeds context max " + std::to_string(c->max_batch));
     if (r->device != c->model->device) return fail(BN_ERR_INVALID_ARG, "recording and context live on different devices");
-    HIP_TRY(hipSetDevice(c->model->device));
+    HIP_TRY(bn::use_device(c->model->device));
     (void)hipGetLastError();
     // stream order keeps this behind whatever the context still has in flight
     launch_windows(c->stream, c->d_input, r->d_pcm, r->format == BN_PCM_I16, r->n_samples, (uint64_t)first_window * step_samples, step_samples, (uint32_t)S,

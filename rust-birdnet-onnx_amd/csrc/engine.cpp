@@ -12,6 +12,7 @@
 //  * Conv+BatchNorm+activation(+residual Add) and MatMul/Gemm+bias+activation
 //    chains are folded into one launch at import time.
 #include "engine.h"
+#include "plan_rules.h"
 
 #include <algorithm>
 #include <cmath>

@@ -31,16 +31,13 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include "plan_rules.h"
 
 namespace bn {
 namespace {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-// epilogue activations this kernel carries (one dispatch on the launch-uniform code); other codes keep the older kernels
-inline __host__ __device__ bool gd_act_ok(int act) {
-    return act == ACT_NONE || act == ACT_RELU || act == ACT_CLIP || act == ACT_SILU || act == ACT_HSWISH || act == ACT_SIGMOID || act == ACT_HSIGMOID;
-}
 template <int N>
 __device__ __forceinline__ void gd_act(int act, float p0, float p1, float (&v)[N]) {
     if (act == ACT_RELU) map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); });
@@ -338,20 +335,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int MTW, int NTW, int WM, int WN, int KS, int D>
-size_t cfg_lds(const GemmDesc &d, int se_cr = 0) {
-    constexpr int TR = 16 * MTW * WM, BN = 16 * NTW * WN;
-    const int gate_floats = d.has_scale ? (d.K + 1023) / 1024 * 1024 : 0;  // whole 1-KiB pieces
-    const int se_floats = d.se_inline ? ((d.K + 3) & ~3) + ((se_cr + 3) & ~3) : 0;  // squeeze means + hidden units
-    return std::max((size_t)(KS * D * (TR + BN) * 32 + gate_floats + se_floats), (size_t)((KS - 1) * WM * WN * MTW * NTW * 256)) * sizeof(float);
-}
-
-template <int MTW, int NTW, int WM, int WN, int KS, int D>
 void launch_cfg(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res, const float *scale,
                 int64_t batch, const SeInline *se) {
     constexpr int TR = 16 * MTW * WM, BN = 16 * NTW * WN;
     const int tps = (int)(d.rows / TR);
     const int gate_floats = d.has_scale ? (d.K + 1023) / 1024 * 1024 : 0;
-    const size_t lds = cfg_lds<MTW, NTW, WM, WN, KS, D>(d, se ? se->se.Cr : 0);
+    const size_t lds = gemm_dma_lds_bytes(d, MTW, NTW, WM, WN, KS, D, se ? se->se.Cr : 0);
     dim3 grid((unsigned)(batch * tps), (unsigned)((d.N + BN - 1) / BN));
     SeInline none{};
     if (d.se_inline && se)
@@ -362,37 +351,7 @@ void launch_cfg(hipStream_t s, const GemmDesc &d, float *C, const float *A, cons
         hipLaunchKernelGGL((gemm_dma_kernel<MTW, NTW, WM, WN, KS, D, 0>), grid, dim3(64 * WM * WN * KS), lds, s, d, C, A, W, bias, res, scale, tps, gate_floats, none);
 }
 
-// K slices per block: a property of the layer's SHAPE (it enters the summation order), deep products (project convs:
-// K 240 .. 1152, head conv) run as two interleaved slices
-inline int gd_kslices(const GemmDesc &d) {
-    const int force = getenv("BN_GEMMDMA_KS") ? atoi(getenv("BN_GEMMDMA_KS")) : 0;
-    if (force == 1 || force == 2) return force;
-    return d.K >= 192 ? 2 : 1;
-}
-
 }  // namespace
-
-// which block family the LDS-DMA kernel would take for this GEMM (0 = not eligible): per-sample quantities only
-int gemm_dma_shape(const GemmDesc &d) {
-    const int mode = getenv("BN_GEMMDMA") ? atoi(getenv("BN_GEMMDMA")) : 1;  // read per call (tests switch it at run time)
-    if (mode == 0) return 0;
-    if (d.fold || d.npost || d.out_strided || d.lda != d.K || d.K % 16 || d.K < 32 || d.N % 4 || d.N < 16 || !gd_act_ok(d.act)) return 0;
-    if (d.ldc % 4 || d.c_bs % 4 || d.a_bs % 4 || (d.has_res && (d.ldr % 4 || d.r_bs % 4)) || (d.has_scale && d.s_bs % 4)) return 0;
-    if ((int64_t)d.rows * d.K >= ((int64_t)1 << 30) || (int64_t)d.N * d.K >= ((int64_t)1 << 30)) return 0;  // 32-bit lane offsets
-    if (d.has_scale && d.K > 8192) return 0;
-    // Where it pays (measured, batch 32 and 128, tools/kernel_table.py): deep products with few output channels -- the
-    // project convs and the head conv.  Short-K, wide-N expands are bound by their output stores and their launch, not by
-    // staging: the tiled kernel keeps them (mode 2 sends every eligible shape here, for tests).
-    // ... and the project convs of the big feature maps (few output channels, K 32 .. 144): memory-bound either way, but
-    // the tiled kernel spends 17 - 27 vector instructions per matrix instruction on them, and at four contexts every
-    // vector instruction is taken from the budget the other contexts' matrix work needs (BN_GEMMDMA_SMALLN=0 keeps
-    // them on the tiled kernel)
-    const bool small_n = d.N <= 32 && d.has_scale && !(getenv("BN_GEMMDMA_SMALLN") && atoi(getenv("BN_GEMMDMA_SMALLN")) == 0);
-    if (mode != 2 && d.K < 128 && !small_n) return 0;
-    if (d.rows % 32 == 0) return 1;  // 64- or 32-row tiles x up to 128 channels, waves along the rows
-    if (d.rows % 48 == 0) return 2;  // 48-row tiles x 32 / 64 / 128 channels, waves along the channels
-    return 0;
-}
 
 void register_gemm_dma_kernels() {
 #define GD_REG1(MTW, NTW, WM, WN, KS)                                                                               \
@@ -407,8 +366,6 @@ void register_gemm_dma_kernels() {
 #undef GD_REG1
 }
 
-int gemm_dma_se_max_channels() { return getenv("BN_SEGEMM_MAXC") ? atoi(getenv("BN_SEGEMM_MAXC")) : 768; }
-
 bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res, const float *scale,
                      int64_t batch, const SeInline *se) {
     const int shape = gemm_dma_shape(d);
@@ -416,7 +373,7 @@ bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A,
         (d.has_scale && !d.se_inline && !al16(scale)))
         return false;
     if (d.se_inline && !se) return false;
-    const int ks = gd_kslices(d);
+    const int ks = gemm_dma_kslices(d, se ? se->se.Cr : 0);  // decided for the layer, not for the tile (plan_rules.h)
     // Tile shape by the size of the launch: big tiles (16 - 24 flop per byte staged from L2) as soon as they give 64 blocks,
     // smaller ones below that.  With four contexts in flight a step is bound by the SUM of its launches' marginal costs,
     // not by any launch's own latency (three contexts already reach 94 % of four), so the efficient tile wins even when
@@ -425,10 +382,8 @@ bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A,
     const int64_t min_blocks = getenv("BN_GEMMDMA_MINBLOCKS") ? atoll(getenv("BN_GEMMDMA_MINBLOCKS")) : 64;
 #define GD_GO(MTW, NTW, WM, WN)                                                                  \
     do {                                                                                         \
-        if (ks == 2 && cfg_lds<MTW, NTW, WM, WN, 2, 3>(d, se ? se->se.Cr : 0) <= 156 * 1024)     \
-            launch_cfg<MTW, NTW, WM, WN, 2, 3>(s, d, C, A, W, bias, res, scale, batch, se);      \
-        else                                                                                     \
-            launch_cfg<MTW, NTW, WM, WN, 1, 3>(s, d, C, A, W, bias, res, scale, batch, se);      \
+        if (ks == 2) launch_cfg<MTW, NTW, WM, WN, 2, 3>(s, d, C, A, W, bias, res, scale, batch, se); \
+        else launch_cfg<MTW, NTW, WM, WN, 1, 3>(s, d, C, A, W, bias, res, scale, batch, se);         \
     } while (0)
 #define GD_GO_N(WM)                                 \
     do {                                            \

@@ -98,7 +98,7 @@ bn_status gfail(bn_status st, const std::string &msg) {
 }
 
 void free_rank_buffers(bn_group::Rank &r) {
-    (void)hipSetDevice(r.device);
+    (void)bn::use_device(r.device);
     if (r.d_logits) (void)gated::Free(r.d_logits);
     if (r.d_topk) (void)gated::Free(r.d_topk);
     r.d_logits = nullptr;
@@ -148,13 +148,13 @@ bn_status bn_group_create(bn_model *const *models, const int32_t *devices, int32
     auto cleanup = [&](bn_status st, const std::string &msg) {
         for (auto &rk : g->ranks) {
             for (bn_ctx *c : rk.ctxs) bn_ctx_destroy(c);
-            if (rk.stream) { (void)hipSetDevice(rk.device); (void)gated::StreamDestroy(rk.stream); }
+            if (rk.stream) { (void)bn::use_device(rk.device); (void)gated::StreamDestroy(rk.stream); }
             if (rk.comm && rccl().ok()) (void)rccl().CommDestroy(rk.comm);
         }
         return gfail(st, msg);
     };
     for (auto &rk : g->ranks) {
-        if (hipSetDevice(rk.device) != hipSuccess) return cleanup(BN_ERR_NO_DEVICE, "device " + std::to_string(rk.device) + " is not usable");
+        if (bn::use_device(rk.device) != hipSuccess) return cleanup(BN_ERR_NO_DEVICE, "device " + std::to_string(rk.device) + " is not usable");
         if (gated::StreamCreateWithFlags(&rk.stream, hipStreamNonBlocking) != hipSuccess) return cleanup(BN_ERR_BACKEND, "hipStreamCreate failed");
         for (int k = 0; k < contexts_per_device; k++) {
             bn_ctx *c = nullptr;
@@ -195,7 +195,7 @@ void bn_group_destroy(bn_group *g) {
         for (bn_ctx *c : rk.ctxs) bn_ctx_destroy(c);
         free_rank_buffers(rk);
         if (rk.comm && rccl().ok()) (void)rccl().CommDestroy(rk.comm);
-        if (rk.stream) { (void)hipSetDevice(rk.device); (void)gated::StreamDestroy(rk.stream); }
+        if (rk.stream) { (void)bn::use_device(rk.device); (void)gated::StreamDestroy(rk.stream); }
     }
     delete g;
 }
@@ -217,6 +217,7 @@ bn_status bn_group_get_stats(const bn_group *g, bn_ctx_stats *out, size_t struct
             sum.capture_fallbacks += s.capture_fallbacks;
             sum.evictions += s.evictions;
             sum.cached_graphs += s.cached_graphs;
+            sum.input_copies += s.input_copies;
             if (s.last_fallback[0]) memcpy(sum.last_fallback, s.last_fallback, sizeof(sum.last_fallback));
         }
     memcpy(out, &sum, std::min(struct_size, sizeof(sum)));
@@ -245,7 +246,7 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
         bn_group::Rank &rk = g->ranks[r];
         auto fail = [&](bn_status st, const std::string &m) { rk.status = st; rk.error = "rank " + std::to_string(r) + ": " + m; };
         rk.status = BN_OK;
-        if (hipSetDevice(rk.device) != hipSuccess) return fail(BN_ERR_NO_DEVICE, "hipSetDevice failed");
+        if (bn::use_device(rk.device) != hipSuccess) return fail(BN_ERR_NO_DEVICE, "hipSetDevice failed");
         // the [R * per, N] logits slab (751 MB for the 24 h recording of BASELINE configs[4]) exists only on request;
         // the default gather moves the packed top-K rows alone (2k + 1 words per window)
         if (per > rk.cap_rows || k > rk.cap_k || (logits_out && per > rk.cap_rows_logits)) {
@@ -342,7 +343,7 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
                 int res = rc.GroupStart();
                 for (size_t r = 0; r < R && res == 0; r++) {
                     bn_group::Rank &rk = g->ranks[r];
-                    (void)hipSetDevice(rk.device);
+                    (void)bn::use_device(rk.device);
                     if (!topk) res = rc.AllGather(rk.d_logits + r * per * N, rk.d_logits, per * N, kNcclFloat32, rk.comm, rk.stream);
                     else res = rc.AllGather(rk.d_topk + r * per * tkw, rk.d_topk, per * tkw, kNcclUint32, rk.comm, rk.stream);
                 }
@@ -359,7 +360,7 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
                 for (size_t src = 0; src < R; src++) {
                     if (src == dst) continue;
                     bn_group::Rank &d = g->ranks[dst], &s = g->ranks[src];
-                    (void)hipSetDevice(d.device);
+                    (void)bn::use_device(d.device);
                     hipError_t e = hipSuccess;
                     if (logits_out) e = hipMemcpyPeerAsync(d.d_logits + src * per * N, d.device, s.d_logits + src * per * N, s.device, per * N * sizeof(float), d.stream);
                     if (e == hipSuccess && k && count_out)
@@ -368,7 +369,7 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
                 }
         }
         for (auto &rk : g->ranks) {
-            (void)hipSetDevice(rk.device);
+            (void)bn::use_device(rk.device);
             if (hipStreamSynchronize(rk.stream) != hipSuccess) return gfail(BN_ERR_BACKEND, "the collective failed");
         }
     }
@@ -377,7 +378,7 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
     // the collective for every slab but its own, so a broken gather cannot go unnoticed)
     {
         bn_group::Rank &rk = g->ranks[R - 1];
-        (void)hipSetDevice(rk.device);
+        (void)bn::use_device(rk.device);
         for (size_t r = 0; r < R; r++) {
             size_t lo, hi;
             bn_shard_range(G, (int32_t)r, (int32_t)R, &lo, &hi);

@@ -15,6 +15,12 @@
 #include <shared_mutex>
 
 namespace bn {
+void note_launch_device(int dev);  // kernels.hip
+// every device selection of the library: the runtime call + the thread-local note the launchers read
+inline hipError_t use_device(int dev) {
+    note_launch_device(dev);
+    return ::hipSetDevice(dev);
+}
 inline std::shared_mutex &capture_gate() {
     static std::shared_mutex m;
     return m;

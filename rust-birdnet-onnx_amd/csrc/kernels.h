@@ -190,7 +190,6 @@ void launch_mbconv_row(hipStream_t s, const MbDesc &d, float *out, const float *
                        const float *b2, float *gap, int64_t batch);
 // whole-map form with the input resident in LDS (mbmap.hip): configuration this block takes (0 = none; per-sample
 // quantities only), and the launch (false = not eligible, nothing launched)
-int mbmap_config(const MbDesc &d);
 bool launch_mbmap(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
                   float *gap, int64_t batch);
 struct SeTail;
@@ -261,18 +260,15 @@ inline bool gemm_use_splitk(const GemmDesc &d) {
 // true when the launch would run a kernel variant that supports npost / out_strided
 inline bool gemm_accepts_post(const GemmDesc &d) { return !d.fold && !d.has_scale && !d.has_res && !gemm_use_splitk(d); }
 // Folded framing GEMM with the product over its rows fused behind it (planner rule J; kernels.hip, frame_fold_kernel<true>)
-bool frame_fold_pair_ok(const GemmDesc &d, const GemmDesc &d2);
 void launch_gemm_fold_pair(hipStream_t s, const GemmDesc &d, const GemmDesc &d2, float *C2, const float *A, const float *W, const float *bias,
                            const float *W2, const float *bias2, int64_t batch);
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W,
                  const float *bias, const float *res, const float *scale, int64_t batch);
 // LDS-DMA GEMM (gemm_dma.hip): 0 = not eligible, 1 = 64-row tiles, 2 = 48-row tiles (per-sample quantities only);
 // launch_gemm_dma returns false (nothing launched) when the shape or a pointer's alignment rules it out.  BN_GEMMDMA=0 disables.
-int gemm_dma_shape(const GemmDesc &d);
 bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res,
                      const float *scale, int64_t batch, const SeInline *se = nullptr);
 // the largest channel count whose excite products a GEMM block computes for itself (BN_SEGEMM_MAXC; 0 = never)
-int gemm_dma_se_max_channels();
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w,
                  const float *bias, const float *res, int64_t batch);
 void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, const float *w,
@@ -341,7 +337,6 @@ struct StftPtrs {
 inline bool stft_act_supported(int act) { return act != ACT_TANH && act != ACT_ERF && act != ACT_SOFTPLUS && act != ACT_HSIGMOID && act != ACT_HSWISH; }
 inline bool stft_bin_supported(int bin) { return bin != BIN_POW; }
 void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t batch);
-size_t stft_lds_bytes(const FftDesc &d, int nwaves);
 
 void launch_null(hipStream_t s);  // empty kernel (timing calibration)
 
@@ -356,7 +351,10 @@ const char *take_launch_error();
 // used (bn_model_load, bn_ctx_create, the stand-alone top-K entry points); launchers never call the runtime for it.
 bool prepare_device(int dev);
 void register_dynamic_lds_kernel(const void *kernel);  // used by each .hip file's register_*_kernels()
-// launch-time check only (no runtime call): true when `bytes` fits and some device was prepared
+// The device the calling thread's launches go to: noted (thread-local, no runtime call) by the C ABI wherever it selects a device,
+// so that the two launch-time questions below are answered for THAT device (hipFuncSetAttribute is per device: ADVICE r3).
+void note_launch_device(int dev);
+// launch-time check only (no runtime call): true when `bytes` fits and the thread's launch device was prepared
 bool ensure_dynamic_lds(const void *kernel, size_t bytes);
 int device_cu_count();
 size_t topk_lds_bytes(int64_t n, int64_t k);
@@ -370,6 +368,5 @@ struct CopyOut {
     int n;
 };
 void launch_copy_out(hipStream_t s, const CopyOut &c);
-size_t mbconv_lds_bytes(const MbDesc &d);  // dynamic LDS of mbconv_expand_dw_kernel for this shape
 
 }  // namespace bn

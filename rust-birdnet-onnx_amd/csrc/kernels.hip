@@ -25,6 +25,7 @@
 #include <atomic>
 
 #include "kernels.h"
+#include "plan_rules.h"
 #include "device_common.h"
 
 namespace bn {
@@ -106,14 +107,22 @@ bool prepare_device(int dev) {
 }
 // the launch-time side: no runtime call at all.  A launcher that needs the opt-in on a device nobody prepared
 // (a programming error in the C ABI layer) refuses the launch instead of asking the runtime mid-capture.
+static thread_local int t_launch_dev = -1;
+void note_launch_device(int dev) { t_launch_dev = dev; }
 bool ensure_dynamic_lds(const void *kernel, size_t bytes) {
     (void)kernel;
     if (bytes <= 64 * 1024) return true;  // within the default limit
-    return bytes <= 160 * 1024 && g_prepared_mask.load(std::memory_order_acquire) != 0;
+    if (bytes > 160 * 1024) return false;
+    const uint64_t m = g_prepared_mask.load(std::memory_order_acquire);
+    const int dev = t_launch_dev;
+    // a thread that never went through the C ABI's device selection (the stand-alone probes under tools/) is answered for
+    // "some prepared device"; everything the library launches itself has noted its device
+    return dev >= 0 && dev < 64 ? (m >> dev) & 1ull : m != 0;
 }
 int device_cu_count() {
-    // every device of a process is the same part (gfx950 only, capi.cpp): the first prepared device answers
     const uint64_t m = g_prepared_mask.load(std::memory_order_acquire);
+    const int dev = t_launch_dev;
+    if (dev >= 0 && dev < 64 && ((m >> dev) & 1ull)) return g_cu_count[dev].load(std::memory_order_relaxed);
     for (int d = 0; d < 64; d++)
         if (m & (1ull << d)) return g_cu_count[d].load(std::memory_order_relaxed);
     return 256;
@@ -793,6 +802,7 @@ struct FrameDesc {
     int32_t has_bias;
 };
 constexpr int FRAME_BM = 64;
+static_assert(FRAME_BM == FRAME_BM_RULE && GEMM_BK == GEMM_BK_RULE && GEMM_LD == GEMM_LD_RULE, "plan_rules.h restates the framing GEMM tile sizes");
 // One shared copy of the compact stage dispatch (device_common.h) for a wave's 16 accumulators, by value: registers in, registers out.
 // (The generic gemm_epilogue inlines libm for every stage code: behind this kernel it took 256 registers and scratch.)
 __device__ __noinline__ floatx16 act_small16(int act, float p0, float p1, floatx16 a) {
@@ -2609,15 +2619,6 @@ static void launch_gemm_splitk(hipStream_t s, const GemmDesc &d, float *C, const
     }
 }
 
-// Folded framing GEMM from an LDS-resident signal span; false when the shape does not fit (the caller then runs the
-// generic folded GEMM).  Decided from per-sample quantities and pointer alignment only.  BN_FRAMELDS=0 disables.
-static bool frame_fold_shape_ok(const GemmDesc &d, const float *W) {
-    if (getenv("BN_FRAMELDS") && atoi(getenv("BN_FRAMELDS")) == 0) return false;
-    if (d.has_res || d.has_scale || d.act != ACT_NONE || d.K % GEMM_BK || d.fold_n != 2 * d.K || d.K % 4 || (W && !aligned16(W))) return false;
-    if (d.lda <= 0 || d.lda > 4096 || d.rows < 32 || d.c_bs < 0) return false;
-    return true;
-}
-
 // pair != nullptr: the fused second product (frame_fold_kernel<true>); the caller has checked frame_fold_pair_ok
 static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, int64_t batch,
                               const GemmDesc *pair = nullptr, float *C2 = nullptr, const float *W2 = nullptr, const float *bias2 = nullptr) {
@@ -2653,28 +2654,6 @@ static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const 
     if (pair) hipLaunchKernelGGL(frame_fold_kernel<true>, grid, dim3(128 * wn), lds, s, f, C, A, W, bias, *pair, C2, W2, bias2);
     else hipLaunchKernelGGL(frame_fold_kernel<false>, grid, dim3(128 * wn), lds, s, f, C, A, W, bias, none, nullptr, nullptr, nullptr);
     return true;
-}
-
-// Planner rule J and its launcher agree through this: the folded framing GEMM `d` (its LDS-resident kernel) followed by a plain
-// product over its rows
-bool frame_fold_pair_ok(const GemmDesc &d, const GemmDesc &d2) {
-    // opt-in (BN_FRAMEPAIR=1): correct, one launch and the spectrum's round trip less -- and slower: behind the K loop the block's eight
-    // waves stage the second product's filter rows and run its epilogue with the CU to themselves, 68.4 us against 50 + 19 at batch 32 and
-    // 63 against 56 us of marginal cost, where the separate launch spreads the same work over the chip beside the other contexts' kernels
-    if (!(getenv("BN_FRAMEPAIR") && atoi(getenv("BN_FRAMEPAIR")) == 1)) return false;
-    if (!d.fold || !frame_fold_shape_ok(d, nullptr)) return false;
-    if (d.N > 128 || d.ldc != d.N) return false;
-    const int wn = std::max(2, (d.N + 31) / 32);
-    const int64_t span = (int64_t)(FRAME_BM - 1) * d.lda + d.fold_n;
-    if ((size_t)(((span + 3) & ~3) + 2 * FRAME_BM * GEMM_LD + 2 * 32 * wn * GEMM_LD) * sizeof(float) > 160 * 1024) return false;
-    // the second product's tiles must fit the two tile buffers: K tiles of the spectrum + one step of its filter rows
-    const int n2pad = (d2.N + 31) / 32 * 32;
-    if (wn * FRAME_BM * GEMM_LD + n2pad * GEMM_LD > 2 * FRAME_BM * GEMM_LD + 2 * 32 * wn * GEMM_LD) return false;
-    if (d2.N > 32 * wn || d2.N < 1 || d2.K != d.N || d2.lda != d2.K || d2.rows != d.rows || d2.a_bs != d.c_bs) return false;
-    if (d2.fold || d2.has_scale || d2.has_res || d2.se_inline) return false;
-    bool stages = stft_act_supported(d2.act);  // the compact stage functions only
-    for (int q = 0; q < d2.npost && q < 4; q++) stages = stages && stft_act_supported(d2.post_act[q]);
-    return stages && d2.npost <= 4;
 }
 
 void launch_gemm_fold_pair(hipStream_t s, const GemmDesc &d, const GemmDesc &d2, float *C2, const float *A, const float *W, const float *bias,
@@ -2739,29 +2718,6 @@ void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, 
     const int64_t total = (int64_t)d.OH * d.OW * d.Cout;
     dim3 grid(cap_blocks((total + 255) / 256, 8192), (unsigned)batch);
     hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), 0, s, d, out, in, w, bias, res);
-}
-
-size_t mbconv_lds_bytes(const MbDesc &d) {
-    if (d.whole_map) {
-        const int mt = (d.H * d.W + 31) / 32, ks = (d.Cin + 7) / 8 * 8 + 4;
-        return (size_t)(32 * ks + mt * 32 * 32 + 8 * 32) * sizeof(float);
-    }
-    const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
-    const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
-    const int mp = (hp + 31) / 32 * 32;
-    const int ks = (d.Cin + 7) / 8 * 8 + 4;
-    const int nchunks = (d.C + 31) / 32;
-    return (size_t)(mp * ks + mp * 32 + mp + nchunks * 8 * 32) * sizeof(float);
-}
-
-// dynamic LDS of the pipelined variant (Es double-buffered)
-size_t mbconv_pipe_lds_bytes(const MbDesc &d) {
-    const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
-    const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
-    const int mp = (hp + 31) / 32 * 32;
-    const int ks = (d.Cin + 7) / 8 * 8 + 4;
-    const int nchunks = (d.C + 31) / 32;
-    return (size_t)(mp * ks + 2 * mp * 32 + mp + nchunks * 8 * 32) * sizeof(float);
 }
 
 void launch_mbconv(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2,

@@ -31,6 +31,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include "plan_rules.h"
 
 namespace bn {
 namespace {
@@ -40,7 +41,6 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define MM_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 #define MM_GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 
-__host__ __device__ constexpr int mm_kib(int floats) { return (floats + 255) & ~255; }  // LDS-DMA writes whole 1-KiB pieces
 
 // Row swizzle of the [rows][Cin] LDS images (input map, filter chunk).  A ds_read_b128 fragment read touches 16 rows at
 // one k position; with a row stride of Cin floats they fall on 64 / gcd(64, Cin mod 64) ... banks: 2-way conflicts for
@@ -330,40 +330,9 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
     }
 }
 
-template <int MW, int NW, int WM, int WN, int KSP = 1>
-size_t cfg_lds(const MbDesc &d) {
-    constexpr int HW = 16 * MW * WM, NC = 16 * NW * WN, NG = 64 * WM * WN * KSP / NC;
-    return (size_t)(mm_kib(HW * d.Cin) + 2 * mm_kib(NC * d.Cin) + mm_kib(d.H * (d.W + d.k - 1) * (NC + 4)) + NG * NC) * sizeof(float);
-}
-
 inline bool mm_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
-
-// Which configuration takes this block (0 = none).  Per-sample quantities only.
-//   1: 192-pixel map, chunks of 64 channels, 8 waves      2: 192-pixel map, chunks of 32, 8 waves (wider inputs)
-//   3: 48-pixel map, chunks of 64 channels, 8 waves (two K slices)
-int mbmap_config(const MbDesc &d) {
-    const int mode = getenv("BN_MBMAP2") ? atoi(getenv("BN_MBMAP2")) : 1;  // read per call: plans are built (and tests switch it) at run time
-    if (mode == 0) return 0;
-    if (d.k1 > 0 || !((d.k == 3 || d.k == 5) && (d.s == 1 || d.s == 2))) return 0;
-    if (d.Cin % 16 || d.Cin < 16 || d.C % 4 || d.in_bs % 4 || d.W % 4) return 0;
-    const int pad = (d.k - 1) / 2;  // the kernels are compiled for symmetric "same" padding
-    if (d.pt != pad || d.pl != pad || d.OH != (d.H + 2 * pad - d.k) / d.s + 1 || d.OW != (d.W + 2 * pad - d.k) / d.s + 1) return 0;
-    if (!mbconv_row_act_supported(d.act1) || !mbconv_row_act_supported(d.act2)) return 0;
-    const size_t cap = 160 * 1024;
-    const int cls = d.Cin % 64;
-    // (the row swizzle each configuration is compiled with: see mm_swz)
-    if (d.H == 6 && d.W == 32 && (cls == 16 || cls == 48)) {
-        if (cfg_lds<3, 2, 4, 2>(d) <= cap) return 1;
-        if (cfg_lds<3, 1, 4, 2>(d) <= cap) return 2;
-    } else if (d.H == 3 && d.W == 16 && cls == 0) {
-        if (cfg_lds<3, 1, 1, 4, 2>(d) <= cap) return 3;
-    } else if (d.H == 4 && d.W == 16 && cls == 0 && d.s == 1) {  // BirdNET v3.0's last stage (5 s segments: one more row than v2.4's 3 x 16)
-        if (cfg_lds<2, 1, 2, 2, 2>(d) <= cap) return 4;  // 32-channel chunks (Cin = 192: two filter chunks of 64 would not fit), eight waves
-    }
-    return 0;
-}
 
 // chunks of channels one block walks (the input is fetched once per block): the fewest blocks that still give every CU
 // one -- the blocks are LDS-bound to one per CU, so more blocks than CUs means a second round (measured, batch 32:
@@ -404,7 +373,7 @@ bool launch_mbmap(hipStream_t s, const MbDesc &d, float *out, const float *in, c
     do {                                                                                                                              \
         constexpr int NC = 16 * NW * WN;                                                                                              \
         dim3 grid((unsigned)((d.C + nch * NC - 1) / (nch * NC)), (unsigned)batch);                                                    \
-        const size_t lds_ = cfg_lds<MW, NW, WM, WN, KSP>(d);                                                                               \
+        const size_t lds_ = mbmap_lds_bytes(d, MW, NW, WM, WN, KSP);                                                                               \
         hipLaunchKernelGGL((mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW>), grid, dim3(64 * WM * WN * KSP), lds_, s, dd, out, in, w1, b1, w2, b2, gap, nch, \
                            inv_ch);                                                                                                   \
     } while (0)

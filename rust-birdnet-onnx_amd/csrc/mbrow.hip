@@ -32,6 +32,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include "plan_rules.h"
 
 namespace bn {
 namespace {

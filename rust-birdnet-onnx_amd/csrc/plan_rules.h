@@ -1,0 +1,209 @@
+// Shape rules the planner (engine.cpp, host C++) and the launchers (*.hip) must agree on: which kernel a descriptor may
+// take and how much LDS that kernel carves up for it.  They are pure functions of per-sample quantities (and of the
+// documented BN_* switches, read per call because the tests flip them), defined ONCE here and included by both sides --
+// so the host-only sanitizer build of the planner (tools/asan_plan.cpp, tests/test_planner_sanitizers.py) links without
+// any HIP object and without restating a rule.
+#pragma once
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+
+#include "kernels.h"
+
+#if defined(__HIPCC__)
+#define BN_HD __host__ __device__
+#else
+#define BN_HD
+#endif
+
+namespace bn {
+
+inline bool ptr_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// ---- tiled GEMM family (kernels.hip) ------------------------------------------------------------------------------
+constexpr int GEMM_BK_RULE = 32, GEMM_LD_RULE = GEMM_BK_RULE + 4, FRAME_BM_RULE = 64;
+
+// Folded framing GEMM from an LDS-resident signal span (frame_fold_kernel): per-sample quantities and, when given, the
+// filter pointer's alignment.  BN_FRAMELDS=0 disables.
+inline bool frame_fold_shape_ok(const GemmDesc &d, const float *W) {
+    if (env_int("BN_FRAMELDS", 1) == 0) return false;
+    if (d.has_res || d.has_scale || d.act != ACT_NONE || d.K % GEMM_BK_RULE || d.fold_n != 2 * d.K || d.K % 4 || (W && !ptr_aligned16(W))) return false;
+    if (d.lda <= 0 || d.lda > 4096 || d.rows < 32 || d.c_bs < 0) return false;
+    return true;
+}
+
+// Planner rule J and its launcher agree through this: the folded framing GEMM `d` (its LDS-resident kernel) followed by a plain
+// product over its rows (frame_fold_kernel<true>).
+// Opt-in (BN_FRAMEPAIR=1): correct, one launch and the spectrum's round trip less -- and slower: behind the K loop the block's eight
+// waves stage the second product's filter rows and run its epilogue with the CU to themselves, 68.4 us against 50 + 19 at batch 32 and
+// 63 against 56 us of marginal cost, where the separate launch spreads the same work over the chip beside the other contexts' kernels
+inline bool frame_fold_pair_ok(const GemmDesc &d, const GemmDesc &d2) {
+    if (env_int("BN_FRAMEPAIR", 0) != 1) return false;
+    if (!d.fold || !frame_fold_shape_ok(d, nullptr)) return false;
+    if (d.N > 128 || d.ldc != d.N) return false;
+    const int wn = std::max(2, (d.N + 31) / 32);
+    const int64_t span = (int64_t)(FRAME_BM_RULE - 1) * d.lda + d.fold_n;
+    if ((size_t)(((span + 3) & ~3) + 2 * FRAME_BM_RULE * GEMM_LD_RULE + 2 * 32 * wn * GEMM_LD_RULE) * sizeof(float) > 160 * 1024) return false;
+    // the second product's tiles must fit the two tile buffers: K tiles of the spectrum + one step of its filter rows
+    const int n2pad = (d2.N + 31) / 32 * 32;
+    if (wn * FRAME_BM_RULE * GEMM_LD_RULE + n2pad * GEMM_LD_RULE > 2 * FRAME_BM_RULE * GEMM_LD_RULE + 2 * 32 * wn * GEMM_LD_RULE) return false;
+    if (d2.N > 32 * wn || d2.N < 1 || d2.K != d.N || d2.lda != d2.K || d2.rows != d.rows || d2.a_bs != d.c_bs) return false;
+    if (d2.fold || d2.has_scale || d2.has_res || d2.se_inline) return false;
+    bool stages = stft_act_supported(d2.act);  // the compact stage functions only
+    for (int q = 0; q < d2.npost && q < 4; q++) stages = stages && stft_act_supported(d2.post_act[q]);
+    return stages && d2.npost <= 4;
+}
+
+// ---- LDS-DMA GEMM (gemm_dma.hip) ----------------------------------------------------------------------------------
+// epilogue activations the kernel carries (one dispatch on the launch-uniform code); other codes keep the older kernels
+BN_HD inline bool gemm_dma_act_ok(int act) {
+    return act == ACT_NONE || act == ACT_RELU || act == ACT_CLIP || act == ACT_SILU || act == ACT_HSWISH || act == ACT_SIGMOID || act == ACT_HSIGMOID;
+}
+
+// floats of LDS a (tile, K-slice count, ring depth) configuration needs for this layer
+inline size_t gemm_dma_lds_bytes(const GemmDesc &d, int mtw, int ntw, int wm, int wn, int ks, int depth, int se_cr = 0) {
+    const int tr = 16 * mtw * wm, bn = 16 * ntw * wn;
+    const int gate_floats = d.has_scale ? (d.K + 1023) / 1024 * 1024 : 0;  // whole 1-KiB pieces
+    const int se_floats = d.se_inline ? ((d.K + 3) & ~3) + ((se_cr + 3) & ~3) : 0;  // squeeze means + hidden units
+    return std::max((size_t)(ks * depth * (tr + bn) * 32 + gate_floats + se_floats), (size_t)((ks - 1) * wm * wn * mtw * ntw * 256)) * sizeof(float);
+}
+
+// which block family the LDS-DMA kernel would take for this GEMM (0 = not eligible): per-sample quantities only
+inline int gemm_dma_shape(const GemmDesc &d) {
+    const int mode = env_int("BN_GEMMDMA", 1);
+    if (mode == 0) return 0;
+    if (d.fold || d.npost || d.out_strided || d.lda != d.K || d.K % 16 || d.K < 32 || d.N % 4 || d.N < 16 || !gemm_dma_act_ok(d.act)) return 0;
+    if (d.ldc % 4 || d.c_bs % 4 || d.a_bs % 4 || (d.has_res && (d.ldr % 4 || d.r_bs % 4)) || (d.has_scale && d.s_bs % 4)) return 0;
+    if ((int64_t)d.rows * d.K >= ((int64_t)1 << 30) || (int64_t)d.N * d.K >= ((int64_t)1 << 30)) return 0;  // 32-bit lane offsets
+    if (d.has_scale && d.K > 8192) return 0;
+    // Where it pays (measured, batch 32 and 128, tools/kernel_table.py): deep products with few output channels -- the
+    // project convs and the head conv.  Short-K, wide-N expands are bound by their output stores and their launch, not by
+    // staging: the tiled kernel keeps them (mode 2 sends every eligible shape here, for tests).
+    // ... and the project convs of the big feature maps (few output channels, K 32 .. 144): memory-bound either way, but
+    // the tiled kernel spends 17 - 27 vector instructions per matrix instruction on them, and at four contexts every
+    // vector instruction is taken from the budget the other contexts' matrix work needs (BN_GEMMDMA_SMALLN=0 keeps
+    // them on the tiled kernel)
+    const bool small_n = d.N <= 32 && d.has_scale && env_int("BN_GEMMDMA_SMALLN", 1) != 0;
+    if (mode != 2 && d.K < 128 && !small_n) return 0;
+    if (d.rows % 32 == 0) return 1;  // 64- or 32-row tiles x up to 128 channels, waves along the rows
+    if (d.rows % 48 == 0) return 2;  // 48-row tiles x 32 / 64 / 128 channels, waves along the channels
+    return 0;
+}
+
+// K slices per block: a property of the layer's SHAPE (it enters the summation order).  Deep products (project convs:
+// K 240 .. 1152, head conv) run as two interleaved slices -- unless two slices of the LARGEST tile the launcher may pick
+// for this layer would not fit the LDS: the tile follows the batch, so "fall back to one slice for the big tile only"
+// would make a segment's bits depend on its batch (gated layers with K > 3072).
+inline int gemm_dma_kslices(const GemmDesc &d, int se_cr = 0) {
+    const int force = env_int("BN_GEMMDMA_KS", 0);
+    int ks = (force == 1 || force == 2) ? force : (d.K >= 192 ? 2 : 1);
+    if (ks == 2) {
+        const size_t cap = 156 * 1024;
+        const bool fits = d.rows % 32 == 0 ? gemm_dma_lds_bytes(d, 1, 8, 4, 1, 2, 3, se_cr) <= cap   // 64 x 128, the widest shape-1 tile
+                                           : gemm_dma_lds_bytes(d, 3, 2, 1, 4, 2, 3, se_cr) <= cap;  // 48 x 128
+        if (!fits) ks = 1;
+    }
+    return ks;
+}
+
+// the largest channel count whose excite products a GEMM block computes for itself (BN_SEGEMM_MAXC; 0 = never)
+inline int gemm_dma_se_max_channels() { return env_int("BN_SEGEMM_MAXC", 768); }
+
+// ---- tiled fused MBConv (kernels.hip) -----------------------------------------------------------------------------
+// dynamic LDS of mbconv_expand_dw_kernel for this shape
+inline size_t mbconv_lds_bytes(const MbDesc &d) {
+    if (d.whole_map) {
+        const int mt = (d.H * d.W + 31) / 32, ks = (d.Cin + 7) / 8 * 8 + 4;
+        return (size_t)(32 * ks + mt * 32 * 32 + 8 * 32) * sizeof(float);
+    }
+    const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
+    const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
+    const int mp = (hp + 31) / 32 * 32;
+    const int ks = (d.Cin + 7) / 8 * 8 + 4;
+    const int nchunks = (d.C + 31) / 32;
+    return (size_t)(mp * ks + mp * 32 + mp + nchunks * 8 * 32) * sizeof(float);
+}
+// dynamic LDS of the pipelined variant (Es double-buffered)
+inline size_t mbconv_pipe_lds_bytes(const MbDesc &d) {
+    const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
+    const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
+    const int mp = (hp + 31) / 32 * 32;
+    const int ks = (d.Cin + 7) / 8 * 8 + 4;
+    const int nchunks = (d.C + 31) / 32;
+    return (size_t)(mp * ks + 2 * mp * 32 + mp + nchunks * 8 * 32) * sizeof(float);
+}
+
+// ---- small-map MBConv (mbmap.hip) ---------------------------------------------------------------------------------
+BN_HD constexpr int mm_kib(int floats) { return (floats + 255) & ~255; }  // LDS-DMA writes whole 1-KiB pieces
+
+// LDS of the <MW, NW, WM, WN, KSP> block for this layer: input image + two filter chunks + the expanded chunk image + partial sums
+inline size_t mbmap_lds_bytes(const MbDesc &d, int mw, int nw, int wm, int wn, int ksp = 1) {
+    const int hw = 16 * mw * wm, nc = 16 * nw * wn, ng = 64 * wm * wn * ksp / nc;
+    return (size_t)(mm_kib(hw * d.Cin) + 2 * mm_kib(nc * d.Cin) + mm_kib(d.H * (d.W + d.k - 1) * (nc + 4)) + ng * nc) * sizeof(float);
+}
+
+// Which configuration takes this block (0 = none).  Per-sample quantities only.  BN_MBMAP2=0 disables.
+//   1: 192-pixel map, chunks of 64 channels, 8 waves      2: 192-pixel map, chunks of 32, 8 waves (wider inputs)
+//   3: 48-pixel map (3 x 16), chunks of 64 channels, 8 waves (two K slices)
+//   4: 64-pixel map (4 x 16), chunks of 32 channels, 8 waves (two K slices)
+inline int mbmap_config(const MbDesc &d) {
+    if (env_int("BN_MBMAP2", 1) == 0) return 0;
+    if (d.k1 > 0 || !((d.k == 3 || d.k == 5) && (d.s == 1 || d.s == 2))) return 0;
+    if (d.Cin % 16 || d.Cin < 16 || d.C % 4 || d.in_bs % 4 || d.W % 4) return 0;
+    const int pad = (d.k - 1) / 2;  // the kernels are compiled for symmetric "same" padding
+    if (d.pt != pad || d.pl != pad || d.OH != (d.H + 2 * pad - d.k) / d.s + 1 || d.OW != (d.W + 2 * pad - d.k) / d.s + 1) return 0;
+    if (!mbconv_row_act_supported(d.act1) || !mbconv_row_act_supported(d.act2)) return 0;
+    const size_t cap = 160 * 1024;
+    const int cls = d.Cin % 64;
+    // (the row swizzle each configuration is compiled with: see mm_swz)
+    if (d.H == 6 && d.W == 32 && (cls == 16 || cls == 48)) {
+        if (mbmap_lds_bytes(d, 3, 2, 4, 2) <= cap) return 1;
+        if (mbmap_lds_bytes(d, 3, 1, 4, 2) <= cap) return 2;
+    } else if (d.H == 3 && d.W == 16 && cls == 0) {
+        if (mbmap_lds_bytes(d, 3, 1, 1, 4, 2) <= cap) return 3;
+    } else if (d.H == 4 && d.W == 16 && cls == 0 && d.s == 1) {  // BirdNET v3.0's last stage (5 s segments: one more row than v2.4's 3 x 16)
+        if (mbmap_lds_bytes(d, 2, 1, 2, 2, 2) <= cap) return 4;  // 32-channel chunks (Cin = 192: two filter chunks of 64 would not fit), eight waves
+    }
+    return 0;
+}
+
+// ---- FFT front end (stft.hip) -------------------------------------------------------------------------------------
+// LDS carve-up (floats), shared by the kernel and stft_lds_bytes.  Table regions are whole KiB: the asynchronous
+// global -> LDS copies write 1 KiB per wave instruction.
+struct StftLds {
+    int sig, tw, wbuf, window, otab, mstart, ment, spec, mel, total;
+};
+BN_HD constexpr int stft_wbuf_slots(int slots) { return slots + slots / 8; }
+BN_HD inline int stft_kib(int floats) { return (floats + 255) & ~255; }
+BN_HD inline StftLds stft_layout(const FftDesc &d, int nw, int slots) {
+    StftLds l;
+    int o = 0;
+    l.sig = o; o += ((d.tpb - 1) * d.hop + d.L + 3) & ~3;
+    l.wbuf = o; o += 2 * nw * stft_wbuf_slots(slots);
+    l.tw = o; o += stft_kib(2 * d.tw_count);
+    l.window = o; o += stft_kib(d.L);
+    l.otab = o; o += stft_kib(d.otab_planar ? (d.power ? 10 : 6) * d.nout : (d.otab_stride > 0 ? d.otab_stride : 8) * d.nout);
+    const bool csr = d.nmel && d.mel_mode == 0;  // (MFMA mode reads its tiles from global memory / L2: nothing of the bank in LDS)
+    l.mstart = o; o += csr ? stft_kib(d.nmel + 1) : 0;
+    l.ment = o; o += csr ? stft_kib(2 * d.mel_nnz) : 0;  // (column, value) pairs
+    l.spec = o; o += d.nmel ? d.tpb * (d.spec_stride > 0 ? d.spec_stride : d.nout) : 0;  // the tile's spectrum rows (mel fusion only)
+    l.mel = o;
+    l.total = o;
+    return l;
+}
+// 16 waves x 512 slots where a frame fits 512 complex points (opt-in BN_STFT_NW=16: measured slower -- 128-register cap at
+// 16 waves: 156 B of scratch per lane; 74.6 vs 69.1 us), else 8 x 1024
+inline bool stft_wide(const FftDesc &d) {
+    if (env_int("BN_STFT_NW", 8) != 16) return false;
+    return d.M <= 512 && d.tpb % (512 / d.M) == 0;
+}
+inline size_t stft_lds_bytes(const FftDesc &d, int /*nwaves*/) {
+    return (size_t)(stft_wide(d) ? stft_layout(d, 16, 512) : stft_layout(d, 8, 1024)).total * sizeof(float);
+}
+
+}  // namespace bn

@@ -31,6 +31,7 @@
 
 #include "device_common.h"
 #include "kernels.h"
+#include "plan_rules.h"
 
 namespace bn {
 namespace {
@@ -38,7 +39,6 @@ namespace {
 // complex slots of one wave's transform buffer: SLOTS / 16 blocks of 16 + 2 slots of padding each.  SLOTS = 1024 with 8 waves per
 // block, or 512 with 16 waves (M <= 512: one frame per wave at a time) -- the same LDS either way, but four waves per SIMD
 // instead of two to cover the LDS round trips and barriers the kernel is bound by
-__host__ __device__ constexpr int wbuf_slots(int slots) { return slots + slots / 8; }
 
 __device__ __forceinline__ int phys(int i) { return i + 2 * (i >> 4); }
 
@@ -186,28 +186,6 @@ __device__ __forceinline__ void pre_chain(const PreChain &c, float (&v)[N]) {
     pre_stage<3, N>(c, v);
 }
 
-// LDS carve-up (floats), shared by the kernel and stft_lds_bytes.  Table regions are whole KiB: the asynchronous
-// global -> LDS copies write 1 KiB per wave instruction.
-struct StftLds {
-    int sig, tw, wbuf, window, otab, mstart, ment, spec, mel, total;
-};
-__host__ __device__ __forceinline__ int kib(int floats) { return (floats + 255) & ~255; }
-__host__ __device__ __forceinline__ StftLds stft_layout(const FftDesc &d, int nw, int slots) {
-    StftLds l;
-    int o = 0;
-    l.sig = o; o += ((d.tpb - 1) * d.hop + d.L + 3) & ~3;
-    l.wbuf = o; o += 2 * nw * wbuf_slots(slots);
-    l.tw = o; o += kib(2 * d.tw_count);
-    l.window = o; o += kib(d.L);
-    l.otab = o; o += kib(d.otab_planar ? (d.power ? 10 : 6) * d.nout : (d.otab_stride > 0 ? d.otab_stride : 8) * d.nout);
-    const bool csr = d.nmel && d.mel_mode == 0;  // (MFMA mode reads its tiles from global memory / L2: nothing of the bank in LDS)
-    l.mstart = o; o += csr ? kib(d.nmel + 1) : 0;
-    l.ment = o; o += csr ? kib(2 * d.mel_nnz) : 0;  // (column, value) pairs
-    l.spec = o; o += d.nmel ? d.tpb * (d.spec_stride > 0 ? d.spec_stride : d.nout) : 0;  // the tile's spectrum rows (mel fusion only)
-    l.mel = o;
-    l.total = o;
-    return l;
-}
 
 // contiguous global -> LDS copy without registers (global_load_lds_dwordx4: each lane names its 16 source bytes, the
 // wave writes 1 KiB at a wave-uniform LDS address).  `floats` is rounded up to whole 16-byte chunks; lanes past the
@@ -284,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     const StftLds lay = stft_layout(d, NW, SLOTS);
     float *sig = lds + lay.sig;
     float2 *tw = reinterpret_cast<float2 *>(lds + lay.tw);
-    float2 *wbuf = reinterpret_cast<float2 *>(lds + lay.wbuf) + wave * wbuf_slots(SLOTS);
+    float2 *wbuf = reinterpret_cast<float2 *>(lds + lay.wbuf) + wave * stft_wbuf_slots(SLOTS);
     float2 *wnd = reinterpret_cast<float2 *>(lds + lay.window);
     float *otab = lds + lay.otab;
     float *mstart = lds + lay.mstart;
@@ -603,19 +581,6 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
 
 
 }  // namespace
-
-// 16 waves x 512 slots where a frame fits 512 complex points (BN_STFT_NW=8 keeps the 8 x 1024 form), else 8 x 1024
-static bool stft_wide(const FftDesc &d) {
-    const char *e = getenv("BN_STFT_NW");  // (read per call: the tests flip it)
-    if (e && atoi(e) == 8) return false;
-    if (!e || atoi(e) != 16) return false;  // opt-in: measured slower (128-register cap at 16 waves: 156 B of scratch per lane; 74.6 vs 69.1 us)
-    return d.M <= 512 && d.tpb % (512 / d.M) == 0;
-}
-
-size_t stft_lds_bytes(const FftDesc &d, int nwaves) {
-    (void)nwaves;
-    return (size_t)(stft_wide(d) ? stft_layout(d, 16, 512) : stft_layout(d, 8, 1024)).total * sizeof(float);
-}
 
 void register_stft_kernels() {
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(stft_kernel<8, 1024, false, 0>));

@@ -121,12 +121,13 @@ def chunk_step(segment_samples: int, overlap_secs: float, sample_rate: int) -> i
 
 
 def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: float, batch: int = 32, streams: int = 4, top_k: int = 10,
-                              min_confidence: Optional[float] = None, dist=None, gather: str = "topk", ctxs=None):
+                              min_confidence: Optional[float] = None, dist=None, gather: str = "logits", ctxs=None):
     """BASELINE.json configs[4]: a long mono recording (int16 or float32), sharded by window across the
     ranks of one node.  Every rank uploads its slice once (bn_recording_create), cuts windows on the
     device and keeps `streams` contexts in flight (bn_step_windows); ONE collective at the end
-    assembles only the [G, k] top-K rows (gather="topk", the default: 80 B per window at k = 10) or also the [G, N]
-    logits (gather="logits": 26 KB per window for BirdNET v2.4 -- what the reference's `raw_scores` need).
+    assembles the [G, N] logits and the [G, k] top-K rows (gather="logits", the default: 26 KB per window for BirdNET
+    v2.4 -- the reference's PredictionResult carries `raw_scores` for every segment, classifier.rs:907,948) or, as an
+    explicit opt-in, the top-K rows only (gather="topk": 80 B per window at k = 10; `raw_scores` are then None).
 
     Returns (logits or None, topk_idx, topk_conf, topk_count) for all G windows, in time order."""
     import torch

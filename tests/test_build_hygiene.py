@@ -20,11 +20,13 @@ ALLOWED = [re.compile(r"stft_kernelILi16ELi512E")]
 
 
 def kernels_with_scratch(obj, tmp):
-    fat, hsaco = os.path.join(tmp, "x.fatbin"), os.path.join(tmp, "x.hsaco")
-    for f in (fat, hsaco):
+    fat, hsaco, scratch_copy = os.path.join(tmp, "x.fatbin"), os.path.join(tmp, "x.hsaco"), os.path.join(tmp, "x.o")
+    for f in (fat, hsaco, scratch_copy):
         if os.path.exists(f):
             os.unlink(f)
-    r = subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj], capture_output=True, text=True)
+    # an explicit OUTPUT operand: without one llvm-objcopy rewrites its input in place, i.e. this test re-stamped the build's own
+    # object files and the next `make` relinked the library from them -- a test must not mutate the build
+    r = subprocess.run([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, scratch_copy], capture_output=True, text=True)
     if r.returncode != 0 or not os.path.exists(fat):
         return None  # no device code in this object
     r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}",
@@ -47,6 +49,7 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
     objs = sorted(glob.glob(os.path.join(CSRC, "*.o")))
     if not objs or not all(os.path.exists(f"{LLVM}/{t}") for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
         pytest.skip("needs the in-tree build's object files and the ROCm LLVM binutils")
+    before = {o: (os.stat(o).st_mtime_ns, os.stat(o).st_size) for o in objs}
     seen, offenders = 0, []
     for obj in objs:
         ks = kernels_with_scratch(obj, str(tmp_path))
@@ -54,5 +57,6 @@ def test_no_kernel_uses_scratch_memory(tmp_path):
             continue
         seen += len(ks)
         offenders += [(os.path.basename(obj), n, b) for n, b in ks if b > 0 and not any(p.search(n) for p in ALLOWED)]
+    assert before == {o: (os.stat(o).st_mtime_ns, os.stat(o).st_size) for o in objs}, "the test touched the build's object files"
     assert seen > 200, f"only {seen} kernels found: the objects are not the HIP build"
     assert not offenders, "kernels with scratch memory (register spills): " + "; ".join(f"{o}:{n} {b} B" for o, n, b in offenders[:8])

@@ -73,7 +73,7 @@ def test_24h_recording_through_the_group_api_on_one_gpu(bn):
     model = bn.Model(path)
     grp = bn.Group([model], max_batch=32, contexts_per_device=4)
     k, min_conf = 10, 0.02
-    logits, idx, conf, cnt = grp.analyze_recording(pcm, S, top_k=k, min_confidence=min_conf)  # default: top-K rows only
+    logits, idx, conf, cnt = grp.analyze_recording(pcm, S, top_k=k, min_confidence=min_conf, want_logits=False)  # top-K rows only (opt-in: the default gathers raw_scores too)
     assert logits is None and idx.shape == (28800, k) and conf.shape == (28800, k) and cnt.shape == (28800,)
     gst = grp.stats()
     assert gst["capture_fallbacks"] == 0 and gst["eager_runs"] == 0 and gst["replays"] == 900, gst

@@ -23,7 +23,11 @@ def asan_binary(tmp_path_factory):
            os.path.join(src, "onnx_proto.cpp"), os.path.join(src, "engine.cpp"), os.path.join(src, "detect.cpp"), "-o", str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        pytest.skip("sanitizer build unavailable: " + r.stderr[-400:])
+        # only a missing sanitizer runtime is a reason to skip; any other compile / link error is a finding (round 3: the planner had
+        # started to call predicates defined in .hip files, the host-only link failed and this test skipped silently for a whole round)
+        if "cannot find -lasan" in r.stderr or "cannot find -lubsan" in r.stderr or "libasan" in r.stderr and "No such file" in r.stderr:
+            pytest.skip("no libasan / libubsan in this image")
+        pytest.fail("host-only sanitizer build of the reader + planner failed:\n" + r.stderr[-3000:])
     return str(out)
 
 
@@ -41,3 +45,27 @@ def test_reader_and_planner_under_asan_ubsan(asan_binary, tmp_path):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
     assert r.stdout.count("none crashed") == 4 and r.stdout.count("  ok:") == 4, r.stdout
+
+
+# the planner rules of rounds 2-3, each flipped away from its default: rule I (BN_SEGEMM), rule J (BN_FRAMEPAIR), the FFT front end
+# forced on / off, the small-map and LDS-DMA kernels off, the row kernel off -- at the FULL model sizes the bench runs
+RULE_SETS = [
+    {},
+    {"BN_SEGEMM": "1", "BN_FRAMEPAIR": "1", "BN_STFT": "1", "BN_STFT_MEL": "force"},
+    {"BN_STFT": "0", "BN_MBMAP2": "0", "BN_GEMMDMA": "0", "BN_MBROW": "0", "BN_CONVFOLD": "0", "BN_GEMMPOST": "0"},
+    {"BN_GEMMDMA": "2", "BN_MBFUSE": "force", "BN_MBMAP": "1", "BN_STFT_MELMFMA": "0", "BN_STFT_POWER": "0", "BN_REDUCE_SPLIT": "0"},
+]
+
+
+@pytest.mark.parametrize("rules", RULE_SETS, ids=["default", "optins", "rewrites_off", "forced"])
+def test_full_size_plans_under_asan_ubsan_with_rules_on_and_off(asan_binary, tmp_path, rules):
+    files = []
+    for name, data in (("v24", synth.birdnet_v24()), ("v30", synth.birdnet_v30()), ("perch", synth.perch_v2()), ("meta", synth.meta_model())):
+        p = tmp_path / f"{name}.onnx"
+        p.write_bytes(data)
+        files.append(str(p))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", ASAN_PLAN_MUTATIONS="4", **rules)
+    r = subprocess.run([asan_binary] + files, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.stdout.count("  ok:") == 4, r.stdout

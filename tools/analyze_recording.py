@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--overlap", type=float, default=0.0)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--streams", type=int, default=4)
-    ap.add_argument("--gather", choices=["logits", "topk"], default="topk")
+    ap.add_argument("--gather", choices=["logits", "topk"], default="logits")
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--device", type=int, default=None)
     a = ap.parse_args()

@@ -2,7 +2,8 @@
 //   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude \
 //       -Irust-birdnet-onnx_amd/csrc tools/asan_plan.cpp rust-birdnet-onnx_amd/csrc/{onnx_proto,engine,detect}.cpp -o /tmp/asan_plan
 //   /tmp/asan_plan model.onnx [more.onnx ...]      (also feeds truncated / bit-flipped copies of each file)
-// The kernel-side helpers the planner calls are restated here so that no HIP object is linked.
+// The shape rules the planner shares with the launchers live in csrc/plan_rules.h (inline, host C++), so nothing is restated here and
+// no HIP object is linked.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -10,28 +11,6 @@
 #include <vector>
 
 #include "engine.h"
-
-namespace bn {
-size_t mbconv_lds_bytes(const MbDesc &d) {
-    if (d.whole_map) {
-        const int mt = (d.H * d.W + 31) / 32, ks = (d.Cin + 7) / 8 * 8 + 4;
-        return (size_t)(32 * ks + mt * 32 * 32 + 8 * 32) * sizeof(float);
-    }
-    const int toh = d.s == 1 ? 8 : 4, tow = d.s == 1 ? 16 : 8;
-    const int hp = ((toh - 1) * d.s + d.k) * ((tow - 1) * d.s + d.k);
-    const int mp = (hp + 31) / 32 * 32;
-    const int ks = (d.Cin + 7) / 8 * 8 + 4;
-    const int nchunks = (d.C + 31) / 32;
-    return (size_t)(mp * ks + mp * 32 + mp + nchunks * 8 * 32) * sizeof(float);
-}
-size_t topk_lds_bytes(int64_t, int64_t) { return 1; }
-size_t stft_lds_bytes(const FftDesc &d, int nw) {  // stft.hip's carve-up, table regions rounded to whole KiB
-    auto kib = [](int f) { return (f + 255) & ~255; };
-    int o = (((d.tpb - 1) * d.hop + d.L + 3) & ~3) + 2 * nw * (1024 + 128) + kib(2 * d.tw_count) + kib(d.L) + kib(8 * d.nout);
-    if (d.nmel) o += kib(d.nmel + 1) + kib(2 * d.mel_nnz) + d.tpb * d.nout;
-    return (size_t)o * sizeof(float);
-}
-}  // namespace bn
 
 static int plan_bytes(const std::vector<uint8_t> &bytes, bool quiet) {
     try {

@@ -1,6 +1,6 @@
 import importlib, os, sys, tempfile, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 bn = importlib.import_module("rust-birdnet-onnx_amd"); synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
 

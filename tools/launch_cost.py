@@ -1,5 +1,5 @@
 import importlib, os, sys, tempfile, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 bn = importlib.import_module("rust-birdnet-onnx_amd"); synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
 p = tempfile.mktemp(suffix=".onnx"); open(p, "wb").write(synth.birdnet_v24()); m = bn.Model(p)

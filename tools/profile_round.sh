@@ -21,4 +21,6 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_
 # the same two SQ passes per kernel NAME (template arguments kept): profiles/<tag>_pmc_by_kernel.txt
 (python3 $R/tools/pmc_kernels.py $O/pmc_sq > $O/pmc_by_kernel_sq.txt; python3 $R/tools/pmc_kernels.py $O/pmc_inst > $O/pmc_by_kernel_inst.txt; true) &&
 # BASELINE configs[4] on ONE GPU: the 24 h recording (28 800 windows), log kept
-python3 $R/tools/analyze_recording.py --hours 24 --gather topk > $O/recording_24h.log 2>&1
+# (both gathers, labelled: "logits" = the reference-equivalent output with raw_scores, the figure rounds 1-2 quoted; "topk" = rows only)
+python3 $R/tools/analyze_recording.py --hours 24 --gather logits > $O/recording_24h.log 2>&1 &&
+python3 $R/tools/analyze_recording.py --hours 24 --gather topk >> $O/recording_24h.log 2>&1
