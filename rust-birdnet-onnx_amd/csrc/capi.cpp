@@ -316,7 +316,12 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
     // that wants no copy at all writes its batch into that buffer (bn_ctx_input_device).  Any other device pointer is
     // copied in on the context's stream, ahead of the plan: 18 MB at batch 32, about 10 us.
     if (d_in != c->d_input) {
-        HIP_TRY(hipMemcpyAsync(c->d_input, d_in, batch * (size_t)p.sample_count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        static const bool runtime_copy = getenv("BN_INPUT_MEMCPY") && atoi(getenv("BN_INPUT_MEMCPY")) != 0;
+        if (runtime_copy) HIP_TRY(hipMemcpyAsync(c->d_input, d_in, batch * (size_t)p.sample_count * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        else {
+            launch_copy_dev(c->stream, c->d_input, d_in, batch * (size_t)p.sample_count * sizeof(float));
+            HIP_TRY(hipGetLastError());
+        }
         c->n_input_copies++;
         d_in = c->d_input;
     }

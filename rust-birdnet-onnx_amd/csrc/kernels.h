@@ -368,5 +368,6 @@ struct CopyOut {
     int n;
 };
 void launch_copy_out(hipStream_t s, const CopyOut &c);
+void launch_copy_dev(hipStream_t s, void *dst, const void *src, uint64_t bytes);  // device -> device, bytes % 4 == 0
 
 }  // namespace bn

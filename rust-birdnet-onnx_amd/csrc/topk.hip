@@ -491,6 +491,25 @@ void launch_copy_out(hipStream_t s, const CopyOut &c) {
     hipLaunchKernelGGL(copy_out_kernel, dim3(blocks), dim3(256), 0, s, c);
 }
 
+// device -> device with the same kernel over the whole chip (a caller's batch into the context's input buffer): the runtime's
+// hipMemcpyAsync is a command of its own kind on the queue; a kernel of the library's own is ordinary stream work like the plan
+// behind it (BN_INPUT_MEMCPY=1 restores the runtime copy)
+void launch_copy_dev(hipStream_t s, void *dst, const void *src, uint64_t bytes) {
+    if (bytes == 0) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(2048, (bytes / 16 + 255) / 256 + 1);
+    uint64_t done = 0;
+    while (done < bytes) {  // 32-bit word counts per launch: 8 GiB pieces
+        const uint64_t piece = std::min<uint64_t>(bytes - done, (uint64_t)0x7ffffff0u * 4);
+        CopyOut c{};
+        c.n = 1;
+        c.dst[0] = static_cast<char *>(dst) + done;
+        c.src[0] = static_cast<const char *>(src) + done;
+        c.words[0] = (uint32_t)(piece / 4);
+        hipLaunchKernelGGL(copy_out_kernel, dim3(blocks), dim3(256), 0, s, c);
+        done += piece;
+    }
+}
+
 size_t topk_lds_bytes(int64_t n, int64_t k) {
     (void)n;
     size_t b = (size_t)(2 * (k + 1) + 2 * k) * 4;

@@ -512,3 +512,58 @@ def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, mon
     ref = onnx_ref.run_model(data, x)["output"]
     assert_close(got, ref, str(env))
     assert np.array_equal(got.argmax(1), ref.argmax(1))
+
+
+# ---- BASELINE configs[2] / configs[3] at their OWN model size against the oracle ----------------------------
+# The reduced-width fixtures above keep the map sizes but not the channel counts, so kernel instances only the full-size models
+# reach (the 5 x 5 SiLU row-kernel instances at one wave per SIMD, Perch's 40-channel stem, its K = 24 project conv, the
+# column-streaming blocks at 125 x 32, v3.0's 8 x 32 / 4 x 16 maps) met the oracle nowhere; permutation / duplicate-row
+# properties cannot see a deterministic wrong answer.  Each switch set names the kernel family a disagreement would belong to.
+FULL_SIZE_ENVS = [{}, {"BN_MBROW": "0", "BN_GEMMDMA": "0"}, {"BN_MBMAP2": "0", "BN_MBLATE": "0"}, {"BN_MBROW_TR": "0"}, {"BN_STFT": "0"}, {"BN_GEMMDMA": "2"}]
+FULL_SIZE_IDS = ["default", "tiled_mbconv_and_gemm", "no_small_map_kernels", "no_column_streaming", "matrix_front_end", "dma_gemm_everywhere"]
+
+
+@pytest.fixture(scope="module")
+def v30_full():
+    data = synth.birdnet_v30()
+    x = synth.synthetic_segments(3, 160000, 32000)
+    x[1] = 0.0  # a silent segment (tests/integration_test.rs:52-54)
+    return data, write_model(data), x, onnx_ref.run_model(data, x)
+
+
+@pytest.fixture(scope="module")
+def perch_full():
+    data = synth.perch_v2()
+    x = synth.synthetic_segments(2, 160000, 32000)
+    return data, write_model(data), x, onnx_ref.run_model(data, x)
+
+
+@pytest.mark.parametrize("env", FULL_SIZE_ENVS, ids=FULL_SIZE_IDS)
+def test_v30_full_size_model_against_the_oracle(bn, v30_full, monkeypatch, env):
+    """synth.birdnet_v30() as bench.py's `extra.v30` times it: logits and the 1024-d embeddings (detection.rs:44-56,
+    classifier.rs:917-934: output 1 = logits, output 0 = embeddings) within the suite's tolerance of the oracle, identical top-1."""
+    data, path, x, ref = v30_full
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    clf = bn.Classifier.builder().model_path(path).labels(labels(ref["output_1"].shape[1])).top_k(5).with_rocm().build()
+    cfg = clf.config()
+    assert (cfg.model_type, cfg.sample_count, cfg.embedding_dim) == (bn.ModelType.BirdNetV30, 160000, 1024)
+    check_results(clf.predict_batch(list(x)), ref["output_1"], ref["output_0"], 5, None)
+    check_results([clf.predict(x[2])], ref["output_1"][2:], ref["output_0"][2:], 5, None)
+
+
+@pytest.mark.parametrize("env", FULL_SIZE_ENVS, ids=FULL_SIZE_IDS)
+def test_perch_full_size_model_against_the_oracle(bn, perch_full, monkeypatch, env):
+    """synth.perch_v2() as bench.py's `extra.perch` times it: logits [14795] + embedding [1536] (outputs 3 and 0,
+    detection.rs:58-71), and through the native context the spectrogram [500,128] and the spatial embedding [16,4,1536]."""
+    data, path, x, ref = perch_full
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    clf = bn.Classifier.builder().model_path(path).labels(labels(14795)).top_k(5).with_rocm().build()
+    cfg = clf.config()
+    assert (cfg.model_type, cfg.sample_count, cfg.num_species, cfg.embedding_dim) == (bn.ModelType.PerchV2, 160000, 14795, 1536)
+    check_results(clf.predict_batch(list(x)), ref["label"], ref["embedding"], 5, None)
+    ctx = clf.create_native_batch_context(2, all_outputs=True)
+    check_results(clf.predict_batch_with_context(ctx, list(x)), ref["label"], ref["embedding"], 5, None)
+    assert_close(ctx.read_output(2, 2).reshape(ref["spectrogram"].shape), ref["spectrogram"], "spectrogram")
+    assert_close(ctx.read_output(1, 2).reshape(ref["spatial_embedding"].shape), ref["spatial_embedding"], "spatial")
