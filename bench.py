@@ -417,6 +417,9 @@ def main():
 
         extra = {}
         for key, bsz in (("v30", 64), ("perch", 128)):
+            if os.environ.get("BN_BENCH_EXTRAS_INPROCESS") == "1":  # diagnosis of the in-process / child difference (tools/two_models.sh)
+                extra = None
+                break
             try:
                 r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--model", key, "--batch", str(bsz), "--steps", "60", "--warmup", "8",
                                      "--streams", str(S_), "--no-extras", "--no-cpu-baseline", "--no-host-leg", "--no-saturated"],
@@ -427,6 +430,10 @@ def main():
                               "median_ms": j_.get("median_ms"), "p10_ms": j_.get("p10_ms"), "p90_ms": j_.get("p90_ms"), "steps": j_["steps"],
                               "flops_performed_per_segment": j_["roofline"].get("flops_performed_per_segment"),
                               "frac_mfma_f32_whole_path": j_.get("whole_path_frac_mfma_f32"), "capture_fallbacks": j_.get("capture_fallbacks"),
+                              "roofline": {k_: j_["roofline"].get(k_) for k_ in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches_per_step", "avg_launch_us", "share_of_step",
+                                                                                "mfma_busy", "mfma_busy_source", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "pmc_refused")},
+                              "kernel_families": j_.get("kernel_families"),
+                              "device_us_per_step_sum_of_launches": j_.get("device_us_per_step_sum_of_launches"),
                               "mode": "child process: " + " ".join(r_.args[1:])}
             except Exception as e_:  # noqa: BLE001 -- fall back to the in-process loop below
                 print(f"bench: child run of {key} failed ({e_}); measuring it in this process", file=sys.stderr)
@@ -470,11 +477,16 @@ def main():
                 lg2 = cs2[(nst - 1) % S_].step_results(bsz)[0]
                 assert np.isfinite(lg2).all()
                 c2 = m2.cost()
+                rows2 = cs2[0].time_kernels(bsz)
+                for _ in range(2):
+                    rows2 = [(a[0], a[1] + b_[1], a[2], a[3]) for a, b_ in zip(rows2, cs2[0].time_kernels(bsz))]
+                sum2 = sum(r_[1] for r_ in rows2) / 3.0
                 extra[key] = {"workload": f"{name2}, batch={bsz} synthetic {SR2 // 1000} kHz {SEC2:g} s segments, inputs resident in HBM",
                               "value": round(nst * bsz / d2, 1), "unit": "segments/s", "ms_per_step": round(d2 / nst * 1e3, 4), "steps": nst,
                               "flops_performed_per_segment": round(2.0 * (c2.macs_mfma + c2.macs_valu)),
                               "frac_mfma_f32_whole_path": round(2.0 * (c2.macs_mfma + c2.macs_valu) * nst * bsz / d2 / 1e12 / MFMA_F32_PEAK_TF, 4),
-                              "capture_fallbacks": sum(c_.stats()["capture_fallbacks"] for c_ in cs2), "mode": "in-process"}
+                              "capture_fallbacks": sum(c_.stats()["capture_fallbacks"] for c_ in cs2), "mode": "in-process",
+                              "device_us_per_step_sum_of_launches": round(sum2, 1)}
                 del cs2, m2
             out["extra"] = extra
 
@@ -554,9 +566,10 @@ def main():
         stale = []
         traffic, traffic_src = None, None
         try:
-            tj = json.load(open(os.path.join(prof_dir, "pmc_traffic.json")))
+            psuf = "" if args.model == "v24" else "_" + args.model  # per-model summaries: profiles/pmc_traffic_v30.json, ..._perch.json
+            tj = json.load(open(os.path.join(prof_dir, f"pmc_traffic{psuf}.json")))
             if tag_key(tj.get("tag")) < newest:
-                stale.append(f"profiles/pmc_traffic.json (tag {tj.get('tag')}) is older than the newest kernel stats r{newest[0]:02d}_v{newest[1]}")
+                stale.append(f"profiles/pmc_traffic{psuf}.json (tag {tj.get('tag')}) is older than the newest kernel stats r{newest[0]:02d}_v{newest[1]}")
             elif tj.get("batch") == B and dname in tj.get("families", {}):
                 traffic = tj["families"][dname]["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{tj['tag']}_pmc_traffic.json"
@@ -565,9 +578,9 @@ def main():
         # matrix-pipe utilisation of the same family from the committed SQ counter pass (profiles/pmc_mfma.json)
         mfma_busy, mfma_src = None, None
         try:
-            mj = json.load(open(os.path.join(prof_dir, "pmc_mfma.json")))
+            mj = json.load(open(os.path.join(prof_dir, f"pmc_mfma{psuf}.json")))
             if tag_key(mj.get("tag")) < newest:
-                stale.append(f"profiles/pmc_mfma.json (tag {mj.get('tag')}) is older than the newest kernel stats r{newest[0]:02d}_v{newest[1]}")
+                stale.append(f"profiles/pmc_mfma{psuf}.json (tag {mj.get('tag')}) is older than the newest kernel stats r{newest[0]:02d}_v{newest[1]}")
             elif mj.get("batch") == B and dname in mj.get("families", {}):
                 mfma_busy = mj["families"][dname]["mfma_busy"]
                 mfma_src = f"profiles/{mj['tag']}_pmc_mfma.json"
@@ -706,12 +719,21 @@ def main():
         else:
             out["cpu_baseline"] = None
         if world == 1 and not args.no_extras and args.model == "v24":
-            ctxs.clear()
-            logit_views.clear()
-            ev_streams.clear()
+            # teardown order (DESIGN.md 7, round 3's SIGSEGV): first everything torch holds that names a context's stream or memory
+            # (ExternalStream wrappers, events recorded on them, zero-copy views), then a device drain, THEN the contexts
             import gc
+            torch.cuda.synchronize()
+            ev_pool.clear()
+            ev_streams.clear()
+            logit_views.clear()
+            if ctx_streams is not None:
+                ctx_streams.clear()
             gc.collect()
             torch.cuda.synchronize()
+            for c_ in ctxs:
+                c_.close()
+            ctxs.clear()
+            gc.collect()
             run_extras()
         print(json.dumps(out))
     if use_dist:

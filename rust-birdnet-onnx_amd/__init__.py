@@ -604,6 +604,13 @@ class Context:
             lib.bn_ctx_destroy(self._h)
             self._h = None
 
+    def close(self):
+        """Drain the context's stream and destroy it now (instead of whenever the object is collected).  Anything that wraps
+        `stream()` -- torch.cuda.ExternalStream, events recorded on it, tensors copied on it -- must be released first; never
+        `tensor.record_stream()` a context's stream: the allocator would record an event on it when the tensor is freed, possibly
+        after bn_ctx_destroy has destroyed the hipStream_t (round 3's SIGSEGV)."""
+        self.__del__()
+
     def input_device(self):
         """(device pointer, capacity in floats) of the context's own input buffer: a batch written here runs without a copy."""
         p, n = C.c_void_p(), C.c_size_t()

@@ -52,9 +52,16 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
+        // BN_RCCL_LIB names the library to load instead (a site's own build -- or the test stub that lets the RCCL branch
+        // below execute on a one-GPU box, tests/stubs/rccl_stub.cpp); when it is set, nothing else is tried
+        if (const char *forced = getenv("BN_RCCL_LIB")) {
+            r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) fprintf(stderr, "libbirdnet_hip: BN_RCCL_LIB=%s could not be loaded (%s); the group gathers with device copies\n", forced, dlerror());
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) break;
+            }
         }
         if (!r.lib) return;
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
@@ -174,7 +181,10 @@ bn_status bn_group_create(bn_model *const *models, const int32_t *devices, int32
         g->N = row;
     }
     // RCCL only for n > 1 ranks on pairwise distinct devices (one communicator per device in this process)
-    if (n > 1 && (int)distinct.size() == n && !getenv("BN_GROUP_NO_RCCL")) {
+    // (BN_GROUP_FORCE_RCCL=1 takes the branch for ranks that SHARE a device too: the real library refuses such a communicator --
+    // its error is reported below --, the test stub accepts it, which is how the branch is exercised on a one-GPU box)
+    const bool force_rccl = getenv("BN_GROUP_FORCE_RCCL") && atoi(getenv("BN_GROUP_FORCE_RCCL")) != 0;
+    if (n > 1 && ((int)distinct.size() == n || force_rccl) && !getenv("BN_GROUP_NO_RCCL")) {
         Rccl &rc = rccl();
         if (rc.ok()) {
             std::vector<void *> comms((size_t)n, nullptr);

@@ -215,6 +215,16 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
             c.synchronize()  # every slab copy has landed (`full` stays referenced here until the gather has read it)
         dist.all_gather_into_tensor(full, slab)
         g_logits = full[:G].cpu().numpy()
+        # Teardown order, explicit (round 3's SIGSEGV): everything torch holds that names a context's stream or memory
+        # -- the ExternalStream wrappers, the zero-copy views of the contexts' logits, the gather buffer the slab copies ran into on
+        # those streams -- is released and the device drained BEFORE the contexts (locals of this frame when the caller passed none)
+        # destroy their hipStream_t.  Round 3 additionally called full.record_stream(<context stream>): torch's caching allocator then
+        # records an event on that stream when `full` is FREED -- at function exit, where CPython drops the parameter `ctxs` (an
+        # early slot: bn_ctx_destroy -> hipStreamDestroy) before the later local `full` -- i.e. hipEventRecord on a destroyed stream,
+        # the crash in gpurun_out/r3c/tests.log.  record_stream is not needed (every context is synchronised before the collective
+        # reads the slab) and must never be used with a context's stream.
+        del views, streams, slab, full
+        torch.cuda.synchronize(model.device)
         # (rows of rank r sit at [r * cap, r * cap + n_r): with equal capacities the first G rows are exactly the windows in
         # time order, because only the LAST ranks can be short and their padding lies behind row G)
     else:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense one tools/profile_round.sh run into the files that are committed under profiles/.
 
-    python tools/profile_summary.py gpurun_out/<tag> <tag>
+    python tools/profile_summary.py gpurun_out/<tag> <tag> [v24|v30|perch] [batch]
 
 Writes profiles/<tag>_bench_default.json, _bench_1stream.json, _kernel_stats_default.csv,
 _kernel_stats_1stream.csv (rocprofv3 --kernel-trace --stats), <tag>_pmc_traffic.json and refreshes
@@ -65,6 +65,11 @@ def counters_by_family(path):
     return out
 
 
+MODEL, BATCH = "v24", 32  # set by main() from the command line
+def suffix():
+    return "" if MODEL == "v24" else "_" + MODEL
+
+
 def mfma_summary(src, tag):
     """profiles/<tag>_pmc_mfma.json: per kernel family, per launch -- matrix-pipe busy fraction, LDS bank-conflict share,
     wait breakdown, effective clock.  SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the chip's 1024 SIMDs;
@@ -88,8 +93,8 @@ def mfma_summary(src, tag):
             ni = max(i["_launches"], 1.0)
             e["per_launch"] = {k[3:].lower(): round(i[k] / ni) for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES") if k in i}
         fams[fam] = e
-    doc = {"tag": tag, "batch": 32,
-           "command": "rocprofv3 --pmc <SQ counters + GRBM_GUI_ACTIVE> (separate passes, no trace domains) -- python3 tools/pmc_run.py 32 3",
+    doc = {"tag": tag, "batch": BATCH, "model": MODEL,
+           "command": f"rocprofv3 --pmc <SQ counters + GRBM_GUI_ACTIVE> (separate passes, no trace domains) -- python3 tools/pmc_run.py {BATCH} 3 {MODEL}",
            "definitions": {"mfma_busy": "SQ_VALU_MFMA_BUSY_CYCLES (= 64 per v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_16x16x4_f32, per SIMD) / (1024 SIMDs x launch duration x 2.4 GHz): "
                                         "the fraction of the matrix pipes' peak-clock cycles the launch kept busy",
                            "mfma_busy_grbm": "the same over GRBM_GUI_ACTIVE / 8; that quotient reads high on dispatches under ~0.3 ms "
@@ -98,7 +103,7 @@ def mfma_summary(src, tag):
                            "lds_bank_conflict_share": "SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE"},
            "families": fams}
     json.dump(doc, open(f"profiles/{tag}_pmc_mfma.json", "w"), indent=1)
-    json.dump(doc, open("profiles/pmc_mfma.json", "w"), indent=1)
+    json.dump(doc, open(f"profiles/pmc_mfma{suffix()}.json", "w"), indent=1)
     return doc
 
 
@@ -114,7 +119,10 @@ def stats_by_family(path):
 
 
 def main():
+    global MODEL, BATCH
     src, tag = sys.argv[1], sys.argv[2]
+    MODEL = sys.argv[3] if len(sys.argv) > 3 else "v24"
+    BATCH = int(sys.argv[4]) if len(sys.argv) > 4 else 32
     os.makedirs("profiles", exist_ok=True)
     for name in ("bench_default", "bench_1stream"):
         line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
@@ -131,13 +139,13 @@ def main():
         n = max(n, n2, 1)
         traffic[fam] = {"launches_profiled": n, "fetch_size_kib_raw_per_launch": round(fk / n, 1), "write_size_kib_per_launch": round(wk / n, 1),
                         "hbm_bytes_per_launch": round((2.0 * fk + wk) * 1024.0 / n)}
-    doc = {"tag": tag, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/pmc_run.py 32 3",
+    doc = {"tag": tag, "model": MODEL, "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/pmc_run.py {BATCH} 3 {MODEL}",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
-           "batch": 32, "families": traffic,
+           "batch": BATCH, "families": traffic,
            "kernel_stats_1stream": stats_by_family(os.path.join(src, "trace_1stream")),
            "kernel_stats_default": stats_by_family(os.path.join(src, "trace_default"))}
     json.dump(doc, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
-    json.dump(doc, open("profiles/pmc_traffic.json", "w"), indent=1)
+    json.dump(doc, open(f"profiles/pmc_traffic{suffix()}.json", "w"), indent=1)
     print(json.dumps(doc["families"], indent=1))
     print(json.dumps(doc["kernel_stats_1stream"], indent=1))
     if os.path.isdir(os.path.join(src, "pmc_sq")):
