@@ -587,7 +587,8 @@ class Builder {
     // spectrum, window and amplitudes by alternating least squares over all rows, and the model is accepted only if
     // every tap of every row agrees with it within f32 rounding of the taps (BN_STFT_TOL x max|row|, default 4e-7).
     // Then ONE launch of stft_kernel (kernels.h, FftDesc) computes all rows -- cos and sin blocks together -- instead
-    // of one folded GEMM per symmetry run.  L must be a power of two in 128..2048.  Whether a recognised bank runs as an FFT: emit_stft.
+    // of one folded GEMM per symmetry run.  L must be a power of two in 128..2048, or five times a power of two (Perch's L = 640:
+    // mixed radix 5 x 4 x 16).  Whether a recognised bank runs as an FFT: emit_stft.
     struct DftBank {
         int64_t L = 0;
         std::vector<float> window;
@@ -614,8 +615,34 @@ class Builder {
                 }
         }
     }
+    // L = 10 * 4^j * 16 ... in the kernel's terms: M = L / 2 = 5 q with q = 4^j * 16 a power of FOUR times 16 (radix 5 first, then
+    // radix-4 passes down to the 16-point register blocks; a radix-2 pass exists only as a FIRST pass) -- 640 is the one in use
+    static bool fft_five_pow2(int64_t L) {
+        if (L % 10) return false;
+        int64_t q = L / 10;
+        if (q < 64 || (q & (q - 1))) return false;
+        int lg = 0;
+        while (((int64_t)1 << lg) < q) lg++;
+        return lg % 2 == 0;  // q = 16 * 4^j
+    }
+    // bins 0 .. n/2 of the DFT of a real row by the definition (any n; the peak search below reads no other bin)
+    static void host_dft_half(std::vector<double> &re, std::vector<double> &im) {
+        const size_t n = re.size();
+        std::vector<double> c(n), s_(n), xr(re);
+        for (size_t t = 0; t < n; t++) { c[t] = std::cos(2.0 * M_PI * (double)t / (double)n); s_[t] = std::sin(2.0 * M_PI * (double)t / (double)n); }
+        for (size_t k = 0; k <= n / 2; k++) {
+            double ar = 0, ai = 0;
+            for (size_t t = 0; t < n; t++) {
+                const size_t ph = (k * t) % n;
+                ar += xr[t] * c[ph];
+                ai -= xr[t] * s_[ph];
+            }
+            re[k] = ar; im[k] = ai;
+        }
+    }
     bool detect_dft_bank(const std::vector<float> &wf, int64_t Cout, int64_t L, const std::vector<int> &cls, DftBank &bank) {
-        if (L < 128 || L > 2048 || (L & (L - 1))) return false;
+        const bool pow2 = (L & (L - 1)) == 0;
+        if (L < 128 || L > 2048 || !(pow2 || fft_five_pow2(L))) return false;
         const double tol = getenv("BN_STFT_TOL") ? atof(getenv("BN_STFT_TOL")) : 4e-7;
         bank.L = L;
         bank.k.assign((size_t)Cout, 0);
@@ -636,7 +663,8 @@ class Builder {
             live[(size_t)c] = 1;
             is_sin[(size_t)c] = cls[(size_t)c] < 0;
             std::vector<double> re(w, w + L), im((size_t)L, 0.0);
-            host_fft(re, im);
+            if (pow2) host_fft(re, im);
+            else host_dft_half(re, im);
             int best = 0;
             double bm = -1;
             for (int64_t q = 0; q <= L / 2; q++) {
@@ -816,8 +844,7 @@ class Builder {
         if (mode == "0") return false;
         if (getenv("BN_STFT_MINBINS") && Cout < atoll(getenv("BN_STFT_MINBINS"))) return false;
         if (mode != "1") {
-            double lg = 0;
-            while ((1 << (int)lg) < bank.L) lg += 1;
+            const double lg = std::log2((double)bank.L);
             const double gemm_cycles = (double)Cout * (double)(bank.L / 2) / 32.0, fft_cycles = 0.18 * (double)bank.L * lg;
             if (!(gemm_cycles > 1.5 * fft_cycles)) return false;
         }
@@ -835,20 +862,28 @@ class Builder {
         d.logM = 0;
         while ((1 << d.logM) < M) d.logM++;
         d.F = 1024 / M;
+        const bool five = M % 5 == 0;  // M = 5 q (detect_dft_bank: q = 16 * 4^j): three frames of 320 slots per wave pass
         // frames per tile: as many as keep the tile's signal span within the kernel's staging registers (8192 floats)
-        d.tpb = 16;
-        while (d.tpb > d.F && (int64_t)(d.tpb - 1) * g.lda + L > 8192) d.tpb /= 2;
+        if (five) {
+            // whole wave passes, one per wave of the block where the span allows: 8 waves x F frames
+            d.tpb = 8 * d.F;
+            while (d.tpb > d.F && (int64_t)(d.tpb - 1) * g.lda + L > 8192) d.tpb -= d.F;
+        } else {
+            d.tpb = 16;
+            while (d.tpb > d.F && (int64_t)(d.tpb - 1) * g.lda + L > 8192) d.tpb /= 2;
+        }
         if ((int64_t)(d.tpb - 1) * g.lda + L > 8192 || d.tpb % d.F) return false;
         d.a_bs = g.a_bs; d.ldc = g.ldc; d.c_bs = g.c_bs; d.has_bias = has_bias ? 1 : 0;
         d.out_rs = g.ldc; d.out_cs = 1;
         d.power = 0; d.otab_stride = 8;
-        // pass structure: radix 2 first when log2 M is odd, radix 4 down to 16-point blocks (registers)
+        // pass structure: radix 5 first for M = 5 q, radix 2 first when log2 M is odd, radix 4 down to 16-point blocks (registers)
         std::vector<int> radix;
         std::vector<float> tw;
         int nn = M;
         d.npass = 0;
         while (nn > 16) {
-            const int r = (d.npass == 0 && (d.logM & 1)) ? 2 : 4;
+            const int r = (d.npass == 0 && five) ? 5 : (d.npass == 0 && (d.logM & 1)) ? 2 : 4;
+            if (nn % r) return false;
             const int q = nn / r;
             d.pass_n[d.npass] = nn; d.pass_r[d.npass] = r; d.pass_tw[d.npass] = (int32_t)(tw.size() / 2);
             for (int pw = 1; pw < r; pw++)
@@ -887,8 +922,7 @@ class Builder {
         op.w = Ref{Space::CONSTS, add_const(bank.window), 0};
         op.w2 = Ref{Space::CONSTS, add_const(tw), 0};
         op.bias2 = Ref{Space::CONSTS, add_const(otab), 0};
-        double log2L = 0;
-        while ((1 << (int)log2L) < L) log2L += 1;
+        const double log2L = std::log2((double)L);
         op.flops_fft = (double)OW * 2.5 * L * log2L;
         op.macs = op.flops_fft / 2;  // multiply-add equivalents actually performed (vector ALU)
         op.mfma = false;
@@ -949,11 +983,7 @@ class Builder {
         if (runs.size() > 4) return false;
         dft_gemm_macs_ += (double)OW * Cout * L;
         dft_performed_macs_ += (double)OW * Cout * (L / 2);  // folded: half the taps
-        {
-            double lg = 0;
-            while ((1 << (int)lg) < L) lg += 1;
-            if ((int64_t)1 << (int)lg == L) dft_fft_equiv_flops_ += (double)OW * 2.5 * (double)L * lg;  // the same frames as real FFTs
-        }
+        dft_fft_equiv_flops_ += (double)OW * 2.5 * (double)L * std::log2((double)L);  // the same frames as real FFTs (SURVEY 8(d) pricing, any L)
         const int64_t K = L / 2;
         for (const Run &r : runs) {
             const int sign = r.sign == 0 ? 1 : r.sign;
@@ -3027,6 +3057,7 @@ class Builder {
             for (size_t i = 0; i < plan_.ops.size() && !changed; i++) {
                 PlanOp &f = plan_.ops[i];
                 if (f.kind != OpKind::FFT || f.fft.nmel || f.out.space != Space::ARENA || plan_.storages[f.out.id].pinned) continue;
+                if (f.fft.tpb & (f.fft.tpb - 1)) continue;  // the mel phases index a tile's frames by shifts / 16-frame matrix tiles (M = 5 q banks: tiles of 24)
                 const auto &u = users[f.out.id];
                 if (u.size() != 2 || u[0] != (int)i) continue;
                 PlanOp &g = plan_.ops[u[1]];

@@ -61,6 +61,25 @@ __device__ __forceinline__ void bfly4(float2 &u0, float2 &u1, float2 &u2, float2
     u3 = make_float2(t1.x - t3.x, t1.y - t3.y);
 }
 
+// forward radix-5 butterfly (omega_5 = e^(-2 pi i / 5)): v_p = sum_m u_m omega_5^(m p)
+//   t1 = u1 + u4, t2 = u2 + u3, t3 = u1 - u4, t4 = u2 - u3;  a1 = u0 + c1 t1 + c2 t2, a2 = u0 + c2 t1 + c1 t2;
+//   b1 = s1 t3 + s2 t4, b2 = s2 t3 - s1 t4;  v1 = a1 - i b1, v4 = a1 + i b1, v2 = a2 - i b2, v3 = a2 + i b2
+__device__ __forceinline__ void bfly5(float2 &u0, float2 &u1, float2 &u2, float2 &u3, float2 &u4) {
+    constexpr float C1 = 0.30901699437494742410f, C2 = -0.80901699437494742410f;  // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float S1 = 0.95105651629515357212f, S2 = 0.58778525229247312917f;   // sin(2 pi / 5), sin(4 pi / 5)
+    const float2 t1 = make_float2(u1.x + u4.x, u1.y + u4.y), t2 = make_float2(u2.x + u3.x, u2.y + u3.y);
+    const float2 t3 = make_float2(u1.x - u4.x, u1.y - u4.y), t4 = make_float2(u2.x - u3.x, u2.y - u3.y);
+    const float2 a1 = make_float2(u0.x + C1 * t1.x + C2 * t2.x, u0.y + C1 * t1.y + C2 * t2.y);
+    const float2 a2 = make_float2(u0.x + C2 * t1.x + C1 * t2.x, u0.y + C2 * t1.y + C1 * t2.y);
+    const float2 b1 = make_float2(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
+    const float2 b2 = make_float2(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
+    u0 = make_float2(u0.x + t1.x + t2.x, u0.y + t1.y + t2.y);
+    u1 = make_float2(a1.x + b1.y, a1.y - b1.x);  // a1 - i b1
+    u4 = make_float2(a1.x - b1.y, a1.y + b1.x);
+    u2 = make_float2(a2.x + b2.y, a2.y - b2.x);
+    u3 = make_float2(a2.x - b2.y, a2.y + b2.x);
+}
+
 // one in-place DIF pass over the wave's 1024 slots: sub-problems of size n, radix R, twiddles tw[(p-1)*q + j].
 // Two butterflies per lane are in flight at a time (register budget: 256 per lane at 8 waves per CU).
 template <int R, int SLOTS>
@@ -248,6 +267,36 @@ __device__ __forceinline__ void first_pass(float2 *__restrict__ x, const float2 
     }
 }
 
+// the same for a frame of M = 5 q complex points (q a power of two: Perch's L = 640 bank is 5 x 64): radix 5 first, the rest of the
+// transform then runs on power-of-two sub-problems of size q with the passes above.  F frames per wave pass, frame fi at slot fi M.
+template <int SLOTS>
+__device__ __forceinline__ void first_pass5(float2 *__restrict__ x, const float2 *__restrict__ tw, const float *__restrict__ sig,
+                                            const float2 *__restrict__ wnd, int M, int logq, int F, int hop, int frame0, int rows_here, int lane) {
+    const int q = 1 << logq, total = F << logq;
+#pragma unroll 1
+    for (int g = lane; g < total; g += 64) {
+        const int fi = g >> logq, j = g & (q - 1);
+        int fr = frame0 + fi;
+        fr = fr < rows_here ? fr : rows_here - 1;
+        const float *sp = sig + fr * hop;
+        float2 u[5];
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const int i = j + m * q;
+            const float2 w2 = wnd[i];
+            u[m] = make_float2(sp[2 * i] * w2.x, sp[2 * i + 1] * w2.y);
+        }
+        const float2 w1 = tw[j], w2 = tw[q + j], w3 = tw[2 * q + j], w4 = tw[3 * q + j];
+        bfly5(u[0], u[1], u[2], u[3], u[4]);
+        const int base = fi * M + j;
+        x[phys(base)] = u[0];
+        x[phys(base + q)] = cmul(u[1], w1);
+        x[phys(base + 2 * q)] = cmul(u[2], w2);
+        x[phys(base + 3 * q)] = cmul(u[3], w3);
+        x[phys(base + 4 * q)] = cmul(u[4], w4);
+    }
+}
+
 // Persistent blocks: a block walks the (sample, frame tile) work items blockIdx.x, + gridDim.x, ...; the tables are
 // copied to LDS once, and the NEXT tile's signal span is fetched into registers while the current tile is transformed.
 // PRE: the launch carries an absorbed prologue chain (false: none of its state exists -- the kernel keeps far more launch-uniform
@@ -268,7 +317,8 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     float *mstart = lds + lay.mstart;
     float2 *ment = reinterpret_cast<float2 *>(lds + lay.ment);
     float *spec = lds + lay.spec;
-    const int M = d.M, logM = d.logM, hop = d.hop, nout = d.nout, nmel = MELM == 0 ? 0 : d.nmel, F = SLOTS >> d.logM;  // frames per wave pass
+    const int M = d.M, logM = d.logM, hop = d.hop, nout = d.nout, nmel = MELM == 0 ? 0 : d.nmel;
+    const int F = SLOTS == 1024 ? d.F : (SLOTS >> d.logM);  // frames per wave pass (M = 5 q: three frames of 320 slots)
     const int dbg = d.dbg;
 
     // ---- tables -> LDS, once per block
@@ -301,7 +351,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     const float po_p00 = d.post_p0[0], po_p01 = d.post_p0[1], po_p02 = d.post_p0[2], po_p03 = d.post_p0[3];
     const float po_p10 = d.post_p1[0], po_p11 = d.post_p1[1], po_p12 = d.post_p1[2], po_p13 = d.post_p1[3];
     // log2 of the sub-problem sizes of the strided passes after the first (each a quarter of its predecessor)
-    const int ln1 = logM - (d.pass_r[0] == 2 ? 1 : 2), ln2 = ln1 - 2, ln3 = ln1 - 4;
+    const int ln1 = 31 - __builtin_clz((unsigned)max(d.pass_n[1], 1)), ln2 = ln1 - 2, ln3 = ln1 - 4;  // (pass_n[1] = M / first radix)
     const int pt0 = d.pass_tw[0], pt1 = d.pass_tw[1], pt2 = d.pass_tw[2], pt3 = d.pass_tw[3];
     const int npass = d.npass, first_radix = d.pass_r[0];
 
@@ -399,7 +449,8 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
         const int groups = (rows_here + F - 1) / F;
         for (int g = wave; g < groups; g += NW) {
             if (!(dbg & 1)) {
-                if (first_radix == 2) first_pass<2, SLOTS>(wbuf, tw + pt0, sig, wnd, M, logM, hop, g * F, rows_here, lane);
+                if (first_radix == 5) first_pass5<SLOTS>(wbuf, tw + pt0, sig, wnd, M, 31 - __builtin_clz((unsigned)(M / 5)), F, hop, g * F, rows_here, lane);
+                else if (first_radix == 2) first_pass<2, SLOTS>(wbuf, tw + pt0, sig, wnd, M, logM, hop, g * F, rows_here, lane);
                 else first_pass<4, SLOTS>(wbuf, tw + pt0, sig, wnd, M, logM, hop, g * F, rows_here, lane);
                 wave_sync();
                 if (1 < npass) { strided_pass<4, SLOTS>(wbuf, tw + pt1, ln1, lane); wave_sync(); }

@@ -132,7 +132,7 @@ def test_conv1d_folded_dft_framing(bn, n_fft, hop, kind, bias, monkeypatch):
         u = g.node("Unsqueeze", [x, g.const(np.array([1], dtype=np.int64))])
         return g.node("Conv", [u, g.const(w)] + ([g.const(b)] if bias else []), kernel_shape=[n_fft], strides=[hop])
     data = op_graph(build, [w.shape[0], frames])
-    pow2 = n_fft & (n_fft - 1) == 0
+    pow2 = n_fft & (n_fft - 1) == 0 or n_fft == 640  # (640 = 2 x 5 x 64: radix 5 first, round 4)
     monkeypatch.setenv("BN_STFT", "1")
     text = bn.plan_describe(write_model(data))
     if pow2:
@@ -169,10 +169,11 @@ def test_conv1d_folded_dft_framing(bn, n_fft, hop, kind, bias, monkeypatch):
     assert_close(got, plain, "folded vs unfolded plan", atol=2e-5 * float(np.abs(plain).max()), rtol=0)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(128, 64), (256, 100), (512, 160), (1024, 320), (2048, 278)])
+@pytest.mark.parametrize("n_fft,hop", [(128, 64), (256, 100), (512, 160), (1024, 320), (2048, 278), (640, 320), (640, 203)])
 def test_stft_every_transform_size(bn, n_fft, hop, monkeypatch):
-    """All supported frame lengths (one radix-2 pass first when log2 of the half length is odd), a non-Hann window,
-    rows in scrambled bin order with per-row gains and a bias."""
+    """All supported frame lengths (one radix-2 pass first when log2 of the half length is odd; radix 5 first for Perch's
+    L = 640 = 2 x 5 x 64, three frames per wave pass and tiles of 24 / 21 frames), a non-Hann window, rows in scrambled
+    bin order with per-row gains and a bias."""
     rng = np.random.default_rng(n_fft)
     n = np.arange(n_fft, dtype=np.float64)
     win = 0.54 - 0.46 * np.cos(2.0 * np.pi * n / n_fft)  # periodic Hamming: w[0] != 0 ...
@@ -236,7 +237,7 @@ def test_stft_with_absorbed_mel_bank_sizes(bn, n_mels, bias, monkeypatch):
     assert_close(got, walk, "matrix cores vs sparse walk", atol=tol, rtol=2e-4)
 
 
-@pytest.mark.parametrize("n_fft,hop,root", [(1024, 320, True), (512, 160, False), (256, 100, True)])
+@pytest.mark.parametrize("n_fft,hop,root", [(1024, 320, True), (512, 160, False), (256, 100, True), (640, 320, False), (640, 320, True)])
 def test_stft_power_spectrum_folded_into_the_launch(bn, n_fft, hop, root, monkeypatch):
     """re^2 + im^2 (-> sqrt) behind a cos | sin bank: the planner folds it into the FFT launch (FftDesc::power 1 / 2), which then
     writes one value per bin; with the rule off the elementwise launch comes back.  Both against the oracle."""
