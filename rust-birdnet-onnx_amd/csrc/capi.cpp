@@ -1623,6 +1623,10 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 snprintf(line, sizeof(line), " %dx%dx%d->(%d)->%dx%dx%d k=%d s=%d tiles=%dx%d squeeze=%d se=%d rows=%d%s", op.mb.H, op.mb.W, op.mb.Cin, op.mb.C, op.mb.OH, op.mb.OW, op.mb.C, op.mb.k, op.mb.s, op.mb.tiles_y, op.mb.tiles_x, op.mb.has_gap, op.se_fused,
                          op.mb.row_mode ? op.mb.toh : 0, op.mb.row_mode && op.mb.row_tr ? "(columns)" : "");
                 extra = line;
+                if (op.mb.whole_map == 2) {  // mbmap.hip: configuration, bands, transposition, padded k
+                    snprintf(line, sizeof(line), " map=cfg%d%s%s kpad=%d", mbmap_config(op.mb), op.mb.map_bands > 1 ? ",bands" : "", op.mb.map_tr ? ",transposed" : "", op.mb.cin_pad);
+                    extra += line;
+                }
             } else if (op.kind == OpKind::POOL) {
                 snprintf(line, sizeof(line), " %dx%dx%d->%dx%d k=%dx%d s=%dx%d max=%d", op.pool.H, op.pool.W, op.pool.C, op.pool.OH, op.pool.OW, op.pool.kh, op.pool.kw,
                          op.pool.sh, op.pool.sw, op.pool.is_max);

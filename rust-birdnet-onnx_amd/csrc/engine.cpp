@@ -2613,12 +2613,14 @@ class Builder {
                 // mid channels, input fetched once per block by LDS-DMA, no staging on the vector ALU.  Default wherever a
                 // configuration fits (192- and 48-pixel maps); BN_MBMAP2=0 disables.
                 int map2 = 0;
+                MbmapShape mshape;
                 if (producer0) {
                     MbDesc q{};
                     q.H = (int32_t)H; q.W = (int32_t)W; q.Cin = pe.gemm.K; q.C = (int32_t)Cin; q.OH = (int32_t)OH; q.OW = (int32_t)OW;
                     q.k = (int32_t)kw; q.s = (int32_t)strides[1]; q.pt = (int32_t)pt; q.pl = (int32_t)pl;
                     q.act1 = pe.gemm.act; q.act2 = act.act; q.in_bs = pe.gemm.a_bs;
-                    map2 = mbmap_config(q);
+                    mshape = mbmap_shape(q);
+                    map2 = mshape.cfg;
                 }
                 const bool whole_map = map2 != 0 || (!map_off && H * W <= map_maxhw);
                 const bool producer = producer0 && (map2 != 0 || pe.gemm.K <= (whole_map ? 256 : maxk));
@@ -2643,7 +2645,15 @@ class Builder {
                     mb.a = pe.a;
                     // expand filters repacked for the kernel: [C][KW] rows = Cin weights | zeros, KW = Cin rounded up to
                     // 8-wide K groups (the bias starts the accumulators)
-                    if (whole_map) {
+                    if (whole_map && map2 && mshape.cin_pad != pe.gemm.K) {
+                        // mbmap.hip with padded k: the filter rows get the zeros the input rows get from the zero page
+                        const int64_t Kc = pe.gemm.K, KP = mshape.cin_pad;
+                        const std::vector<float> &w0 = plan_.consts[pe.w.id];
+                        std::vector<float> wpk((size_t)(Cin * KP), 0.0f);
+                        for (int64_t nn = 0; nn < Cin; nn++)
+                            for (int64_t k = 0; k < Kc; k++) wpk[nn * KP + k] = w0[pe.w.offset + nn * Kc + k];
+                        mb.w = Ref{Space::CONSTS, add_const(wpk), 0};
+                    } else if (whole_map) {
                         mb.w = pe.w;  // [C][Cin] as the GEMM had it
                     } else {
                         const int64_t Kc = pe.gemm.K, KW = (Kc + 7) / 8 * 8;
@@ -2668,6 +2678,13 @@ class Builder {
                         m.whole_map = map2 ? 2 : 1;
                         m.tiles_x = m.tiles_y = 1;  // one squeeze partial per sample
                         halo = (double)H * W;
+                        if (map2) {
+                            m.map_bands = mshape.bands; m.map_tr = mshape.tr; m.cin_pad = mshape.cin_pad;
+                            m.tiles_y = mshape.bands;  // ... per band
+                            // expand work performed: every band expands the 6 rows it loads (the rows two bands share twice), over the padded k
+                            if (mshape.bands > 1) halo = (double)mshape.bands * 6.0 * (double)(mshape.tr ? H : W);
+                            halo *= (double)mshape.cin_pad / (double)pe.gemm.K;
+                        }
                     } else {
                         row_streaming(m, halo);
                     }

@@ -162,6 +162,10 @@ struct MbDesc {
     // several; H/W, OH/OW, pt/pl, tiles_x/tiles_y and toh stay in MAP terms in the plan, the launcher swaps them for the kernel
     int32_t row_tr;
     int32_t dbg;  // mbmap.hip experiments (BN_MM_DBG bit mask, set by the launcher): skip phases to time the rest
+    // mbmap.hip, round 4 (plan_rules.h, MbmapShape; all 0 for the other kernels): bands of the map a sample is cut into (one block
+    // each, squeeze sums partial per band: tiles_y = bands), the kernel's rows are the map's columns, floats per input / filter row
+    // in LDS (Cin rounded up to 16: the planner pads w1's rows to it, the missing input chunks are read from a page of zeros)
+    int32_t map_bands, map_tr, cin_pad;
 };
 // MaxPool / AveragePool over an NHWC tensor (1-D pooling = H == 1).
 struct PoolDesc {
@@ -357,6 +361,7 @@ void note_launch_device(int dev);
 // launch-time check only (no runtime call): true when `bytes` fits and the thread's launch device was prepared
 bool ensure_dynamic_lds(const void *kernel, size_t bytes);
 int device_cu_count();
+const float *device_zero_page();  // 4 KiB of zeros on the thread's launch device (allocated by prepare_device)
 size_t topk_lds_bytes(int64_t n, int64_t k);
 
 // device -> pinned host memory by a kernel's own stores (topk.hip): up to three regions of 32-bit words per launch;

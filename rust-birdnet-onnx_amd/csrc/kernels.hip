@@ -26,6 +26,7 @@
 
 #include "kernels.h"
 #include "plan_rules.h"
+#include "hip_gate.h"
 #include "device_common.h"
 
 namespace bn {
@@ -58,6 +59,7 @@ namespace {
 std::mutex g_prep_mu;
 std::atomic<uint64_t> g_prepared_mask{0};  // device ordinals < 64 that prepare_device() has completed on
 std::atomic<int> g_cu_count[64];
+std::atomic<float *> g_zero_page[64];
 std::vector<const void *> &dyn_lds_kernels() {
     static std::vector<const void *> v;
     return v;
@@ -101,6 +103,14 @@ bool prepare_device(int dev) {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
     g_cu_count[dev].store(v, std::memory_order_relaxed);
+    {  // a page of zeros: the source of LDS-DMA lanes whose chunk lies in a row's padding (mbmap.hip)
+        float *z = nullptr;
+        if (gated::Malloc(&z, 4096) != hipSuccess || gated::Memset(z, 0, 4096) != hipSuccess || gated::DeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            ok = false;
+        }
+        g_zero_page[dev].store(z, std::memory_order_relaxed);
+    }
     if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
     if (ok) g_prepared_mask.fetch_or(1ull << dev, std::memory_order_release);
     return ok;
@@ -118,6 +128,14 @@ bool ensure_dynamic_lds(const void *kernel, size_t bytes) {
     // a thread that never went through the C ABI's device selection (the stand-alone probes under tools/) is answered for
     // "some prepared device"; everything the library launches itself has noted its device
     return dev >= 0 && dev < 64 ? (m >> dev) & 1ull : m != 0;
+}
+const float *device_zero_page() {
+    const uint64_t m = g_prepared_mask.load(std::memory_order_acquire);
+    const int dev = t_launch_dev;
+    if (dev >= 0 && dev < 64 && ((m >> dev) & 1ull)) return g_zero_page[dev].load(std::memory_order_relaxed);
+    for (int d = 0; d < 64; d++)
+        if (m & (1ull << d)) return g_zero_page[d].load(std::memory_order_relaxed);
+    return nullptr;
 }
 int device_cu_count() {
     const uint64_t m = g_prepared_mask.load(std::memory_order_acquire);

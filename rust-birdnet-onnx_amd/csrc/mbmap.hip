@@ -21,6 +21,17 @@
 //     row segments with run-time bounds: 5 - 7 us per chunk against 3 us for the expand it follows);
 //   * the squeeze sums are complete per (sample, channel): the excite kernel adds nothing up (splits = 1).
 //
+// Round 4 -- three generalisations, all in this one kernel (plan_rules.h, mbmap_shape):
+//   * BANDS (NB = 2, HM = 8: BirdNET v3.0's 8 x 32 stage, Perch's 32 x 8 one walked transposed): a sample's map is cut into NB bands
+//     of OHM / NB output rows; a band is a block of its own (blockIdx.z) that loads the H = 6 input rows its outputs reach.  Those are
+//     REAL rows of the map (the first loaded row gy0 is clamped into the map), so nothing is padded at run time: which (input
+//     row, tap row) pairs feed which output row is still resolved at compile time, per band (ROFF = PT + gy0 - band * OHB * S);
+//     the squeeze sums are partial per band (gap[b][band][C], the excite kernel adds the NB partials in band order);
+//   * TRANSPOSED maps (d.map_tr, run time): the kernel's row index is the map's x -- only the input gather, the output
+//     address and the order of the depthwise taps change;
+//   * PADDED k (d.cin_pad > d.Cin, run time): rows of the LDS images are cin_pad floats, the chunks past Cin of an input row
+//     come from a page of zeros (the LDS-DMA source address is per lane), the planner pads the filter rows with zeros.
+//
 // Arithmetic order per output: expand = bias + k ascending in 16-wide groups (k-slot j of a group: k = 16 g + 4 q + j),
 // depthwise = bias2 + taps (ky, kx) ascending -- independent of the batch and of the channel grouping.
 #include <hip/hip_runtime.h>
@@ -28,6 +39,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_common.h"
 #include "kernels.h"
@@ -69,6 +81,39 @@ __device__ __forceinline__ void mm_copy(float *lds_dst, const float *gsrc, int r
     }
 }
 
+// every real map row the outputs of band b reach lies inside the H rows the band's block loads (first row gy0, clamped into the map)
+constexpr bool mm_bands_ok(int K, int S, int H, int HM, int NB) {
+    const int PT = (K - 1) / 2, OHM = (HM + 2 * PT - K) / S + 1, OH = OHM / NB;
+    for (int b = 0; b < NB; b++) {
+        const int first = b * OH * S - PT, last = (b * OH + OH - 1) * S + K - 1 - PT;
+        const int lo = first < 0 ? 0 : first, hi = last > HM - 1 ? HM - 1 : last;
+        int gy0 = NB > 1 ? first : 0;
+        gy0 = gy0 < 0 ? 0 : (gy0 > HM - H ? HM - H : gy0);
+        if (lo < gy0 || hi >= gy0 + H) return false;
+    }
+    return true;
+}
+
+// the input image of a block: rows = pixels of the band (row-major in the KERNEL's geometry, W pixels per row), CHP chunks per LDS
+// row of which the first CHS exist in memory; transposed maps gather (kernel pixel (r, c) is map pixel (y = c, x = gy0 + r) of a
+// map that is HM wide), padding chunks read the page of zeros
+template <int NWAVES, bool SWZ16, int W, int HM>
+__device__ __forceinline__ void mm_copy_in(float *lds_dst, const float *gsrc, const float *zpage, int rows, int CHP, int CHS, int Cin, uint32_t inv_ch,
+                                           int gy0, int tr, int wave, int lane) {
+    const int n16 = rows * CHP;
+    for (int c0 = wave * 64; c0 < n16; c0 += NWAVES * 64) {
+        int sl = c0 + lane;
+        sl = sl < n16 ? sl : n16 - 1;
+        const int r = (int)__umulhi((uint32_t)sl, inv_ch);
+        const int c = sl - r * CHP;
+        const int cl = c ^ mm_swz<SWZ16>(r);
+        const int pr = r / W, pc = r - pr * W;  // W is a power of two
+        const int pix = tr ? pc * HM + gy0 + pr : gy0 * W + r;
+        const float *src = cl < CHS ? gsrc + (size_t)pix * (size_t)Cin + 4 * cl : zpage;
+        __builtin_amdgcn_global_load_lds(MM_GLB_PTR(src), MM_LDS_PTR(lds_dst + 4 * c0), 16, 0, 0);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void mm_act(int act, float p0, float p1, float (&v)[N]) {
     if (act == ACT_RELU) map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); });
@@ -81,21 +126,24 @@ __device__ __forceinline__ void mm_act(int act, float p0, float p1, float (&v)[N
 // the expand are split between two sets of waves whose partial tiles are added through the chunk image -- twice the
 // waves for the same LDS, used where a map of 48 pixels gives four waves too little to hide anything); the map has
 // exactly H W = 16 MW WM pixels, a chunk 16 NW WN channels
-template <int K, int S, int MW, int NW, int WM, int WN, int KSP, int H, int W, bool SWZ16>
+template <int K, int S, int MW, int NW, int WM, int WN, int KSP, int H, int W, bool SWZ16, int NB = 1, int HM = H>
 __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                                    const float *__restrict__ w1, const float *__restrict__ b1,
                                                                    const float *__restrict__ w2, const float *__restrict__ b2,
-                                                                   float *__restrict__ gap, int nch, uint32_t inv_ch) {
+                                                                   float *__restrict__ gap, int nch, uint32_t inv_ch, const float *__restrict__ zpage) {
     constexpr int WPS = WM * WN, NWAVES = WPS * KSP, T = 64 * NWAVES, HW = 16 * MW * WM, NC = 16 * NW * WN, NG = T / NC;
-    static_assert(H * W == HW, "the map is exactly the pixels of the wave tiles");
+    static_assert(H * W == HW, "the band is exactly the pixels of the wave tiles");
     static_assert(KSP == 1 || (KSP == 2 && SWZ16), "the K split walks the 4-group blocks of the SWZ16 layout");
-    constexpr int PT = (K - 1) / 2;  // padding on every side (checked by mbmap_config)
-    constexpr int OH = (H + 2 * PT - K) / S + 1, OW = (W + 2 * PT - K) / S + 1;
+    static_assert((W & (W - 1)) == 0 && NB >= 1 && NB <= 2 && (NB > 1 || HM == H), "bands: one or two, of a map HM rows high");
+    constexpr int PT = (K - 1) / 2;  // padding on every side (checked by mbmap_shape)
+    constexpr int OHM = (HM + 2 * PT - K) / S + 1, OH = OHM / NB, OW = (W + 2 * PT - K) / S + 1;  // OH: output rows of ONE band
+    static_assert(OHM % NB == 0 && mm_bands_ok(K, S, H, HM, NB), "a band's outputs reach only the rows its block loads");
     static_assert(OW % NG == 0, "one strip of output columns per lane group");
     constexpr int PPG = OW / NG, IWS = (PPG - 1) * S + K, WP = W + K - 1;
     constexpr int EP = NC + 4;  // floats per pixel of the chunk image: 4 of padding make the tile stores conflict free
     extern __shared__ __align__(1024) float mm_lds[];
-    const int Cin = d.Cin, CH = Cin >> 2;
+    const int Cin = d.cin_pad, CH = Cin >> 2;             // floats / chunks per LDS row (the padded k; == d.Cin unless the planner padded)
+    const int tr = d.map_tr;
     float *Xs = mm_lds;                                   // [HW][Cin]
     float *Ws = Xs + mm_kib(HW * Cin);                    // [2][NC][Cin]
     const int wsz = mm_kib(NC * Cin);
@@ -107,11 +155,13 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
     const int kh = wave / WPS, w4 = wave % WPS;           // K slice, wave inside the slice
     const int wm = w4 % WM, wn = w4 / WM;
     const int64_t b = blockIdx.y;
+    const int band = NB > 1 ? (int)blockIdx.z : 0;        // (block-uniform)
+    const int gy0 = NB > 1 ? min(max(band * OH * S - PT, 0), HM - H) : 0;  // first map row of the band's image
     const int cbase = blockIdx.x * nch * NC;              // first mid channel of this block
     const int nchunks = min(nch, (d.C - cbase + NC - 1) / NC);
 
     // ---- prologue: the sample's input and the first filter chunk on their way, the padding of the chunk image zeroed
-    mm_copy<NWAVES, SWZ16>(Xs, in + b * d.in_bs, HW, CH, inv_ch, wave, lane);
+    mm_copy_in<NWAVES, SWZ16, W, HM>(Xs, in + b * d.in_bs, zpage, HW, CH, d.Cin >> 2, d.Cin, inv_ch, gy0, tr, wave, lane);
     mm_copy<NWAVES, SWZ16>(Ws, w1 + (int64_t)cbase * Cin, min(NC, d.C - cbase), CH, inv_ch, wave, lane);
     // the K - 1 padding columns of every row of the chunk image are zero and stay zero (the expand writes the interior)
     for (int i = tid; i < H * (K - 1) * (EP / 4); i += T) {
@@ -163,7 +213,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
         // sign-extended and added 64 bits on the vector ALU for every tap, 110 of the chunk's 800 vector instructions)
         const unsigned cl = (unsigned)min(c0 + c, d.C - 1);
 #pragma unroll
-        for (int q = 0; q < K * K; q++) cc_.wd[q] = (w2 + (size_t)q * (size_t)d.C)[cl];
+        for (int q = 0; q < K * K; q++) cc_.wd[q] = (w2 + (size_t)(tr ? (q % K) * K + q / K : q) * (size_t)d.C)[cl];  // kernel tap (ky, kx) = map tap (kx, ky) when transposed
         cc_.bz = d.has_bias2 ? b2[cl] : 0.0f;
     };
     ChunkConst nxt;
@@ -273,9 +323,12 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
-        // ---- depthwise + squeeze: all OH x PPG outputs of the strip in registers, input rows read once each
+        // ---- depthwise + squeeze: all OH x PPG outputs of the strip in registers, input rows read once each.  ROFF = PT + gy0 -
+        // band * OH * S places the band's outputs on its image rows: output row oy (of the band) takes image row oy * S + ky - ROFF
+        // where that row exists (compile time; for a whole map ROFF = PT and the skipped rows are the zero padding)
         float sum = 0.0f;
-        if (!(d.dbg & 2)) {
+        auto dw_phase = [&](auto roff_c) {
+            constexpr int ROFF = decltype(roff_c)::value;
             float ov[OH][PPG];
 #pragma unroll
             for (int oy = 0; oy < OH; oy++)
@@ -284,12 +337,19 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
             const float *rp0 = Es + (ox0 * S) * EP + c;
 #pragma unroll
             for (int iy = 0; iy < H; iy++) {
+                bool used = false;  // (compile time) an image row no output of the band reaches is not read
+#pragma unroll
+                for (int ky = 0; ky < K; ky++) {
+                    const int t = iy + ROFF - ky;
+                    used = used || (t >= 0 && t % S == 0 && t / S < OH);
+                }
+                if (!used) continue;
                 float val[IWS];
 #pragma unroll
                 for (int ix = 0; ix < IWS; ix++) val[ix] = rp0[(iy * WP + ix) * EP];
 #pragma unroll
                 for (int ky = 0; ky < K; ky++) {
-                    const int t = iy + PT - ky;  // = oy * S for the output row this (input row, tap row) pair feeds
+                    const int t = iy + ROFF - ky;  // = oy * S for the output row this (image row, tap row) pair feeds
                     if (t >= 0 && t % S == 0 && t / S < OH) {  // compile time after unrolling
 #pragma unroll
                         for (int q = 0; q < PPG; q++)
@@ -298,8 +358,11 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
                     }
                 }
             }
+            // output element (row, column) of the kernel's geometry: + row * o_rs + column * o_cs floats (transposed: the map's (x, y))
             float *ob = out + b * d.out_bs;                                  // uniform
-            const unsigned olane = (unsigned)(cg + ox0 * d.C);                // this lane's channel + strip offset
+            const unsigned o_cs = tr ? (unsigned)(OHM * d.C) : (unsigned)d.C;
+            const unsigned o_rs = tr ? (unsigned)d.C : (unsigned)(OW * d.C);
+            const unsigned olane = (unsigned)cg + (unsigned)ox0 * o_cs;        // this lane's channel + strip offset
 #pragma unroll
             for (int oy = 0; oy < OH; oy++) {
                 float r[PPG];
@@ -309,10 +372,19 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
                 if (cact) {
 #pragma unroll
                     for (int q = 0; q < PPG; q++) {
-                        if (!(d.dbg & 4)) (ob + (size_t)(oy * OW + q) * (size_t)d.C)[olane] = r[q];
+                        if (!(d.dbg & 4)) (ob + (size_t)((unsigned)(band * OH + oy) * o_rs + (unsigned)q * o_cs))[olane] = r[q];
                         sum += r[q];
                     }
                 }
+            }
+        };
+        if (!(d.dbg & 2)) {
+            if constexpr (NB == 1) {
+                dw_phase(std::integral_constant<int, PT>{});
+            } else {
+                constexpr int G1 = (OH * S - PT) < 0 ? 0 : ((OH * S - PT) > HM - H ? HM - H : (OH * S - PT));  // gy0 of band 1
+                if (band == 0) dw_phase(std::integral_constant<int, PT>{});               // gy0 = 0
+                else dw_phase(std::integral_constant<int, PT + G1 - OH * S>{});
             }
         }
         if (d.has_gap) red[grp * NC + c] = sum;
@@ -325,7 +397,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
             float t = red[c];
 #pragma unroll
             for (int y = 1; y < NG; y++) t += red[y * NC + c];
-            gap[b * d.gap_bs + cg] = t;  // (read before the next chunk writes `red`: that happens behind its own barrier)
+            gap[b * d.gap_bs + (int64_t)band * d.C + cg] = t;  // (read before the next chunk writes `red`: that happens behind its own barrier)
         }
     }
 }
@@ -338,57 +410,69 @@ inline bool mm_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15
 // one -- the blocks are LDS-bound to one per CU, so more blocks than CUs means a second round (measured, batch 32:
 // 1152 channels as 288 blocks 32 us, as 192 blocks 25 us) and fewer blocks amortise the input fetch better.  The
 // grouping does not enter the arithmetic (squeeze sums are complete per channel inside a block).
-int mbmap_chunks_per_block(const MbDesc &d, int cfg, int64_t batch) {
+int mbmap_chunks_per_block(const MbDesc &d, const MbmapShape &sh, int64_t batch) {
     const int force = getenv("BN_MBMAP2_NCH") ? atoi(getenv("BN_MBMAP2_NCH")) : 0;
-    const int nc = (cfg == 2 || cfg == 4) ? 32 : 64;
+    const int nc = (sh.cfg == 1 || sh.cfg == 3) ? 64 : 32;
     const int chunks = (d.C + nc - 1) / nc;
     if (force > 0) return std::min(force, chunks);
     const int64_t ncu = device_cu_count();
-    return (int)std::max<int64_t>(1, std::min<int64_t>(chunks, (chunks * batch + ncu - 1) / ncu));
+    return (int)std::max<int64_t>(1, std::min<int64_t>(chunks, (chunks * batch * sh.bands + ncu - 1) / ncu));
 }
 
 void register_mbmap_kernels() {
-#define MM_REG(K, S, MW, NW, WM, WN, KSP, H, W, SW) \
-    register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW>));
-#define MM_REG_KS(MW, NW, WM, WN, KSP, H, W, SW)                                                 \
-    MM_REG(3, 1, MW, NW, WM, WN, KSP, H, W, SW) MM_REG(5, 1, MW, NW, WM, WN, KSP, H, W, SW) \
-    MM_REG(3, 2, MW, NW, WM, WN, KSP, H, W, SW) MM_REG(5, 2, MW, NW, WM, WN, KSP, H, W, SW)
-    MM_REG_KS(3, 2, 4, 2, 1, 6, 32, false)
-    MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false)
-    MM_REG_KS(3, 1, 1, 4, 2, 3, 16, true)
-    MM_REG(3, 1, 2, 1, 2, 2, 2, 4, 16, true) MM_REG(5, 1, 2, 1, 2, 2, 2, 4, 16, true)
+#define MM_REG(K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM) \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM>));
+#define MM_REG_KS(MW, NW, WM, WN, KSP, H, W, SW, NB, HM)                                                     \
+    MM_REG(3, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM) MM_REG(5, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM) \
+    MM_REG(3, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM) MM_REG(5, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM)
+    MM_REG_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6)
+    MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6)
+    MM_REG_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3)
+    MM_REG(3, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4) MM_REG(5, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4)
+    MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false, 2, 8)                                                          // cfg 5: 8 x 32 in two bands
+    MM_REG(3, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4) MM_REG(5, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4)  // cfg 6
 #undef MM_REG_KS
 #undef MM_REG
 }
 
 bool launch_mbmap(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
                   float *gap, int64_t batch) {
-    const int cfg = mbmap_config(d);
-    if (!cfg || !mm_al16(in) || !mm_al16(w1) || !mm_al16(b1)) return false;
+    const MbmapShape sh = mbmap_shape(d);
+    const float *zpage = device_zero_page();
+    if (!sh.cfg || !mm_al16(in) || !mm_al16(w1) || !mm_al16(b1) || !zpage) return false;
+    // the plan was built under the same rules: a descriptor whose padding / transposition / bands disagree with them is refused
+    if (d.cin_pad != sh.cin_pad || d.map_tr != sh.tr || d.map_bands != sh.bands) return false;
     MbDesc dd = d;
     dd.dbg = getenv("BN_MM_DBG") ? atoi(getenv("BN_MM_DBG")) : 0;
-    const int nch = mbmap_chunks_per_block(d, cfg, batch);
-    const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(d.Cin / 4)) + 1u;  // slot -> row of the swizzled copies
-#define MM_GO(K, S, MW, NW, WM, WN, KSP, H, W, SW)                                                                                          \
+    const int nch = mbmap_chunks_per_block(d, sh, batch);
+    const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(sh.cin_pad / 4)) + 1u;  // slot -> row of the swizzled copies
+    MbDesc lds_d = d;  // LDS sizes: padded rows, the kernel's geometry (transposed maps: H <-> W), a band's rows
+    lds_d.Cin = sh.cin_pad;
+    if (sh.tr) std::swap(lds_d.H, lds_d.W);
+    if (sh.bands > 1) lds_d.H = 6;
+#define MM_GO(K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM)                                                                                    \
     do {                                                                                                                              \
         constexpr int NC = 16 * NW * WN;                                                                                              \
-        dim3 grid((unsigned)((d.C + nch * NC - 1) / (nch * NC)), (unsigned)batch);                                                    \
-        const size_t lds_ = mbmap_lds_bytes(d, MW, NW, WM, WN, KSP);                                                                               \
-        hipLaunchKernelGGL((mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW>), grid, dim3(64 * WM * WN * KSP), lds_, s, dd, out, in, w1, b1, w2, b2, gap, nch, \
-                           inv_ch);                                                                                                   \
+        dim3 grid((unsigned)((d.C + nch * NC - 1) / (nch * NC)), (unsigned)batch, (unsigned)NB);                                      \
+        const size_t lds_ = mbmap_lds_bytes(lds_d, MW, NW, WM, WN, KSP);                                                              \
+        hipLaunchKernelGGL((mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM>), grid, dim3(64 * WM * WN * KSP), lds_, s, dd, out, in, w1, b1, w2, b2, \
+                           gap, nch, inv_ch, zpage);                                                                                  \
     } while (0)
-#define MM_GO_KS(MW, NW, WM, WN, KSP, H, W, SW)                                    \
-    do {                                                                          \
-        if (d.k == 3 && d.s == 1) MM_GO(3, 1, MW, NW, WM, WN, KSP, H, W, SW);      \
-        else if (d.k == 5 && d.s == 1) MM_GO(5, 1, MW, NW, WM, WN, KSP, H, W, SW); \
-        else if (d.k == 3) MM_GO(3, 2, MW, NW, WM, WN, KSP, H, W, SW);             \
-        else MM_GO(5, 2, MW, NW, WM, WN, KSP, H, W, SW);                           \
+#define MM_GO_KS(MW, NW, WM, WN, KSP, H, W, SW, NB, HM)                                    \
+    do {                                                                                  \
+        if (d.k == 3 && d.s == 1) MM_GO(3, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM);      \
+        else if (d.k == 5 && d.s == 1) MM_GO(5, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM); \
+        else if (d.k == 3) MM_GO(3, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM);             \
+        else MM_GO(5, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM);                           \
     } while (0)
-    if (cfg == 1) MM_GO_KS(3, 2, 4, 2, 1, 6, 32, false);
-    else if (cfg == 2) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false);
-    else if (cfg == 3) MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true);
-    else if (d.k == 3) MM_GO(3, 1, 2, 1, 2, 2, 2, 4, 16, true);
-    else MM_GO(5, 1, 2, 1, 2, 2, 2, 4, 16, true);
+    if (sh.cfg == 1) MM_GO_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6);
+    else if (sh.cfg == 2) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6);
+    else if (sh.cfg == 3) MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3);
+    else if (sh.cfg == 4 && d.k == 3) MM_GO(3, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4);
+    else if (sh.cfg == 4) MM_GO(5, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4);
+    else if (sh.cfg == 5) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false, 2, 8);
+    else if (d.k == 3) MM_GO(3, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4);
+    else MM_GO(5, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4);
 #undef MM_GO_KS
 #undef MM_GO
     return true;

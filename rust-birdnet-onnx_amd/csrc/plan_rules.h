@@ -147,30 +147,73 @@ inline size_t mbmap_lds_bytes(const MbDesc &d, int mw, int nw, int wm, int wn, i
     return (size_t)(mm_kib(hw * d.Cin) + 2 * mm_kib(nc * d.Cin) + mm_kib(d.H * (d.W + d.k - 1) * (nc + 4)) + ng * nc) * sizeof(float);
 }
 
-// Which configuration takes this block (0 = none).  Per-sample quantities only.  BN_MBMAP2=0 disables.
-//   1: 192-pixel map, chunks of 64 channels, 8 waves      2: 192-pixel map, chunks of 32, 8 waves (wider inputs)
+// Which configuration takes this block (cfg 0 = none).  Per-sample quantities only.  BN_MBMAP2=0 disables.
+//   1: 192-pixel map (6 x 32), chunks of 64 channels, 8 waves      2: the same, chunks of 32 (wider inputs)
 //   3: 48-pixel map (3 x 16), chunks of 64 channels, 8 waves (two K slices)
-//   4: 64-pixel map (4 x 16), chunks of 32 channels, 8 waves (two K slices)
-inline int mbmap_config(const MbDesc &d) {
-    if (env_int("BN_MBMAP2", 1) == 0) return 0;
-    if (d.k1 > 0 || !((d.k == 3 || d.k == 5) && (d.s == 1 || d.s == 2))) return 0;
-    if (d.Cin % 16 || d.Cin < 16 || d.C % 4 || d.in_bs % 4 || d.W % 4) return 0;
+//   4: 64-pixel map (4 x 16), chunks of 32 channels, 8 waves (two K slices; Cin % 64 == 0)
+//   5: 256-pixel map (8 x 32) as TWO BANDS of 4 output rows (2 at stride 2), each band a block of its own that loads the 6 input rows
+//      its outputs reach (the band's halo rows are real rows of the map: nothing is padded or recomputed except the expand
+//      of the 4 rows the two bands share); chunks of 32 channels, 8 waves            (round 4: BirdNET v3.0's 8 x 32 stage)
+//   6: 64-pixel map (4 x 16), chunks of 32 channels, 4 waves, for Cin % 64 in {16, 48}
+// Round 4 also lets every configuration run TRANSPOSED (tr: the kernel's rows are the map's columns -- Perch's maps are 32 x 8
+// and 16 x 4) and with the input rows PADDED in LDS to whole 16-wide k groups (cin_pad > Cin: the missing chunks are read from
+// a page of zeros, the planner pads the filter rows; Perch's Cin = 136 / 232).
+// MEASURED (round 4, one box per comparison, four contexts): correct (op tests + the full-size models against the oracle) and a
+// shorter launch chain -- BirdNET v3.0 at batch 64: 1766 against 1810 us of launches, Perch at batch 128: 7036 against 7125 -- but
+// LOWER throughput where those models run saturated: v3.0 48.2 k against 49.0 k segments/s, Perch 19.55 k (all), 19.78 k (cfg 6
+// only) against 20.13 k.  A band expands 6 rows for 4 (1.5 x the expand work of the layer), and even without recompute (cfg 6)
+// the fused block's marginal cost per batch is above GEMM + whole-map depthwise, as round 1 found for its whole-map kernel.
+// Which kernel a layer takes may not depend on the batch (a segment's bits must not), so the round-4 configurations are
+// OPT-IN: BN_MBMAP3=1 (BN_MBMAP_BANDS=0 then keeps the banded one off).  Default: round 3's set (cfg 1-4, plain).
+struct MbmapShape {
+    int cfg = 0;
+    int bands = 1;    // blocks per (sample, channel group) along the map's rows; the squeeze sums are partial per band
+    int cin_pad = 0;  // floats per input / filter row in LDS (multiple of 16)
+    int tr = 0;
+};
+inline MbmapShape mbmap_shape(const MbDesc &d) {
+    MbmapShape none, sh;
+    if (env_int("BN_MBMAP2", 1) == 0) return none;
+    const bool r4 = env_int("BN_MBMAP3", 0) != 0;
+    if (d.k1 > 0 || !((d.k == 3 || d.k == 5) && (d.s == 1 || d.s == 2))) return none;
+    if (d.Cin % 4 || d.Cin < 16 || d.C % 4 || d.in_bs % 4) return none;
     const int pad = (d.k - 1) / 2;  // the kernels are compiled for symmetric "same" padding
-    if (d.pt != pad || d.pl != pad || d.OH != (d.H + 2 * pad - d.k) / d.s + 1 || d.OW != (d.W + 2 * pad - d.k) / d.s + 1) return 0;
-    if (!mbconv_row_act_supported(d.act1) || !mbconv_row_act_supported(d.act2)) return 0;
+    if (d.pt != pad || d.pl != pad || d.OH != (d.H + 2 * pad - d.k) / d.s + 1 || d.OW != (d.W + 2 * pad - d.k) / d.s + 1) return none;
+    if (!mbconv_row_act_supported(d.act1) || !mbconv_row_act_supported(d.act2)) return none;
+    // the kernel's geometry: R rows x Wc columns, Wc in {32, 16}; a tall narrow map is walked transposed
+    int R = d.H, Wc = d.W;
+    if (r4 && d.W < 16 && (d.H == 32 || d.H == 16)) { R = d.W; Wc = d.H; sh.tr = 1; }
+    if (Wc % 4) return none;
+    sh.cin_pad = (d.Cin + 15) & ~15;
+    if (!r4 && sh.cin_pad != d.Cin) return none;
+    MbDesc p = d;
+    p.Cin = sh.cin_pad;  // LDS sizes follow the padded rows
+    p.H = R; p.W = Wc;
     const size_t cap = 160 * 1024;
-    const int cls = d.Cin % 64;
+    const int cls = sh.cin_pad % 64;
+    const bool c1648 = cls == 16 || cls == 48;
     // (the row swizzle each configuration is compiled with: see mm_swz)
-    if (d.H == 6 && d.W == 32 && (cls == 16 || cls == 48)) {
-        if (mbmap_lds_bytes(d, 3, 2, 4, 2) <= cap) return 1;
-        if (mbmap_lds_bytes(d, 3, 1, 4, 2) <= cap) return 2;
-    } else if (d.H == 3 && d.W == 16 && cls == 0) {
-        if (mbmap_lds_bytes(d, 3, 1, 1, 4, 2) <= cap) return 3;
-    } else if (d.H == 4 && d.W == 16 && cls == 0 && d.s == 1) {  // BirdNET v3.0's last stage (5 s segments: one more row than v2.4's 3 x 16)
-        if (mbmap_lds_bytes(d, 2, 1, 2, 2, 2) <= cap) return 4;  // 32-channel chunks (Cin = 192: two filter chunks of 64 would not fit), eight waves
+    if (R == 6 && Wc == 32 && c1648) {
+        if (mbmap_lds_bytes(p, 3, 2, 4, 2) <= cap) sh.cfg = 1;
+        else if (mbmap_lds_bytes(p, 3, 1, 4, 2) <= cap) sh.cfg = 2;
+    } else if (R == 3 && Wc == 16 && cls == 0) {
+        if (mbmap_lds_bytes(p, 3, 1, 1, 4, 2) <= cap) sh.cfg = 3;
+    } else if (R == 4 && Wc == 16 && cls == 0 && d.s == 1) {  // BirdNET v3.0's last stage (5 s segments: one more row than v2.4's 3 x 16)
+        if (mbmap_lds_bytes(p, 2, 1, 2, 2, 2) <= cap) sh.cfg = 4;  // 32-channel chunks (Cin = 192: two filter chunks of 64 would not fit), eight waves
+    } else if (r4 && R == 4 && Wc == 16 && c1648 && d.s == 1) {
+        if (mbmap_lds_bytes(p, 2, 1, 2, 2, 1) <= cap) sh.cfg = 6;
+    } else if (r4 && R == 8 && Wc == 32 && env_int("BN_MBMAP_BANDS", 1) != 0) {
+        // rows whose length is 0 or 32 mod 64 floats (Perch: Cin = 96) would meet the fragment reads' bank pattern: one more k group
+        // of zeros moves them into a class the compiled swizzle serves (96 -> 112: a sixth more expand work, still ahead of the
+        // GEMM + depthwise pair it replaces)
+        if (!c1648) sh.cin_pad += 16;
+        p.Cin = sh.cin_pad;
+        p.H = 6;  // a band's rows
+        if ((sh.cin_pad % 64 == 16 || sh.cin_pad % 64 == 48) && mbmap_lds_bytes(p, 3, 1, 4, 2) <= cap) { sh.cfg = 5; sh.bands = 2; }
     }
-    return 0;
+    return sh.cfg ? sh : none;
 }
+inline int mbmap_config(const MbDesc &d) { return mbmap_shape(d).cfg; }
 
 // ---- FFT front end (stft.hip) -------------------------------------------------------------------------------------
 // LDS carve-up (floats), shared by the kernel and stft_lds_bytes.  Table regions are whole KiB: the asynchronous
