@@ -104,6 +104,10 @@ typedef struct bn_model_cost {
      * FFT-normalised count SURVEY.md 8(d) prices the front end at. */
     double dft_performed_macs;
     double dft_fft_equiv_flops;
+    /* (appended in round 4; callers pass their struct size) multiply-accumulates of macs_mfma that are RECOMPUTE: the fused
+     * MBConv launches expand the halo rows / columns of neighbouring bands and strips again (and the padded k of an opt-in
+     * configuration); 2 x (macs_mfma - recompute_macs + macs_valu) is the work the graph asks for. */
+    double recompute_macs;
 } bn_model_cost;
 
 /* ---- version / device ------------------------------------------------- */

@@ -79,7 +79,8 @@ class BnModelConfig(C.Structure):
 class BnModelCost(C.Structure):
     _fields_ = [("macs_mfma", C.c_double), ("macs_valu", C.c_double), ("weight_bytes", C.c_double),
                 ("activation_bytes", C.c_double), ("n_launches", C.c_int32), ("dft_gemm_macs", C.c_double), ("fft_flops", C.c_double),
-                ("dft_performed_macs", C.c_double), ("dft_fft_equiv_flops", C.c_double)]
+                ("dft_performed_macs", C.c_double), ("dft_fft_equiv_flops", C.c_double),
+                ("recompute_macs", C.c_double)]
 
 
 class BnCtxStats(C.Structure):

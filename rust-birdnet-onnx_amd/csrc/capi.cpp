@@ -614,6 +614,7 @@ bn_status bn_model_get_cost(const bn_model *m, bn_model_cost *out, size_t struct
     c.fft_flops = p.fft_flops;
     c.dft_performed_macs = p.dft_performed_macs;
     c.dft_fft_equiv_flops = p.dft_fft_equiv_flops;
+    c.recompute_macs = p.recompute_macs;
     memcpy(out, &c, std::min(struct_size, sizeof(c)));  // never writes past the caller's struct (ABI 2: the struct grew in ABI 1 without a version bump)
     return BN_OK;
 }

@@ -186,6 +186,7 @@ class Builder {
         for (auto &op : plan_.ops) {
             (op.mfma ? plan_.macs_mfma : plan_.macs_valu) += op.macs;
             plan_.macs_mfma += op.macs_mfma_extra;
+            plan_.recompute_macs += op.macs_recompute;
             plan_.macs_valu += op.macs_valu_extra;
             plan_.act_bytes += op.bytes;
             plan_.weight_bytes += op.weight_bytes;
@@ -2583,6 +2584,7 @@ class Builder {
                     mb.bytes = 4.0 * ((double)cd.H * cd.W * cd.Cin + (double)OH * OW * Cin);
                     mb.mfma = false;
                     mb.macs_mfma_extra = halo * (double)K1 * Cin;
+                    mb.macs_recompute = std::max(0.0, mb.macs_mfma_extra - (double)H * W * (double)K1 * Cin);
                     plan_.ops.pop_back();
                     push_op(std::move(mb));
                     define(cur, out);
@@ -2693,6 +2695,7 @@ class Builder {
                     mb.bytes = 4.0 * ((double)H * W * pe.gemm.K + (double)OH * OW * Cin);
                     mb.mfma = false;
                     mb.macs_mfma_extra = halo * pe.gemm.K * Cin;          // expand part incl. halo recompute
+                    mb.macs_recompute = std::max(0.0, mb.macs_mfma_extra - (double)H * W * (double)pe.gemm.K * Cin);
                     plan_.ops.pop_back();
                     push_op(std::move(mb));
                     define(cur, out);

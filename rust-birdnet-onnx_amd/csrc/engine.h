@@ -56,6 +56,7 @@ struct PlanOp {
     double flops_fft = 0;   // FFT: algorithmic flops per sample counted as an FFT (2.5 L log2 L per real frame) + sparse mel
     double macs = 0;        // per sample
     double macs_mfma_extra = 0;  // MBCONV: the expand part runs on the matrix cores
+    double macs_recompute = 0;   // ... of which: beyond one expansion per input pixel (halo rows / columns, shared band rows, padded k)
     double macs_valu_extra = 0;  // GEMM with the squeeze-excite products in its prologue: those run on the vector ALU
     double bytes = 0;       // algorithmic bytes read+written per sample (weights excluded)
     double weight_bytes = 0;
@@ -103,6 +104,7 @@ struct Plan {
     // dft_performed_macs: multiply-adds the plan spends on those banks as it runs them (folded matrix product: half the
     // taps; FFT: fft flops / 2); dft_fft_equiv_flops: 2.5 L log2 L per frame of the same banks, whichever way they run
     double dft_performed_macs = 0, dft_fft_equiv_flops = 0;
+    double recompute_macs = 0;  // part of macs_mfma: halo / band / padded-k recompute of the fused MBConv launches
 };
 
 // wanted_outputs: graph output indices that must be computed (others are dead code).
