@@ -332,6 +332,197 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
     }
 }
 
+// ---- streaming form (round 4): ONE K slice, no gate, a block walks `tpb` CONSECUTIVE row tiles of the batch against the same
+// channel tile and its ring never drains between them.
+// Why: the expand convs of the late stages (K 64 .. 232, N 480 .. 1392: short K, wide N) are two to eight K steps per tile -- with one
+// tile per block, prologue (first stages from L2) and epilogue (bias, activation, store) are as long as the product between them, which
+// is why round 3 left these shapes on the tiled kernel.  Here step i of the block's step sequence (tile i / nst, K step i % nst) is
+// issued D - 1 steps ahead whatever tile it belongs to, so the next tile's operands arrive while this tile's epilogue runs; at
+// 74 KB of LDS two blocks share a CU and cover each other's barriers.  Same fragment layout, same k order (k-slot j of a 16-wide
+// group: k = 16 g + 4 q + j, groups ascending), same epilogue as gemm_dma_kernel<.., KS = 1, GATE = 0>: the bits of an output do not
+// depend on tpb or on the tile shape.
+template <int MTW, int NTW, int WM, int WN, int D>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_dma_stream_kernel(GemmDesc d, float *__restrict__ C, const float *__restrict__ A, const float *__restrict__ W,
+                                                                        const float *__restrict__ bias, const float *__restrict__ res, int tiles_per_sample,
+                                                                        int total_tiles, int tpb) {
+    constexpr int WPS = WM * WN;
+    static_assert(WPS == 2 || WPS == 4, "two or four waves");
+    constexpr int TR = 16 * MTW * WM, BN = 16 * NTW * WN;
+    constexpr int XP = TR / 8, WP = BN / 8, PIECES = XP + WP;
+    constexpr int NP = (PIECES + WPS - 1) / WPS;
+    constexpr int STAGE_FLOATS = (TR + BN) * 32;
+    extern __shared__ __align__(1024) float gd_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w4 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lc = lane & 15, lq = lane >> 4;
+    const int wm = w4 % WM, wn = w4 / WM;
+    const int n0 = blockIdx.y * BN;
+    const int K = d.K;
+    const int t_first = blockIdx.x * tpb;
+    const int ntiles = min(tpb, total_tiles - t_first);
+    if (ntiles <= 0) return;
+
+    const int prow = lane >> 3, pslot = lane & 7;
+    uint32_t off[NP];
+    bool is_w[NP];
+    uint32_t dst[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        int p = w4 + WPS * j;
+        if (p >= PIECES) p = w4 % PIECES;
+        const bool w_img = p >= XP;
+        const int row = 8 * (w_img ? p - XP : p) + prow;
+        const int chunk = pslot ^ ((row >> 1) & 7);
+        int grow = row;
+        if (w_img) {
+            grow = n0 + row;
+            grow = grow < d.N ? grow : d.N - 1;
+        }
+        is_w[j] = w_img;
+        off[j] = (uint32_t)grow * (uint32_t)K + 4u * (uint32_t)chunk;
+        dst[j] = (uint32_t)(p * 256);
+    }
+    const int nfs = K >> 5;
+    const bool half_tail = (K & 31) != 0;
+    const int nst = nfs + (half_tail ? 1 : 0);
+    const int total_steps = ntiles * nst;
+    // the issuing side's position in the step sequence (tile, K step, ring slot), advanced by one per issue()
+    int is_t = 0, is_s = 0, is_slot = 0;
+    auto tile_rows = [&](int t) -> const float * {  // first activation row of the block's t-th tile (uniform)
+        const int g = t_first + t;
+        const int b = g / tiles_per_sample, rt = g - b * tiles_per_sample;
+        return A + (int64_t)b * d.a_bs + (int64_t)rt * TR * d.lda;
+    };
+    const float *is_x = tile_rows(0);
+    auto issue = [&]() {
+        float *sb = gd_lds + is_slot * STAGE_FLOATS;
+        const int k0 = (half_tail && is_s == nst - 1) ? K - 32 : 32 * is_s;
+        const float *xk = is_x + k0, *wk = W + k0;
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+            __builtin_amdgcn_global_load_lds(GD_GLB_PTR((is_w[j] ? wk : xk) + off[j]), GD_LDS_PTR(sb + dst[j]), 16, 0, 0);
+        is_slot = is_slot + 1 == D ? 0 : is_slot + 1;
+        if (++is_s == nst) {
+            is_s = 0;
+            if (++is_t < ntiles) is_x = tile_rows(is_t);
+        }
+    };
+    int issued = 0;
+#pragma unroll
+    for (int i = 0; i < D - 1; i++)
+        if (issued < total_steps) { issue(); issued++; }
+
+    int xoff[MTW][2], woff[NTW][2];
+#pragma unroll
+    for (int mt = 0; mt < MTW; mt++) {
+        const int r = (wm * MTW + mt) * 16 + lc;
+#pragma unroll
+        for (int g = 0; g < 2; g++) xoff[mt][g] = r * 32 + 4 * ((4 * g + lq) ^ ((r >> 1) & 7));
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+        const int r = (wn * NTW + nt) * 16 + lc;
+#pragma unroll
+        for (int g = 0; g < 2; g++) woff[nt][g] = TR * 32 + r * 32 + 4 * ((4 * g + lq) ^ ((r >> 1) & 7));
+    }
+    floatx4 acc[MTW][NTW];
+    auto group = [&](const float *sb, int g) {
+        floatx4 xf[MTW], wf[NTW];
+#pragma unroll
+        for (int mt = 0; mt < MTW; mt++) xf[mt] = *reinterpret_cast<const floatx4 *>(sb + xoff[mt][g]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) wf[nt] = *reinterpret_cast<const floatx4 *>(sb + woff[nt][g]);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++)
+#pragma unroll
+                for (int mt = 0; mt < MTW; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][j], xf[mt][j], acc[mt][nt], 0, 0, 0);
+    };
+    // wait + barrier that make step `done` (counted over the whole block) readable, then the refill of the slot read one step ago
+    int done = 0, rd_slot = 0;
+    auto turn = [&]() {
+        if (total_steps - 1 - done >= D - 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 2) * NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issued < total_steps) { issue(); issued++; }
+    };
+    static_assert(D == 3, "the counted waits are written for a ring of three");
+
+    // the channel tile's bias: the same for every row tile of the block
+    floatx4 bpre[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; nt++) {
+        const int n = min(n0 + (wn * NTW + nt) * 16 + 4 * lq, d.N - 4);
+        bpre[nt] = d.has_bias ? *reinterpret_cast<const floatx4 *>(bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int t = 0; t < ntiles; t++) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; mt++)
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++) acc[mt][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        // the residual rows of this tile are requested before its product (clamped addresses): their round trip runs under it
+        const int g_t = t_first + t;
+        const int b = g_t / tiles_per_sample, rt = g_t - b * tiles_per_sample;
+        floatx4 rpre[MTW][NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) {
+            const int n = min(n0 + (wn * NTW + nt) * 16 + 4 * lq, d.N - 4);
+#pragma unroll
+            for (int mt = 0; mt < MTW; mt++) {
+                const int64_t m = (int64_t)rt * TR + (wm * MTW + mt) * 16 + lc;
+                rpre[mt][nt] = d.has_res ? *reinterpret_cast<const floatx4 *>(res + (int64_t)b * d.r_bs + m * d.ldr + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // (the residual loads above are younger than the stage pieces in flight: the counted waits below still cover the stages,
+        // because vmcnt completes in order and waits for "all but the N youngest" -- so the residual, when there is one, is simply
+        // waited for along with them: has_res launches pay that, the expand convs this kernel is for have none)
+        for (int s_ = 0; s_ < nfs; s_++) {
+            if (d.has_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            turn();
+            const float *sb = gd_lds + rd_slot * STAGE_FLOATS;
+            group(sb, 0);
+            group(sb, 1);
+            rd_slot = rd_slot + 1 == D ? 0 : rd_slot + 1;
+            done++;
+        }
+        if (half_tail) {
+            if (d.has_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            turn();
+            group(gd_lds + rd_slot * STAGE_FLOATS, 1);
+            rd_slot = rd_slot + 1 == D ? 0 : rd_slot + 1;
+            done++;
+        }
+        // ---- epilogue of the tile (the next tile's first stages are already in flight)
+        float v[MTW * NTW * 4];
+#pragma unroll
+        for (int nt = 0; nt < NTW; nt++) {
+            const floatx4 bv = bpre[nt];
+#pragma unroll
+            for (int mt = 0; mt < MTW; mt++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[(mt * NTW + nt) * 4 + i] = acc[mt][nt][i] + bv[i];
+        }
+        gd_act<MTW * NTW * 4>(d.act, d.p0, d.p1, v);
+#pragma unroll
+        for (int mt = 0; mt < MTW; mt++) {
+            const int64_t m = (int64_t)rt * TR + (wm * MTW + mt) * 16 + lc;
+            float *crow = C + (int64_t)b * d.c_bs + m * d.ldc;
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++) {
+                const int n = n0 + (wn * NTW + nt) * 16 + 4 * lq;
+                if (n < d.N) {
+                    floatx4 o = floatx4{v[(mt * NTW + nt) * 4], v[(mt * NTW + nt) * 4 + 1], v[(mt * NTW + nt) * 4 + 2], v[(mt * NTW + nt) * 4 + 3]};
+                    if (d.has_res) o += rpre[mt][nt];
+                    *reinterpret_cast<floatx4 *>(crow + n) = o;
+                }
+            }
+        }
+    }
+}
+
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 template <int MTW, int NTW, int WM, int WN, int KS, int D>
@@ -362,6 +553,12 @@ void register_gemm_dma_kernels() {
     GD_REG(1, 1, 4, 1) GD_REG(1, 1, 2, 1) GD_REG(1, 2, 4, 1) GD_REG(1, 3, 4, 1) GD_REG(1, 4, 4, 1) GD_REG(1, 5, 4, 1) GD_REG(1, 6, 4, 1) GD_REG(1, 7, 4, 1) GD_REG(1, 8, 4, 1)
     GD_REG(1, 2, 2, 1) GD_REG(1, 3, 2, 1) GD_REG(1, 4, 2, 1) GD_REG(1, 5, 2, 1) GD_REG(1, 6, 2, 1) GD_REG(1, 7, 2, 1) GD_REG(1, 8, 2, 1)
     GD_REG(3, 1, 1, 2) GD_REG(3, 1, 1, 4) GD_REG(3, 2, 1, 4)
+#define GD_REG_S(NTW) \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_stream_kernel<1, NTW, 4, 1, 3>)); \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_stream_kernel<1, NTW, 2, 1, 3>)); \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(gemm_dma_stream_kernel<2, NTW, 4, 1, 3>));
+    GD_REG_S(4) GD_REG_S(5) GD_REG_S(6) GD_REG_S(7) GD_REG_S(8)
+#undef GD_REG_S
 #undef GD_REG
 #undef GD_REG1
 }
@@ -373,6 +570,47 @@ bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A,
         (d.has_scale && !d.se_inline && !al16(scale)))
         return false;
     if (d.se_inline && !se) return false;
+    if (shape == 3) {
+        // streaming form: the fewest channel tiles of at most 128 (whole 16-channel tiles, evenly sized); 64-row tiles where a
+        // sample's rows allow; tiles per block so that the launch is about two blocks per CU deep (two fit a CU: 74 KB each) --
+        // neither enters the arithmetic
+        int ntw = 8;  // channel tile of 64 .. 128 with the least padding over the layer (ties: the wider tile)
+        {
+            int64_t best = -1;
+            for (int c = 8; c >= 4; c--) {
+                const int64_t padded = (int64_t)((d.N + 16 * c - 1) / (16 * c)) * 16 * c;
+                if (best < 0 || padded < best) { best = padded; ntw = c; }
+            }
+        }
+        const bool r64 = d.rows % 64 == 0;
+        const bool r128 = d.rows % 128 == 0 && getenv("BN_GEMMSTREAM_TR") && atoi(getenv("BN_GEMMSTREAM_TR")) == 128;  // experiment: 128-row tiles measured slower (191 against 125 us)
+        const int tr = r128 ? 128 : r64 ? 64 : 32;
+        const int tps = (int)(d.rows / tr);
+        const int64_t tiles = batch * tps, nbn = (d.N + 16 * ntw - 1) / (16 * ntw);
+        const int64_t want_blocks = 2 * (int64_t)device_cu_count();
+        const int force_tpb = getenv("BN_GEMMSTREAM_TPB") ? atoi(getenv("BN_GEMMSTREAM_TPB")) : 0;  // tests / experiments
+        // (whole rounds: grid.x * nbn must not exceed what is resident at once, or a handful of left-over blocks run a round of their own --
+        // measured: 516 blocks on 512 slots 180 us, 474 blocks 125 us)
+        const int64_t gx = std::max<int64_t>(1, want_blocks / nbn);
+        const int tpb = force_tpb > 0 ? force_tpb : (int)std::max<int64_t>(1, (tiles + gx - 1) / gx);
+        dim3 grid((unsigned)((tiles + tpb - 1) / tpb), (unsigned)nbn);
+        const size_t lds = (size_t)3 * (tr + 16 * ntw) * 32 * sizeof(float);
+#define GD_STREAM(NTW)                                                                                                                         \
+    do {                                                                                                                                       \
+        if (r128) hipLaunchKernelGGL((gemm_dma_stream_kernel<2, NTW, 4, 1, 3>), grid, dim3(256), lds, s, d, C, A, W, bias, res, tps, (int)tiles, tpb); \
+        else if (r64) hipLaunchKernelGGL((gemm_dma_stream_kernel<1, NTW, 4, 1, 3>), grid, dim3(256), lds, s, d, C, A, W, bias, res, tps, (int)tiles, tpb); \
+        else hipLaunchKernelGGL((gemm_dma_stream_kernel<1, NTW, 2, 1, 3>), grid, dim3(128), lds, s, d, C, A, W, bias, res, tps, (int)tiles, tpb);      \
+    } while (0)
+        switch (ntw) {
+            case 4: GD_STREAM(4); break;
+            case 5: GD_STREAM(5); break;
+            case 6: GD_STREAM(6); break;
+            case 7: GD_STREAM(7); break;
+            default: GD_STREAM(8); break;
+        }
+#undef GD_STREAM
+        return true;
+    }
     const int ks = gemm_dma_kslices(d, se ? se->se.Cr : 0);  // decided for the layer, not for the tile (plan_rules.h)
     // Tile shape by the size of the launch: big tiles (16 - 24 flop per byte staged from L2) as soon as they give 64 blocks,
     // smaller ones below that.  With four contexts in flight a step is bound by the SUM of its launches' marginal costs,

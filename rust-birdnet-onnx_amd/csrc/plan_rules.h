@@ -73,7 +73,8 @@ inline size_t gemm_dma_lds_bytes(const GemmDesc &d, int mtw, int ntw, int wm, in
     return std::max((size_t)(ks * depth * (tr + bn) * 32 + gate_floats + se_floats), (size_t)((ks - 1) * wm * wn * mtw * ntw * 256)) * sizeof(float);
 }
 
-// which block family the LDS-DMA kernel would take for this GEMM (0 = not eligible): per-sample quantities only
+// which block family the LDS-DMA kernel would take for this GEMM (0 = not eligible; 1 / 2: one tile per block, 64- / 48-row tiles;
+// 3: the streaming form): per-sample quantities only
 inline int gemm_dma_shape(const GemmDesc &d) {
     const int mode = env_int("BN_GEMMDMA", 1);
     if (mode == 0) return 0;
@@ -89,6 +90,13 @@ inline int gemm_dma_shape(const GemmDesc &d) {
     // vector instruction is taken from the budget the other contexts' matrix work needs (BN_GEMMDMA_SMALLN=0 keeps
     // them on the tiled kernel)
     const bool small_n = d.N <= 32 && d.has_scale && env_int("BN_GEMMDMA_SMALLN", 1) != 0;
+    // Round 4: the expand convs of the late stages (K 64 .. 127 here, N >= 128, no gate, no residual) CAN take the streaming form of the
+    // kernel (gemm_dma_stream_kernel: a block walks consecutive row tiles, its ring never drains) -- family 3.  Opt-in (BN_GEMMSTREAM=1):
+    // measured EQUAL to the tiled kernel on these shapes (BirdNET v3.0, K = 112 -> N = 672: 37.4 - 38.0 against 37.5 us at batch 64, 125
+    // against 124 us at batch 256, i.e. 79 TF/s either way; K = 80 -> 480: 76 against 82 us at batch 256, 26.0 against 25.6 at 64) --
+    // removing the per-tile prologue does not move a launch that already runs at the rate every f32-MFMA kernel of this library
+    // reaches at saturation.  The default plan is unchanged (and so are its bits).
+    if (env_int("BN_GEMMSTREAM", 0) != 0 && !d.has_scale && !d.has_res && !d.se_inline && d.K >= 64 && d.K < 128 && d.N >= 128 && d.rows % 32 == 0) return 3;
     if (mode != 2 && d.K < 128 && !small_n) return 0;
     if (d.rows % 32 == 0) return 1;  // 64- or 32-row tiles x up to 128 channels, waves along the rows
     if (d.rows % 48 == 0) return 2;  // 48-row tiles x 32 / 64 / 128 channels, waves along the channels

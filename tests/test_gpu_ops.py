@@ -52,6 +52,53 @@ def test_pointwise_conv_gemm(bn, cin, h, w, cout):
     assert_close(got, ref, f"1x1 conv {cin}->{cout}")
 
 
+@pytest.mark.parametrize("cin,h,w,cout,act,stream", [(80, 8, 32, 480, "silu", True), (112, 8, 32, 672, "silu", True), (96, 32, 8, 576, "silu", True),
+                                                     (64, 6, 16, 128, "relu", True), (96, 4, 16, 1100, "relu6", True), (96, 5, 7, 200, "relu", False),
+                                                     (48, 8, 32, 288, "silu", False)])
+def test_streaming_expand_gemm(bn, cin, h, w, cout, act, stream, monkeypatch):
+    """Round 4: the expand convs of the late stages (K 64 .. 127, N >= 128, no gate) on the streaming form of the LDS-DMA GEMM
+    (gemm_dma_stream_kernel: a block walks consecutive row tiles -- across samples -- and its ring never drains).  Against the oracle;
+    the number of tiles per block must not change a bit (1, 3 and 16 forced; 64- and 32-row tiles by the rows of a sample); the tiled
+    kernel (BN_GEMMSTREAM=0) agrees within the tolerance."""
+    rng = np.random.default_rng(cin + cout)
+
+    def build(g, x):  # 1x1 (puts the map into the channels-last layout) -> the expand conv under test -> a project conv that reads it
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(cin * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, cin, h, w)])
+        x = g.node("Conv", [x, g.const((rng.standard_normal((cin, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32))], kernel_shape=[1, 1])
+        y = g.node("Conv", [x, g.const((rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)),
+                            g.const(rng.standard_normal(cout).astype(np.float32))], kernel_shape=[1, 1])
+        if act == "relu":
+            y = g.node("Relu", [y])
+        elif act == "silu":
+            y = g.node("Mul", [y, g.node("Sigmoid", [y])])
+        else:
+            y = g.node("Clip", [y, g.const(np.float32(0)), g.const(np.float32(6))])
+        return g.node("Conv", [y, g.const((rng.standard_normal((24, cout, 1, 1)) / np.sqrt(cout)).astype(np.float32))], kernel_shape=[1, 1])
+    data = op_graph(build, [24, h, w])
+    assert "kernel=dma-stream" not in bn.plan_describe(write_model(data))  # opt-in (measured equal to the tiled kernel: plan_rules.h)
+    monkeypatch.setenv("BN_GEMMSTREAM", "1")
+    desc = bn.plan_describe(write_model(data))
+    assert ("kernel=dma-stream" in desc) == stream, desc
+    got, ref = run_both(bn, data, batch=5)
+    assert_close(got, ref, f"expand {cin}->{cout} rows {h * w}")
+    if not stream:
+        return
+    for tpb in ("1", "3", "16"):
+        monkeypatch.setenv("BN_GEMMSTREAM_TPB", tpb)
+        forced, _ = run_both(bn, data, batch=5)
+        assert np.array_equal(forced.view(np.uint32), got.view(np.uint32)), tpb
+    monkeypatch.delenv("BN_GEMMSTREAM_TPB")
+    one, _ = run_both(bn, data, batch=1)
+    assert np.array_equal(one.view(np.uint32), got[:1].view(np.uint32))
+    monkeypatch.setenv("BN_GEMMSTREAM", "0")
+    assert "kernel=dma-stream" not in bn.plan_describe(write_model(data))
+    tiled, _ = run_both(bn, data, batch=5)
+    assert_close(tiled, ref, "tiled kernel")
+    assert_close(got, tiled, "streaming vs tiled")
+
+
 @pytest.mark.parametrize("c,h,w,k,stride,act", [(32, 24, 30, 3, 1, "relu"), (96, 24, 30, 3, 2, "relu"),
                                                 (144, 12, 17, 5, 2, "silu"), (240, 6, 9, 5, 1, "relu6"),
                                                 (30, 9, 11, 3, 1, None), (8, 5, 5, 7, 1, None)])

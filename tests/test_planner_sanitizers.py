@@ -51,7 +51,7 @@ def test_reader_and_planner_under_asan_ubsan(asan_binary, tmp_path):
 # forced on / off, the small-map and LDS-DMA kernels off, the row kernel off -- at the FULL model sizes the bench runs
 RULE_SETS = [
     {},
-    {"BN_SEGEMM": "1", "BN_FRAMEPAIR": "1", "BN_STFT": "1", "BN_STFT_MEL": "force", "BN_MBMAP3": "1"},
+    {"BN_SEGEMM": "1", "BN_FRAMEPAIR": "1", "BN_STFT": "1", "BN_STFT_MEL": "force", "BN_MBMAP3": "1", "BN_GEMMSTREAM": "1"},
     {"BN_STFT": "0", "BN_MBMAP2": "0", "BN_GEMMDMA": "0", "BN_MBROW": "0", "BN_CONVFOLD": "0", "BN_GEMMPOST": "0"},
     {"BN_GEMMDMA": "2", "BN_MBFUSE": "force", "BN_MBMAP": "1", "BN_STFT_MELMFMA": "0", "BN_STFT_POWER": "0", "BN_REDUCE_SPLIT": "0"},
 ]
