@@ -407,7 +407,7 @@ def main():
             "streams_per_gpu": max(1, args.streams),
             "num_species": int(N),
             "x_realtime": round(value * SEC, 1),
-            "parallelism": f"segment-sharded x{world}" + (f" + RCCL all-gather of logits (one collective per {S_} steps)" if world > 1 else ""),
+            "parallelism": f"segment-sharded x{world}" + ((f" + RCCL all-gather of logits (one collective per {S_} steps)" if args.backend == "nccl" else f" + {args.backend} all-gather of logits on the host (rehearsal backend)") if world > 1 else ""),
         },
     }
 
