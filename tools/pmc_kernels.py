@@ -47,7 +47,11 @@ def main():
         if "SQ_INSTS_VALU" in c:
             line += f" valu={c['SQ_INSTS_VALU']:.0f} salu={c.get('SQ_INSTS_SALU', 0):.0f} lds={c.get('SQ_INSTS_LDS', 0):.0f} vmem_rd={c.get('SQ_INSTS_VMEM_RD', 0):.0f} vmem_wr={c.get('SQ_INSTS_VMEM_WR', 0):.0f} waves={c.get('SQ_WAVES', 0):.0f}"
         if c.get("SQ_INSTS_MFMA"):
-            line += f" valu/mfma={c.get('SQ_INSTS_VALU', 0) / c['SQ_INSTS_MFMA']:.1f} mfma={c['SQ_INSTS_MFMA']:.0f}"
+            # SQ_INSTS_VALU COUNTS the matrix instructions too (round 4, tools/mfma_valu_probe under --pmc: a matrix-only kernel reads
+            # SQ_INSTS_VALU == SQ_INSTS_MFMA to 0.04 %): "vector" below is the difference; the valu/mfma ratio of the round 2 / 3 tables
+            # was (vector + matrix) / matrix, i.e. one too high
+            vec = c.get('SQ_INSTS_VALU', 0) - c['SQ_INSTS_MFMA']
+            line += f" vector(valu-mfma)={vec:.0f} vector/mfma={vec / c['SQ_INSTS_MFMA']:.1f} mfma={c['SQ_INSTS_MFMA']:.0f}"
         if c.get("SQ_LDS_IDX_ACTIVE"):
             line += f" lds_conf={c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.2f} lds_idx_cycles={c['SQ_LDS_IDX_ACTIVE']:.0f} lds_conf_cycles={c.get('SQ_LDS_BANK_CONFLICT', 0):.0f}"
         for extra in ("FETCH_SIZE", "WRITE_SIZE"):
