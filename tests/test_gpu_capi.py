@@ -221,3 +221,44 @@ def test_many_input_buffers_through_one_context(bn, small):
     ctx.infer_device(ptr, 4, sync=True)
     assert ctx.stats()["input_copies"] == before
     assert ctx.read_output(1, 4).tobytes() == want[5].tobytes()
+
+
+def test_context_teardown_order_with_framework_objects_on_its_stream(bn, small):
+    """Round 3's SIGSEGV: torch objects that name a context's stream -- an ExternalStream wrapper, events recorded on it,
+    tensors copied on it -- are released and the device drained BEFORE the context destroys its hipStream_t; Context.close() destroys
+    it now (not whenever the object is collected) and is safe to call twice.  The copies made on the stream are complete and correct."""
+    import gc
+    import torch
+    data, path = small
+    m = bn.Model(path)
+    ctx = bn.Context(m, 2)
+    x = synth.synthetic_segments(2, 160000, 32000)
+    want, _ = ctx.infer(x)
+    want = want.copy()
+    ptr, n = ctx.output_device(m.config.logits_output)
+
+    class _View:
+        def __init__(self, p, shape):
+            self.__cuda_array_interface__ = {"data": (p, False), "shape": shape, "typestr": "<f4", "version": 2}
+    view = torch.as_tensor(_View(ptr, (2, n)), device="cuda")
+    es = torch.cuda.ExternalStream(ctx.stream())
+    staged = torch.empty((2, n), dtype=torch.float32, device="cuda")
+    dx = torch.from_numpy(x).cuda()  # (kept alive until the device has been drained below)
+    torch.cuda.synchronize()
+    ctx.infer_device(dx.data_ptr(), 2, sync=False)
+    with torch.cuda.stream(es):
+        staged.copy_(view, non_blocking=True)  # ordered behind the step on the context's own stream
+        ev = torch.cuda.Event()
+        ev.record(es)
+    ev.synchronize()
+    assert staged.cpu().numpy().tobytes() == want.tobytes()
+    # the order: wrappers / events / views first, drain, then the context
+    del ev, es, view, staged, dx
+    gc.collect()
+    torch.cuda.synchronize()
+    ctx.close()
+    ctx.close()  # idempotent
+    assert getattr(ctx, "_h", None) is None
+    # the model outlives its contexts and serves a new one
+    again, _ = bn.Context(m, 2).infer(x)
+    assert again.tobytes() == want.tobytes()
