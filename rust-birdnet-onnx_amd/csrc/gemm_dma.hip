@@ -48,6 +48,16 @@ __device__ __forceinline__ void gd_act(int act, float p0, float p1, float (&v)[N
     else if (act == ACT_HSIGMOID) map_array<N>(v, [=](float x) { return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f); });
 }
 
+#ifdef BN_GD_STAMPS  // tools/gemm_stamps.cpp: shader-clock stamps of block (0, 0)'s waves around every K step (diagnostic build only)
+__device__ unsigned long long bn_gd_stamps[8][96][3];  // [wave][iteration][before the wait | behind the barrier + refill | behind the matrix instructions]
+#define GD_STAMP(IT, WHICH)                                                                                                \
+    do {                                                                                                                   \
+        if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0 && (IT) < 96) bn_gd_stamps[wave][(IT)][(WHICH)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GD_STAMP(IT, WHICH)
+#endif
+
 #define GD_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 #define GD_GLB_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
 
@@ -241,12 +251,24 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
 
     // main loop: every slice multiplies a full step, nothing conditional around the matrix instructions (a branch there
     // makes the compiler copy all accumulators through VGPRs every iteration)
+    // Round 4, in-kernel stamps (tools/gemm_stamps.cpp, -DBN_GD_STAMPS; gpurun_out/r4k/stamps*.txt): a K-step pair of this loop takes
+    // ~4 800 cycles for 3 584 cycles of matrix instructions per SIMD.  The difference is the ISSUE of the LDS-DMA pieces: ~100 - 170 cycles
+    // per global_load_lds_dwordx4 (1 KiB), 12 per SIMD and K-step pair, during which that SIMD multiplies nothing.  Behind the barrier
+    // (here) they show as wait time -- the first slice's waves, older, win the matrix pipe, finish 2 100 cycles early and wait; the
+    // second slice's waves spend ~1 000 cycles issuing.  Spread between the matrix instructions of the step (one piece behind each k
+    // slot's block, sched_barrier-pinned) the wait share falls from 0.44 / 0.24 to 0.17 / 0.08 of the loop AND THE LOOP TAKES AS LONG
+    // (48 880 against 48 172 cycles at K = 672; 113 456 against 114 700 at K = 1392): the cost moves, it does not overlap.  What a
+    // step pays is bytes staged per multiply-add -- (TR + BN) * 128 B per TR * BN * 32 -- i.e. the tile shape, which the LDS bounds
+    // (two K slices x three stages: TR + BN <= 208 rows).  The simple order stays.
     for (int i = 0; i < nmain; i++) {
+        GD_STAMP(i, 0);
         turn(i);
+        GD_STAMP(i, 1);
         const float *sb = ring + (i % D) * STAGE_FLOATS;
         const int kcol = 32 * (ks + i * KS);
         group(sb, 0, kcol);
         group(sb, 1, kcol + 16);
+        GD_STAMP(i, 2);
     }
     // ragged end: at most two more iterations in which some slices have a full step, one the half step, some none
     for (int i = nmain; i < niter; i++) {
@@ -543,6 +565,10 @@ void launch_cfg(hipStream_t s, const GemmDesc &d, float *C, const float *A, cons
 }
 
 }  // namespace
+
+#ifdef BN_GD_STAMPS
+void gemm_dma_read_stamps(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(bn_gd_stamps), sizeof(unsigned long long) * 8 * 96 * 3); }
+#endif
 
 void register_gemm_dma_kernels() {
 #define GD_REG1(MTW, NTW, WM, WN, KS)                                                                               \
