@@ -24,7 +24,13 @@ $(OUT): $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
+# diagnostic build: the LDS-DMA GEMM with shader-clock stamps around every K step of one block (tools/gemm_stamps.cpp; never linked into the library)
+stamps: $(OUT)
+	$(HIPCC) $(HIPFLAGS) -DBN_GD_STAMPS -c $(SRC)/gemm_dma.hip -o /tmp/bn_gd_stamps.o
+	$(HIPCC) -O3 -std=c++17 --offload-arch=$(ARCH) -Iinclude -I$(SRC) -c tools/gemm_stamps.cpp -o /tmp/bn_gemm_stamps_main.o
+	$(HIPCC) --offload-arch=$(ARCH) /tmp/bn_gemm_stamps_main.o /tmp/bn_gd_stamps.o $(SRC)/kernels.o $(SRC)/stft.o $(SRC)/topk.o $(SRC)/mbrow.o $(SRC)/mbmap.o -o tools/gemm_stamps -lpthread -ldl
+
 clean:
 	rm -f $(OBJS) $(OUT)
 	$(MAKE) -C oracle clean
-.PHONY: all oracle clean
+.PHONY: all oracle clean stamps
