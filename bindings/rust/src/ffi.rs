@@ -87,6 +87,9 @@ extern "C" {
     pub fn bn_group_last_error(buf: *mut c_char, cap: usize) -> usize;
     // recording-level ingest (optional; birdnet-analyze.rs read_wav + chunk_audio on the device)
     pub fn bn_recording_create(device: i32, pcm: *const core::ffi::c_void, n_samples: usize, format: i32, out: *mut *mut bn_recording) -> i32;
+    /// returns at once; `pcm` must outlive `bn_recording_wait` / `bn_recording_free` (the windows' calls wait for the samples they read)
+    pub fn bn_recording_create_async(device: i32, pcm: *const core::ffi::c_void, n_samples: usize, format: i32, out: *mut *mut bn_recording) -> i32;
+    pub fn bn_recording_wait(r: *const bn_recording) -> i32;
     pub fn bn_recording_free(r: *mut bn_recording);
     pub fn bn_chunk_count(n_samples: usize, step_samples: usize) -> usize;
     pub fn bn_infer_windows(c: *mut bn_ctx, r: *const bn_recording, step_samples: usize, first_window: usize, count: usize,

@@ -302,6 +302,16 @@ typedef struct bn_recording bn_recording;
 #define BN_PCM_F32 1 /* float mono, used as is */
 bn_status bn_recording_create(int32_t device, const void *pcm, size_t n_samples, int32_t format,
                               bn_recording **out);
+/* The same, returning at once: a thread of the recording's own uploads `pcm` chunk by chunk (32 MiB; BN_UPLOAD_CHUNK_MB) while
+ * the caller already analyses the first windows -- bn_infer_windows / bn_step_windows / bn_recording_windows / bn_recording_read_f32
+ * block (on the host) until the last sample they read has arrived, so a loop over the windows in time order overlaps the
+ * upload of a long recording with its analysis (a 24 h recording on one GPU: 0.72 s -> the analysis time alone).
+ * `pcm` must stay valid and unchanged until bn_recording_wait() has returned or the recording is freed (the reference CLI
+ * keeps the whole file in memory for the run, src/bin/birdnet-analyze.rs:653-704). */
+bn_status bn_recording_create_async(int32_t device, const void *pcm, size_t n_samples, int32_t format,
+                                    bn_recording **out);
+/* Blocks until the whole recording is on the device (BN_ERR_BACKEND if the upload failed). */
+bn_status bn_recording_wait(const bn_recording *r);
 /* Sample-rate conversion front end (the reference CLI refuses a WAV whose rate differs
  * from the model's, src/bin/birdnet-analyze.rs:447-455).  The recording is uploaded in its storage format and
  * converted ON THE DEVICE to f32 at dst_rate by a polyphase windowed-sinc FIR: L/M = dst/src reduced, cutoff

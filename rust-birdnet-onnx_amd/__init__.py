@@ -45,7 +45,7 @@ ENGINE_SYMBOLS = [
     "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_submit", "bn_infer_collect", "bn_infer_device",
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
     "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
-    "bn_recording_create", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
+    "bn_recording_create", "bn_recording_create_async", "bn_recording_wait", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
     "bn_infer_windows", "bn_step_windows", "bn_ctx_step_device_rows", "bn_group_create", "bn_group_destroy", "bn_group_size",
     "bn_group_uses_rccl", "bn_group_get_stats", "bn_shard_range", "bn_group_analyze_recording", "bn_group_last_error", "bn_recording_create_resampled", "bn_resample_table", "bn_recording_read_f32", "bn_last_error",
 ]
@@ -139,6 +139,8 @@ def _load() -> C.CDLL:
         "bn_step_results": (i32, [vp, C.POINTER(f32p), C.POINTER(u32p), C.POINTER(f32p), C.POINTER(u32p), C.POINTER(sz)]),
         "bn_plan_describe": (sz, [C.c_char_p, i32, i32, C.c_char_p, sz, C.POINTER(i32)]),
         "bn_recording_create": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
+        "bn_recording_create_async": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
+        "bn_recording_wait": (i32, [vp]),
         "bn_recording_free": (None, [vp]),
         "bn_recording_samples": (sz, [vp]),
         "bn_chunk_count": (sz, [sz, sz]),
@@ -787,9 +789,11 @@ class Recording:
     """bn_recording: a mono recording uploaded once in its storage format (int16 or float32)."""
 
     def __init__(self, samples: np.ndarray, device: int = 0, src_rate: Optional[int] = None, dst_rate: Optional[int] = None,
-                 zero_crossings: int = 0):
+                 zero_crossings: int = 0, async_upload: bool = False):
         """src_rate / dst_rate given and different: converted on the device by the polyphase resampler
-        (bn_recording_create_resampled); the recording then holds f32 samples at dst_rate."""
+        (bn_recording_create_resampled); the recording then holds f32 samples at dst_rate.
+        async_upload: bn_recording_create_async -- returns at once, the windows' calls wait for the samples they read (this object
+        keeps the array alive until the upload is done)."""
         a = np.ascontiguousarray(samples)
         if a.ndim != 1 or a.dtype not in (np.int16, np.float32):
             raise ValueError("mono int16 or float32 samples expected")
@@ -797,12 +801,22 @@ class Recording:
         fmt = 0 if a.dtype == np.int16 else 1
         if src_rate and dst_rate:
             st = lib.bn_recording_create_resampled(device, a.ctypes.data_as(C.c_void_p), a.shape[0], fmt, src_rate, dst_rate, zero_crossings, C.byref(h))
+        elif async_upload:
+            self._keep = a  # the uploader thread reads it until wait() / free
+            st = lib.bn_recording_create_async(device, a.ctypes.data_as(C.c_void_p), a.shape[0], fmt, C.byref(h))
         else:
             st = lib.bn_recording_create(device, a.ctypes.data_as(C.c_void_p), a.shape[0], fmt, C.byref(h))
         if st:
             raise EngineError(st)
         self._h = h
         self.n_samples = int(lib.bn_recording_samples(h))
+
+    def wait(self):
+        """The whole recording is on the device (no-op for a synchronous upload)."""
+        st = lib.bn_recording_wait(self._h)
+        if st:
+            raise EngineError(st)
+        self._keep = None
 
     def read_f32(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
         count = self.n_samples - first if count is None else count

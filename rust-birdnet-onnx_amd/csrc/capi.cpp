@@ -1350,7 +1350,30 @@ struct bn_recording {
     int32_t format = BN_PCM_I16;
     void *d_pcm = nullptr;
     size_t n_samples = 0;
+    // asynchronous upload (bn_recording_create_async): a thread of the recording's own copies the caller's buffer chunk by chunk
+    // (synchronous copies under the capture gate, like every other copy of the library); chunks_done chunks are on the device
+    size_t chunk_samples = 0;  // 0: the whole recording was uploaded at creation
+    size_t n_chunks = 0;
+    std::atomic<size_t> chunks_done{0};
+    std::atomic<int> upload_error{0};
+    std::thread uploader;
+    std::mutex mu;
+    std::condition_variable cv;
 };
+
+namespace {
+// blocks until sample `last` of the recording is on the device (kernels launched afterwards may read it); false if the upload failed
+bool recording_wait_samples(const bn_recording *rc, size_t last) {
+    bn_recording *r = const_cast<bn_recording *>(rc);
+    if (!r->chunk_samples || r->n_chunks == 0) return true;
+    const size_t need = std::min(last / r->chunk_samples, r->n_chunks - 1) + 1;
+    if (r->chunks_done.load(std::memory_order_acquire) >= need) return r->upload_error.load() == 0;
+    std::unique_lock<std::mutex> lk(r->mu);
+    r->cv.wait(lk, [&] { return r->chunks_done.load(std::memory_order_acquire) >= need || r->upload_error.load() != 0; });
+    return r->upload_error.load() == 0;
+}
+bool recording_wait_all(const bn_recording *r) { return recording_wait_samples(r, r->n_samples ? r->n_samples - 1 : 0); }
+}  // namespace
 
 bn_status bn_recording_create(int32_t device, const void *pcm, size_t n_samples, int32_t format, bn_recording **out) {
     if (!out) return fail(BN_ERR_INVALID_ARG, "null argument");
@@ -1373,6 +1396,55 @@ bn_status bn_recording_create(int32_t device, const void *pcm, size_t n_samples,
         }
     }
     *out = r.release();
+    return BN_OK;
+}
+
+bn_status bn_recording_create_async(int32_t device, const void *pcm, size_t n_samples, int32_t format, bn_recording **out) {
+    if (!out) return fail(BN_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (format != BN_PCM_I16 && format != BN_PCM_F32) return fail(BN_ERR_INVALID_ARG, "unknown PCM format");
+    if (n_samples && !pcm) return fail(BN_ERR_INVALID_ARG, "null PCM buffer");
+    if (bn_device_count() <= 0) return fail(BN_ERR_NO_DEVICE, "no gfx950 device visible");
+    HIP_TRY(bn::use_device(device));
+    const size_t esz = format == BN_PCM_I16 ? sizeof(int16_t) : sizeof(float);
+    const size_t chunk_mb = getenv("BN_UPLOAD_CHUNK_MB") ? (size_t)std::max(1, atoi(getenv("BN_UPLOAD_CHUNK_MB"))) : 32;
+    auto r = std::make_unique<bn_recording>();
+    r->device = device;
+    r->format = format;
+    r->n_samples = n_samples;
+    HIP_TRY(gated::Malloc(&r->d_pcm, std::max<size_t>(n_samples * esz, 16)));
+    r->chunk_samples = std::max<size_t>(1, (chunk_mb << 20) / esz);
+    r->n_chunks = (n_samples + r->chunk_samples - 1) / r->chunk_samples;
+    bn_recording *raw = r.get();
+    if (r->n_chunks)
+        r->uploader = std::thread([raw, pcm, esz]() {
+            if (bn::use_device(raw->device) != hipSuccess) raw->upload_error.store(1);
+            for (size_t k = 0; k < raw->n_chunks && raw->upload_error.load() == 0; k++) {
+                const size_t a = k * raw->chunk_samples, n = std::min(raw->chunk_samples, raw->n_samples - a);
+                // a synchronous copy of its own kind (null stream; the contexts' streams are non-blocking and do not wait for it)
+                if (gated::Memcpy(static_cast<char *>(raw->d_pcm) + a * esz, static_cast<const char *>(pcm) + a * esz, n * esz, hipMemcpyHostToDevice) != hipSuccess) {
+                    (void)hipGetLastError();
+                    raw->upload_error.store(1);
+                }
+                {
+                    std::lock_guard<std::mutex> lk(raw->mu);
+                    raw->chunks_done.store(k + 1, std::memory_order_release);
+                }
+                raw->cv.notify_all();
+            }
+            if (raw->upload_error.load()) {  // wake every waiter
+                std::lock_guard<std::mutex> lk(raw->mu);
+                raw->chunks_done.store(raw->n_chunks, std::memory_order_release);
+                raw->cv.notify_all();
+            }
+        });
+    *out = r.release();
+    return BN_OK;
+}
+
+bn_status bn_recording_wait(const bn_recording *r) {
+    if (!r) return fail(BN_ERR_INVALID_ARG, "null recording");
+    if (!recording_wait_all(r)) return fail(BN_ERR_BACKEND, "recording upload failed");
     return BN_OK;
 }
 
@@ -1476,6 +1548,7 @@ bn_status bn_recording_read_f32(const bn_recording *r, size_t first, size_t coun
     if (r->format != BN_PCM_F32) return fail(BN_ERR_INVALID_ARG, "recording is not f32");
     if (first > r->n_samples || count > r->n_samples - first) return fail(BN_ERR_INVALID_ARG, "sample range exceeds the recording");
     if (count == 0) return BN_OK;
+    if (!recording_wait_samples(r, first + count - 1)) return fail(BN_ERR_BACKEND, "recording upload failed");
     HIP_TRY(bn::use_device(r->device));
     HIP_TRY(gated::Memcpy(host_out, static_cast<const float *>(r->d_pcm) + first, count * sizeof(float), hipMemcpyDeviceToHost));
     return BN_OK;
@@ -1483,6 +1556,7 @@ bn_status bn_recording_read_f32(const bn_recording *r, size_t first, size_t coun
 
 void bn_recording_free(bn_recording *r) {
     if (!r) return;
+    if (r->uploader.joinable()) r->uploader.join();  // (the caller's buffer is read until here at the latest)
     (void)bn::use_device(r->device);
     if (r->d_pcm) (void)gated::Free(r->d_pcm);
     delete r;
@@ -1501,6 +1575,9 @@ static bn_status check_windows(const bn_recording *r, size_t S, size_t step, siz
     if (step == 0) return fail(BN_ERR_INVALID_ARG, "step_samples must be positive (overlap shorter than the segment)");
     const size_t total = bn_chunk_count(r->n_samples, step);
     if (first > total || count > total - first) return fail(BN_ERR_INVALID_ARG, "window range [" + std::to_string(first) + ", " + std::to_string(first + count) + ") exceeds the " + std::to_string(total) + " windows of the recording");
+    // an asynchronously uploaded recording: the last sample these windows read must have arrived before their kernel is launched
+    if (count && r->n_samples && !recording_wait_samples(r, std::min(r->n_samples - 1, (first + count - 1) * step + S - 1)))
+        return fail(BN_ERR_BACKEND, "recording upload failed");
     return BN_OK;
 }
 

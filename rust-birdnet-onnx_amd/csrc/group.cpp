@@ -284,7 +284,9 @@ bn_status bn_group_analyze_recording(bn_group *g, const void *pcm, size_t n_samp
         // the samples windows [lo, hi) touch: [lo * step, min(n, (hi - 1) * step + S))
         const size_t a = lo * step_samples, bnd = std::min(n_samples, (hi - 1) * step_samples + S);
         bn_recording *rec = nullptr;
-        bn_status st = bn_recording_create(rk.device, static_cast<const char *>(pcm) + a * esz, bnd - a, format, &rec);
+        // (asynchronous: the rank's first windows are analysed while the rest of its slice is still crossing the bus; the caller's
+        // buffer is only read inside this call -- bn_recording_free below joins the upload)
+        bn_status st = bn_recording_create_async(rk.device, static_cast<const char *>(pcm) + a * esz, bnd - a, format, &rec);
         if (st != BN_OK) {
             char msg[512];
             bn_last_error(msg, sizeof(msg));

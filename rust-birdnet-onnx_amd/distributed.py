@@ -146,7 +146,9 @@ def analyze_recording_sharded(bn, model, samples: np.ndarray, overlap_secs: floa
         return empty, np.zeros((0, k0), dtype=np.uint32), np.zeros((0, k0), dtype=np.float32), np.zeros(0, dtype=np.uint32)
     lo, hi = shard_range(G, rank, world)
     a, b = shard_sample_range(n, S, step, lo, hi)
-    rec = bn.Recording(np.ascontiguousarray(samples[a:b]), device=model.device)
+    # asynchronous upload: the first windows are analysed while the rest of this rank's slice is still crossing the bus (the step
+    # calls block until the samples they read have arrived; the Recording keeps the array alive)
+    rec = bn.Recording(np.ascontiguousarray(samples[a:b]), device=model.device, async_upload=True)
     if ctxs is None:  # callers analysing many recordings keep their contexts (arena + captured graphs)
         ctxs = [bn.Context(model, batch) for _ in range(max(1, streams))]
     N = ctxs[0].output_device(cfg.logits_output)[1]

@@ -255,3 +255,47 @@ def test_resampled_recording_through_the_network(bn):
     assert got.shape == ref.shape
     assert np.all(np.abs(got - ref) <= ATOL + RTOL * np.abs(ref))
     assert (np.argmax(got, axis=1) == np.argmax(ref, axis=1)).all()
+
+
+def test_asynchronous_upload_is_chunked_and_bit_identical(bn, monkeypatch):
+    """bn_recording_create_async: the recording crosses the bus chunk by chunk on a thread of its own while the first windows are already
+    being cut and analysed; a call that reads samples which have not arrived yet blocks until they have.  Tiny chunks (1 MiB: the 4.3 MB
+    recording is five of them), windows consumed in time order and out of order, read-back: everything bit-identical to the synchronous
+    upload.  Freeing the recording right away (upload still running) joins the thread."""
+    S, sr = 144000, 48000
+    rng = np.random.default_rng(21)
+    pcm = rng.integers(-20000, 20000, size=S * 15 + 777, dtype=np.int16)
+    step = S - sr
+    path = write_model(synth.birdnet_v24(num_species=300, width=0.5))
+    model = bn.Model(path)
+    ctx = bn.Context(model, 4)
+    sync = bn.Recording(pcm)
+    G = sync.n_windows(step)
+    want = np.concatenate([ctx.infer_windows(sync, step, f, min(4, G - f))[0].copy() for f in range(0, G, 4)])
+    monkeypatch.setenv("BN_UPLOAD_CHUNK_MB", "1")
+    rec = bn.Recording(pcm, async_upload=True)
+    assert rec.n_windows(step) == G
+    got = np.concatenate([ctx.infer_windows(rec, step, f, min(4, G - f))[0].copy() for f in range(0, G, 4)])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # the LAST windows first on a fresh recording (the call waits for the final chunk), then the first ones
+    rec2 = bn.Recording(pcm, async_upload=True)
+    tail, _ = ctx.infer_windows(rec2, step, G - 3, 3)
+    assert np.array_equal(tail.view(np.uint32), want[G - 3:].view(np.uint32))
+    head, _ = ctx.infer_windows(rec2, step, 0, 4)
+    assert np.array_equal(head.view(np.uint32), want[:4].view(np.uint32))
+    rec2.wait()
+    # windows on the host and the step path (top-K fused) read the same samples
+    assert np.array_equal(rec2.windows(S, step, 2, 3), sync.windows(S, step, 2, 3))
+    ctx.step_windows(rec2, step, 4, 4, 5, 0.02)
+    ctx.synchronize()
+    lg = ctx.step_results(4)[0]
+    assert np.array_equal(lg.view(np.uint32), want[4:8].view(np.uint32))
+    # f32 recordings and read-back through the same path
+    f32 = (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+    recf = bn.Recording(f32, async_upload=True)
+    assert np.array_equal(recf.read_f32(len(f32) - 1000, 1000), f32[-1000:])
+    # free while the upload may still be running: joins, no crash; an empty recording has nothing to upload
+    for _ in range(3):
+        r3 = bn.Recording(pcm, async_upload=True)
+        del r3
+    assert bn.Recording(np.zeros(0, dtype=np.int16), async_upload=True).n_windows(step) == 0
