@@ -532,13 +532,16 @@ def main():
         desc = bn.plan_describe(path_for_describe(model_bytes))
         plan_lines = [l for l in desc.splitlines() if l[:3].strip().isdigit()]
         kind_of = [l.split()[1] for l in plan_lines]
-        gemm_kernel_of = [("frame_fold_kernel" if " kernel=frame_fold" in l else "gemm_dma_kernel" if " kernel=dma" in l else "gemm_splitk_kernel" if " kernel=splitk" in l else "gemm_mfma_kernel")
+        gemm_kernel_of = [("frame_fold2_kernel" if " kernel=frame_fold2" in l else "frame_fold_kernel" if " kernel=frame_fold" in l else "gemm_dma_kernel" if " kernel=dma" in l else "gemm_splitk_kernel" if " kernel=splitk" in l else "gemm_mfma_kernel")
                           if l.split()[1] == "GEMM" else None for l in plan_lines]
         fam_name = {"GEMM": "gemm_mfma_kernel", "DWCONV": "dwconv_kernel", "CONV": "conv_direct_kernel", "MBCONV": "mbconv_row_kernel",
                     "REDUCE": "reduce_kernel", "ELT": "elt_kernel", "GAP": "gap_partial_kernel", "SEFC": "se_fc_kernel", "POOL": "pool_kernel", "FFT": "stft_kernel"}
+        # (the fused MBConv launches are two different kernels -- the row-streaming one, mbrow.hip, and the small-map one, mbmap.hip --
+        # and are counted as two families since round 4: which family is "dominant" should not hang on a sum over unrelated kernels)
         fam = {}
-        for (name, us, macs, byts), k in zip(rows, kind_of):
-            f_ = fam.setdefault(fam_name[k], {"us": 0.0, "macs": 0.0, "bytes": 0.0, "launches": 0})
+        for (name, us, macs, byts), k, line in zip(rows, kind_of, plan_lines):
+            fname = "mbmap_kernel" if k == "MBCONV" and " map=cfg" in line else fam_name[k]
+            f_ = fam.setdefault(fname, {"us": 0.0, "macs": 0.0, "bytes": 0.0, "launches": 0})
             f_["us"] += us
             f_["macs"] += macs
             f_["bytes"] += byts

@@ -936,6 +936,106 @@ class Builder {
         return true;
     }
 
+    // ------------------------------------------------------------- quarter-folded cosine banks (round 4)
+    // A recognised bank of windowed COSINES only (the real part of an STFT) with a window symmetric about the frame centre: the even
+    // bins see the frame through S[n] = ye[n] + ye[L/2 - n], the odd ones through D[n] = ye[n] - ye[L/2 - n], n <= L/4 (kernels.h,
+    // GemmDesc::fold == 2; kernels.hip, frame_fold2_kernel) -- L/4 + 1 taps per output instead of L/2.  The filter rows become pure
+    // cosines x the fitted row amplitude (double -> f32), the window moves to the signal (two tables), the columns are grouped (even bins,
+    // padded to 32, then odd bins) and a column map sends every result to its output channel.  v2.4's 127 mel-live bins of the 2048-point
+    // branch: 17 K steps instead of 32.  BN_CONVFOLD2=0 keeps the half fold.
+    bool emit_quarter_fold(const OnnxNode &n, const PlanOp &base, const DftBank &bank, const std::vector<int> &cls, int64_t Cout, int64_t OW, bool has_bias) {
+        if (env_int("BN_CONVFOLD2", 1) == 0) return false;
+        const int64_t L = bank.L;
+        if (L % 128 != 0) return false;
+        for (int64_t c = 0; c < Cout; c++)
+            if (cls[(size_t)c] < 0 || bank.b[(size_t)c] != 0.0) return false;  // a sine row: the half fold (or the FFT) keeps the bank
+        // the window: symmetric about the centre, nothing at tap 0 (the fold check saw that on the rows; here on the fitted window itself)
+        // (a tap at which every row's cosine vanishes -- n = L/4 for a bank of odd bins -- is invisible in the rows: the fitted window holds
+        // noise there, and nothing it multiplies reaches an output.  Such taps count as zero.)
+        std::vector<float> w = bank.window;
+        {
+            std::vector<double> seen((size_t)L, 0.0);
+            double smax = 0;
+            for (int64_t t = 0; t < L; t++) {
+                for (int64_t c = 0; c < Cout; c++) {
+                    const double v = bank.a[(size_t)c] * std::cos(2.0 * M_PI * (double)((bank.k[(size_t)c] * t) % L) / (double)L);
+                    seen[(size_t)t] += v * v;
+                }
+                smax = std::max(smax, seen[(size_t)t]);
+            }
+            for (int64_t t = 0; t < L; t++)
+                if (!(seen[(size_t)t] > 1e-20 * smax)) w[(size_t)t] = 0.0f;
+        }
+        float wmax = 0.0f;
+        for (float v : w) wmax = std::max(wmax, std::fabs(v));
+        const float eps = 4e-7f * wmax;
+        const bool dbg = getenv("BN_STFT_DEBUG") != nullptr;
+        if (!(std::fabs(w[0]) <= eps)) {
+            if (dbg) fprintf(stderr, "quarter fold: window tap 0 = %.3g\n", (double)w[0]);
+            return false;
+        }
+        for (int64_t t = 1; t < L / 2; t++)
+            if (!(std::fabs(w[(size_t)t] - w[(size_t)(L - t)]) <= eps)) {
+                if (dbg) fprintf(stderr, "quarter fold: window not symmetric at tap %lld: %.9g vs %.9g\n", (long long)t, (double)w[(size_t)t], (double)w[(size_t)(L - t)]);
+                return false;
+            }
+        std::vector<int32_t> even, odd, dead;
+        for (int64_t c = 0; c < Cout; c++) (bank.a[(size_t)c] == 0.0 ? dead : (bank.k[(size_t)c] & 1) ? odd : even).push_back((int32_t)c);
+        for (int32_t c : dead) {  // an all-zero row (its output is the bias) joins the group with room in its last wave column
+            const size_t se = (32 - even.size() % 32) % 32, so = (32 - odd.size() % 32) % 32;
+            (so > se ? odd : even).push_back(c);
+        }
+        const int64_t ne = ((int64_t)even.size() + 31) / 32 * 32, no = ((int64_t)odd.size() + 31) / 32 * 32, N2 = ne + no;
+        const int64_t Q = L / 4, K2 = Q + 32;
+        PlanOp f = base;
+        f.gemm.N = (int32_t)N2;
+        f.gemm.K = (int32_t)K2;
+        f.gemm.fold = 2;
+        f.gemm.fold_n = (int32_t)L;
+        f.gemm.fold_ne = (int32_t)ne;
+        if (!frame_fold2_shape_ok(f.gemm, nullptr)) {
+            if (dbg) fprintf(stderr, "quarter fold: shape outside the kernel (N = %lld + %lld columns, %zu bytes of LDS)\n", (long long)ne, (long long)no, frame_fold2_lds_bytes(f.gemm));
+            return false;
+        }
+        std::vector<float> colmap_bits((size_t)N2), wk((size_t)(N2 * K2), 0.0f), tabs((size_t)(2 * K2), 0.0f);
+        std::vector<int32_t> colmap((size_t)N2, -1);
+        for (size_t i = 0; i < even.size(); i++) colmap[i] = even[i];
+        for (size_t i = 0; i < odd.size(); i++) colmap[(size_t)ne + i] = odd[i];
+        static_assert(sizeof(int32_t) == sizeof(float), "the column map travels in a constant of floats");
+        std::memcpy(colmap_bits.data(), colmap.data(), (size_t)N2 * sizeof(float));
+        std::vector<double> ctab((size_t)L);
+        for (int64_t t = 0; t < L; t++) ctab[(size_t)t] = std::cos(2.0 * M_PI * (double)t / (double)L);
+        for (int64_t col = 0; col < N2; col++) {
+            const int32_t c = colmap[(size_t)col];
+            if (c < 0) continue;
+            const int64_t k = bank.k[(size_t)c];
+            const double a = bank.a[(size_t)c];
+            float *row = &wk[(size_t)(col * K2)];
+            for (int64_t t = 0; t < Q; t++) row[t] = (float)(a * ctab[(size_t)((k * t) % L)]);
+            row[Q] = (k & 1) ? 0.0f : (float)(a * ctab[(size_t)((k * Q) % L)]);  // cos(pi k / 2) = +-1 for even k
+        }
+        // S[n] = wa[n] (x[n] + x[L-n]) + wb[n] (x[L/2-n] + x[L/2+n]); n = 0: ye[0] = 0 and ye[L/2] = y[L/2] once; n = L/4: ye[L/4] once
+        for (int64_t t = 1; t < Q; t++) {
+            tabs[(size_t)t] = w[(size_t)t];
+            tabs[(size_t)(K2 + t)] = w[(size_t)(L / 2 - t)];
+        }
+        tabs[0] = 0.0f;
+        tabs[(size_t)K2] = 0.5f * w[(size_t)(L / 2)];
+        tabs[(size_t)Q] = w[(size_t)Q];
+        tabs[(size_t)(K2 + Q)] = 0.0f;
+        f.name = "Conv:" + n.name + "~quarter";
+        f.w = Ref{Space::CONSTS, add_const(wk), 0};
+        f.w2 = Ref{Space::CONSTS, add_const(tabs), 0};
+        f.bias2 = Ref{Space::CONSTS, add_const(colmap_bits), 0};
+        f.macs = (double)OW * (double)Cout * (double)(Q + 1);  // multiplications actually performed (padding columns excluded)
+        f.weight_bytes = 4.0 * (wk.size() + tabs.size() + colmap.size() + (has_bias ? Cout : 0));
+        dft_gemm_macs_ += (double)OW * Cout * L;
+        dft_performed_macs_ += f.macs;
+        dft_fft_equiv_flops_ += (double)OW * 2.5 * (double)L * std::log2((double)L);
+        push_op(std::move(f));
+        return true;
+    }
+
     // ------------------------------------------------------------- folded framing convolutions
     // A long single-channel 1-D filter bank whose rows are symmetric (w[n] == w[L-n], windowed cosine bases) or
     // antisymmetric (w[n] == -w[L-n], windowed sine bases) about the frame centre, with w[0] == 0 (Hann-type
@@ -970,7 +1070,10 @@ class Builder {
         }
         {
             DftBank bank;
-            if (detect_dft_bank(wf, Cout, L, cls, bank) && emit_stft(n, base, bank, Cout, OW, has_bias)) return true;
+            if (detect_dft_bank(wf, Cout, L, cls, bank)) {
+                if (emit_stft(n, base, bank, Cout, OW, has_bias)) return true;
+                if (emit_quarter_fold(n, base, bank, cls, Cout, OW, has_bias)) return true;
+            }
         }
         struct Run { int64_t n0, n1; int sign; };
         std::vector<Run> runs;

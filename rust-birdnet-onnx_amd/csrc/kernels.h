@@ -98,7 +98,14 @@ struct GemmDesc {
     // Folded framing rows (filters that are symmetric / antisymmetric about their centre, e.g. windowed DFT
     // bases): fold = +1 / -1, fold_n = the filter length.  Column c < K = fold_n / 2 of the operand is then
     // x[1 + c] + fold * x[fold_n - 1 - c] of the frame, and W holds the first-half taps 1 .. fold_n/2.
+    // fold = 2 (round 4, "quarter fold"; frame_fold2_kernel): a bank of WINDOWED COSINES whose window is symmetric about the frame centre.
+    // With y = window * x, ye[n] = y[n] + y[L-n]:  cos(2 pi k (L/2 - n) / L) = (-1)^k cos(2 pi k n / L), so the EVEN bins need only
+    // S[n] = ye[n] + ye[L/2-n] and the odd ones D[n] = ye[n] - ye[L/2-n], n < L/4 (+ the lone tap n = L/4 for the even bins): a
+    // quarter of the filter length per output.  W is [N][K] with K = fold_n / 4 + 32 (pure cosines x the row's amplitude, zero past
+    // tap L/4), the first fold_ne columns are the even-bin group (a multiple of 32), the rest the odd-bin group; the launch takes the
+    // window tables and the column -> output channel map as two more operands (launch_gemm_fold2).
     int32_t fold, fold_n;
+    int32_t fold_ne;
     // Absorbed elementwise chain (planner rule E): unary stages applied after act, and the consumer's output view.
     int32_t npost, out_strided;
     int32_t post_act[4];
@@ -268,6 +275,11 @@ void launch_gemm_fold_pair(hipStream_t s, const GemmDesc &d, const GemmDesc &d2,
                            const float *W2, const float *bias2, int64_t batch);
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W,
                  const float *bias, const float *res, const float *scale, int64_t batch);
+// quarter-folded framing GEMM (GemmDesc::fold == 2): wtab = [2][K] window tables (wa | wb), colmap = [N] output channel of every
+// column (-1: padding), bias indexed by output channel.  The planner emits it only where frame_fold2_shape_ok (plan_rules.h) holds; a
+// launch outside that is an error (there is no other kernel for this operand form).
+void launch_gemm_fold2(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *wtab,
+                       const int32_t *colmap, int64_t batch);
 // LDS-DMA GEMM (gemm_dma.hip): 0 = not eligible, 1 = 64-row tiles, 2 = 48-row tiles (per-sample quantities only);
 // launch_gemm_dma returns false (nothing launched) when the shape or a pointer's alignment rules it out.  BN_GEMMDMA=0 disables.
 bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res,

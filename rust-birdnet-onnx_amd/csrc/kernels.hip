@@ -1000,6 +1000,170 @@ __global__ __launch_bounds__(PAIR ? 512 : 640) void frame_fold_kernel(FrameDesc 
     }
 }
 
+// ------------------------------------------------------------------ quarter-folded framing GEMM (round 4)
+// A bank of windowed COSINES (the real part of an STFT: v2.4's 127 mel-live bins of a 2048-point transform) needs a quarter of the filter
+// length per output, not half.  With y[n] = w[n] x[n] (w symmetric about the frame centre, w[0] = 0) and ye[n] = y[n] + y[L-n]:
+//     X[k] = sum_{n=0}^{L/2} ye[n] cos(2 pi k n / L),        cos(2 pi k (L/2 - n) / L) = (-1)^k cos(2 pi k n / L)
+//  =>  even k:  sum_{n<L/4} S[n] cos(2 pi k n / L) + ye[L/4] cos(pi k / 2),   S[n] = ye[n] + ye[L/2-n]
+//      odd  k:  sum_{n<L/4} D[n] cos(2 pi k n / L),                            D[n] = ye[n] - ye[L/2-n]
+// (n = 0 pairs ye[0] = 0 with the centre tap ye[L/2] = y[L/2]: table entries wa[0] = 0, wb[0] = w[L/2] / 2 say so.)  The window cannot stay
+// inside the filter rows as in the half fold -- w[n] != w[L/2-n] -- so it multiplies the signal: S[n] = wa[n] a + wb[n] b, D[n] = wa[n] a -
+// wb[n] b with a = x[n] + x[L-n], b = x[L/2-n] + x[L/2+n]; the filter rows are the planner's pure cosines (double -> f32) times the row's
+// amplitude.  Same structure as frame_fold_kernel: the block's signal span in LDS once, per 32-tap step TWO operand tiles (S and D) built
+// LDS -> LDS and one filter tile streamed through registers, one barrier per step; wave (w & 1, w >> 1) owns rows 32 (w & 1).. of the
+// columns 32 (w >> 1).. and reads the S tile if its columns are even bins (column < n_even), else the D tile.  L / 128 full steps + one
+// step of a single 8-wide group that carries tap L/4.  Half the matrix instructions of the half fold for ~3x its (small) staging
+// arithmetic.  Arithmetic differs from the half fold in the last place (window on the signal, cosines rounded once, another pairing) --
+// the same kind of difference as between the half fold and the plain convolution, far inside the path's 2e-4 tolerance; both forms are
+// held against the oracle (tests/test_gpu_ops.py, test_gpu_models.py with BN_CONVFOLD2=0 and default).
+struct Frame2Desc {
+    int32_t rows, N, K, L, hop;  // per-sample frames, columns (both groups, padded), filter row length (L/4 + 32), frame length, hop
+    int32_t tiles, span, vec4;   // 64-row tiles per sample; floats of signal a block keeps: 63 * hop + L; span loads as float4
+    int32_t n_even;              // columns of the even-bin group
+    int32_t has_bias;
+    int64_t a_bs, ldc, c_bs;
+};
+// LDS addresses as 32-bit byte offsets (ds_* instructions take base register + immediate; generic pointers cost an add each)
+typedef __attribute__((address_space(3))) float lds_float;
+typedef float lds_f2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) lds_f2v lds_float2;
+__device__ __forceinline__ uint32_t lds_offset_of(const float *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)p; }
+__device__ __forceinline__ float lds_ld(uint32_t byte_off) { return *(const lds_float *)(uintptr_t)byte_off; }
+__device__ __forceinline__ float2 lds_ld2(uint32_t byte_off) {
+    const lds_f2v v = *(const lds_float2 *)(uintptr_t)byte_off;
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_st2(uint32_t byte_off, float2 v) { *(lds_float2 *)(uintptr_t)byte_off = lds_f2v{v.x, v.y}; }
+
+// WN wave columns of 32 outputs (N == 32 WN), 2 WN waves; a thread owns SLOTS (row, column pair) slots of the two 64 x 32 operand tiles.
+// Schedule of a step: the signal / table reads of the NEXT step's operand tiles are issued, this step's matrix instructions run over them,
+// then the next tiles are finished (12 vector operations per slot) and written -- nothing conditional around the matrix instructions
+// (a branch there makes the compiler copy the accumulators twice per step), the single-group tail step sits behind the loop.
+template <int WN>
+__global__ __launch_bounds__(128 * WN) void frame_fold2_kernel(Frame2Desc d, float *__restrict__ C, const float *__restrict__ A, const float *__restrict__ W,
+                                                               const float *__restrict__ bias, const float *__restrict__ wtab, const int32_t *__restrict__ colmap) {
+    extern __shared__ __align__(16) float frame_lds[];
+    constexpr int T = 128 * WN, BN = 32 * WN, TILE = FRAME_BM * GEMM_LD, SLOTS = (FRAME_BM * 16 + T - 1) / T;
+    const int tid = threadIdx.x;
+    float *sig = frame_lds;
+    float *tab = sig + ((d.span + 4 + 3) & ~3);  // [2][K]: wa | wb
+    float *As = tab + 2 * d.K;                   // [2 buffers][S | D][64][GEMM_LD]
+    float *Ws = As + 4 * TILE;                   // [2 buffers][BN][GEMM_LD]
+    const int b = blockIdx.x / d.tiles, rt = blockIdx.x - b * d.tiles;
+    const int row0 = rt * FRAME_BM;
+    const int rows_here = min(FRAME_BM, d.rows - row0);
+    const float *src = A + (int64_t)b * d.a_bs + (int64_t)row0 * d.hop;
+    const int count = (rows_here - 1) * d.hop + d.L;
+    if (d.vec4) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(sig);
+        const int n4 = count >> 2;
+        for (int i = tid; i < n4; i += T) d4[i] = s4[i];
+        for (int i = (n4 << 2) + tid; i < count; i += T) sig[i] = src[i];
+    } else {
+        for (int i = tid; i < count; i += T) sig[i] = src[i];
+    }
+    if (tid < 4) sig[count + tid] = 0.0f;  // tap 0 pairs x[0] with "x[L]" under a zero coefficient: a finite value, not whatever LDS held
+    for (int i = tid; i < 2 * d.K; i += T) tab[i] = wtab[i];
+    const int wq = tid & 7, wr = tid >> 3;  // filter tile staging: BN rows x 32 taps = BN * 8 float4, two per thread (T = 4 * BN)
+    constexpr int WROWS = T >> 3;           // = BN / 2
+    const int nfull = d.L / (4 * GEMM_BK);  // full steps; step nfull carries tap L/4 in its first 8-wide group
+    const float *wrow0 = W + (int64_t)wr * d.K + 4 * wq, *wrow1 = wrow0 + (int64_t)WROWS * d.K;
+    float4 rw0, rw1;
+    // operand staging: byte addresses of the slot's four signal streams at step 0 (forward streams advance 128 B per step, mirrored ones
+    // retreat), of the thread's table entries (every slot of a thread has the same column pair) and of its destination
+    uint32_t a_fw[SLOTS], a_rv[SLOTS], a_hm[SLOTS], a_hp[SLOTS], a_dst[SLOTS];
+    const uint32_t sig0 = lds_offset_of(sig), as0 = lds_offset_of(As);
+    const int cp = (tid & 15) * 2;
+    uint32_t a_wa = lds_offset_of(tab) + 4u * cp, a_wb = a_wa + 4u * d.K;
+#pragma unroll
+    for (int i = 0; i < SLOTS; i++) {
+        const int p = tid + i * T;
+        const int r = (p >> 4) & (FRAME_BM - 1);
+        const int re = r < rows_here ? r : rows_here - 1;
+        const uint32_t f = sig0 + 4u * (uint32_t)(re * d.hop);
+        a_fw[i] = f + 4u * cp;                       // x[n], x[n+1]
+        a_rv[i] = f + 4u * (d.L - cp - 1);           // x[L-n-1], x[L-n]
+        a_hm[i] = f + 4u * (d.L / 2 - cp - 1);       // x[L/2-n-1], x[L/2-n]
+        a_hp[i] = f + 4u * (d.L / 2 + cp);           // x[L/2+n], x[L/2+n+1]
+        a_dst[i] = as0 + 4u * (uint32_t)(r * GEMM_LD + cp);
+    }
+    constexpr bool LAST_PARTIAL = (FRAME_BM * 16) % T != 0;  // the last slot exists only for the first threads
+    const bool last_on = !LAST_PARTIAL || tid + (SLOTS - 1) * T < FRAME_BM * 16;
+    float2 xf[SLOTS], xr[SLOTS], xm[SLOTS], xp[SLOTS], cwa, cwb;
+    auto load_a = [&]() {  // the reads of one step's slots (two neighbouring floats per stream: one ds_read2_b32 each)
+        cwa = lds_ld2(a_wa); cwb = lds_ld2(a_wb);
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) {
+            xf[i] = make_float2(lds_ld(a_fw[i]), lds_ld(a_fw[i] + 4));
+            xr[i] = make_float2(lds_ld(a_rv[i]), lds_ld(a_rv[i] + 4));
+            xm[i] = make_float2(lds_ld(a_hm[i]), lds_ld(a_hm[i] + 4));
+            xp[i] = make_float2(lds_ld(a_hp[i]), lds_ld(a_hp[i] + 4));
+        }
+    };
+    auto finish_a = [&](uint32_t buf_off) {  // buf_off: byte offset of the destination buffer (S tile; the D tile follows it); then the streams move on
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) {
+            if (i < SLOTS - 1 || last_on) {
+                const float a0 = xf[i].x + xr[i].y, a1 = xf[i].y + xr[i].x;
+                const float b0 = xm[i].y + xp[i].x, b1 = xm[i].x + xp[i].y;
+                const float ya0 = cwa.x * a0, ya1 = cwa.y * a1, yb0 = cwb.x * b0, yb1 = cwb.y * b1;
+                lds_st2(a_dst[i] + buf_off, make_float2(ya0 + yb0, ya1 + yb1));
+                lds_st2(a_dst[i] + buf_off + 4u * TILE, make_float2(ya0 - yb0, ya1 - yb1));
+            }
+            a_fw[i] += 4 * GEMM_BK; a_hp[i] += 4 * GEMM_BK;
+            a_rv[i] -= 4 * GEMM_BK; a_hm[i] -= 4 * GEMM_BK;
+        }
+        a_wa += 4 * GEMM_BK; a_wb += 4 * GEMM_BK;
+    };
+    auto store_w = [&](float *dst) {
+        *reinterpret_cast<float4 *>(dst + wr * GEMM_LD + 4 * wq) = rw0;
+        *reinterpret_cast<float4 *>(dst + (wr + WROWS) * GEMM_LD + 4 * wq) = rw1;
+    };
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int kind = wn * 32 < d.n_even ? 0 : 1;  // wave-uniform: S or D tile
+    rw0 = *reinterpret_cast<const float4 *>(wrow0); rw1 = *reinterpret_cast<const float4 *>(wrow1);
+    __syncthreads();  // signal span and window tables complete
+    load_a();
+    finish_a(0);
+    store_w(Ws);
+    rw0 = *reinterpret_cast<const float4 *>(wrow0 + GEMM_BK); rw1 = *reinterpret_cast<const float4 *>(wrow1 + GEMM_BK);  // (nfull >= 2)
+    __syncthreads();
+    floatx16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[0][r] = 0.0f;
+    const float *ap0 = As + kind * TILE + (wm * 32 + lr) * GEMM_LD + 4 * lh;
+    const float *wp0 = Ws + (wn * 32 + lr) * GEMM_LD + 4 * lh;
+    for (int ks = 0; ks < nfull; ks++) {
+        const int cur = ks & 1;
+        load_a();  // step ks + 1 (<= nfull: the tail step's tiles are staged like any other)
+        mfma_ktile_full<1>(ap0 + cur * 2 * TILE, wp0 + cur * BN * GEMM_LD, acc);
+        finish_a((uint32_t)((cur ^ 1) * 2 * TILE * 4));
+        store_w(Ws + (cur ^ 1) * BN * GEMM_LD);
+        {  // filter rows of step ks + 2; behind the last one the same rows again (never used)
+            const int k2 = min(ks + 2, nfull) * GEMM_BK;
+            rw0 = *reinterpret_cast<const float4 *>(wrow0 + k2); rw1 = *reinterpret_cast<const float4 *>(wrow1 + k2);
+        }
+        // LDS-only rendezvous (the filter rows requested a moment ago are only needed after the next step's products)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    mfma_ktile_partial<1>(ap0 + (nfull & 1) * 2 * TILE, wp0 + (nfull & 1) * BN * GEMM_LD, acc, 1);
+    const int col = wn * 32 + lr;
+    const int n = colmap[col];  // output channel of this lane's column (-1: padding)
+    if (n >= 0) {
+        const float bv = d.has_bias ? bias[n] : 0.0f;
+        float *cb = C + (int64_t)b * d.c_bs + (int64_t)row0 * d.ldc + n;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (r < rows_here) cb[(int64_t)r * d.ldc] = acc[0][reg] + bv;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ small-M GEMM: intra-block split-K
 // When the output has few 128-row tiles (late CNN stages, FC head) the kernel above leaves most
 // CUs idle.  Here a block owns one 32 x BN tile and its 4 waves split K between them (k-steps
@@ -2384,6 +2548,10 @@ inline unsigned cap_blocks(int64_t want, int64_t cap) { return (unsigned)std::ma
 void register_kernels_hip() {
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold_kernel<false>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold_kernel<true>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<2>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<3>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<4>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<5>));
 #define BN_REG_KS(KERNEL)                                                     \
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 1>)); \
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 2>)); \
@@ -2681,9 +2849,44 @@ void launch_gemm_fold_pair(hipStream_t s, const GemmDesc &d, const GemmDesc &d2,
         launch_error("folded framing GEMM + fused product: shape outside what the planner may fuse");
 }
 
+void launch_gemm_fold2(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *wtab,
+                       const int32_t *colmap, int64_t batch) {
+    if (batch <= 0) return;
+    if (!frame_fold2_shape_ok(d, W) || !wtab || !colmap) {
+        launch_error("quarter-folded framing GEMM: shape outside what the planner may emit");
+        return;
+    }
+    Frame2Desc f{};
+    f.rows = (int32_t)d.rows; f.N = d.N; f.K = d.K; f.L = d.fold_n; f.hop = (int32_t)d.lda;
+    f.tiles = (int32_t)((d.rows + FRAME_BM - 1) / FRAME_BM);
+    f.span = (FRAME_BM - 1) * f.hop + f.L;
+    f.vec4 = d.a_bs % 4 == 0 && (FRAME_BM * (int64_t)f.hop) % 4 == 0 && aligned16(A);
+    f.n_even = d.fold_ne; f.has_bias = d.has_bias;
+    f.a_bs = d.a_bs; f.ldc = d.ldc; f.c_bs = d.c_bs;
+    const size_t lds = frame_fold2_lds_bytes(d);
+    const dim3 grid((unsigned)((int64_t)f.tiles * batch));
+#define FOLD2_GO(WN)                                                                                                   \
+    do {                                                                                                               \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(frame_fold2_kernel<WN>), lds)) {                        \
+            launch_error("quarter-folded framing GEMM: the device refused the dynamic-LDS opt-in");                    \
+            return;                                                                                                    \
+        }                                                                                                              \
+        hipLaunchKernelGGL(frame_fold2_kernel<WN>, grid, dim3(128 * WN), lds, s, f, C, A, W, bias, wtab, colmap);      \
+    } while (0)
+    if (d.N == 64) FOLD2_GO(2);
+    else if (d.N == 96) FOLD2_GO(3);
+    else if (d.N == 128) FOLD2_GO(4);
+    else FOLD2_GO(5);
+#undef FOLD2_GO
+}
+
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
                  const float *res, const float *scale, int64_t batch) {
     if (batch <= 0) return;
+    if (d.fold == 2) {  // (its operands do not fit this signature)
+        launch_error("quarter-folded framing GEMM launched without its window tables");
+        return;
+    }
     const int64_t total_rows = batch * d.rows;
     if (d.npost || d.out_strided) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
     if (d.fold && launch_frame_fold(s, d, C, A, W, bias, batch)) return;

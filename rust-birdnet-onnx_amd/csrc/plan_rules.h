@@ -37,6 +37,23 @@ inline bool frame_fold_shape_ok(const GemmDesc &d, const float *W) {
     return true;
 }
 
+// Quarter-folded framing GEMM (frame_fold2_kernel, GemmDesc::fold == 2): per-sample quantities and, when given, the filter pointer's
+// alignment.  One N tile holds every column (two to five wave columns of 32), the block keeps the signal span, both window tables, two
+// operand tiles (S and D) and the filter tile double-buffered in LDS.  BN_FRAMELDS=0 / BN_CONVFOLD2=0 disable (the planner then keeps
+// the half fold).
+inline size_t frame_fold2_lds_bytes(const GemmDesc &d) {
+    const int64_t span = (int64_t)(FRAME_BM_RULE - 1) * d.lda + d.fold_n + 4;  // (+ the one element behind the last frame that tap 0 pairs with)
+    return (size_t)(((span + 3) & ~3) + 2 * d.K + 4 * FRAME_BM_RULE * GEMM_LD_RULE + 2 * d.N * GEMM_LD_RULE) * sizeof(float);
+}
+inline bool frame_fold2_shape_ok(const GemmDesc &d, const float *W) {
+    if (env_int("BN_FRAMELDS", 1) == 0 || env_int("BN_CONVFOLD2", 1) == 0) return false;
+    if (d.fold != 2 || d.has_res || d.has_scale || d.act != ACT_NONE || d.npost || d.out_strided || d.se_inline) return false;
+    if (d.fold_n < 256 || d.fold_n % 128 || d.K != d.fold_n / 4 + GEMM_BK_RULE || (W && !ptr_aligned16(W))) return false;
+    if (d.N % 32 || d.N < 64 || d.N > 160 || d.fold_ne % 32 || d.fold_ne < 0 || d.fold_ne > d.N) return false;
+    if (d.lda <= 0 || d.lda > 4096 || d.rows < 32 || d.c_bs < 0) return false;
+    return frame_fold2_lds_bytes(d) <= 160 * 1024;
+}
+
 // Planner rule J and its launcher agree through this: the folded framing GEMM `d` (its LDS-resident kernel) followed by a plain
 // product over its rows (frame_fold_kernel<true>).
 // Opt-in (BN_FRAMEPAIR=1): correct, one launch and the spectrum's round trip less -- and slower: behind the K loop the block's eight

@@ -216,6 +216,62 @@ def test_conv1d_folded_dft_framing(bn, n_fft, hop, kind, bias, monkeypatch):
     assert_close(got, plain, "folded vs unfolded plan", atol=2e-5 * float(np.abs(plain).max()), rtol=0)
 
 
+@pytest.mark.parametrize("n_fft,hop,which,window", [(2048, 278, "low", "hann"), (1024, 280, "mixed", "tapered"), (256, 100, "even", "hann"),
+                                                    (512, 37, "odd", "tapered"), (2048, 200, "wide", "hann")])
+def test_conv1d_quarter_folded_cosine_bank(bn, n_fft, hop, which, window, monkeypatch):
+    """A bank of windowed cosines only (the real part of an STFT, v2.4's first spectrogram branch) with a window symmetric about the frame
+    centre runs as the QUARTER-folded framing GEMM (planner: emit_quarter_fold; kernels.hip: frame_fold2_kernel): even bins against
+    S[n] = ye[n] + ye[L/2 - n], odd bins against D[n], L/4 + 1 taps per output.  Scrambled bin order, per-row gains, a dead row, DC and
+    Nyquist rows, banks of even bins only / odd bins only / more than one wave column per group, a bias, ragged last row tile (batch 2
+    and 3) -- against the oracle, against the half fold and against the plain convolution."""
+    rng = np.random.default_rng(n_fft + hop)
+    n = np.arange(n_fft, dtype=np.float64)
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)
+    if window == "tapered":
+        win = (0.54 - 0.46 * np.cos(2.0 * np.pi * n / n_fft)) * np.sin(np.pi * n / n_fft) ** 2
+    half = n_fft // 2
+    if which == "low":
+        bins = np.arange(0, 127)                                  # v2.4: the mel-live bins of the 2048-point branch
+    elif which == "mixed":
+        bins = np.concatenate([rng.permutation(np.arange(1, half))[:70], [0, half]])
+    elif which == "even":
+        bins = rng.permutation(np.arange(0, half + 1, 2))[:40]
+    elif which == "odd":
+        bins = rng.permutation(np.arange(1, half, 2))[:33]
+    else:
+        bins = np.concatenate([rng.permutation(np.arange(0, half + 1, 2))[:60], rng.permutation(np.arange(1, half, 2))[:90]])  # five wave columns
+        bins = rng.permutation(bins)
+    rows = [win * np.cos(2.0 * np.pi * k * n / n_fft) * rng.uniform(0.3, 3.0) * rng.choice([-1.0, 1.0]) for k in bins]
+    rows.insert(3, np.zeros(n_fft))                               # a dead row: its output is the bias
+    w = np.ascontiguousarray(np.array(rows, dtype=np.float32)[:, None, :])
+    b = rng.standard_normal(w.shape[0]).astype(np.float32)
+    frames = (144000 - n_fft) // hop + 1
+
+    def build(g, x):
+        u = g.node("Unsqueeze", [x, g.const(np.array([1], dtype=np.int64))])
+        return g.node("Conv", [u, g.const(w), g.const(b)], kernel_shape=[n_fft], strides=[hop])
+    data = op_graph(build, [w.shape[0], frames])
+    monkeypatch.setenv("BN_STFT", "0")  # (the default would decide FFT / matrix product per bank by estimated cost)
+    text = bn.plan_describe(write_model(data))
+    assert "~quarter" in text and "kernel=frame_fold2" in text and f"fold=2/{n_fft}" in text, text
+    got, ref = run_both(bn, data, batch=2)
+    tol = 2e-5 * float(np.abs(ref).max())
+    assert_close(got, ref, f"quarter-folded conv1d n_fft={n_fft} {which}", atol=tol, rtol=0)
+    assert np.array_equal(got[:, 3], np.broadcast_to(b[3], got[:, 3].shape))  # the dead row
+    got3, ref3 = run_both(bn, data, batch=3)
+    assert_close(got3, ref3, f"quarter-folded conv1d n_fft={n_fft} {which} batch 3", atol=tol, rtol=0)
+    assert np.array_equal(got3[:2].view(np.uint32), got.view(np.uint32))  # a segment's bits do not depend on the batch
+    monkeypatch.setenv("BN_CONVFOLD2", "0")
+    text = bn.plan_describe(write_model(data))
+    assert "~sym" in text and "~quarter" not in text, text
+    halfold, _ = run_both(bn, data, batch=2)
+    assert_close(got, halfold, "quarter fold vs half fold", atol=tol, rtol=0)
+    monkeypatch.setenv("BN_CONVFOLD", "0")
+    assert "~" not in bn.plan_describe(write_model(data))
+    plain, _ = run_both(bn, data, batch=2)
+    assert_close(got, plain, "quarter fold vs plain convolution", atol=tol, rtol=0)
+
+
 @pytest.mark.parametrize("n_fft,hop", [(128, 64), (256, 100), (512, 160), (1024, 320), (2048, 278), (640, 320), (640, 203)])
 def test_stft_every_transform_size(bn, n_fft, hop, monkeypatch):
     """All supported frame lengths (one radix-2 pass first when log2 of the half length is odd; radix 5 first for Perch's
