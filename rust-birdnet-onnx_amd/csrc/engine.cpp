@@ -945,6 +945,7 @@ class Builder {
     // branch: 17 K steps instead of 32.  BN_CONVFOLD2=0 keeps the half fold.
     bool emit_quarter_fold(const OnnxNode &n, const PlanOp &base, const DftBank &bank, const std::vector<int> &cls, int64_t Cout, int64_t OW, bool has_bias) {
         if (env_int("BN_CONVFOLD2", 1) == 0) return false;
+        if (env_int("BN_FRAMEPAIR", 0) == 1) return false;  // (opt-in rule J fuses the mel product behind the HALF fold's launch)
         const int64_t L = bank.L;
         if (L % 128 != 0) return false;
         for (int64_t c = 0; c < Cout; c++)

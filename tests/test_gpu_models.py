@@ -484,7 +484,7 @@ def test_round3_kernels_tile_shape_and_grouping_do_not_enter_the_arithmetic(bn, 
 
 
 @pytest.mark.parametrize("env", [{"BN_GEMMDMA": "0"}, {"BN_GEMMDMA": "2"}, {"BN_MBMAP2": "0"}, {"BN_SEGEMM": "1"}, {"BN_GEMMDMA_KS": "1"},
-                                 {"BN_STFT_MELMFMA": "0"}, {"BN_STFT_NW": "16"}, {"BN_MBROW_TOH": "8"}, {"BN_FRAMEPAIR": "1"}])
+                                 {"BN_STFT_MELMFMA": "0"}, {"BN_STFT_NW": "16"}, {"BN_MBROW_TOH": "8"}, {"BN_FRAMEPAIR": "1"}, {"BN_CONVFOLD2": "0"}])
 def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, monkeypatch, env):
     """Every round-3 rewrite has an off switch (and two opt-ins): the older kernels (BN_GEMMDMA=0, BN_MBMAP2=0), the
     LDS-DMA GEMM on every eligible shape (BN_GEMMDMA=2), the squeeze-excite products in the GEMM prologue (BN_SEGEMM=1),
@@ -503,6 +503,9 @@ def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, mon
         assert "se_inline=" in desc
     if env.get("BN_FRAMEPAIR") == "1":  # the mel product of the matrix-path branch behind the folded DFT conv, one launch
         assert " pair=" in desc and desc.count("MatMul:MatMul_11") == 1
+    assert ("~quarter" in desc) == (not env.get("BN_FRAMEPAIR") and env.get("BN_CONVFOLD2") != "0"), desc  # (round 4) the 127-bin cosine bank
+    if env.get("BN_CONVFOLD2") == "0":
+        assert "~sym" in desc
     if env.get("BN_STFT_MELMFMA") == "0":
         assert "(csr)" in desc and "(mfma)" not in desc
     else:
