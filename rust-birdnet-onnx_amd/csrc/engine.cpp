@@ -158,6 +158,7 @@ class Builder {
         }
 
         prune_zero_rows();
+        merge_framing_products();
 
         for (size_t k = 0; k < nodes_.size(); k++) {
             if (!live_[k] || absorbed_[k]) continue;
@@ -577,6 +578,104 @@ class Builder {
                     bi->second.f = nb; bi->second.dims[0] = (int64_t)keep.size();
                 }
             }
+        }
+    }
+
+    // ------------------------------------------------------------- framing conv x constant product -> one framing conv (round 4)
+    // Conv1D(one input channel, C filters of length L) -> Transpose -> MatMul(const W[C, N]) is ONE linear map of the frame when nothing
+    // sits between the two (v2.4 takes the REAL PART of its STFT straight into the mel bank): N filters  sum_c W[c][n] w_c  of length L,
+    // bias  sum_c W[c][n] b_c.  Worth it when N filters cost less than the C filters (as an FFT or as folded matrix products) plus the
+    // product: v2.4's 312 mel-live bins of the 1024-point branch -> 96 mel filters of 512 folded taps (the rows stay symmetric about the
+    // frame centre), against an FFT of every frame plus the mel phase; NOT its 127 bins of the 2048-point branch, which the quarter fold
+    // evaluates in 512 taps each where 96 merged filters would need 1024.  Costs in f32-MFMA SIMD-cycles per frame, the scale emit_stft
+    // calibrated.  The filters are summed in double and rounded once.  BN_CONVMERGE=0 disables, =1 merges wherever the pattern matches.
+    void merge_framing_products() {
+        const int mode = env_int("BN_CONVMERGE", -1);
+        if (mode == 0) return;
+        const std::string stft_mode = getenv("BN_STFT") ? getenv("BN_STFT") : "auto";
+        if (stft_mode == "1" && mode != 1) return;  // every recognised bank as an FFT: the banks stay banks
+        for (size_t k = 0; k < nodes_.size(); k++) {
+            if (!live_[k] || nodes_[k].op_type != "Conv") continue;
+            OnnxNode &conv = nodes_[k];
+            const int c1 = sole_consumer(conv.outputs[0]);
+            if (c1 < 0 || nodes_[c1].op_type != "Transpose" || nodes_[c1].attr_ints("perm") != std::vector<int64_t>{0, 2, 1}) continue;
+            const int mm = sole_consumer(nodes_[c1].outputs[0]);
+            if (mm < 0 || nodes_[mm].op_type != "MatMul" || nodes_[mm].inputs[0] != nodes_[c1].outputs[0]) continue;
+            auto wi = vals_.find(nodes_[mm].inputs[1]);
+            auto cw = vals_.find(conv.inputs[1]);
+            if (wi == vals_.end() || cw == vals_.end() || !wi->second.is_const || !cw->second.is_const || wi->second.is_int || cw->second.is_int) continue;
+            Val &W = wi->second;
+            Val &CW = cw->second;
+            if (W.dims.size() != 2 || CW.dims.size() != 3 || CW.dims[1] != 1 || W.dims[0] != CW.dims[0]) continue;  // [C, 1, L] x [C, N]
+            if (live_consumers(nodes_[mm].inputs[1]).size() != 1 || live_consumers(conv.inputs[1]).size() != 1) continue;
+            if (conv.attr_i("group", 1) != 1) continue;
+            const int64_t C = CW.dims[0], L = CW.dims[2], N = W.dims[1];
+            if (L < 128 || N >= C) continue;
+            Val *bias = nullptr;
+            if (conv.inputs.size() > 2 && !conv.inputs[2].empty()) {
+                auto bi = vals_.find(conv.inputs[2]);
+                if (bi == vals_.end() || !bi->second.is_const || bi->second.is_int || live_consumers(conv.inputs[2]).size() != 1) continue;
+                bias = &bi->second;
+            }
+            // symmetry of the rows about the frame centre (the fold rule's test, its tolerance)
+            float maxabs = 0.0f;
+            for (float v : CW.f) maxabs = std::max(maxabs, std::fabs(v));
+            const float eps = 1.1920929e-7f * maxabs;
+            bool all_sym = L % 64 == 0, all_folded = L % 64 == 0;
+            for (int64_t c = 0; c < C && all_folded; c++) {
+                const float *w = &CW.f[(size_t)(c * L)];
+                bool sym = std::fabs(w[0]) <= eps, anti = sym && std::fabs(w[L / 2]) <= eps;
+                for (int64_t t = 1; t < L / 2 && (sym || anti); t++) {
+                    if (!(std::fabs(w[t] - w[L - t]) <= eps)) sym = false;
+                    if (!(std::fabs(w[t] + w[L - t]) <= eps)) anti = false;
+                }
+                all_sym = all_sym && sym;
+                all_folded = all_folded && (sym || anti);
+            }
+            // separate: the cheapest form the bank may take + the product; merged: N filters, folded if every row is symmetric
+            const bool fft_size = L <= 2048 && ((L & (L - 1)) == 0 || fft_five_pow2(L));
+            double bank = (double)C * (double)(all_folded ? L / 2 : L) / 32.0;
+            bool product_inside = false;
+            if (all_sym && L % 128 == 0 && C <= 160) bank = std::min(bank, (double)C * (double)(L / 4 + 1) / 32.0);  // quarter fold
+            if (all_folded && fft_size && stft_mode != "0") {
+                const double fft = 0.18 * (double)L * std::log2((double)L);  // (with its mel phase: emit_stft's calibration)
+                if (fft < bank) { bank = fft; product_inside = true; }
+            }
+            const double separate = bank + (product_inside ? 0.0 : (double)C * (double)N / 32.0);
+            const double merged = (double)N * (double)(all_sym ? L / 2 : L) / 32.0;
+            if (mode != 1 && !(merged < 0.9 * separate)) continue;
+            std::vector<float> nw((size_t)(N * L));
+            std::vector<double> acc((size_t)L);
+            for (int64_t n2 = 0; n2 < N; n2++) {
+                std::fill(acc.begin(), acc.end(), 0.0);
+                for (int64_t c = 0; c < C; c++) {
+                    const double m = (double)W.f[(size_t)(c * N + n2)];
+                    if (m == 0.0) continue;
+                    const float *w = &CW.f[(size_t)(c * L)];
+                    for (int64_t t = 0; t < L; t++) acc[(size_t)t] += m * (double)w[t];
+                }
+                for (int64_t t = 0; t < L; t++) nw[(size_t)(n2 * L + t)] = (float)acc[(size_t)t];
+                if (all_sym) {  // exactly symmetric again after the rounding (the fold keeps the first half)
+                    nw[(size_t)(n2 * L)] = 0.0f;
+                    for (int64_t t = 1; t < L / 2; t++) nw[(size_t)(n2 * L + L - t)] = nw[(size_t)(n2 * L + t)];
+                }
+            }
+            if (bias) {
+                std::vector<float> nb((size_t)N);
+                for (int64_t n2 = 0; n2 < N; n2++) {
+                    double a = 0.0;
+                    for (int64_t c = 0; c < C; c++) a += (double)W.f[(size_t)(c * N + n2)] * (double)bias->f[(size_t)c];
+                    nb[(size_t)n2] = (float)a;
+                }
+                bias->f = nb;
+                bias->dims[0] = N;
+            }
+            CW.f = nw;
+            CW.dims[0] = N;
+            // the product is gone: its node hands the transposed conv result on
+            OnnxNode &prod = nodes_[mm];
+            prod.op_type = "Identity";
+            prod.inputs.resize(1);
         }
     }
 
@@ -3448,14 +3547,16 @@ class Builder {
                 if (prod.kind != OpKind::GEMM || prod.out.space != Space::ARENA || prod.out.id != cons.a.id) continue;
                 GemmDesc g = prod.gemm;
                 const EltDesc &ce = cons.elt;
-                if (g.npost || g.out_strided || !gemm_accepts_post(g) || g.ldc != g.N || g.c_bs != g.rows * g.N || ce.ba != g.c_bs) continue;
-                bool unary = true;
+                // (round 4: the LDS-resident folded framing GEMM carries a chain of the compact stage functions and the consumer's view too)
+                const bool fold_post = (g.fold == 1 || g.fold == -1) && frame_fold_post_ok(g);
+                if (g.npost || g.out_strided || !(gemm_accepts_post(g) || fold_post) || g.ldc != g.N || g.c_bs != g.rows * g.N || ce.ba != g.c_bs) continue;
+                bool unary = true, compact = true;
                 int npost = 0;
                 for (int k = 0; k < ce.nstages; k++) {
                     unary = unary && ce.st[k].bin == BIN_NONE;
-                    if (ce.st[k].act != ACT_NONE) npost++;
+                    if (ce.st[k].act != ACT_NONE) { npost++; compact = compact && stft_act_supported(ce.st[k].act); }
                 }
-                if (!unary || npost > 4 || ce.per_sample != g.rows * g.N) continue;
+                if (!unary || npost > 4 || ce.per_sample != g.rows * g.N || (fold_post && !compact)) continue;
                 // the chain's index space must be (a signed permutation of) rows x N
                 int64_t rs = 0, cs = 0, base = cons.out.offset, want_delta = 0;
                 bool ok = true, have_row = g.rows == 1, have_col = g.N == 1;

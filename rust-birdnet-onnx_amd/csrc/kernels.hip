@@ -818,6 +818,11 @@ struct FrameDesc {
     int64_t a_bs, ldc, c_bs;
     float sign;
     int32_t has_bias;
+    // absorbed elementwise chain (planner rule E) and the consumer's view: element (row m, column n) of sample b at C + b c_bs + m out_rs + n out_cs
+    int32_t npost, out_strided;
+    int32_t post_act[4];
+    float post_p0[4], post_p1[4];
+    int64_t out_rs, out_cs;
 };
 constexpr int FRAME_BM = 64;
 static_assert(FRAME_BM == FRAME_BM_RULE && GEMM_BK == GEMM_BK_RULE && GEMM_LD == GEMM_LD_RULE, "plan_rules.h restates the framing GEMM tile sizes");
@@ -986,6 +991,26 @@ __global__ __launch_bounds__(PAIR ? 512 : 640) void frame_fold_kernel(FrameDesc 
                 }
             }
             (void)rb;
+        }
+    } else if (d.npost || d.out_strided) {  // bias, the absorbed chain (compact stage functions), the consumer's view
+        floatx16 a2 = acc[0];
+        if (d.has_bias) {
+            const float bv = n < d.N ? bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) a2[r] += bv;
+        }
+        if (0 < d.npost) a2 = act_small16(d.post_act[0], d.post_p0[0], d.post_p1[0], a2);
+        if (1 < d.npost) a2 = act_small16(d.post_act[1], d.post_p0[1], d.post_p1[1], a2);
+        if (2 < d.npost) a2 = act_small16(d.post_act[2], d.post_p0[2], d.post_p1[2], a2);
+        if (3 < d.npost) a2 = act_small16(d.post_act[3], d.post_p0[3], d.post_p1[3], a2);
+        if (n < d.N) {
+            const int64_t rs = d.out_strided ? d.out_rs : d.ldc, cs = d.out_strided ? d.out_cs : 1;
+            float *cb = C + (int64_t)b * d.c_bs + (int64_t)n * cs;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                if (r < rows_here) cb[(int64_t)(row0 + r) * rs] = a2[reg];
+            }
         }
     } else if (n < d.N) {
         const float bv = d.has_bias ? bias[n] : 0.0f;
@@ -2816,6 +2841,9 @@ static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const 
     f.vec4 = d.a_bs % 4 == 0 && (FRAME_BM * (int64_t)f.hop) % 4 == 0 && aligned16(A);
     f.a_bs = d.a_bs; f.ldc = d.ldc; f.c_bs = d.c_bs;
     f.sign = (float)d.fold; f.has_bias = d.has_bias;
+    f.npost = d.npost; f.out_strided = d.out_strided; f.out_rs = d.out_rs; f.out_cs = d.out_cs;
+    for (int q = 0; q < 4; q++) { f.post_act[q] = d.post_act[q]; f.post_p0[q] = d.post_p0[q]; f.post_p1[q] = d.post_p1[q]; }
+    if (pair && (d.npost || d.out_strided)) return false;  // (the fused second product carries its own chain)
     // wave columns: the N tile (32 * WN) with the least padding among 128 and 160 (fewer, wider tiles on a tie)
     static const int force_wn = getenv("BN_FRAME_WN") ? atoi(getenv("BN_FRAME_WN")) : 0;  // experiments only
     auto padded = [&](int bn) { return (d.N + bn - 1) / bn * bn; };
@@ -2888,8 +2916,12 @@ void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, con
         return;
     }
     const int64_t total_rows = batch * d.rows;
-    if (d.npost || d.out_strided) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
     if (d.fold && launch_frame_fold(s, d, C, A, W, bias, batch)) return;
+    if (d.fold && (d.npost || d.out_strided)) {  // (planner rule E fuses a chain into a folded GEMM only where frame_fold_post_ok holds)
+        launch_error("folded framing GEMM with an absorbed chain: the LDS-resident kernel refused the launch and no other kernel carries both");
+        return;
+    }
+    if (d.npost || d.out_strided) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
     if (launch_gemm_dma(s, d, C, A, W, bias, res, scale, batch)) return;  // LDS-DMA kernel (gemm_dma.hip) where its tiles fit the shape
     if (gemm_use_splitk(d)) launch_gemm_splitk(s, d, C, A, W, bias, res, scale, total_rows);
     else launch_gemm_tiled(s, d, C, A, W, bias, res, scale, total_rows);

@@ -37,6 +37,15 @@ inline bool frame_fold_shape_ok(const GemmDesc &d, const float *W) {
     return true;
 }
 
+// ... with an absorbed elementwise chain / the consumer's output view (planner rule E, round 4): only where the LDS-resident kernel is
+// certain to take the launch -- the generic folded GEMM has no such epilogue -- i.e. whatever tile width the launcher picks fits the LDS
+inline bool frame_fold_post_ok(const GemmDesc &d) {
+    if (!frame_fold_shape_ok(d, nullptr)) return false;
+    const int64_t span = (int64_t)(FRAME_BM_RULE - 1) * d.lda + d.fold_n;
+    const int wn = d.N <= 96 ? std::max(2, (d.N + 31) / 32) : 5;  // (the launcher's widest choice)
+    return (size_t)(((span + 3) & ~3) + 2 * FRAME_BM_RULE * GEMM_LD_RULE + 2 * 32 * wn * GEMM_LD_RULE) * sizeof(float) <= 160 * 1024;
+}
+
 // Quarter-folded framing GEMM (frame_fold2_kernel, GemmDesc::fold == 2): per-sample quantities and, when given, the filter pointer's
 // alignment.  One N tile holds every column (two to five wave columns of 32), the block keeps the signal span, both window tables, two
 // operand tiles (S and D) and the filter tile double-buffered in LDS.  BN_FRAMELDS=0 / BN_CONVFOLD2=0 disable (the planner then keeps

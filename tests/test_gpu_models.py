@@ -125,12 +125,13 @@ def test_fft_front_end_whole_models(bn, v24_full, v30_small, monkeypatch):
     x3 = synth.synthetic_segments(3, 160000, 32000)
     out3 = onnx_ref.run_model(data3, x3)
     check_results(clf3.predict_batch(list(x3)), out3["output_1"], out3["output_0"], 5, None)
-    # the all-matrix plan and the default (per-bank choice: v2.4 runs its 309-bin bank as an FFT, the 127-bin one folded)
-    for mode, nfft in (("0", 0), (None, 1)):
-        if mode is None:
-            monkeypatch.delenv("BN_STFT")
-        else:
-            monkeypatch.setenv("BN_STFT", mode)
+    # the all-matrix plan, the default (round 4: the 127-bin bank quarter-folded, the 309-bin bank merged with its mel product into 96
+    # folded filters -- no FFT left in v2.4's plan) and the per-bank choice of round 3 (the 309-bin bank as an FFT, the other folded)
+    for env, nfft in (({"BN_STFT": "0"}, 0), ({}, 0), ({"BN_CONVMERGE": "0"}, 1)):
+        monkeypatch.delenv("BN_STFT", raising=False)
+        monkeypatch.delenv("BN_CONVMERGE", raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
         assert bn.plan_describe(path).count(" FFT ") == nfft
         other = bn.Classifier.builder().model_path(path).labels(labels(6522)).with_rocm().build().predict_batch(list(x))
         check_results(other, ref, None, 10, None)
@@ -484,7 +485,8 @@ def test_round3_kernels_tile_shape_and_grouping_do_not_enter_the_arithmetic(bn, 
 
 
 @pytest.mark.parametrize("env", [{"BN_GEMMDMA": "0"}, {"BN_GEMMDMA": "2"}, {"BN_MBMAP2": "0"}, {"BN_SEGEMM": "1"}, {"BN_GEMMDMA_KS": "1"},
-                                 {"BN_STFT_MELMFMA": "0"}, {"BN_STFT_NW": "16"}, {"BN_MBROW_TOH": "8"}, {"BN_FRAMEPAIR": "1"}, {"BN_CONVFOLD2": "0"}])
+                                 {"BN_STFT_MELMFMA": "0", "BN_CONVMERGE": "0"}, {"BN_STFT_NW": "16", "BN_CONVMERGE": "0"}, {"BN_MBROW_TOH": "8"}, {"BN_FRAMEPAIR": "1"},
+                                 {"BN_CONVFOLD2": "0"}, {"BN_CONVMERGE": "0"}])
 def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, monkeypatch, env):
     """Every round-3 rewrite has an off switch (and two opt-ins): the older kernels (BN_GEMMDMA=0, BN_MBMAP2=0), the
     LDS-DMA GEMM on every eligible shape (BN_GEMMDMA=2), the squeeze-excite products in the GEMM prologue (BN_SEGEMM=1),
@@ -506,9 +508,11 @@ def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, mon
     assert ("~quarter" in desc) == (not env.get("BN_FRAMEPAIR") and env.get("BN_CONVFOLD2") != "0"), desc  # (round 4) the 127-bin cosine bank
     if env.get("BN_CONVFOLD2") == "0":
         assert "~sym" in desc
+    # (round 4) the 309-bin bank and its mel product are one bank of 96 folded filters unless BN_CONVMERGE=0 keeps them apart (then: an FFT)
+    assert (" FFT " in desc) == (env.get("BN_CONVMERGE") == "0"), desc
     if env.get("BN_STFT_MELMFMA") == "0":
         assert "(csr)" in desc and "(mfma)" not in desc
-    else:
+    elif env.get("BN_CONVMERGE") == "0":
         assert "(mfma)" in desc
     x = synth.synthetic_segments(3, 144000, 48000)
     got, _ = bn.Context(bn.Model(path), 3).infer(x)

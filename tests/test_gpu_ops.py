@@ -272,6 +272,48 @@ def test_conv1d_quarter_folded_cosine_bank(bn, n_fft, hop, which, window, monkey
     assert_close(got, plain, "quarter fold vs plain convolution", atol=tol, rtol=0)
 
 
+@pytest.mark.parametrize("n_fft,hop,n_mels,fmin,fmax,bias,expect", [(1024, 280, 96, 500.0, 15000.0, False, True), (1024, 280, 40, 0.0, 24000.0, True, True),
+                                                                    (2048, 278, 96, 0.0, 3000.0, False, False), (512, 160, 64, 1000.0, 20000.0, True, True)])
+def test_framing_conv_merged_with_the_product_behind_it(bn, n_fft, hop, n_mels, fmin, fmax, bias, expect, monkeypatch):
+    """Conv1D (real-part DFT bank) -> Transpose -> MatMul (mel bank) with nothing between them is one linear map of the frame: the planner
+    (merge_framing_products) sums the filters -- n_mels symmetric rows, folded to half their taps, with the compression chain and the
+    consumer's view in the launch's epilogue -- where that costs less than the bank plus the product (v2.4's 1024-point branch: yes; its
+    127-bin 2048-point branch, which the quarter fold serves: no).  Against the oracle and against the unmerged plan."""
+    import importlib
+    synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+    rng = np.random.default_rng(n_fft + n_mels)
+    w = synth.dft_basis(n_fft, "real")
+    mel = synth.mel_filterbank(n_fft // 2 + 1, n_mels, 48000, fmin, fmax).astype(np.float32)
+    b = (rng.standard_normal(w.shape[0]) * 0.1).astype(np.float32)
+    frames = (144000 - n_fft) // hop + 1
+
+    def build(g, x):
+        u = g.node("Unsqueeze", [x, g.const(np.array([1], dtype=np.int64))])
+        c = g.node("Conv", [u, g.const(w)] + ([g.const(b)] if bias else []), kernel_shape=[n_fft], strides=[hop])
+        t = g.node("Transpose", [c], perm=[0, 2, 1])
+        m = g.node("MatMul", [t, g.const(mel)])
+        p = g.node("Pow", [m, g.const(np.float32(2.0))])
+        return g.node("Pow", [p, g.const(np.float32(0.5))])  # (|m|: a two-stage chain whose slope stays bounded where m crosses zero)
+    data = op_graph(build, [frames, n_mels])
+    text = bn.plan_describe(write_model(data))
+    merged = "MatMul" not in text
+    assert merged == expect, text
+    if merged:
+        assert "~sym" in text and f"N={n_mels} " in text and f"K={n_fft // 2} " in text and "kernel=frame_fold" in text and "post=" in text, text
+        assert text.count("\n") <= 5, text  # one launch (+ totals / outputs lines): the chain rides in its epilogue
+    got, ref = run_both(bn, data, batch=2)
+    tol = 2e-5 * float(np.abs(ref).max())
+    assert_close(got, ref, f"merged framing conv n_fft={n_fft}", atol=tol, rtol=0)
+    got3, ref3 = run_both(bn, data, batch=3)
+    assert_close(got3, ref3, f"merged framing conv n_fft={n_fft} batch 3", atol=tol, rtol=0)
+    assert np.array_equal(got3[:2].view(np.uint32), got.view(np.uint32))
+    monkeypatch.setenv("BN_CONVMERGE", "1" if not merged else "0")  # the other form
+    text2 = bn.plan_describe(write_model(data))
+    assert ("MatMul" not in text2) == (not merged), text2
+    other, _ = run_both(bn, data, batch=2)
+    assert_close(got, other, "merged vs separate", atol=tol, rtol=0)
+
+
 @pytest.mark.parametrize("n_fft,hop", [(128, 64), (256, 100), (512, 160), (1024, 320), (2048, 278), (640, 320), (640, 203)])
 def test_stft_every_transform_size(bn, n_fft, hop, monkeypatch):
     """All supported frame lengths (one radix-2 pass first when log2 of the half length is odd; radix 5 first for Perch's

@@ -113,11 +113,25 @@ def test_plan_of_v24_model(bn, tmp_path, monkeypatch):
     # folded matrix product, the L = 1024 bank with its ~300 live bins runs as an FFT with its mel bank absorbed; the
     # normalisation pass stays a launch of its own because the matrix branch still reads its output
     monkeypatch.delenv("BN_STFT")
+    monkeypatch.setenv("BN_CONVMERGE", "0")
+    monkeypatch.setenv("BN_CONVFOLD2", "0")
     auto = bn.plan_describe(str(p))
     afft = [l for l in auto.splitlines() if " FFT " in l]
     assert len(afft) == 1 and " L=1024 hop=280 " in afft[0] and "mel=96" in afft[0] and "pre=0" in afft[0], afft
     assert sum("~sym" in l and " K=1024 " in l for l in auto.splitlines()) == 1, auto
-    # BN_STFT=0: both banks as folded GEMMs
+    # round 4, the default: the cosine-only L = 2048 bank quarter-folded (even bins against S, odd bins against D: L/4 + 1 taps each, K
+    # padded to whole steps), the L = 1024 bank and the mel product behind it merged into 96 symmetric filters of 512 folded taps with
+    # the compression chain in the launch -- no FFT, no mel launch for that branch
+    monkeypatch.delenv("BN_CONVMERGE")
+    monkeypatch.delenv("BN_CONVFOLD2")
+    r4 = bn.plan_describe(str(p)).splitlines()
+    assert not any(" FFT " in l for l in r4), r4
+    assert sum("~quarter" in l and " K=544 " in l and "fold=2/2048" in l and "kernel=frame_fold2" in l for l in r4) == 1, r4
+    assert sum("Conv_18~sym" in l and " K=512 " in l and " N=96 " in l and "post=3" in l and "kernel=frame_fold" in l for l in r4) == 1, r4
+    assert sum("MatMul:" in l for l in r4) == 1  # (the 2048-point branch keeps its mel product)
+    # BN_STFT=0 with the round-4 rules off: both banks as half-folded GEMMs
+    monkeypatch.setenv("BN_CONVMERGE", "0")
+    monkeypatch.setenv("BN_CONVFOLD2", "0")
     monkeypatch.setenv("BN_STFT", "0")
     text = bn.plan_describe(str(p))
     lines = text.splitlines()
@@ -154,6 +168,7 @@ def test_round3_planner_rules(bn, tmp_path, monkeypatch):
     row-streaming MBConv; every rule with its switch."""
     p24 = tmp_path / "v24.onnx"
     p24.write_bytes(synth.birdnet_v24())
+    monkeypatch.setenv("BN_CONVMERGE", "0")  # (round 4 merges this bank with its mel product: no FFT in the default v2.4 plan any more)
     d24 = bn.plan_describe(str(p24))
     fft = [l for l in d24.splitlines() if " FFT " in l]
     assert len(fft) == 1 and "mel=96(mfma)" in fft[0] and "power=0" in fft[0] and "tpb=16" in fft[0], fft
@@ -192,7 +207,12 @@ def test_plan_without_folding(bn, tmp_path, monkeypatch):
     # a looser tolerance than the bases' rounding noise is never needed; a zero tolerance only folds exact mirror images
     monkeypatch.delenv("BN_CONVFOLD")
     monkeypatch.setenv("BN_CONVFOLD_TOL", "0")
+    monkeypatch.setenv("BN_CONVMERGE", "0")
     assert not any("~" in l or " FFT " in l for l in bn.plan_describe(str(p)).splitlines())
+    # (round 4: the 96 merged filters of the 1024-point branch are made exact mirror images when they are rounded: they fold at tolerance zero)
+    monkeypatch.delenv("BN_CONVMERGE")
+    tilde = [l for l in bn.plan_describe(str(p)).splitlines() if "~" in l]
+    assert len(tilde) == 1 and "Conv_18~sym" in tilde[0] and " N=96 " in tilde[0], tilde
 
 
 def test_dead_outputs_are_not_planned(bn, tmp_path):
