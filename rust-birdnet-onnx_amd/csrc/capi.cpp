@@ -264,13 +264,17 @@ void launch_op(const bn_ctx *c, const PlanOp &op, const float *d_in, int64_t bat
                                       resolve(c, op.bias2, d_in), batch);
                 break;
             }
-            if (op.gemm.fold == 2) {  // quarter-folded cosine bank: window tables and column map ride in w2 / bias2
-                launch_gemm_fold2(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
-                                  reinterpret_cast<const int32_t *>(resolve(c, op.bias2, d_in)), batch);
-                break;
+            {
+                FramePre pre = op.pre;  // the signal chain a framing GEMM applies while it loads its span (planner rule G): operands in eb
+                for (int k = 0; k < ELT_MAX_STAGES; k++) pre.sc[k] = k < pre.n ? resolve(c, op.eb[k], d_in) : nullptr;
+                if (op.gemm.fold == 2) {  // quarter-folded cosine bank: window tables and column map ride in w2 / bias2
+                    launch_gemm_fold2(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.w2, d_in),
+                                      reinterpret_cast<const int32_t *>(resolve(c, op.bias2, d_in)), batch, &pre);
+                    break;
+                }
+                launch_gemm(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in),
+                            resolve(c, op.scale, d_in), batch, &pre);
             }
-            launch_gemm(c->stream, op.gemm, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in),
-                        resolve(c, op.scale, d_in), batch);
             break;
         case OpKind::CONV:
             launch_conv(c->stream, op.conv, out, a, resolve(c, op.w, d_in), resolve(c, op.bias, d_in), resolve(c, op.res, d_in), batch);
@@ -1682,6 +1686,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 snprintf(line, sizeof(line), " rows=%lld K=%d N=%d lda=%lld act=%d bias=%d res=%d gate=%d", (long long)op.gemm.rows, op.gemm.K, op.gemm.N, (long long)op.gemm.lda, op.gemm.act, op.gemm.has_bias, op.gemm.has_res, op.gemm.has_scale);
                 extra = line;
                 if (op.gemm.fold) { snprintf(line, sizeof(line), " fold=%d/%d", op.gemm.fold, op.gemm.fold_n); extra += line; }
+                if (op.pre.n) { snprintf(line, sizeof(line), " pre=%d", op.pre.n); extra += line; }
                 if (op.gemm.se_inline) { snprintf(line, sizeof(line), " se_inline=%d/%d", op.se.C, op.se.Cr); extra += line; }
                 if (op.gemm2.N > 0) { snprintf(line, sizeof(line), " pair=%dx%d post=%d out_rs=%lld out_cs=%lld", op.gemm2.K, op.gemm2.N, op.gemm2.npost, (long long)op.gemm2.out_rs, (long long)op.gemm2.out_cs); extra += line; }
                 // which of the three matrix kernels the launcher picks (the LDS-resident framing kernel may still fall back to

@@ -170,4 +170,45 @@ __device__ __forceinline__ void act_small(int act, float p0, float p1, float (&v
     else if (act == ACT_CEIL) map_array<N>(v, [](float x) { return ceilf(x); });
 }
 
+// binary stage against ONE scalar for the whole array (the absorbed per-sample chains: stft.hip, the framing GEMMs of kernels.hip)
+template <int N>
+__device__ __forceinline__ void bin_small(int bin, float b, float (&v)[N]) {
+    if (bin == BIN_ADD) map_array<N>(v, [=](float a) { return a + b; });
+    else if (bin == BIN_SUB) map_array<N>(v, [=](float a) { return a - b; });
+    else if (bin == BIN_MUL) map_array<N>(v, [=](float a) { return a * b; });
+    else if (bin == BIN_DIV) {
+        // one divisor for the whole array: 1 / b once, then q = a r corrected by one residual step, which is what the
+        // hardware's division sequence computes minus its scaling for denormal / overflowing quotients (3 instructions per
+        // element instead of ~10; the absorbed chain divides the whole segment by max - min)
+        const float r = 1.0f / b;
+        map_array<N>(v, [=](float a) {
+            const float q = a * r;
+            return fmaf(fmaf(-q, b, a), r, q);
+        });
+    }
+    else if (bin == BIN_MAX) map_array<N>(v, [=](float a) { return fmaxf(a, b); });
+    else if (bin == BIN_MIN) map_array<N>(v, [=](float a) { return fminf(a, b); });
+}
+
+// The absorbed per-sample chain: up to four stages  v = act(bin(v, scalar)).  All indices are literals so that the
+// fields stay in registers.
+struct PreChain {
+    int n, bin[4], act[4];
+    float sc[4], p0[4], p1[4];
+};
+template <int S, int N>
+__device__ __forceinline__ void pre_stage(const PreChain &c, float (&v)[N]) {
+    if (S < c.n) {
+        bin_small<N>(c.bin[S], c.sc[S], v);
+        act_small<N>(c.act[S], c.p0[S], c.p1[S], v);
+    }
+}
+template <int N>
+__device__ __forceinline__ void pre_chain(const PreChain &c, float (&v)[N]) {
+    pre_stage<0, N>(c, v);
+    pre_stage<1, N>(c, v);
+    pre_stage<2, N>(c, v);
+    pre_stage<3, N>(c, v);
+}
+
 }  // namespace bn

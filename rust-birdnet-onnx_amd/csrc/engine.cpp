@@ -3394,23 +3394,46 @@ class Builder {
                 if (!scalar_ops) continue;
                 const auto &u = users[el.out.id];
                 if (u.size() < 2 || u[0] != (int)e) continue;
+                // every reader is a launch that can apply the chain while it loads its span: an STFT, or (round 4) a folded framing GEMM that
+                // is certain to run on its LDS-resident kernel (half fold: frame_fold_post_ok; quarter fold: always)
+                auto framing_gemm = [&](const PlanOp &f) {
+                    const GemmDesc &g = f.gemm;
+                    if (f.kind != OpKind::GEMM || f.pre.n != 0 || f.gemm2.N > 0 || f.se_fused || env_int("BN_FRAME_PRE", 1) == 0) return false;
+                    if (env_int("BN_FRAMEPAIR", 0) == 1) return false;  // (opt-in rule J runs later and its kernel does not carry the chain)
+                    if (!(g.fold == 2 ? frame_fold2_shape_ok(g, nullptr) : (g.fold == 1 || g.fold == -1) && frame_fold_post_ok(g))) return false;
+                    return g.a_bs == ed.bo && (g.rows - 1) * g.lda + g.fold_n <= ed.per_sample;
+                };
                 bool all_fft = true;
                 for (size_t q = 1; q < u.size(); q++) {
                     const PlanOp &f = plan_.ops[u[q]];
-                    all_fft = all_fft && f.kind == OpKind::FFT && f.fft.npre == 0 && f.a.space == Space::ARENA && f.a.id == el.out.id && f.a.offset == 0 &&
-                              f.fft.a_bs == ed.bo && (int64_t)(f.fft.frames - 1) * f.fft.hop + f.fft.L <= ed.per_sample;
-                    // (the STFT must read the chain's result only through `a`)
-                    for (const Ref &r : f.eb) all_fft = all_fft && !(r.space == Space::ARENA && r.id == el.out.id);
+                    const bool stft_ok = f.kind == OpKind::FFT && f.fft.npre == 0 && f.fft.a_bs == ed.bo && (int64_t)(f.fft.frames - 1) * f.fft.hop + f.fft.L <= ed.per_sample;
+                    all_fft = all_fft && (stft_ok || framing_gemm(f)) && f.a.space == Space::ARENA && f.a.id == el.out.id && f.a.offset == 0;
+                    // (the launch must read the chain's result only through `a`)
+                    std::vector<Ref *> refs;
+                    all_refs(const_cast<PlanOp &>(f), refs);
+                    int reads = 0;
+                    for (Ref *r : refs) reads += (r->space == Space::ARENA && r->id == el.out.id) ? 1 : 0;
+                    all_fft = all_fft && reads == 1;
                 }
                 if (!all_fft) continue;
                 for (size_t q = 1; q < u.size(); q++) {
                     PlanOp &f = plan_.ops[u[q]];
                     f.a = el.a;
-                    f.fft.a_bs = ed.ba;
-                    f.fft.npre = ed.nstages;
+                    if (f.kind == OpKind::FFT) {
+                        f.fft.a_bs = ed.ba;
+                        f.fft.npre = ed.nstages;
+                    } else {
+                        f.gemm.a_bs = ed.ba;
+                        f.pre.n = ed.nstages;
+                    }
                     for (int k = 0; k < ed.nstages; k++) {
-                        f.fft.pre_bin[k] = ed.st[k].bin; f.fft.pre_act[k] = ed.st[k].act;
-                        f.fft.pre_p0[k] = ed.st[k].p0; f.fft.pre_p1[k] = ed.st[k].p1; f.fft.pre_bb[k] = ed.st[k].bb;
+                        if (f.kind == OpKind::FFT) {
+                            f.fft.pre_bin[k] = ed.st[k].bin; f.fft.pre_act[k] = ed.st[k].act;
+                            f.fft.pre_p0[k] = ed.st[k].p0; f.fft.pre_p1[k] = ed.st[k].p1; f.fft.pre_bb[k] = ed.st[k].bb;
+                        } else {
+                            f.pre.bin[k] = ed.st[k].bin; f.pre.act[k] = ed.st[k].act;
+                            f.pre.p0[k] = ed.st[k].p0; f.pre.p1[k] = ed.st[k].p1; f.pre.bb[k] = ed.st[k].bb;
+                        }
                         f.eb[k] = el.eb[k];
                     }
                     f.name = el.name + "+" + f.name;

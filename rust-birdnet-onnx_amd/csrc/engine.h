@@ -39,6 +39,7 @@ struct PlanOp {
     EltDesc elt{};
     ReduceDesc red{};
     GemmDesc gemm{};
+    FramePre pre{};    // GEMM with fold (LDS-resident framing kernels): per-sample chain applied while the span is loaded; operands in eb
     GemmDesc gemm2{};  // GEMM with fold (planner rule J): the product fused behind it (N == 0: none); its weights in w2, its bias in bias2
     ConvDesc conv{};
     DwDesc dw{};

@@ -259,6 +259,16 @@ void launch_reduce(hipStream_t s, const ReduceDesc &d, float *out, const float *
 // Which of the two GEMM kernels runs is decided from per-sample quantities only, so that the
 // summation order of every output element -- and with it the result bits -- does not depend on
 // how many segments share a batch (a shard's last, shorter batch matches the single-GPU run).
+// Per-sample scalar chain applied to the signal while a framing GEMM loads its span into LDS (planner rule G "pre", the same rule that fills
+// FftDesc::npre): up to four stages  v = act(bin(v, the sample's scalar)) -- v2.4's min-max normalisation of the segment, which then is never
+// written.  sc[k]: operand of stage k (batch stride bb[k] elements; unused where bin[k] is BIN_NONE); the plan keeps the operands in PlanOp::eb.
+struct FramePre {
+    int32_t n, bin[ELT_MAX_STAGES], act[ELT_MAX_STAGES];
+    float p0[ELT_MAX_STAGES], p1[ELT_MAX_STAGES];
+    int64_t bb[ELT_MAX_STAGES];
+    const float *sc[ELT_MAX_STAGES];
+};
+
 // (host logic shared by the launcher and the planner)
 inline bool gemm_use_splitk(const GemmDesc &d) {
     static const int min_k = getenv("BN_SPLITK_MINK") ? atoi(getenv("BN_SPLITK_MINK")) : 256;
@@ -274,12 +284,12 @@ inline bool gemm_accepts_post(const GemmDesc &d) { return !d.fold && !d.has_scal
 void launch_gemm_fold_pair(hipStream_t s, const GemmDesc &d, const GemmDesc &d2, float *C2, const float *A, const float *W, const float *bias,
                            const float *W2, const float *bias2, int64_t batch);
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W,
-                 const float *bias, const float *res, const float *scale, int64_t batch);
+                 const float *bias, const float *res, const float *scale, int64_t batch, const FramePre *pre = nullptr);
 // quarter-folded framing GEMM (GemmDesc::fold == 2): wtab = [2][K] window tables (wa | wb), colmap = [N] output channel of every
 // column (-1: padding), bias indexed by output channel.  The planner emits it only where frame_fold2_shape_ok (plan_rules.h) holds; a
 // launch outside that is an error (there is no other kernel for this operand form).
 void launch_gemm_fold2(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *wtab,
-                       const int32_t *colmap, int64_t batch);
+                       const int32_t *colmap, int64_t batch, const FramePre *pre = nullptr);
 // LDS-DMA GEMM (gemm_dma.hip): 0 = not eligible, 1 = 64-row tiles, 2 = 48-row tiles (per-sample quantities only);
 // launch_gemm_dma returns false (nothing launched) when the shape or a pointer's alignment rules it out.  BN_GEMMDMA=0 disables.
 bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res,

@@ -1025,6 +1025,225 @@ __global__ __launch_bounds__(PAIR ? 512 : 640) void frame_fold_kernel(FrameDesc 
     }
 }
 
+// LDS addresses as 32-bit byte offsets (ds_* instructions take base register + immediate; generic pointers cost an add each)
+typedef __attribute__((address_space(3))) float lds_float;
+typedef float lds_f2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) lds_f2v lds_float2;
+__device__ __forceinline__ uint32_t lds_offset_of(const float *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)p; }
+__device__ __forceinline__ float lds_ld(uint32_t byte_off) { return *(const lds_float *)(uintptr_t)byte_off; }
+__device__ __forceinline__ float2 lds_ld2(uint32_t byte_off) {
+    const lds_f2v v = *(const lds_float2 *)(uintptr_t)byte_off;
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void lds_st2(uint32_t byte_off, float2 v) { *(lds_float2 *)(uintptr_t)byte_off = lds_f2v{v.x, v.y}; }
+
+// The block's signal span into LDS, with the absorbed per-sample chain (FramePre) applied on the way when there is one: the normalised
+// segment is never written.  Literal indices into the by-value descriptor (a run-time index would move it to scratch memory).
+__device__ __forceinline__ void frame_load_span(float *sig, const float *__restrict__ src, int count, bool vec4, int tid, int T, const FramePre &pre, int64_t b) {
+    if (pre.n > 0) {
+        static_assert(ELT_MAX_STAGES == 4, "the stages below are spelled out");
+        PreChain c{pre.n, {pre.bin[0], pre.bin[1], pre.bin[2], pre.bin[3]}, {pre.act[0], pre.act[1], pre.act[2], pre.act[3]}, {0.f, 0.f, 0.f, 0.f},
+                   {pre.p0[0], pre.p0[1], pre.p0[2], pre.p0[3]}, {pre.p1[0], pre.p1[1], pre.p1[2], pre.p1[3]}};
+        if (0 < c.n && c.bin[0] != BIN_NONE) c.sc[0] = pre.sc[0][b * pre.bb[0]];
+        if (1 < c.n && c.bin[1] != BIN_NONE) c.sc[1] = pre.sc[1][b * pre.bb[1]];
+        if (2 < c.n && c.bin[2] != BIN_NONE) c.sc[2] = pre.sc[2][b * pre.bb[2]];
+        if (3 < c.n && c.bin[3] != BIN_NONE) c.sc[3] = pre.sc[3][b * pre.bb[3]];
+        // PB float4 per thread and trip: the loads of a trip are in flight together and every stage is dispatched once for 4 PB values
+        // (one float4 per trip made the chain cost more than the launch it replaces: a load round trip and the stage dispatch per value)
+        constexpr int PB = 8;
+        const int n4 = vec4 ? count >> 2 : 0;
+        for (int i0 = tid; i0 < n4; i0 += PB * T) {
+            float v[4 * PB];
+#pragma unroll
+            for (int j = 0; j < PB; j++) {
+                const float4 x = reinterpret_cast<const float4 *>(src)[min(i0 + j * T, n4 - 1)];
+                v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+            }
+            pre_chain<4 * PB>(c, v);
+#pragma unroll
+            for (int j = 0; j < PB; j++)
+                if (i0 + j * T < n4) reinterpret_cast<float4 *>(sig)[i0 + j * T] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+        }
+        for (int i = (n4 << 2) + tid; i < count; i += T) {
+            float v[1] = {src[i]};
+            pre_chain<1>(c, v);
+            sig[i] = v[0];
+        }
+        return;
+    }
+    if (vec4) {
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(sig);
+        const int n4 = count >> 2;
+        for (int i = tid; i < n4; i += T) d4[i] = s4[i];
+        for (int i = (n4 << 2) + tid; i < count; i += T) sig[i] = src[i];
+    } else {
+        for (int i = tid; i < count; i += T) sig[i] = src[i];
+    }
+}
+
+// ------------------------------------------------------------------ half-folded framing GEMM, round-4 form
+// frame_fold_kernel<false>'s job with the structure that paid for the quarter fold below: compile-time block shape (WN wave columns), LDS
+// addresses as 32-bit byte offsets, the signal reads of the NEXT step's operand tile issued before this step's matrix instructions and
+// finished behind them, nothing conditional around the matrix instructions.  KS = 2: the 8-wide k groups of every step are split between
+// two sets of 2 WN waves (groups 0, 1 | groups 2, 3) whose partial tiles are added through LDS at the end, slice 0 + slice 1 -- for
+// THREE wave columns (N = 65 .. 96: v2.4's 96 merged mel filters) six waves leave two of the four SIMDs with one wave and the block
+// runs at the pace of the two that have two; twelve waves balance (3 per SIMD).  KS is a function of N alone (frame_fold_kslices), so a
+// segment's bits do not depend on the batch; with KS = 1 the k order, fragment layout and fold expression are those of
+// gemm_mfma_kernel<.., FOLD> and of frame_fold_kernel (bit-identical, tested), with KS = 2 the sum is cut once more.
+template <int NG>
+__device__ __forceinline__ void mfma_ktile_groups(const float *__restrict__ ap, const float *__restrict__ wp, floatx16 &acc) {
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const float4 a4 = *reinterpret_cast<const float4 *>(ap + 8 * g);
+        const float4 b4 = *reinterpret_cast<const float4 *>(wp + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+}
+template <int WN, int KS>
+__global__ __launch_bounds__(128 * WN * KS) void frame_foldh_kernel(FrameDesc d, float *__restrict__ C, const float *__restrict__ A, const float *__restrict__ W,
+                                                                    const float *__restrict__ bias, FramePre pre) {
+    extern __shared__ __align__(16) float frame_lds[];
+    constexpr int T = 128 * WN * KS, BN = 32 * WN, TILE = FRAME_BM * GEMM_LD, SLOTS = (FRAME_BM * 16 + T - 1) / T;
+    constexpr int WPASS = (8 * BN + T - 1) / T;  // float4 of the filter tile per thread (2, or 1 with two K slices)
+    static_assert(8 * BN == WPASS * T && WPASS <= 2, "the filter tile is one or two whole passes");
+    const int tid = threadIdx.x;
+    float *sig = frame_lds;
+    float *As = sig + ((d.span + 3) & ~3);  // [2][64][GEMM_LD]
+    float *Ws = As + 2 * TILE;              // [2][BN][GEMM_LD]
+    const int b = blockIdx.x / d.tiles, rt = blockIdx.x - b * d.tiles;
+    const int row0 = rt * FRAME_BM;
+    const int rows_here = min(FRAME_BM, d.rows - row0);
+    const float *src = A + (int64_t)b * d.a_bs + (int64_t)row0 * d.hop;
+    const int count = (rows_here - 1) * d.hop + d.L;
+    frame_load_span(sig, src, count, d.vec4 != 0, tid, T, pre, b);
+    const int wq = tid & 7, wr = tid >> 3;
+    constexpr int WROWS = T >> 3;
+    const int ksteps = d.K / GEMM_BK;
+    const uint32_t sig0 = lds_offset_of(sig), as0 = lds_offset_of(As);
+    const int cp = (tid & 15) * 2;
+    uint32_t a_fw0[SLOTS], a_rv0[SLOTS], a_dst[SLOTS];
+#pragma unroll
+    for (int i = 0; i < SLOTS; i++) {
+        const int p = tid + i * T;
+        const int r = (p >> 4) & (FRAME_BM - 1);
+        const int re = r < rows_here ? r : rows_here - 1;
+        const uint32_t f = sig0 + 4u * (uint32_t)(re * d.hop);
+        a_fw0[i] = f + 4u * (1 + cp);            // x[1 + c], x[2 + c]
+        a_rv0[i] = f + 4u * (d.L - 2 - cp);      // x[L - 2 - c], x[L - 1 - c]
+        a_dst[i] = as0 + 4u * (uint32_t)(r * GEMM_LD + cp);
+    }
+    constexpr bool LAST_PARTIAL = (FRAME_BM * 16) % T != 0;
+    const bool last_on = !LAST_PARTIAL || tid + (SLOTS - 1) * T < FRAME_BM * 16;
+    const int wave = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int kh = wave / (2 * WN), wv = wave - kh * 2 * WN;  // K slice, wave inside the slice
+    const int wm = wv & 1, wn = wv >> 1;
+    const float sign = d.sign;
+    __syncthreads();  // signal span complete
+    for (int ny = blockIdx.y; ny * BN < d.N; ny += gridDim.y) {
+        const int n0 = ny * BN;
+        // (scalars, not arrays: a register array captured by a lambda moves to scratch memory)
+        const float *wrow0 = W + (int64_t)min(n0 + wr, d.N - 1) * d.K + 4 * wq;
+        const float *wrow1 = W + (int64_t)min(n0 + wr + WROWS, d.N - 1) * d.K + 4 * wq;  // (WPASS == 2)
+        float4 rw0, rw1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto load_w = [&](int k0) {
+            rw0 = *reinterpret_cast<const float4 *>(wrow0 + k0);
+            if constexpr (WPASS == 2) rw1 = *reinterpret_cast<const float4 *>(wrow1 + k0);
+        };
+        uint32_t a_fw[SLOTS], a_rv[SLOTS];
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) { a_fw[i] = a_fw0[i]; a_rv[i] = a_rv0[i]; }
+        float2 xf[SLOTS], xr[SLOTS];
+        auto load_a = [&]() {
+#pragma unroll
+            for (int i = 0; i < SLOTS; i++) {
+                xf[i] = make_float2(lds_ld(a_fw[i]), lds_ld(a_fw[i] + 4));
+                xr[i] = make_float2(lds_ld(a_rv[i]), lds_ld(a_rv[i] + 4));
+            }
+        };
+        auto finish_a = [&](uint32_t buf_off) {
+#pragma unroll
+            for (int i = 0; i < SLOTS; i++) {
+                if (i < SLOTS - 1 || last_on) lds_st2(a_dst[i] + buf_off, make_float2(fmaf(sign, xr[i].y, xf[i].x), fmaf(sign, xr[i].x, xf[i].y)));
+                a_fw[i] += 4 * GEMM_BK;
+                a_rv[i] -= 4 * GEMM_BK;
+            }
+        };
+        auto store_w = [&](float *dst) {
+            *reinterpret_cast<float4 *>(dst + wr * GEMM_LD + 4 * wq) = rw0;
+            if constexpr (WPASS == 2) *reinterpret_cast<float4 *>(dst + (wr + WROWS) * GEMM_LD + 4 * wq) = rw1;
+        };
+        load_w(0);
+        load_a();
+        finish_a(0);
+        store_w(Ws);
+        load_w(min(1, ksteps - 1) * GEMM_BK);
+        __syncthreads();
+        floatx16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        const float *ap0 = As + (wm * 32 + lr) * GEMM_LD + 4 * lh + (KS == 2 ? 16 * kh : 0);
+        const float *wp0 = Ws + (wn * 32 + lr) * GEMM_LD + 4 * lh + (KS == 2 ? 16 * kh : 0);
+        for (int ks = 0; ks < ksteps; ks++) {
+            const int cur = ks & 1;
+            load_a();  // step ks + 1; behind the last step the streams read one step further inside the span's neighbourhood: see below
+            mfma_ktile_groups<4 / KS>(ap0 + cur * TILE, wp0 + cur * BN * GEMM_LD, acc);
+            finish_a((uint32_t)((cur ^ 1) * TILE * 4));
+            store_w(Ws + (cur ^ 1) * BN * GEMM_LD);
+            load_w(min(ks + 2, ksteps - 1) * GEMM_BK);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if constexpr (KS == 2) {  // slice 1's partial tile through LDS (both tile buffers are free: the loop ended on a barrier)
+            floatx16 *xch = reinterpret_cast<floatx16 *>(As);  // [2 WN waves][64 lanes]
+            if (kh == 1) xch[wv * 64 + lane] = acc;
+            __syncthreads();
+            if (kh == 0) {
+                const floatx16 o = xch[wv * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] += o[r];
+            }
+        }
+        const int n = n0 + wn * 32 + lr;
+        if (kh == 0) {
+            if (d.npost || d.out_strided) {  // bias, the absorbed chain (compact stage functions), the consumer's view
+                floatx16 a2 = acc;
+                if (d.has_bias) {
+                    const float bv = n < d.N ? bias[n] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) a2[r] += bv;
+                }
+                if (0 < d.npost) a2 = act_small16(d.post_act[0], d.post_p0[0], d.post_p1[0], a2);
+                if (1 < d.npost) a2 = act_small16(d.post_act[1], d.post_p0[1], d.post_p1[1], a2);
+                if (2 < d.npost) a2 = act_small16(d.post_act[2], d.post_p0[2], d.post_p1[2], a2);
+                if (3 < d.npost) a2 = act_small16(d.post_act[3], d.post_p0[3], d.post_p1[3], a2);
+                if (n < d.N) {
+                    const int64_t rs = d.out_strided ? d.out_rs : d.ldc, cs = d.out_strided ? d.out_cs : 1;
+                    float *cb = C + (int64_t)b * d.c_bs + (int64_t)n * cs;
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) {
+                        const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                        if (r < rows_here) cb[(int64_t)(row0 + r) * rs] = a2[reg];
+                    }
+                }
+            } else if (n < d.N) {
+                const float bv = d.has_bias ? bias[n] : 0.0f;
+                float *cb = C + (int64_t)b * d.c_bs + (int64_t)row0 * d.ldc + n;
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const int r = wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    if (r < rows_here) cb[(int64_t)r * d.ldc] = acc[reg] + bv;
+                }
+            }
+        }
+        if constexpr (KS == 2) __syncthreads();  // the exchange buffer is the next N tile's first operand tile
+    }
+}
+
 // ------------------------------------------------------------------ quarter-folded framing GEMM (round 4)
 // A bank of windowed COSINES (the real part of an STFT: v2.4's 127 mel-live bins of a 2048-point transform) needs a quarter of the filter
 // length per output, not half.  With y[n] = w[n] x[n] (w symmetric about the frame centre, w[0] = 0) and ye[n] = y[n] + y[L-n]:
@@ -1048,25 +1267,14 @@ struct Frame2Desc {
     int32_t has_bias;
     int64_t a_bs, ldc, c_bs;
 };
-// LDS addresses as 32-bit byte offsets (ds_* instructions take base register + immediate; generic pointers cost an add each)
-typedef __attribute__((address_space(3))) float lds_float;
-typedef float lds_f2v __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) lds_f2v lds_float2;
-__device__ __forceinline__ uint32_t lds_offset_of(const float *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float *)p; }
-__device__ __forceinline__ float lds_ld(uint32_t byte_off) { return *(const lds_float *)(uintptr_t)byte_off; }
-__device__ __forceinline__ float2 lds_ld2(uint32_t byte_off) {
-    const lds_f2v v = *(const lds_float2 *)(uintptr_t)byte_off;
-    return make_float2(v.x, v.y);
-}
-__device__ __forceinline__ void lds_st2(uint32_t byte_off, float2 v) { *(lds_float2 *)(uintptr_t)byte_off = lds_f2v{v.x, v.y}; }
-
 // WN wave columns of 32 outputs (N == 32 WN), 2 WN waves; a thread owns SLOTS (row, column pair) slots of the two 64 x 32 operand tiles.
 // Schedule of a step: the signal / table reads of the NEXT step's operand tiles are issued, this step's matrix instructions run over them,
 // then the next tiles are finished (12 vector operations per slot) and written -- nothing conditional around the matrix instructions
 // (a branch there makes the compiler copy the accumulators twice per step), the single-group tail step sits behind the loop.
 template <int WN>
 __global__ __launch_bounds__(128 * WN) void frame_fold2_kernel(Frame2Desc d, float *__restrict__ C, const float *__restrict__ A, const float *__restrict__ W,
-                                                               const float *__restrict__ bias, const float *__restrict__ wtab, const int32_t *__restrict__ colmap) {
+                                                               const float *__restrict__ bias, const float *__restrict__ wtab, const int32_t *__restrict__ colmap,
+                                                               FramePre pre) {
     extern __shared__ __align__(16) float frame_lds[];
     constexpr int T = 128 * WN, BN = 32 * WN, TILE = FRAME_BM * GEMM_LD, SLOTS = (FRAME_BM * 16 + T - 1) / T;
     const int tid = threadIdx.x;
@@ -1079,15 +1287,7 @@ __global__ __launch_bounds__(128 * WN) void frame_fold2_kernel(Frame2Desc d, flo
     const int rows_here = min(FRAME_BM, d.rows - row0);
     const float *src = A + (int64_t)b * d.a_bs + (int64_t)row0 * d.hop;
     const int count = (rows_here - 1) * d.hop + d.L;
-    if (d.vec4) {
-        const float4 *s4 = reinterpret_cast<const float4 *>(src);
-        float4 *d4 = reinterpret_cast<float4 *>(sig);
-        const int n4 = count >> 2;
-        for (int i = tid; i < n4; i += T) d4[i] = s4[i];
-        for (int i = (n4 << 2) + tid; i < count; i += T) sig[i] = src[i];
-    } else {
-        for (int i = tid; i < count; i += T) sig[i] = src[i];
-    }
+    frame_load_span(sig, src, count, d.vec4 != 0, tid, T, pre, b);
     if (tid < 4) sig[count + tid] = 0.0f;  // tap 0 pairs x[0] with "x[L]" under a zero coefficient: a finite value, not whatever LDS held
     for (int i = tid; i < 2 * d.K; i += T) tab[i] = wtab[i];
     const int wq = tid & 7, wr = tid >> 3;  // filter tile staging: BN rows x 32 taps = BN * 8 float4, two per thread (T = 4 * BN)
@@ -2573,6 +2773,12 @@ inline unsigned cap_blocks(int64_t want, int64_t cap) { return (unsigned)std::ma
 void register_kernels_hip() {
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold_kernel<false>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold_kernel<true>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_foldh_kernel<2, 1>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_foldh_kernel<3, 1>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_foldh_kernel<4, 1>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_foldh_kernel<5, 1>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_foldh_kernel<2, 2>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_foldh_kernel<3, 2>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<2>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<3>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<4>));
@@ -2832,8 +3038,12 @@ static void launch_gemm_splitk(hipStream_t s, const GemmDesc &d, float *C, const
 
 // pair != nullptr: the fused second product (frame_fold_kernel<true>); the caller has checked frame_fold_pair_ok
 static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, int64_t batch,
-                              const GemmDesc *pair = nullptr, float *C2 = nullptr, const float *W2 = nullptr, const float *bias2 = nullptr) {
+                              const GemmDesc *pair = nullptr, float *C2 = nullptr, const float *W2 = nullptr, const float *bias2 = nullptr,
+                              const FramePre *pre = nullptr) {
     if (!frame_fold_shape_ok(d, W)) return false;
+    FramePre pre_v{};
+    if (pre) pre_v = *pre;
+    if (pre_v.n > 0 && (pair || env_int("BN_FRAMEH", 1) == 0)) return false;  // (only the round-4 kernels carry the chain)
     FrameDesc f{};
     f.rows = (int32_t)d.rows; f.N = d.N; f.K = d.K; f.L = d.fold_n; f.hop = (int32_t)d.lda;
     f.tiles = (int32_t)((d.rows + FRAME_BM - 1) / FRAME_BM);
@@ -2851,13 +3061,21 @@ static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const 
     if (d.N <= 96) wn = (d.N + 31) / 32 < 2 ? 2 : (d.N + 31) / 32;
     // a handful of row tiles (predict's single segment: 8): narrow N tiles give the chip more blocks -- the tile width does not
     // enter any output's arithmetic (47 -> 27 us for one segment)
+    // K slices (round 4): from the tile width N ALONE would get -- three wave columns leave the SIMDs unbalanced, see frame_foldh_kernel --
+    // so that a segment's bits do not depend on the batch-dependent choices around it
+    const int ks = (!pair && wn == 3 && env_int("BN_FRAME_KS", 2) == 2) ? 2 : 1;
     if ((int64_t)f.tiles * batch <= 32 && d.N > 64) wn = 2;
     if (force_wn >= 2 && force_wn <= 5) wn = force_wn;
     if (pair) wn = std::max(2, (d.N + 31) / 32);  // one N tile holds the whole spectrum row (N <= 128)
     const int bn = 32 * wn;
     const size_t lds = (size_t)(((f.span + 3) & ~3) + 2 * FRAME_BM * GEMM_LD + 2 * bn * GEMM_LD) * sizeof(float);
     if (lds > 160 * 1024) return false;
-    const void *fn = pair ? reinterpret_cast<const void *>(frame_fold_kernel<true>) : reinterpret_cast<const void *>(frame_fold_kernel<false>);
+    if (ks == 2 && wn > 3) return false;  // (a forced tile width the sliced instances do not cover)
+    const void *fn = pair ? reinterpret_cast<const void *>(frame_fold_kernel<true>)
+                   : ks == 2 ? (wn == 2 ? reinterpret_cast<const void *>(frame_foldh_kernel<2, 2>) : reinterpret_cast<const void *>(frame_foldh_kernel<3, 2>))
+                   : wn == 2 ? reinterpret_cast<const void *>(frame_foldh_kernel<2, 1>)
+                   : wn == 3 ? reinterpret_cast<const void *>(frame_foldh_kernel<3, 1>)
+                   : wn == 4 ? reinterpret_cast<const void *>(frame_foldh_kernel<4, 1>) : reinterpret_cast<const void *>(frame_foldh_kernel<5, 1>);
     if (!ensure_dynamic_lds(fn, lds)) return false;
     // enough row tiles to fill the chip: one block walks all N tiles of its rows (span loaded once); else spread them
     const int64_t row_blocks = (int64_t)f.tiles * batch;
@@ -2866,7 +3084,14 @@ static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const 
     dim3 grid((unsigned)row_blocks, (walk || pair) ? 1u : (unsigned)((d.N + bn - 1) / bn));
     GemmDesc none{};
     if (pair) hipLaunchKernelGGL(frame_fold_kernel<true>, grid, dim3(128 * wn), lds, s, f, C, A, W, bias, *pair, C2, W2, bias2);
-    else hipLaunchKernelGGL(frame_fold_kernel<false>, grid, dim3(128 * wn), lds, s, f, C, A, W, bias, none, nullptr, nullptr, nullptr);
+    else if (env_int("BN_FRAMEH", 1) == 0 && ks == 1)  // the round-3 form of the same launch (A/B; bit-identical)
+        hipLaunchKernelGGL(frame_fold_kernel<false>, grid, dim3(128 * wn), lds, s, f, C, A, W, bias, none, nullptr, nullptr, nullptr);
+    else if (ks == 2 && wn == 2) hipLaunchKernelGGL((frame_foldh_kernel<2, 2>), grid, dim3(512), lds, s, f, C, A, W, bias, pre_v);
+    else if (ks == 2) hipLaunchKernelGGL((frame_foldh_kernel<3, 2>), grid, dim3(768), lds, s, f, C, A, W, bias, pre_v);
+    else if (wn == 2) hipLaunchKernelGGL((frame_foldh_kernel<2, 1>), grid, dim3(256), lds, s, f, C, A, W, bias, pre_v);
+    else if (wn == 3) hipLaunchKernelGGL((frame_foldh_kernel<3, 1>), grid, dim3(384), lds, s, f, C, A, W, bias, pre_v);
+    else if (wn == 4) hipLaunchKernelGGL((frame_foldh_kernel<4, 1>), grid, dim3(512), lds, s, f, C, A, W, bias, pre_v);
+    else hipLaunchKernelGGL((frame_foldh_kernel<5, 1>), grid, dim3(640), lds, s, f, C, A, W, bias, pre_v);
     return true;
 }
 
@@ -2878,8 +3103,10 @@ void launch_gemm_fold_pair(hipStream_t s, const GemmDesc &d, const GemmDesc &d2,
 }
 
 void launch_gemm_fold2(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *wtab,
-                       const int32_t *colmap, int64_t batch) {
+                       const int32_t *colmap, int64_t batch, const FramePre *pre) {
     if (batch <= 0) return;
+    FramePre pre_v{};
+    if (pre) pre_v = *pre;
     if (!frame_fold2_shape_ok(d, W) || !wtab || !colmap) {
         launch_error("quarter-folded framing GEMM: shape outside what the planner may emit");
         return;
@@ -2899,7 +3126,7 @@ void launch_gemm_fold2(hipStream_t s, const GemmDesc &d, float *C, const float *
             launch_error("quarter-folded framing GEMM: the device refused the dynamic-LDS opt-in");                    \
             return;                                                                                                    \
         }                                                                                                              \
-        hipLaunchKernelGGL(frame_fold2_kernel<WN>, grid, dim3(128 * WN), lds, s, f, C, A, W, bias, wtab, colmap);      \
+        hipLaunchKernelGGL(frame_fold2_kernel<WN>, grid, dim3(128 * WN), lds, s, f, C, A, W, bias, wtab, colmap, pre_v); \
     } while (0)
     if (d.N == 64) FOLD2_GO(2);
     else if (d.N == 96) FOLD2_GO(3);
@@ -2909,8 +3136,13 @@ void launch_gemm_fold2(hipStream_t s, const GemmDesc &d, float *C, const float *
 }
 
 void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias,
-                 const float *res, const float *scale, int64_t batch) {
+                 const float *res, const float *scale, int64_t batch, const FramePre *pre) {
     if (batch <= 0) return;
+    if (pre && pre->n > 0) {  // (planner rule G moves a chain into a folded GEMM only where frame_fold_post_ok holds)
+        if (!(d.fold == 1 || d.fold == -1) || !launch_frame_fold(s, d, C, A, W, bias, batch, nullptr, nullptr, nullptr, nullptr, pre))
+            launch_error("framing GEMM with an absorbed signal chain: the LDS-resident kernel refused the launch and no other kernel carries it");
+        return;
+    }
     if (d.fold == 2) {  // (its operands do not fit this signature)
         launch_error("quarter-folded framing GEMM launched without its window tables");
         return;

@@ -155,26 +155,6 @@ __device__ __forceinline__ void block16(float2 *__restrict__ blk) {
     for (int i = 0; i < 8; i++) *reinterpret_cast<float4 *>(blk + 2 * i) = make_float4(x[2 * i].x, x[2 * i].y, x[2 * i + 1].x, x[2 * i + 1].y);
 }
 
-// (the compact stage functions pow_compact / act_small live in device_common.h: the folded framing GEMM's fused product uses them too)
-template <int N>
-__device__ __forceinline__ void bin_small(int bin, float b, float (&v)[N]) {
-    if (bin == BIN_ADD) map_array<N>(v, [=](float a) { return a + b; });
-    else if (bin == BIN_SUB) map_array<N>(v, [=](float a) { return a - b; });
-    else if (bin == BIN_MUL) map_array<N>(v, [=](float a) { return a * b; });
-    else if (bin == BIN_DIV) {
-        // one divisor for the whole array: 1 / b once, then q = a r corrected by one residual step, which is what the
-        // hardware's division sequence computes minus its scaling for denormal / overflowing quotients (3 instructions per
-        // element instead of ~10; the absorbed chain divides the whole segment by max - min)
-        const float r = 1.0f / b;
-        map_array<N>(v, [=](float a) {
-            const float q = a * r;
-            return fmaf(fmaf(-q, b, a), r, q);
-        });
-    }
-    else if (bin == BIN_MAX) map_array<N>(v, [=](float a) { return fmaxf(a, b); });
-    else if (bin == BIN_MIN) map_array<N>(v, [=](float a) { return fminf(a, b); });
-}
-
 // One shared copy of the stage dispatch for the mel phase's four-value arrays (by value: registers in, registers out).  Inlined
 // at its five call sites the dispatch -- a compare chain over every stage code, each with a four-element body -- made the
 // compression chain of 4 values cost 2.4 us per tile (instruction fetch, not arithmetic: 9.5 of the kernel's 61 us).
@@ -183,28 +163,6 @@ __device__ __noinline__ Vals4 act_small4(int act, float p0, float p1, Vals4 v) {
     act_small<4>(act, p0, p1, v.x);
     return v;
 }
-
-// The absorbed per-sample chain: up to four stages  v = act(bin(v, scalar)).  All indices are literals so that the
-// fields stay in registers.
-struct PreChain {
-    int n, bin[4], act[4];
-    float sc[4], p0[4], p1[4];
-};
-template <int S, int N>
-__device__ __forceinline__ void pre_stage(const PreChain &c, float (&v)[N]) {
-    if (S < c.n) {
-        bin_small<N>(c.bin[S], c.sc[S], v);
-        act_small<N>(c.act[S], c.p0[S], c.p1[S], v);
-    }
-}
-template <int N>
-__device__ __forceinline__ void pre_chain(const PreChain &c, float (&v)[N]) {
-    pre_stage<0, N>(c, v);
-    pre_stage<1, N>(c, v);
-    pre_stage<2, N>(c, v);
-    pre_stage<3, N>(c, v);
-}
-
 
 // contiguous global -> LDS copy without registers (global_load_lds_dwordx4: each lane names its 16 source bytes, the
 // wave writes 1 KiB at a wave-uniform LDS address).  `floats` is rounded up to whole 16-byte chunks; lanes past the

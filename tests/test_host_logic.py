@@ -109,16 +109,23 @@ def test_plan_of_v24_model(bn, tmp_path, monkeypatch):
     tot = full.splitlines()[[i for i, l in enumerate(full.splitlines()) if l.startswith("TOTAL")][0]]
     fft_flops, dft_macs = float(tot.split("fft_flops=")[1].split()[0]), float(tot.split("dft_gemm_macs=")[1].split()[0])
     assert 3e7 < fft_flops < 6e7 and dft_macs > 5 * fft_flops  # ~42 MFLOP as FFTs vs the matrix-product count
-    # the default plan picks per bank by estimated cost: the L = 2048 bank keeps few live bins and stays a
+    # the round-3 plan picks per bank by estimated cost: the L = 2048 bank keeps few live bins and stays a
     # folded matrix product, the L = 1024 bank with its ~300 live bins runs as an FFT with its mel bank absorbed; the
-    # normalisation pass stays a launch of its own because the matrix branch still reads its output
+    # normalisation pass stayed a launch of its own because the matrix branch still read its output (BN_FRAME_PRE=0) -- since round 4
+    # the folded framing GEMM applies the chain while it loads its span, like the FFT launch
     monkeypatch.delenv("BN_STFT")
     monkeypatch.setenv("BN_CONVMERGE", "0")
     monkeypatch.setenv("BN_CONVFOLD2", "0")
+    monkeypatch.setenv("BN_FRAME_PRE", "0")
     auto = bn.plan_describe(str(p))
     afft = [l for l in auto.splitlines() if " FFT " in l]
     assert len(afft) == 1 and " L=1024 hop=280 " in afft[0] and "mel=96" in afft[0] and "pre=0" in afft[0], afft
     assert sum("~sym" in l and " K=1024 " in l for l in auto.splitlines()) == 1, auto
+    assert sum(" ELT " in l and "Sub:Sub_2" in l for l in auto.splitlines()) == 1
+    monkeypatch.delenv("BN_FRAME_PRE")
+    auto = bn.plan_describe(str(p)).splitlines()
+    assert sum(" FFT " in l and "pre=4" in l and "Sub:Sub_2" in l for l in auto) == 1 and sum("~sym" in l and " K=1024 " in l and "pre=4" in l for l in auto) == 1, auto
+    assert not any(" ELT " in l and "Sub:Sub_2" in l for l in auto)
     # round 4, the default: the cosine-only L = 2048 bank quarter-folded (even bins against S, odd bins against D: L/4 + 1 taps each, K
     # padded to whole steps), the L = 1024 bank and the mel product behind it merged into 96 symmetric filters of 512 folded taps with
     # the compression chain in the launch -- no FFT, no mel launch for that branch
@@ -129,6 +136,8 @@ def test_plan_of_v24_model(bn, tmp_path, monkeypatch):
     assert sum("~quarter" in l and " K=544 " in l and "fold=2/2048" in l and "kernel=frame_fold2" in l for l in r4) == 1, r4
     assert sum("Conv_18~sym" in l and " K=512 " in l and " N=96 " in l and "post=3" in l and "kernel=frame_fold" in l for l in r4) == 1, r4
     assert sum("MatMul:" in l for l in r4) == 1  # (the 2048-point branch keeps its mel product)
+    # ... and both framing launches apply the min-max normalisation while they load their spans: the normalised segment is never written
+    assert sum(("~quarter" in l or "Conv_18~sym" in l) and "pre=4" in l and "Sub:Sub_2" in l for l in r4) == 2 and not any(" ELT " in l and "Sub:Sub_2" in l for l in r4), r4
     # BN_STFT=0 with the round-4 rules off: both banks as half-folded GEMMs
     monkeypatch.setenv("BN_CONVMERGE", "0")
     monkeypatch.setenv("BN_CONVFOLD2", "0")
