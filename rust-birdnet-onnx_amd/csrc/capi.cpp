@@ -1687,6 +1687,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 extra = line;
                 if (op.gemm.fold) { snprintf(line, sizeof(line), " fold=%d/%d", op.gemm.fold, op.gemm.fold_n); extra += line; }
                 if (op.pre.n) { snprintf(line, sizeof(line), " pre=%d", op.pre.n); extra += line; }
+                if (op.gemm.gap) extra += " gap=1";
                 if (op.gemm.se_inline) { snprintf(line, sizeof(line), " se_inline=%d/%d", op.se.C, op.se.Cr); extra += line; }
                 if (op.gemm2.N > 0) { snprintf(line, sizeof(line), " pair=%dx%d post=%d out_rs=%lld out_cs=%lld", op.gemm2.K, op.gemm2.N, op.gemm2.npost, (long long)op.gemm2.out_rs, (long long)op.gemm2.out_cs); extra += line; }
                 // which of the three matrix kernels the launcher picks (the LDS-resident framing kernel may still fall back to

@@ -3138,6 +3138,7 @@ class Builder {
         planar_stft_tables();
         fuse_fold_pairs();
         pair_minmax_reductions();
+        fuse_gap_into_gemm();
         absorb_se_into_gemms();
         recompute_liveness();
     }
@@ -3439,6 +3440,54 @@ class Builder {
                     f.name = el.name + "+" + f.name;
                 }
                 plan_.ops.erase(plan_.ops.begin() + (long)e);
+                changed = true;
+            }
+        }
+    }
+
+    // (K, round 4) GlobalAveragePool behind a 1x1 conv whose 48 rows per sample sit in one block of the LDS-DMA GEMM (48-row tiles): the
+    // epilogue writes the mean over the rows instead of the rows (gemm_dma.hip; fixed order: m-tiles ascending, then a butterfly over the 16
+    // rows of a tile), the [48, N] tensor is neither written nor read and the reduction launch is gone.  v2.4's head: Conv_261 (320 -> 1024,
+    // ReLU) + GlobalAveragePool_264.  BN_GEMMGAP=0 disables.
+    void fuse_gap_into_gemm() {
+        if (env_int("BN_GEMMGAP", 1) == 0) return;
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            std::vector<std::vector<int>> users(plan_.storages.size());
+            std::vector<Ref *> refs;
+            for (size_t k = 0; k < plan_.ops.size(); k++) {
+                all_refs(plan_.ops[k], refs);
+                for (Ref *r : refs)
+                    if (r->space == Space::ARENA && (users[r->id].empty() || users[r->id].back() != (int)k)) users[r->id].push_back((int)k);
+            }
+            for (size_t j = 0; j < plan_.ops.size() && !changed; j++) {
+                PlanOp &red = plan_.ops[j];
+                const ReduceDesc &r = red.red;
+                if (red.kind != OpKind::REDUCE || r.op != RED_MEAN || r.pair || red.a.space != Space::ARENA || red.out.space != Space::ARENA) continue;
+                const auto &u = users[red.a.id];
+                if (u.size() != 2 || u[1] != (int)j || plan_.storages[red.a.id].pinned) continue;
+                PlanOp &g = plan_.ops[u[0]];
+                if (g.kind != OpKind::GEMM || g.out.space != Space::ARENA || g.out.id != red.a.id || g.out.offset != red.a.offset || g.se_fused || g.gemm2.N > 0) continue;
+                GemmDesc d = g.gemm;
+                if (d.gap || !gemm_gap_shape_ok(d) || gemm_dma_shape(d) != 2 || d.ldc != d.N || d.c_bs != d.rows * d.N) continue;
+                // the reduction: every channel's mean over the sample's rows, [rows, N] -> [N], dense
+                // (the reduced dims -- H, W of the map -- nest into one run of `rows` rows of N floats)
+                bool rows_run = r.nr >= 1 && r.nr <= 3 && r.rin[r.nr - 1] == d.N;
+                int64_t nrows = 1;
+                for (int q = r.nr - 1; q >= 0 && rows_run; q--) {
+                    rows_run = r.rin[q] == d.N * nrows;
+                    nrows *= r.rsize[q];
+                }
+                if (r.nk != 1 || !rows_run || nrows != d.rows || r.ksize[0] != d.N || r.kin[0] != 1 || r.kout[0] != 1 || r.bi != d.c_bs) continue;
+                if (red.out.offset % 4 != 0 || r.bo % 4 != 0) continue;  // (dwordx4 stores)
+                d.gap = 1;
+                d.c_bs = r.bo;
+                g.gemm = d;
+                g.out = red.out;
+                g.name += "+" + red.name;
+                g.bytes += red.bytes - 8.0 * (double)d.rows * d.N;  // the [rows, N] tensor never touches memory
+                plan_.ops.erase(plan_.ops.begin() + (long)j);
                 changed = true;
             }
         }

@@ -338,6 +338,29 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma_kernel(GemmDesc d,
             for (int i = 0; i < 4; i++) v[(mt * NTW + nt) * 4 + i] = acc[mt][nt][i] + bv[i];
     }
     gd_act<MTW * NTW * 4>(d.act, d.p0, d.p1, v);
+    if constexpr (WM == 1) {
+        if (d.gap) {  // the sample's mean over its rows (all TR of them sit in this wave): m-tiles ascending, then the 16 rows of a tile by a
+                      // fixed butterfly over the lanes lc -- one dwordx4 per n-tile and lane group instead of TR rows
+#pragma unroll
+            for (int nt = 0; nt < NTW; nt++) {
+                floatx4 sm = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int mt = 0; mt < MTW; mt++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) sm[i] += v[(mt * NTW + nt) * 4 + i];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) sm[i] += __shfl_xor(sm[i], o);
+                const int n = n0 + (wn * NTW + nt) * 16 + 4 * lq;
+                if (lc == 0 && n < d.N) {
+                    const float inv_rows = (float)TR;
+                    *reinterpret_cast<floatx4 *>(C + (int64_t)b * d.c_bs + n) = floatx4{sm[0] / inv_rows, sm[1] / inv_rows, sm[2] / inv_rows, sm[3] / inv_rows};
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < MTW; mt++) {
         const int64_t m = (int64_t)rt * TR + (wm * MTW + mt) * 16 + lc;
@@ -592,6 +615,7 @@ void register_gemm_dma_kernels() {
 bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res, const float *scale,
                      int64_t batch, const SeInline *se) {
     const int shape = gemm_dma_shape(d);
+    if (d.gap && (shape != 2 || !gemm_gap_shape_ok(d))) return false;  // (the caller reports it: no other kernel pools in its epilogue)
     if (!shape || !al16(A) || !al16(W) || !al16(C) || (d.has_res && !al16(res)) || (d.has_bias && !al16(bias)) ||
         (d.has_scale && !d.se_inline && !al16(scale)))
         return false;

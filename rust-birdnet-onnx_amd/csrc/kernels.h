@@ -114,7 +114,12 @@ struct GemmDesc {
     // squeeze-excite computed in the GEMM's own prologue (planner rule I, gemm_dma.hip): the gate is not read from
     // memory, every block derives it from the squeeze partial sums of its sample
     int32_t se_inline;
+    // (round 4, planner: fuse_gap_into_gemm) the mean over ALL rows of a sample is what leaves the launch: C is [batch][N] (c_bs = N) and
+    // holds  sum_m act(row m) / rows.  Only the LDS-DMA kernel's 48-row tiles with rows == 48 (one block sees every row of the sample for its
+    // channels, one wave every row of its channels): the head conv of v2.4 in front of its GlobalAveragePool.
+    int32_t gap;
 };
+inline bool gemm_gap_shape_ok(const GemmDesc &d) { return d.rows == 48 && !d.has_res && !d.npost && !d.out_strided && !d.fold; }
 
 // Direct NHWC convolution, weights [kh][kw][cin/groups][cout].
 struct ConvDesc {

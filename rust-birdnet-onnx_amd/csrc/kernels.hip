@@ -3155,6 +3155,10 @@ void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, con
     }
     if (d.npost || d.out_strided) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);
     if (launch_gemm_dma(s, d, C, A, W, bias, res, scale, batch)) return;  // LDS-DMA kernel (gemm_dma.hip) where its tiles fit the shape
+    if (d.gap) {
+        launch_error("GEMM with the row mean in its epilogue: the LDS-DMA kernel refused the launch and no other kernel pools");
+        return;
+    }
     if (gemm_use_splitk(d)) launch_gemm_splitk(s, d, C, A, W, bias, res, scale, total_rows);
     else launch_gemm_tiled(s, d, C, A, W, bias, res, scale, total_rows);
 }

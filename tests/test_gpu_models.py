@@ -486,7 +486,7 @@ def test_round3_kernels_tile_shape_and_grouping_do_not_enter_the_arithmetic(bn, 
 
 @pytest.mark.parametrize("env", [{"BN_GEMMDMA": "0"}, {"BN_GEMMDMA": "2"}, {"BN_MBMAP2": "0"}, {"BN_SEGEMM": "1"}, {"BN_GEMMDMA_KS": "1"},
                                  {"BN_STFT_MELMFMA": "0", "BN_CONVMERGE": "0"}, {"BN_STFT_NW": "16", "BN_CONVMERGE": "0"}, {"BN_MBROW_TOH": "8"}, {"BN_FRAMEPAIR": "1"},
-                                 {"BN_CONVFOLD2": "0"}, {"BN_CONVMERGE": "0"}, {"BN_FRAME_PRE": "0"}, {"BN_FRAME_KS": "1"}])
+                                 {"BN_CONVFOLD2": "0"}, {"BN_CONVMERGE": "0"}, {"BN_FRAME_PRE": "0"}, {"BN_FRAME_KS": "1"}, {"BN_GEMMGAP": "0"}])
 def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, monkeypatch, env):
     """Every round-3 rewrite has an off switch (and two opt-ins): the older kernels (BN_GEMMDMA=0, BN_MBMAP2=0), the
     LDS-DMA GEMM on every eligible shape (BN_GEMMDMA=2), the squeeze-excite products in the GEMM prologue (BN_SEGEMM=1),
@@ -508,6 +508,8 @@ def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, mon
     assert ("~quarter" in desc) == (not env.get("BN_FRAMEPAIR") and env.get("BN_CONVFOLD2") != "0"), desc  # (round 4) the 127-bin cosine bank
     if env.get("BN_CONVFOLD2") == "0":
         assert "~sym" in desc
+    # (round 4, rule K) the head conv writes the pooled row: the LDS-DMA GEMM's 48-row tile holds a sample's whole map
+    assert ("gap=1" in desc) == (env.get("BN_GEMMGAP") != "0" and env.get("BN_GEMMDMA") != "0"), desc
     # (round 4) the min-max normalisation rides in the framing launches' span load unless BN_FRAME_PRE=0 (or the opt-in pair rule) keeps it a launch
     assert (" ELT " in "".join(l for l in desc.splitlines() if "Sub:Sub_2" in l)) == (env.get("BN_FRAME_PRE") == "0" or env.get("BN_FRAMEPAIR") == "1"), desc
     # (round 4) the 309-bin bank and its mel product are one bank of 96 folded filters unless BN_CONVMERGE=0 keeps them apart (then: an FFT)

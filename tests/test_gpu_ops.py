@@ -52,6 +52,42 @@ def test_pointwise_conv_gemm(bn, cin, h, w, cout):
     assert_close(got, ref, f"1x1 conv {cin}->{cout}")
 
 
+@pytest.mark.parametrize("cin,cout,act,h,w,expect", [(320, 1024, "relu", 3, 16, True), (128, 200, "silu", 3, 16, True), (192, 36, "relu", 6, 8, True),
+                                                      (320, 128, "relu", 4, 16, False), (144, 96, None, 3, 16, True)])
+def test_global_average_pool_in_the_gemm_epilogue(bn, cin, cout, act, h, w, expect, monkeypatch):
+    """Planner rule K (round 4): GlobalAveragePool behind a 1x1 conv whose 48 rows per sample sit in one block of the LDS-DMA GEMM -- the
+    epilogue writes the mean over the rows (v2.4's head conv + pool); ragged channel counts, no activation, a map of another size (64 rows:
+    the rule steps aside).  Against the oracle, against the separate reduction launch, and bit-identical across batch sizes / tile widths."""
+    rng = np.random.default_rng(cin + cout)
+
+    def build(g, x):  # 1x1 (puts the map into the channels-last layout) -> the conv under test -> pool
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(cin * h * w), i64(1), i64(1)])
+        x = g.node("Reshape", [x, i64(-1, cin, h, w)])
+        x = g.node("Conv", [x, g.const((rng.standard_normal((cin, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32))], kernel_shape=[1, 1])
+        y = g.node("Conv", [x, g.const((rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)),
+                            g.const(rng.standard_normal(cout).astype(np.float32))], kernel_shape=[1, 1])
+        if act == "relu":
+            y = g.node("Relu", [y])
+        elif act == "silu":
+            y = g.node("Mul", [y, g.node("Sigmoid", [y])])
+        p = g.node("GlobalAveragePool", [y])
+        return g.node("Flatten", [p], axis=1)
+    data = op_graph(build, [cout])
+    text = bn.plan_describe(write_model(data))
+    assert ("gap=1" in text and "GlobalAveragePool" in [l for l in text.splitlines() if "gap=1" in l][0]) == expect, text
+    assert (" REDUCE " in text) == (not expect), text
+    got, ref = run_both(bn, data, batch=3)
+    assert_close(got, ref, f"pooled 1x1 conv {cin}->{cout}")
+    if expect:
+        big, _ = run_both(bn, data, batch=40)  # more blocks: another tile width (the width does not enter the arithmetic)
+        assert np.array_equal(big[:3].view(np.uint32), got.view(np.uint32))
+        monkeypatch.setenv("BN_GEMMGAP", "0")
+        assert "gap=1" not in bn.plan_describe(write_model(data))
+        sep, _ = run_both(bn, data, batch=3)
+        assert_close(got, sep, "pooled epilogue vs separate reduction", atol=1e-5 * float(np.abs(sep).max()) + 1e-6, rtol=0)
+
+
 @pytest.mark.parametrize("cin,h,w,cout,act,stream", [(80, 8, 32, 480, "silu", True), (112, 8, 32, 672, "silu", True), (96, 32, 8, 576, "silu", True),
                                                      (64, 6, 16, 128, "relu", True), (96, 4, 16, 1100, "relu6", True), (96, 5, 7, 200, "relu", False),
                                                      (48, 8, 32, 288, "silu", False)])
