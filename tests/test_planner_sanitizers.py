@@ -54,10 +54,13 @@ RULE_SETS = [
     {"BN_SEGEMM": "1", "BN_FRAMEPAIR": "1", "BN_STFT": "1", "BN_STFT_MEL": "force", "BN_MBMAP3": "1", "BN_GEMMSTREAM": "1"},
     {"BN_STFT": "0", "BN_MBMAP2": "0", "BN_GEMMDMA": "0", "BN_MBROW": "0", "BN_CONVFOLD": "0", "BN_GEMMPOST": "0"},
     {"BN_GEMMDMA": "2", "BN_MBFUSE": "force", "BN_MBMAP": "1", "BN_STFT_MELMFMA": "0", "BN_STFT_POWER": "0", "BN_REDUCE_SPLIT": "0"},
+    # round 4: quarter fold / merged filters / span-load chain / pooled epilogue off (the round-3 plan), and merging forced wherever the pattern matches
+    {"BN_CONVFOLD2": "0", "BN_CONVMERGE": "0", "BN_FRAME_PRE": "0", "BN_GEMMGAP": "0"},
+    {"BN_CONVMERGE": "1", "BN_STFT": "0"},
 ]
 
 
-@pytest.mark.parametrize("rules", RULE_SETS, ids=["default", "optins", "rewrites_off", "forced"])
+@pytest.mark.parametrize("rules", RULE_SETS, ids=["default", "optins", "rewrites_off", "forced", "round4_off", "merge_forced"])
 def test_full_size_plans_under_asan_ubsan_with_rules_on_and_off(asan_binary, tmp_path, rules):
     files = []
     for name, data in (("v24", synth.birdnet_v24()), ("v30", synth.birdnet_v30()), ("perch", synth.perch_v2()), ("meta", synth.meta_model())):
