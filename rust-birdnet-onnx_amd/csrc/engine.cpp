@@ -1124,6 +1124,20 @@ class Builder {
         tabs[(size_t)Q] = w[(size_t)Q];
         tabs[(size_t)(K2 + Q)] = 0.0f;
         f.name = "Conv:" + n.name + "~quarter";
+        if (frame_fold2p_ok(f.gemm)) {  // half-height blocks: the filter fragments in the order the waves load them
+            const int64_t steps = K2 / 32;
+            std::vector<float> pk((size_t)(N2 * K2));
+            for (int64_t wn = 0; wn < N2 / 32; wn++)
+                for (int64_t ks = 0; ks < steps; ks++)
+                    for (int64_t g = 0; g < 4; g++)
+                        for (int64_t lane = 0; lane < 64; lane++) {
+                            const int64_t lr = lane & 31, lh = lane >> 5;
+                            for (int64_t j = 0; j < 4; j++)
+                                pk[(size_t)((((wn * steps + ks) * 4 + g) * 64 + lane) * 4 + j)] = wk[(size_t)((wn * 32 + lr) * K2 + ks * 32 + 8 * g + 4 * lh + j)];
+                        }
+            wk.swap(pk);
+            f.gemm.fold_wpk = 1;
+        }
         f.w = Ref{Space::CONSTS, add_const(wk), 0};
         f.w2 = Ref{Space::CONSTS, add_const(tabs), 0};
         f.bias2 = Ref{Space::CONSTS, add_const(colmap_bits), 0};

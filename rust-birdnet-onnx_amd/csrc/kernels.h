@@ -106,6 +106,10 @@ struct GemmDesc {
     // window tables and the column -> output channel map as two more operands (launch_gemm_fold2).
     int32_t fold, fold_n;
     int32_t fold_ne;
+    // fold == 2: W is packed in fragment order for the half-height kernel (frame_fold2p_kernel: [column group of 32][step][8-wide k group]
+    // [lane][4 floats], lane (lr, lh) holding W[32 group + lr][32 step + 8 g + 4 lh .. + 3]); decided by the planner from per-sample
+    // quantities (frame_fold2p_ok): two such blocks fit a CU's LDS
+    int32_t fold_wpk;
     // Absorbed elementwise chain (planner rule E): unary stages applied after act, and the consumer's output view.
     int32_t npost, out_strided;
     int32_t post_act[4];

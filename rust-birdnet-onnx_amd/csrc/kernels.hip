@@ -1389,6 +1389,143 @@ __global__ __launch_bounds__(128 * WN) void frame_fold2_kernel(Frame2Desc d, flo
     }
 }
 
+// Half-height form (round 4): 32 frames per block, WN waves (one per 32-column group), under 80 KB of LDS -- TWO blocks share a CU, each
+// with barriers of its own, so one block's span load, staging and barrier waits run under the other's matrix instructions.  With one
+// wave row every filter element is used by exactly one wave: the filter fragments come STRAIGHT from global memory (L2) into registers,
+// one step ahead, from a copy the planner packs in fragment order ([column group][step][8-wide k group][lane][4]: every load is one
+// coalesced KiB) -- no filter tile in LDS, no store / read of it, half the LDS traffic of a step.  Same products in the same order as the
+// 64-row form: bit-identical (tested).  GemmDesc::fold_wpk says which layout W has.
+template <int WN>
+__global__ __launch_bounds__(64 * WN, 2) void frame_fold2p_kernel(Frame2Desc d, float *__restrict__ C, const float *__restrict__ A, const float *__restrict__ Wp,
+                                                                  const float *__restrict__ bias, const float *__restrict__ wtab, const int32_t *__restrict__ colmap,
+                                                                  FramePre pre) {
+    extern __shared__ __align__(16) float frame_lds[];
+    constexpr int BM = 32, T = 64 * WN, TILE = BM * GEMM_LD, SLOTS = (BM * 16 + T - 1) / T;
+    const int tid = threadIdx.x;
+    float *sig = frame_lds;
+    float *tab = sig + ((d.span + 4 + 3) & ~3);  // [2][K]: wa | wb
+    float *As = tab + 2 * d.K;                   // [2 buffers][S | D][32][GEMM_LD]
+    const int b = blockIdx.x / d.tiles, rt = blockIdx.x - b * d.tiles;
+    const int row0 = rt * BM;
+    const int rows_here = min(BM, d.rows - row0);
+    const float *src = A + (int64_t)b * d.a_bs + (int64_t)row0 * d.hop;
+    const int count = (rows_here - 1) * d.hop + d.L;
+    frame_load_span(sig, src, count, d.vec4 != 0, tid, T, pre, b);
+    if (tid < 4) sig[count + tid] = 0.0f;
+    for (int i = tid; i < 2 * d.K; i += T) tab[i] = wtab[i];
+    const int nfull = d.L / (4 * GEMM_BK), nsteps = nfull + 1;
+    uint32_t a_fw[SLOTS], a_rv[SLOTS], a_hm[SLOTS], a_hp[SLOTS], a_dst[SLOTS];
+    const uint32_t sig0 = lds_offset_of(sig), as0 = lds_offset_of(As);
+    const int cp = (tid & 15) * 2;
+    uint32_t a_wa = lds_offset_of(tab) + 4u * cp, a_wb = a_wa + 4u * d.K;
+#pragma unroll
+    for (int i = 0; i < SLOTS; i++) {
+        const int p = tid + i * T;
+        const int r = (p >> 4) & (BM - 1);
+        const int re = r < rows_here ? r : rows_here - 1;
+        const uint32_t f = sig0 + 4u * (uint32_t)(re * d.hop);
+        a_fw[i] = f + 4u * cp;
+        a_rv[i] = f + 4u * (d.L - cp - 1);
+        a_hm[i] = f + 4u * (d.L / 2 - cp - 1);
+        a_hp[i] = f + 4u * (d.L / 2 + cp);
+        a_dst[i] = as0 + 4u * (uint32_t)(r * GEMM_LD + cp);
+    }
+    constexpr bool LAST_PARTIAL = (BM * 16) % T != 0;
+    const bool last_on = !LAST_PARTIAL || tid + (SLOTS - 1) * T < BM * 16;
+    float2 xf[SLOTS], xr[SLOTS], xm[SLOTS], xp[SLOTS], cwa, cwb;
+    auto load_a = [&]() {
+        cwa = lds_ld2(a_wa); cwb = lds_ld2(a_wb);
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) {
+            xf[i] = make_float2(lds_ld(a_fw[i]), lds_ld(a_fw[i] + 4));
+            xr[i] = make_float2(lds_ld(a_rv[i]), lds_ld(a_rv[i] + 4));
+            xm[i] = make_float2(lds_ld(a_hm[i]), lds_ld(a_hm[i] + 4));
+            xp[i] = make_float2(lds_ld(a_hp[i]), lds_ld(a_hp[i] + 4));
+        }
+    };
+    auto finish_a = [&](uint32_t buf_off) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) {
+            if (i < SLOTS - 1 || last_on) {
+                const float a0 = xf[i].x + xr[i].y, a1 = xf[i].y + xr[i].x;
+                const float b0 = xm[i].y + xp[i].x, b1 = xm[i].x + xp[i].y;
+                const float ya0 = cwa.x * a0, ya1 = cwa.y * a1, yb0 = cwb.x * b0, yb1 = cwb.y * b1;
+                lds_st2(a_dst[i] + buf_off, make_float2(ya0 + yb0, ya1 + yb1));
+                lds_st2(a_dst[i] + buf_off + 4u * TILE, make_float2(ya0 - yb0, ya1 - yb1));
+            }
+            a_fw[i] += 4 * GEMM_BK; a_hp[i] += 4 * GEMM_BK;
+            a_rv[i] -= 4 * GEMM_BK; a_hm[i] -= 4 * GEMM_BK;
+        }
+        a_wa += 4 * GEMM_BK; a_wb += 4 * GEMM_BK;
+    };
+    const int wn = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int kind = wn * 32 < d.n_even ? 0 : 1;
+    // this wave's filter fragments: [wn][step][g][lane] float4 (scalars, not arrays: see frame_foldh_kernel)
+    const float4 *wf = reinterpret_cast<const float4 *>(Wp) + ((int64_t)wn * nsteps * 4) * 64 + lane;
+    float4 w0 = wf[0], w1 = wf[64], w2 = wf[128], w3 = wf[192];
+    float4 n0 = w0, n1 = w1, n2 = w2, n3 = w3;
+    __syncthreads();  // signal span and window tables complete
+    load_a();
+    finish_a(0);
+    __syncthreads();
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    const float *ap0 = As + kind * TILE + lr * GEMM_LD + 4 * lh;
+    for (int ks = 0; ks < nfull; ks++) {
+        const int cur = ks & 1;
+        {  // the fragments of step ks + 1 (<= nfull: the tail step's are there like any other)
+            const float4 *wn_ = wf + (int64_t)(ks + 1) * 256;
+            n0 = wn_[0]; n1 = wn_[64]; n2 = wn_[128]; n3 = wn_[192];
+        }
+        load_a();
+        const float *ap = ap0 + cur * 2 * TILE;
+        {
+            const float4 a0 = *reinterpret_cast<const float4 *>(ap), a1 = *reinterpret_cast<const float4 *>(ap + 8);
+            const float4 a2 = *reinterpret_cast<const float4 *>(ap + 16), a3 = *reinterpret_cast<const float4 *>(ap + 24);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w0.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w0.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w0.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w0.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, w1.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, w1.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, w1.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w1.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, w2.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, w2.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.z, w2.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.w, w2.w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.x, w3.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.y, w3.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.z, w3.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.w, w3.w, acc, 0, 0, 0);
+        }
+        finish_a((uint32_t)((cur ^ 1) * 2 * TILE * 4));
+        w0 = n0; w1 = n1; w2 = n2; w3 = n3;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    {  // tail step: one 8-wide group (tap L/4)
+        const float4 a0 = *reinterpret_cast<const float4 *>(ap0 + (nfull & 1) * 2 * TILE);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w0.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w0.w, acc, 0, 0, 0);
+    }
+    const int col = wn * 32 + lr;
+    const int n = colmap[col];
+    if (n >= 0) {
+        const float bv = d.has_bias ? bias[n] : 0.0f;
+        float *cb = C + (int64_t)b * d.c_bs + (int64_t)row0 * d.ldc + n;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (r < rows_here) cb[(int64_t)r * d.ldc] = acc[reg] + bv;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ small-M GEMM: intra-block split-K
 // When the output has few 128-row tiles (late CNN stages, FC head) the kernel above leaves most
 // CUs idle.  Here a block owns one 32 x BN tile and its 4 waves split K between them (k-steps
@@ -2783,6 +2920,10 @@ void register_kernels_hip() {
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<3>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<4>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<5>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2p_kernel<2>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2p_kernel<3>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2p_kernel<4>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2p_kernel<5>));
 #define BN_REG_KS(KERNEL)                                                     \
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 1>)); \
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<3, 2>)); \
@@ -3113,11 +3254,32 @@ void launch_gemm_fold2(hipStream_t s, const GemmDesc &d, float *C, const float *
     }
     Frame2Desc f{};
     f.rows = (int32_t)d.rows; f.N = d.N; f.K = d.K; f.L = d.fold_n; f.hop = (int32_t)d.lda;
+    f.n_even = d.fold_ne; f.has_bias = d.has_bias;
+    f.a_bs = d.a_bs; f.ldc = d.ldc; f.c_bs = d.c_bs;
+    if (d.fold_wpk) {  // half-height blocks, filter fragments packed by the planner (frame_fold2p_kernel)
+        f.tiles = (int32_t)((d.rows + 31) / 32);
+        f.span = 31 * f.hop + f.L;
+        f.vec4 = d.a_bs % 4 == 0 && (32 * (int64_t)f.hop) % 4 == 0 && aligned16(A);
+        const size_t ldsp = frame_fold2p_lds_bytes(d);
+        const dim3 gridp((unsigned)((int64_t)f.tiles * batch));
+#define FOLD2P_GO(WN)                                                                                                      \
+    do {                                                                                                                   \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(frame_fold2p_kernel<WN>), ldsp)) {                          \
+            launch_error("quarter-folded framing GEMM: the device refused the dynamic-LDS opt-in");                        \
+            return;                                                                                                        \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(frame_fold2p_kernel<WN>, gridp, dim3(64 * WN), ldsp, s, f, C, A, W, bias, wtab, colmap, pre_v); \
+    } while (0)
+        if (d.N == 64) FOLD2P_GO(2);
+        else if (d.N == 96) FOLD2P_GO(3);
+        else if (d.N == 128) FOLD2P_GO(4);
+        else FOLD2P_GO(5);
+#undef FOLD2P_GO
+        return;
+    }
     f.tiles = (int32_t)((d.rows + FRAME_BM - 1) / FRAME_BM);
     f.span = (FRAME_BM - 1) * f.hop + f.L;
     f.vec4 = d.a_bs % 4 == 0 && (FRAME_BM * (int64_t)f.hop) % 4 == 0 && aligned16(A);
-    f.n_even = d.fold_ne; f.has_bias = d.has_bias;
-    f.a_bs = d.a_bs; f.ldc = d.ldc; f.c_bs = d.c_bs;
     const size_t lds = frame_fold2_lds_bytes(d);
     const dim3 grid((unsigned)((int64_t)f.tiles * batch));
 #define FOLD2_GO(WN)                                                                                                   \

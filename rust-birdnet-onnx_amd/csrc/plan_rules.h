@@ -54,6 +54,12 @@ inline size_t frame_fold2_lds_bytes(const GemmDesc &d) {
     const int64_t span = (int64_t)(FRAME_BM_RULE - 1) * d.lda + d.fold_n + 4;  // (+ the one element behind the last frame that tap 0 pairs with)
     return (size_t)(((span + 3) & ~3) + 2 * d.K + 4 * FRAME_BM_RULE * GEMM_LD_RULE + 2 * d.N * GEMM_LD_RULE) * sizeof(float);
 }
+// half-height form (frame_fold2p_kernel): 32-row span, both window tables, two S | D operand tile pairs; taken where two blocks fit a CU
+inline size_t frame_fold2p_lds_bytes(const GemmDesc &d) {
+    const int64_t span = (int64_t)31 * d.lda + d.fold_n + 4;
+    return (size_t)(((span + 3) & ~3) + 2 * d.K + 4 * 32 * GEMM_LD_RULE) * sizeof(float);
+}
+inline bool frame_fold2p_ok(const GemmDesc &d) { return env_int("BN_FRAME2_WPK", 1) != 0 && frame_fold2p_lds_bytes(d) <= 80 * 1024; }
 inline bool frame_fold2_shape_ok(const GemmDesc &d, const float *W) {
     if (env_int("BN_FRAMELDS", 1) == 0 || env_int("BN_CONVFOLD2", 1) == 0) return false;
     if (d.fold != 2 || d.has_res || d.has_scale || d.act != ACT_NONE || d.npost || d.out_strided || d.se_inline) return false;

@@ -297,6 +297,13 @@ def test_conv1d_quarter_folded_cosine_bank(bn, n_fft, hop, which, window, monkey
     got3, ref3 = run_both(bn, data, batch=3)
     assert_close(got3, ref3, f"quarter-folded conv1d n_fft={n_fft} {which} batch 3", atol=tol, rtol=0)
     assert np.array_equal(got3[:2].view(np.uint32), got.view(np.uint32))  # a segment's bits do not depend on the batch
+    # the half-height kernel (filter fragments packed by the planner, straight from global memory) and the 64-row kernel: same products, same order
+    packed = "kernel=frame_fold2p" in text
+    monkeypatch.setenv("BN_FRAME2_WPK", "0")
+    assert "kernel=frame_fold2p" not in bn.plan_describe(write_model(data))
+    tall, _ = run_both(bn, data, batch=2)
+    assert np.array_equal(tall.view(np.uint32), got.view(np.uint32)), packed
+    monkeypatch.delenv("BN_FRAME2_WPK")
     monkeypatch.setenv("BN_CONVFOLD2", "0")
     text = bn.plan_describe(write_model(data))
     assert "~sym" in text and "~quarter" not in text, text
