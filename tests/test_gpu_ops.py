@@ -315,6 +315,51 @@ def test_conv1d_quarter_folded_cosine_bank(bn, n_fft, hop, which, window, monkey
     assert_close(got, plain, "quarter fold vs plain convolution", atol=tol, rtol=0)
 
 
+@pytest.mark.parametrize("start,n_fft,hop,bins", [(3, 1024, 37, 90), (1, 2048, 278, 127), (2, 512, 101, 120)])
+def test_quarter_and_half_fold_on_an_unaligned_signal_with_the_chain_in_the_span_load(bn, start, n_fft, hop, bins, monkeypatch):
+    """The framing kernels' scalar span load: the signal is a view that starts 1 - 3 samples into the segment (no 16-byte alignment, the
+    float4 path is off) and is normalised by the model's per-sample chain ((x - min) / (max - min + eps) - 0.5) * 2 that the planner moves into the span load
+    (rule G) -- cosine-only bank (quarter fold, both block heights) and cos | sin bank (half folds) against the oracle."""
+    import importlib
+    synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
+    w = synth.dft_basis(n_fft, "complex")
+    half = w.shape[0] // 2
+    S = 100000
+    frames = (S - n_fft) // hop + 1
+    for kind in ("cos", "both"):
+        ww = np.ascontiguousarray(w[2:2 + bins] if kind == "cos" else np.concatenate([w[2:2 + bins // 2], w[half + 2:half + 2 + bins // 2]], axis=0))
+
+        def build(g, x):
+            i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+            x = g.node("Slice", [x, i64(start), i64(start + S), i64(1), i64(1)])
+            mn = g.node("ReduceMin", [x], axes=[1], keepdims=1)
+            x1 = g.node("Sub", [x, mn])
+            mx = g.node("ReduceMax", [x1], axes=[1], keepdims=1)
+            x2 = g.node("Div", [x1, g.node("Add", [mx, g.const(np.float32(1e-6))])])
+            # (centred like the model's chain: a segment with a large mean makes every low bin a sum of large cancelling terms whose f32
+            # rounding -- in ANY order -- exceeds a tolerance scaled by the outputs)
+            x3 = g.node("Mul", [g.node("Sub", [x2, g.const(np.float32(0.5))]), g.const(np.float32(2.0))])
+            u = g.node("Unsqueeze", [x3, i64(1)])
+            return g.node("Conv", [u, g.const(ww)], kernel_shape=[n_fft], strides=[hop])
+        data = op_graph(build, [ww.shape[0], frames])
+        monkeypatch.setenv("BN_STFT", "0")
+        text = bn.plan_describe(write_model(data))
+        assert " pre=" in text and ("~quarter" in text) == (kind == "cos"), text
+        got, ref = run_both(bn, data, batch=2)
+        tol = 2e-5 * float(np.abs(ref).max())
+        assert_close(got, ref, f"unaligned {kind} n_fft={n_fft}", atol=tol, rtol=0)
+        monkeypatch.setenv("BN_FRAME_PRE", "0")
+        assert " pre=" not in bn.plan_describe(write_model(data))
+        sep, _ = run_both(bn, data, batch=2)
+        assert_close(got, sep, "chain in the span load vs its own launch", atol=tol, rtol=0)
+        monkeypatch.delenv("BN_FRAME_PRE")
+        if kind == "cos":
+            monkeypatch.setenv("BN_FRAME2_WPK", "0")
+            tall, _ = run_both(bn, data, batch=2)
+            assert np.array_equal(tall.view(np.uint32), got.view(np.uint32))
+            monkeypatch.delenv("BN_FRAME2_WPK")
+
+
 @pytest.mark.parametrize("n_fft,hop,n_mels,fmin,fmax,bias,expect", [(1024, 280, 96, 500.0, 15000.0, False, True), (1024, 280, 40, 0.0, 24000.0, True, True),
                                                                     (2048, 278, 96, 0.0, 3000.0, False, False), (512, 160, 64, 1000.0, 20000.0, True, True)])
 def test_framing_conv_merged_with_the_product_behind_it(bn, n_fft, hop, n_mels, fmin, fmax, bias, expect, monkeypatch):
