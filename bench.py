@@ -306,7 +306,7 @@ def main():
 
     # the round-3 protocol next to it (never `value`): the same loop with each context re-reading the batch in its own buffer
     own_buffer = None
-    if world == 1 and not args.own_buffer:
+    if not args.own_buffer:  # (every world size since round 5: the round-to-round comparison must not depend on prose)
         def run_own(n):
             for i in range(n):
                 if i >= S_:
@@ -316,12 +316,17 @@ def main():
                 c.synchronize()
 
         run_own(2 * S_)
-        torch.cuda.synchronize()
+        fence()
         t_own = time.perf_counter()
         run_own(args.steps)
-        torch.cuda.synchronize()
+        fence()
         d_own = time.perf_counter() - t_own
-        own_buffer = {"value": round(args.steps * B / d_own, 2), "unit": "segments/s", "ms_per_step": round(d_own / args.steps * 1e3, 4), "steps": args.steps,
+        if use_dist:
+            t = torch.tensor([d_own], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d_own = float(t.item())
+        own_buffer = {"value": round(args.steps * B * world / d_own, 2), "unit": "segments/s", "ms_per_step": round(d_own / args.steps * 1e3, 4), "steps": args.steps,
+                      "protocol": "r3-own-buffer" + ("" if world == 1 else " (no logits gather in this leg)"),
                       "what": "each context re-reads the batch pre-placed in its own input buffer: no per-step input copy, input cache-resident (BENCH_r03's protocol)"}
 
     # ---- the drop-in call, host to host (never `value`): the same batches as HOST f32 slices through
@@ -386,6 +391,8 @@ def main():
         "step_interval_stats": step_stats,
         "step_done_ms": [round(float(v), 3) for v in done_ms] if (len(done_ms) <= 64 or args.dump_steps) else None,  # completion time of every timed step since the start of the timed region (short runs only)
         "higher_is_better": True,
+        "protocol": "r4-own-buffer" if args.own_buffer else "r4-rotating-input",  # r4-rotating-input: a fresh device batch per step, one D2D copy inside the timed region (BENCH_r01-r03: own-buffer)
+        "pre_warmup_device_passes": 13 if rank == 0 else 0,  # per-launch HIP-event timing passes (roofline leg) that run before the W warm-up steps
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
@@ -540,6 +547,18 @@ def main():
         cost = model.cost()
         dom = max(fam.items(), key=lambda kv: kv[1]["us"])
         dname, d = dom
+        # the same launches by the kernel FUNCTION that runs them (the symbols rocprofv3 lists): `roofline.kernel` is the symbol with the
+        # most device time inside the dominant family, `roofline.family` the family label the PMC summaries are keyed by
+        symbol_of = [(gk_ if gk_ else ("mbmap_kernel" if k == "MBCONV" and " map=cfg" in line else fam_name[k])) for gk_, k, line in zip(gemm_kernel_of, kind_of, plan_lines)]
+        sym = {}
+        for (name, us, macs, byts), sn, k, line in zip(rows, symbol_of, kind_of, plan_lines):
+            fname = "mbmap_kernel" if k == "MBCONV" and " map=cfg" in line else fam_name[k]
+            e_ = sym.setdefault(sn, {"us": 0.0, "macs": 0.0, "bytes": 0.0, "launches": 0, "family": fname})
+            e_["us"] += us
+            e_["macs"] += macs
+            e_["bytes"] += byts
+            e_["launches"] += 1
+        dom_sym = max(((k_, v_) for k_, v_ in sym.items() if v_["family"] == dname), key=lambda kv: kv[1]["us"])
         tf = 2.0 * d["macs"] / (d["us"] * 1e-6) / 1e12
         gbs = d["bytes"] / (d["us"] * 1e-6) / 1e9
         frac_mfma, frac_hbm = tf / MFMA_F32_PEAK_TF, gbs / HBM_PEAK_GBS
@@ -587,7 +606,12 @@ def main():
         if stale:
             roof["pmc_refused"] = stale
         roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
-                     "kernel": dname, "launches_per_step": d["launches"],
+                     "kernel": dom_sym[0], "family": dname,
+                     "kernel_alone": {"launches_per_step": dom_sym[1]["launches"], "us_per_step": round(dom_sym[1]["us"], 1), "avg_launch_us": round(dom_sym[1]["us"] / dom_sym[1]["launches"], 2),
+                                      "TFLOPs": round(2.0 * dom_sym[1]["macs"] / (dom_sym[1]["us"] * 1e-6) / 1e12, 2),
+                                      "frac_mfma_f32": round(2.0 * dom_sym[1]["macs"] / (dom_sym[1]["us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4)},
+                     "family_members": {k_: v_["launches"] for k_, v_ in sym.items() if v_["family"] == dname},
+                     "launches_per_step": d["launches"],
                      "avg_launch_us": round(d["us"] / d["launches"], 2), "share_of_step": round(d["us"] / total_us, 3),
                      "alt_frac": {"hbm": round(frac_hbm, 4), "mfma_f32": round(frac_mfma, 4)},
                      "flops_performed_per_segment": round(2.0 * (cost.macs_mfma + cost.macs_valu)),
@@ -640,8 +664,13 @@ def main():
         tops = []
         for (name, us, macs, byts), k in sorted(zip(rows, kind_of), key=lambda t: -t[0][1])[:3]:
             tfl, gb = 2.0 * macs / (us * 1e-6) / 1e12, byts / (us * 1e-6) / 1e9
+            # the launch against ITS OWN bound: max(bytes / HBM peak, flops / f32-MFMA peak) -- the N = 16 / 24 / 40 project convs move
+            # 8-20 flop per byte of activation and are not MFMA-bound at all
+            t_hbm_us, t_mfma_us = byts / (HBM_PEAK_GBS * 1e9) * 1e6, 2.0 * macs / (MFMA_F32_PEAK_TF * 1e12) * 1e6
             tops.append({"launch": name, "kind": k, "us": round(us, 1), "TFLOPs": round(tfl, 1), "GBs": round(gb, 1),
-                         "frac_mfma_f32": round(tfl / MFMA_F32_PEAK_TF, 3), "frac_hbm": round(gb / HBM_PEAK_GBS, 3)})
+                         "frac_mfma_f32": round(tfl / MFMA_F32_PEAK_TF, 3), "frac_hbm": round(gb / HBM_PEAK_GBS, 3),
+                         "own_bound": "hbm" if t_hbm_us >= t_mfma_us else "mfma", "own_bound_us": round(max(t_hbm_us, t_mfma_us), 2),
+                         "frac_of_own_bound": round(max(t_hbm_us, t_mfma_us) / us, 3)})
         out["roofline_top_launches"] = tops
         # the GEMM family by the kernel function that runs each launch (the names rocprofv3 reports)
         gk = {}
@@ -657,7 +686,22 @@ def main():
         out["kernel_families"] = {k: {"us_per_step": round(v["us"], 1), "launches": v["launches"],
                                       "TFLOPs": round(2 * v["macs"] / (v["us"] * 1e-6) / 1e12, 2),
                                       "GBs": round(v["bytes"] / (v["us"] * 1e-6) / 1e9, 1)} for k, v in fam.items()}
+        out["kernel_symbols"] = {k: {"us_per_step": round(v["us"], 1), "launches": v["launches"], "family": v["family"],
+                                     "TFLOPs": round(2 * v["macs"] / (v["us"] * 1e-6) / 1e12, 2)} for k, v in sym.items()}
+        # every multiply-add of the plan belongs to exactly one launch (bn_ctx_time_kernels reports op.macs + the fused launches' expand
+        # convs + squeeze-excite prologues since round 5): the families' flops per segment sum to flops_performed_per_segment
+        out["kernel_families_flops_per_segment"] = round(2.0 * sum(v["macs"] for v in fam.values()) / B)
         out["device_us_per_step_sum_of_launches"] = round(total_us, 1)
+        # HBM bytes of one whole step from the committed PMC passes (every launch of the plan, by family) against the step time
+        try:
+            tj = json.load(open(os.path.join(prof_dir, f"pmc_traffic{psuf}.json")))
+            if tag_key(tj.get("tag")) >= newest and tj.get("batch") == B:
+                steps_prof = float(tj.get("steps_profiled", 3))
+                step_bytes = sum(v_["launches_profiled"] / steps_prof * v_["hbm_bytes_per_launch"] for v_ in tj["families"].values())
+                out["hbm_bytes_per_step_pmc"] = round(step_bytes)
+                out["hbm_frac_step"] = round(step_bytes / (dt / args.steps) / (HBM_PEAK_GBS * 1e9), 4)
+        except (OSError, ValueError, KeyError):
+            pass
         if args.kernel_table:
             for (name, us, macs, byts), k in sorted(zip(rows, kind_of), key=lambda t: -t[0][1])[:40]:
                 print(f"{us:9.1f} us  {k:7s} {name:42s} {2 * macs / us / 1e6:8.2f} TF/s {byts / us / 1e3:8.1f} GB/s", file=sys.stderr)

@@ -214,3 +214,136 @@ impl Drop for BatchInferenceContext {
         unsafe { bn_ctx_destroy(self.ctx) } // the model is reference-counted on the native side: order does not matter
     }
 }
+
+// ---- rows f3 / f4 / a10 of SURVEY.md section 8 from Rust (round 5) ------------------------------------------------------
+
+impl crate::Classifier {
+    /// The native context with every graph output kept (`BN_CTX_ALL_OUTPUTS`): Perch v2's spectrogram `[500, 128]` and spatial
+    /// embedding `[16, 4, 1536]` (detection.rs:58-71 names them outputs 2 and 1) stay readable after a run.
+    pub fn create_native_batch_context_all_outputs(&self, max_batch_size: usize) -> Result<BatchInferenceContext> {
+        let mut ctx: *mut bn_ctx = std::ptr::null_mut();
+        match unsafe { bn_ctx_create(self.inner.model, max_batch_size, BN_CTX_ALL_OUTPUTS, &mut ctx) } {
+            BN_OK => Ok(BatchInferenceContext::from_native(ctx, max_batch_size, self.inner.config.sample_count)),
+            _ => Err(Error::Inference(last_error())),
+        }
+    }
+
+    /// What `session.inputs()` / `session.outputs()` report (classifier.rs:387-420): input shape and every output's shape, a
+    /// dynamic dimension as -1 -- the facts `detect_model_type` (detection.rs:15-145) decides on.
+    pub fn io_info(&self) -> Result<(Vec<i64>, Vec<Vec<i64>>)> {
+        let mut info = bn_io_info::default();
+        if unsafe { bn_model_io_info(self.inner.model, &mut info) } != BN_OK {
+            return Err(Error::Inference(last_error()));
+        }
+        let input = info.input_shape[..info.input_rank as usize].to_vec();
+        let outputs = (0..info.n_outputs as usize).map(|o| info.output_shape[o][..info.output_rank[o] as usize].to_vec()).collect();
+        Ok((input, outputs))
+    }
+}
+
+impl BatchInferenceContext {
+    /// Graph output `index` of the last run, `[batch, row]` row-major (the native counterpart of
+    /// `extract_tensor_data`, classifier.rs:1062-1077, for outputs the reference discards).
+    pub fn read_output(&mut self, index: i32, batch: usize) -> Result<Vec<f32>> {
+        let (mut d, mut row) = (std::ptr::null::<f32>(), 0usize);
+        if unsafe { bn_ctx_output_device(self.ctx, index, &mut d, &mut row) } != BN_OK {
+            return Err(Error::Inference(last_error()));
+        }
+        let mut host = vec![0f32; batch * row];
+        match unsafe { bn_ctx_read_output(self.ctx, index, batch, host.as_mut_ptr()) } {
+            BN_OK => Ok(host),
+            _ => Err(Error::Inference(last_error())),
+        }
+    }
+
+    /// Graph captures / replays / fallbacks of this context (`capture_fallbacks` must stay 0).
+    pub fn stats(&self) -> bn_ctx_stats {
+        let mut st = bn_ctx_stats::default();
+        unsafe { bn_ctx_get_stats(self.ctx, &mut st, std::mem::size_of::<bn_ctx_stats>()) };
+        st
+    }
+}
+
+/// A recording resident on the device in its storage format (int16 or f32), cut into windows by `chunk_audio`'s rules
+/// (birdnet-analyze.rs:707-743) inside the first kernel.  `new_resampled` converts a recording of another rate to the
+/// model's rate on the device -- the reference's CLI rejects such files (birdnet-analyze.rs:447-455).
+pub struct Recording {
+    pub(crate) rec: *mut bn_recording,
+}
+
+impl Recording {
+    pub fn from_i16(device: i32, pcm: &[i16]) -> Result<Self> {
+        let mut rec: *mut bn_recording = std::ptr::null_mut();
+        match unsafe { bn_recording_create(device, pcm.as_ptr() as *const _, pcm.len(), BN_PCM_I16, &mut rec) } {
+            BN_OK => Ok(Self { rec }),
+            _ => Err(Error::Inference(last_error())),
+        }
+    }
+
+    pub fn new_resampled(device: i32, pcm: &[f32], src_rate: u32, dst_rate: u32) -> Result<Self> {
+        let mut rec: *mut bn_recording = std::ptr::null_mut();
+        match unsafe { bn_recording_create_resampled(device, pcm.as_ptr() as *const _, pcm.len(), BN_PCM_F32, src_rate, dst_rate, 0, &mut rec) } {
+            BN_OK => Ok(Self { rec }),
+            _ => Err(Error::Inference(last_error())),
+        }
+    }
+
+    /// Blocks until an asynchronous upload has landed (a no-op for the synchronous constructors).
+    pub fn wait(&self) -> Result<()> {
+        match unsafe { bn_recording_wait(self.rec) } {
+            BN_OK => Ok(()),
+            _ => Err(Error::Inference(last_error())),
+        }
+    }
+
+    pub fn samples(&self) -> usize {
+        unsafe { bn_recording_samples(self.rec) }
+    }
+
+    /// Windows `chunk_audio` would cut at this step (`step = sample_count - overlap * sample_rate`).
+    pub fn n_windows(&self, step_samples: usize) -> usize {
+        unsafe { bn_chunk_count(self.samples(), step_samples) }
+    }
+}
+
+impl Drop for Recording {
+    fn drop(&mut self) {
+        unsafe { bn_recording_free(self.rec) }
+    }
+}
+
+/// One node, several GPUs (BASELINE configs[4]): windows sharded by contiguous range, logits gathered over RCCL.
+pub struct Group {
+    pub(crate) g: *mut bn_group,
+}
+
+impl Group {
+    pub fn size(&self) -> i32 {
+        unsafe { bn_group_size(self.g) }
+    }
+
+    pub fn uses_rccl(&self) -> bool {
+        unsafe { bn_group_uses_rccl(self.g) != 0 }
+    }
+
+    /// Counters of every context of every rank, summed.
+    pub fn stats(&self) -> Result<bn_ctx_stats> {
+        let mut st = bn_ctx_stats::default();
+        match unsafe { bn_group_get_stats(self.g, &mut st, std::mem::size_of::<bn_ctx_stats>()) } {
+            BN_OK => Ok(st),
+            _ => Err(Error::Inference(group_last_error())),
+        }
+    }
+}
+
+impl Drop for Group {
+    fn drop(&mut self) {
+        unsafe { bn_group_destroy(self.g) }
+    }
+}
+
+fn group_last_error() -> String {
+    let mut buf = vec![0u8; 1024];
+    unsafe { bn_group_last_error(buf.as_mut_ptr() as *mut _, buf.len()) };
+    String::from_utf8_lossy(&buf).trim_end_matches('\0').to_string()
+}

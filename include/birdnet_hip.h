@@ -248,6 +248,15 @@ void *bn_ctx_stream(const bn_ctx *c);
  * cap (name, microseconds) pairs.  Returns the number of launches. */
 size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch_size, char (*names)[BN_NAME_LEN], float *usec,
                            double *macs, double *bytes, size_t cap);
+/* The planner's cost figures per launch for batch_size (no device work): multiply-adds on the
+ * matrix cores (a fused MBConv launch's expand conv included, with its halo / band recompute),
+ * on the vector ALU, the recompute share of the first, and algorithmic bytes (activations in +
+ * out + weights).  macs_mfma[k] + macs_valu[k] is what bn_ctx_time_kernels reports as macs[k];
+ * summed over the launches they equal bn_model_get_cost's macs_mfma / macs_valu x batch_size.
+ * Measurement only; the reference has no counterpart.  Returns the number of
+ * launches; arrays may be NULL. */
+size_t bn_ctx_launch_costs(const bn_ctx *c, size_t batch_size, double *macs_mfma, double *macs_valu,
+                           double *macs_recompute, double *bytes, size_t cap);
 
 /*
  * top_k_predictions (postprocess.rs:40-87) on the device-resident logits of

@@ -43,7 +43,7 @@ ENGINE_SYMBOLS = [
     "bn_abi_version", "bn_device_count", "bn_model_load", "bn_model_load_buffer", "bn_model_free",
     "bn_model_device", "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create", "bn_ctx_get_stats", "bn_ctx_input_device",
     "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_submit", "bn_infer_collect", "bn_infer_device",
-    "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels",
+    "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels", "bn_ctx_launch_costs",
     "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
     "bn_recording_create", "bn_recording_create_async", "bn_recording_wait", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
     "bn_infer_windows", "bn_step_windows", "bn_ctx_step_device_rows", "bn_group_create", "bn_group_destroy", "bn_group_size",
@@ -132,6 +132,7 @@ def _load() -> C.CDLL:
         "bn_ctx_synchronize": (i32, [vp]),
         "bn_ctx_stream": (vp, [vp]),
         "bn_ctx_time_kernels": (sz, [vp, sz, vp, f32p, C.POINTER(C.c_double), C.POINTER(C.c_double), sz]),
+        "bn_ctx_launch_costs": (sz, [vp, sz, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), sz]),
         "bn_topk": (i32, [vp, sz, sz, i32, C.c_float, sz, u32p, f32p, u32p]),
         "bn_topk_device": (i32, [i32, vp, sz, sz, sz, i32, C.c_float, sz, u32p, f32p, u32p]),
         "bn_topk_host": (i32, [i32, f32p, sz, sz, sz, i32, C.c_float, sz, u32p, f32p, u32p]),
@@ -780,6 +781,13 @@ class Context:
             nm = names.raw[i * BN_NAME_LEN:(i + 1) * BN_NAME_LEN].split(b"\0", 1)[0].decode()
             out.append((nm, float(usec[i]), float(macs[i]), float(byts[i])))
         return out
+
+    def launch_costs(self, batch: int):
+        """Per launch: (macs on the matrix cores, macs on the vector ALU, recompute share of the first, algorithmic bytes)."""
+        cap = 1024
+        a, b, r, by = ((C.c_double * cap)() for _ in range(4))
+        n = lib.bn_ctx_launch_costs(self._h, batch, a, b, r, by, cap)
+        return [(float(a[i]), float(b[i]), float(r[i]), float(by[i])) for i in range(min(n, cap))]
 
     def stream(self) -> int:
         return lib.bn_ctx_stream(self._h) or 0

@@ -1151,10 +1151,26 @@ size_t bn_ctx_time_kernels(bn_ctx *c, size_t batch, char (*names)[BN_NAME_LEN], 
         (void)hipEventElapsedTime(&ms, ev[k], ev[k + 1]);
         if (usec) usec[k] = std::max(0.5f, ms * 1000.0f - overhead_us);
         if (names) snprintf(names[k], BN_NAME_LEN, "%s", p.ops[k].name.c_str());
-        if (macs) macs[k] = p.ops[k].macs * (double)batch;
+        // every multiply-add the launch PERFORMS: a fused MBConv launch carries its expand conv on the matrix cores beside the
+        // depthwise taps (macs_mfma_extra, halo / band recompute included), a GEMM with the squeeze-excite products in its
+        // prologue carries those on the vector ALU -- so that the launches sum to the plan's macs_mfma + macs_valu
+        if (macs) macs[k] = (p.ops[k].macs + p.ops[k].macs_mfma_extra + p.ops[k].macs_valu_extra) * (double)batch;
         if (bytes) bytes[k] = p.ops[k].bytes * (double)batch + p.ops[k].weight_bytes;
     }
     for (auto &e : ev) (void)gated::EventDestroy(e);
+    return p.ops.size();
+}
+
+size_t bn_ctx_launch_costs(const bn_ctx *c, size_t batch, double *macs_mfma, double *macs_valu, double *macs_recompute, double *bytes, size_t cap) {
+    if (!c || batch == 0 || batch > c->max_batch) return 0;
+    const Plan &p = *c->pd->plan;
+    for (size_t k = 0; k < p.ops.size() && k < cap; k++) {
+        const auto &op = p.ops[k];
+        if (macs_mfma) macs_mfma[k] = ((op.mfma ? op.macs : 0.0) + op.macs_mfma_extra) * (double)batch;
+        if (macs_valu) macs_valu[k] = ((op.mfma ? 0.0 : op.macs) + op.macs_valu_extra) * (double)batch;
+        if (macs_recompute) macs_recompute[k] = op.macs_recompute * (double)batch;
+        if (bytes) bytes[k] = op.bytes * (double)batch + op.weight_bytes;
+    }
     return p.ops.size();
 }
 

@@ -99,6 +99,18 @@ def test_per_kernel_timing_report(bn, small):
     rows = ctx.time_kernels(4)
     assert len(rows) > 10 and all(us > 0 for _, us, _, _ in rows)
     assert sum(m for _, _, m, _ in rows) > 1e7
+    #  every multiply-add of the plan belongs to exactly one launch: the fused MBConv launches carry their expand
+    # convs, so the launches sum to the plan's macs_mfma + macs_valu, and bn_ctx_launch_costs splits the same figures by ALU
+    cost = bn.Model(path).cost()
+    costs = ctx.launch_costs(4)
+    assert len(costs) == len(rows)
+    assert sum(m for _, _, m, _ in rows) == pytest.approx(4 * (cost.macs_mfma + cost.macs_valu), rel=1e-9)
+    assert sum(c[0] for c in costs) == pytest.approx(4 * cost.macs_mfma, rel=1e-9)
+    assert sum(c[1] for c in costs) == pytest.approx(4 * cost.macs_valu, rel=1e-9)
+    assert sum(c[2] for c in costs) == pytest.approx(4 * cost.recompute_macs, rel=1e-9)
+    assert all(r[2] == pytest.approx(c[0] + c[1], rel=1e-12) and r[3] == c[3] for r, c in zip(rows, costs))
+    fused = [c for c, l in zip(costs, [l for l in bn.plan_describe(path).splitlines() if l[:3].strip().isdigit()]) if l.split()[1] == "MBCONV"]
+    assert fused and all(c[0] > 0 and c[1] > 0 for c in fused)  # expand conv on the matrix cores + depthwise taps on the vector ALU
 
 
 def test_submit_collect_matches_the_synchronous_call_bit_for_bit(bn, small):

@@ -141,7 +141,7 @@ def main():
                         "hbm_bytes_per_launch": round((2.0 * fk + wk) * 1024.0 / n)}
     doc = {"tag": tag, "model": MODEL, "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 tools/pmc_run.py {BATCH} 3 {MODEL}",
            "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
-           "batch": BATCH, "families": traffic,
+           "batch": BATCH, "steps_profiled": 3, "families": traffic,
            "kernel_stats_1stream": stats_by_family(os.path.join(src, "trace_1stream")),
            "kernel_stats_default": stats_by_family(os.path.join(src, "trace_default"))}
     json.dump(doc, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
