@@ -116,7 +116,11 @@ int32_t bn_abi_version(void);
 int32_t bn_device_count(void);
 
 /* ---- model load: Session::builder()...commit_from_file(path)  (classifier.rs:340-350) ---- */
-/* model_type_override: -1 for auto-detection, else a bn_model_type (ClassifierBuilder::model_type). */
+/* model_type_override: -1 for auto-detection, else a bn_model_type (ClassifierBuilder::model_type).
+ * The BN_* environment switches (diagnostic A/B knobs) are read when the plan is built AND by the
+ * launchers' shape checks: they must not change between bn_model_load and the last launch of that model's contexts.  The
+ * plan forms of round 4 (quarter fold, folded GEMMs with absorbed chains, pooled epilogue) have no generic fallback kernel,
+ * so a switch flipped in between is a launch error (BN_ERR_BACKEND), never a silently different result. */
 bn_status bn_model_load(const char *onnx_path, int32_t device, int32_t model_type_override,
                         bn_model **out);
 bn_status bn_model_load_buffer(const void *onnx_bytes, size_t len, int32_t device,

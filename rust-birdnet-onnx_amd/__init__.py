@@ -14,7 +14,9 @@ Names mirror the reference (tphakala/rust-birdnet-onnx ``src/lib.rs:93-108``):
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 import enum
 import os
 from dataclasses import dataclass
@@ -793,6 +795,21 @@ class Context:
         return lib.bn_ctx_stream(self._h) or 0
 
 
+_pending_uploads = weakref.WeakSet()
+
+
+def _join_uploads():
+    for r in list(_pending_uploads):
+        try:
+            if getattr(r, "_h", None):
+                lib.bn_recording_wait(r._h)
+        except Exception:  # noqa: BLE001 -- exit path
+            pass
+
+
+atexit.register(_join_uploads)
+
+
 class Recording:
     """bn_recording: a mono recording uploaded once in its storage format (int16 or float32)."""
 
@@ -807,6 +824,8 @@ class Recording:
             raise ValueError("mono int16 or float32 samples expected")
         h = C.c_void_p()
         fmt = 0 if a.dtype == np.int16 else 1
+        if async_upload and src_rate and dst_rate:
+            raise ValueError("async_upload cannot be combined with resampling: bn_recording_create_resampled converts during its own (synchronous) upload")
         if src_rate and dst_rate:
             st = lib.bn_recording_create_resampled(device, a.ctypes.data_as(C.c_void_p), a.shape[0], fmt, src_rate, dst_rate, zero_crossings, C.byref(h))
         elif async_upload:
@@ -818,6 +837,8 @@ class Recording:
             raise EngineError(st)
         self._h = h
         self.n_samples = int(lib.bn_recording_samples(h))
+        if async_upload:
+            _pending_uploads.add(self)  # joined at interpreter exit: the uploader thread must not outlive the array it reads
 
     def wait(self):
         """The whole recording is on the device (no-op for a synchronous upload)."""

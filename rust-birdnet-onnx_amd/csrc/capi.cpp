@@ -1432,7 +1432,10 @@ bn_status bn_recording_create_async(int32_t device, const void *pcm, size_t n_sa
     if (bn_device_count() <= 0) return fail(BN_ERR_NO_DEVICE, "no gfx950 device visible");
     HIP_TRY(bn::use_device(device));
     const size_t esz = format == BN_PCM_I16 ? sizeof(int16_t) : sizeof(float);
-    const size_t chunk_mb = getenv("BN_UPLOAD_CHUNK_MB") ? (size_t)std::max(1, atoi(getenv("BN_UPLOAD_CHUNK_MB"))) : 32;
+    // the uploader holds the capture gate (shared) for one chunk's synchronous copy and a context's first-time graph capture takes it
+    // exclusively: 4 MiB keeps a capture's wait behind a chunk well under a millisecond (32 MiB chunks stalled exactly the first
+    // windows' captures the overlap was meant to help)
+    const size_t chunk_mb = getenv("BN_UPLOAD_CHUNK_MB") ? (size_t)std::max(1, atoi(getenv("BN_UPLOAD_CHUNK_MB"))) : 4;
     auto r = std::make_unique<bn_recording>();
     r->device = device;
     r->format = format;
@@ -1441,7 +1444,7 @@ bn_status bn_recording_create_async(int32_t device, const void *pcm, size_t n_sa
     r->chunk_samples = std::max<size_t>(1, (chunk_mb << 20) / esz);
     r->n_chunks = (n_samples + r->chunk_samples - 1) / r->chunk_samples;
     bn_recording *raw = r.get();
-    if (r->n_chunks)
+    if (r->n_chunks) try {
         r->uploader = std::thread([raw, pcm, esz]() {
             if (bn::use_device(raw->device) != hipSuccess) raw->upload_error.store(1);
             for (size_t k = 0; k < raw->n_chunks && raw->upload_error.load() == 0; k++) {
@@ -1463,6 +1466,11 @@ bn_status bn_recording_create_async(int32_t device, const void *pcm, size_t n_sa
                 raw->cv.notify_all();
             }
         });
+    } catch (const std::exception &e) {  // std::system_error from the thread constructor must not cross the C boundary
+        (void)gated::Free(r->d_pcm);
+        r->d_pcm = nullptr;
+        return fail(BN_ERR_BACKEND, std::string("could not start the upload thread: ") + e.what());
+    }
     *out = r.release();
     return BN_OK;
 }

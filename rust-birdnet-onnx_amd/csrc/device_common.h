@@ -67,6 +67,13 @@ __device__ __forceinline__ float act_apply(int act, float x, float p0, float p1)
         case ACT_CEIL: return ceilf(x);
         case ACT_ERF: return erff(x);
         case ACT_SOFTPLUS: return log1pf(expf(x));
+        case ACT_GTC: return x > p0 ? 1.0f : 0.0f;
+        case ACT_LTC: return x < p0 ? 1.0f : 0.0f;
+        case ACT_GEC: return x >= p0 ? 1.0f : 0.0f;
+        case ACT_LEC: return x <= p0 ? 1.0f : 0.0f;
+        case ACT_EQC: return x == p0 ? 1.0f : 0.0f;
+        case ACT_NEZ: return x != 0.0f ? 1.0f : 0.0f;
+        case ACT_TRUNC: return truncf(x);
         default: return x;
     }
 }
@@ -102,6 +109,13 @@ __device__ __forceinline__ void act_array_all(int act, float p0, float p1, float
         case ACT_CEIL: map_array<N>(v, [](float x) { return ceilf(x); }); return;
         case ACT_ERF: map_array<N>(v, [](float x) { return erff(x); }); return;
         case ACT_SOFTPLUS: map_array<N>(v, [](float x) { return log1pf(expf(x)); }); return;
+        case ACT_GTC: map_array<N>(v, [=](float x) { return x > p0 ? 1.0f : 0.0f; }); return;
+        case ACT_LTC: map_array<N>(v, [=](float x) { return x < p0 ? 1.0f : 0.0f; }); return;
+        case ACT_GEC: map_array<N>(v, [=](float x) { return x >= p0 ? 1.0f : 0.0f; }); return;
+        case ACT_LEC: map_array<N>(v, [=](float x) { return x <= p0 ? 1.0f : 0.0f; }); return;
+        case ACT_EQC: map_array<N>(v, [=](float x) { return x == p0 ? 1.0f : 0.0f; }); return;
+        case ACT_NEZ: map_array<N>(v, [](float x) { return x != 0.0f ? 1.0f : 0.0f; }); return;
+        case ACT_TRUNC: map_array<N>(v, [](float x) { return truncf(x); }); return;
         default: return;
     }
 }
@@ -121,6 +135,14 @@ __device__ __forceinline__ void bin_array(int bin, int bsq, float (&v)[N], float
         case BIN_POW: zip_array<N>(v, w, [](float a, float b) { return net_pow(a, b); }); return;
         case BIN_MAX: zip_array<N>(v, w, [](float a, float b) { return fmaxf(a, b); }); return;
         case BIN_MIN: zip_array<N>(v, w, [](float a, float b) { return fminf(a, b); }); return;
+        case BIN_GT: zip_array<N>(v, w, [](float a, float b) { return a > b ? 1.0f : 0.0f; }); return;
+        case BIN_LT: zip_array<N>(v, w, [](float a, float b) { return a < b ? 1.0f : 0.0f; }); return;
+        case BIN_GE: zip_array<N>(v, w, [](float a, float b) { return a >= b ? 1.0f : 0.0f; }); return;
+        case BIN_LE: zip_array<N>(v, w, [](float a, float b) { return a <= b ? 1.0f : 0.0f; }); return;
+        case BIN_EQ: zip_array<N>(v, w, [](float a, float b) { return a == b ? 1.0f : 0.0f; }); return;
+        case BIN_NE: zip_array<N>(v, w, [](float a, float b) { return a != b ? 1.0f : 0.0f; }); return;
+        case BIN_SELA: zip_array<N>(v, w, [](float a, float b) { return b != 0.0f ? a : 0.0f; }); return;
+        case BIN_SELB: zip_array<N>(v, w, [](float a, float b) { return b != 0.0f ? 0.0f : a; }); return;
         default: return;
     }
 }

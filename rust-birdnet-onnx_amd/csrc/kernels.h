@@ -37,9 +37,21 @@ enum Act : int32_t {
     ACT_CEIL,
     ACT_ERF,
     ACT_SOFTPLUS,
+    // (round 5) comparison results are f32 0.0 / 1.0 ("bool" tensors of the ONNX graph); NaN compares false like IEEE / ORT
+    ACT_GTC,       // x > p0 ? 1 : 0
+    ACT_LTC,       // x < p0 ? 1 : 0
+    ACT_GEC,       // x >= p0 ? 1 : 0
+    ACT_LEC,       // x <= p0 ? 1 : 0
+    ACT_EQC,       // x == p0 ? 1 : 0
+    ACT_NEZ,       // x != 0 ? 1 : 0   (Cast to bool)
+    ACT_TRUNC,     // toward zero       (Cast to an integer type; values stay f32)
 };
 
-enum BinOp : int32_t { BIN_NONE = 0, BIN_ADD, BIN_SUB, BIN_MUL, BIN_DIV, BIN_POW, BIN_MAX, BIN_MIN };
+enum BinOp : int32_t { BIN_NONE = 0, BIN_ADD, BIN_SUB, BIN_MUL, BIN_DIV, BIN_POW, BIN_MAX, BIN_MIN,
+                       // (round 5) comparisons -> 0.0 / 1.0; the two halves of Where(cond, a, b) = SELA(a, cond) + SELB(b, cond)
+                       BIN_GT, BIN_LT, BIN_GE, BIN_LE, BIN_EQ, BIN_NE,
+                       BIN_SELA,   // b != 0 ? a : +0
+                       BIN_SELB }; // b != 0 ? +0 : a
 enum RedOp : int32_t { RED_SUM = 0, RED_MEAN, RED_MAX, RED_MIN, RED_PROD, RED_L2, RED_SUMSQ };
 
 constexpr int ELT_MAX_DIMS = 5;  // per-sample loop dims (batch is separate)
@@ -369,8 +381,8 @@ struct StftPtrs {
     const float *mstart, *mcol, *mval, *mel_bias;  // CSR of the mel filter bank: row starts, (column, value) pairs in mcol (indices stored as floats); mval unused
 };
 // stage codes stft_kernel implements (a compact subset: no libm bodies); the planner absorbs only chains made of these
-inline bool stft_act_supported(int act) { return act != ACT_TANH && act != ACT_ERF && act != ACT_SOFTPLUS && act != ACT_HSIGMOID && act != ACT_HSWISH; }
-inline bool stft_bin_supported(int bin) { return bin != BIN_POW; }
+inline bool stft_act_supported(int act) { return act != ACT_TANH && act != ACT_ERF && act != ACT_SOFTPLUS && act != ACT_HSIGMOID && act != ACT_HSWISH && act < ACT_GTC; }
+inline bool stft_bin_supported(int bin) { return bin != BIN_POW && bin < BIN_GT; }
 void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t batch);
 
 void launch_null(hipStream_t s);  // empty kernel (timing calibration)

@@ -105,13 +105,16 @@ bool prepare_device(int dev) {
     g_cu_count[dev].store(v, std::memory_order_relaxed);
     {  // a page of zeros: the source of LDS-DMA lanes whose chunk lies in a row's padding (mbmap.hip)
         float *z = nullptr;
+        // only the opt-in padded-k small-map kernels read it (launch_mbmap refuses them on a null page): a failure here must not
+        // take the device away from every other plan
         if (gated::Malloc(&z, 4096) != hipSuccess || gated::Memset(z, 0, 4096) != hipSuccess || gated::DeviceSynchronize() != hipSuccess) {
             (void)hipGetLastError();
-            ok = false;
+            if (z) (void)gated::Free(z);
+            z = nullptr;
         }
         g_zero_page[dev].store(z, std::memory_order_relaxed);
     }
-    if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
+    if (cur != dev && cur >= 0) (void)bn::use_device(cur);  // (restores the thread's launch-device note with it)
     if (ok) g_prepared_mask.fetch_or(1ull << dev, std::memory_order_release);
     return ok;
 }
@@ -3184,7 +3187,7 @@ static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const 
     if (!frame_fold_shape_ok(d, W)) return false;
     FramePre pre_v{};
     if (pre) pre_v = *pre;
-    if (pre_v.n > 0 && (pair || env_int("BN_FRAMEH", 1) == 0)) return false;  // (only the round-4 kernels carry the chain)
+    if (pre_v.n > 0 && pair) return false;  // (only the round-4 kernels carry the chain; BN_FRAMEH=0 leaves launches WITH a chain on them)
     FrameDesc f{};
     f.rows = (int32_t)d.rows; f.N = d.N; f.K = d.K; f.L = d.fold_n; f.hop = (int32_t)d.lda;
     f.tiles = (int32_t)((d.rows + FRAME_BM - 1) / FRAME_BM);
@@ -3225,7 +3228,7 @@ static bool launch_frame_fold(hipStream_t s, const GemmDesc &d, float *C, const 
     dim3 grid((unsigned)row_blocks, (walk || pair) ? 1u : (unsigned)((d.N + bn - 1) / bn));
     GemmDesc none{};
     if (pair) hipLaunchKernelGGL(frame_fold_kernel<true>, grid, dim3(128 * wn), lds, s, f, C, A, W, bias, *pair, C2, W2, bias2);
-    else if (env_int("BN_FRAMEH", 1) == 0 && ks == 1)  // the round-3 form of the same launch (A/B; bit-identical)
+    else if (env_int("BN_FRAMEH", 1) == 0 && ks == 1 && pre_v.n == 0)  // the round-3 form of the same launch (A/B; bit-identical)
         hipLaunchKernelGGL(frame_fold_kernel<false>, grid, dim3(128 * wn), lds, s, f, C, A, W, bias, none, nullptr, nullptr, nullptr);
     else if (ks == 2 && wn == 2) hipLaunchKernelGGL((frame_foldh_kernel<2, 2>), grid, dim3(512), lds, s, f, C, A, W, bias, pre_v);
     else if (ks == 2) hipLaunchKernelGGL((frame_foldh_kernel<3, 2>), grid, dim3(768), lds, s, f, C, A, W, bias, pre_v);

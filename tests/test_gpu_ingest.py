@@ -299,3 +299,5 @@ def test_asynchronous_upload_is_chunked_and_bit_identical(bn, monkeypatch):
         r3 = bn.Recording(pcm, async_upload=True)
         del r3
     assert bn.Recording(np.zeros(0, dtype=np.int16), async_upload=True).n_windows(step) == 0
+    with pytest.raises(ValueError):  #  the combination used to drop async_upload silently
+        bn.Recording(f32, src_rate=44100, dst_rate=48000, async_upload=True)
