@@ -405,6 +405,13 @@ size_t bn_group_last_error(char *buf, size_t cap);
  * text description (one line per launch, then totals) into buf.  Returns the
  * number of bytes the full text needs (excluding the NUL); *status receives the
  * outcome of the parse / detection / planning steps. */
+/* First contact with a model file, needs no device: opset, graph input / outputs, what detect_model_type decides (detection.rs:15-145),
+ * every operator type with its node count and whether the lowering has a rule for it ("NOT MAPPED" + the first such node), and the
+ * outcome of planning -- for every graph output and for the audio path (logits + embeddings) -- with the refusal's node and reason.
+ * The reference loads whatever ONNX Runtime loads (classifier.rs:340-350); this says in one call what stands between a real export
+ * and the native path.  *status: BN_OK, BN_ERR_UNSUPPORTED_MODEL (a plan was refused) or BN_ERR_MODEL_LOAD (unreadable file).
+ * Returns the number of bytes the full text needs (excluding the NUL). */
+size_t bn_model_survey(const char *onnx_path, char *buf, size_t cap, bn_status *status);
 size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int32_t all_outputs,
                         char *buf, size_t cap, bn_status *status);
 

@@ -184,14 +184,25 @@ class Graph:
     inits: dict
     inputs: list
     outputs: list
+    opset: int = 0
 
 
 def load_graph(data: bytes) -> Graph:
     mv = memoryview(data)
     g = None
+    opset = 0
     for f, wt, v in _fields(mv):
         if f == 7:
             g = v
+        elif f == 8:  # opset_import: OperatorSetIdProto {1: domain, 2: version}; the default domain's version
+            dom, ver = "", 0
+            for f2, _, v2 in _fields(v):
+                if f2 == 1:
+                    dom = bytes(v2).decode()
+                elif f2 == 2:
+                    ver = int(v2)
+            if dom in ("", "ai.onnx"):
+                opset = ver
     if g is None:
         raise ValueError("no graph in model")
     nodes, inits, inputs, outputs = [], {}, [], []
@@ -206,12 +217,12 @@ def load_graph(data: bytes) -> Graph:
         elif f == 12:
             outputs.append(_value_info_name(v))
     inputs = [i for i in inputs if i not in inits]
-    return Graph(nodes, inits, inputs, outputs)
+    return Graph(nodes, inits, inputs, outputs, opset)
 
 
 # ------------------------------------------------------------------ operator semantics (ONNX spec)
 def _t(a, dtype):
-    t = torch.from_numpy(np.ascontiguousarray(a))
+    t = torch.from_numpy(np.ascontiguousarray(a)).reshape(np.shape(a))  # (ascontiguousarray promotes a 0-d array to [1]: a scalar Gather index must stay 0-d)
     return t.to(dtype) if t.is_floating_point() else t
 
 
@@ -314,7 +325,18 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
                 r = i[0]
             elif op == "Cast":
                 to = int(a["to"])
-                r = i[0].to(dtype) if to in (1, 10, 11) else i[0].to(torch.int64)
+                r = i[0].to(dtype) if to in (1, 10, 11, 16) else i[0].to(torch.bool) if to == 9 else i[0].to(torch.int64)
+            elif op in ("Greater", "Less", "GreaterOrEqual", "LessOrEqual", "Equal"):
+                r = {"Greater": torch.gt, "Less": torch.lt, "GreaterOrEqual": torch.ge, "LessOrEqual": torch.le, "Equal": torch.eq}[op](i[0], i[1])
+            elif op in ("And", "Or", "Xor"):
+                r = {"And": torch.logical_and, "Or": torch.logical_or, "Xor": torch.logical_xor}[op](i[0], i[1])
+            elif op == "Not":
+                r = torch.logical_not(i[0])
+            elif op == "Where":
+                x_, y_ = i[1], i[2]
+                if x_.dtype != y_.dtype:  # (an integer constant against a float tensor: the graph's declared type is the float one)
+                    x_, y_ = x_.to(dtype), y_.to(dtype)
+                r = torch.where(i[0].to(torch.bool), x_, y_)
             elif op == "Transpose":
                 perm = a.get("perm") or list(reversed(range(i[0].dim())))
                 r = i[0].permute(*[int(p) for p in perm])
@@ -465,9 +487,25 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
             elif op == "Shape":
                 r = torch.tensor(list(i[0].shape), dtype=torch.int64)
             elif op == "Gather":
-                r = torch.index_select(i[0], int(a.get("axis", 0)), i[1].reshape(-1).to(torch.int64))
-                if i[1].dim() == 0:
-                    r = r.squeeze(int(a.get("axis", 0)))
+                ax = int(a.get("axis", 0)) % i[0].dim()
+                idx = i[1].to(torch.int64)
+                idx = torch.where(idx < 0, idx + i[0].shape[ax], idx)
+                r = torch.index_select(i[0], ax, idx.reshape(-1))
+                r = r.reshape(list(i[0].shape[:ax]) + list(idx.shape) + list(i[0].shape[ax + 1:]))  # output rank = data rank - 1 + indices rank
+            elif op == "DFT":
+                # ONNX DFT: input [..., signal dims ..., 1 (real) | 2 (complex)]; axis = attribute (opset 17, default 1) or third input
+                # (opset 20, default -2); optional dft_length pads with zeros / truncates; onesided keeps N / 2 + 1 bins; output [..., bins, 2]
+                if int(a.get("inverse", 0)):
+                    raise NotImplementedError("oracle: inverse DFT")
+                ax = int(a["axis"]) if "axis" in a else (int(i[2].reshape(-1)[0]) if len(i) > 2 and i[2] is not None else (-2 if g.opset >= 20 else 1))
+                ax = ax % i[0].dim()
+                z = i[0][..., 0] if i[0].shape[-1] == 1 else torch.view_as_complex(i[0].contiguous())
+                nfft = int(i[1].reshape(-1)[0]) if len(i) > 1 and i[1] is not None else int(z.shape[ax])
+                if int(a.get("onesided", 0)):
+                    spec = torch.fft.rfft(z, n=nfft, dim=ax)
+                else:
+                    spec = torch.fft.fft(z, n=nfft, dim=ax)
+                r = torch.view_as_real(spec).to(i[0].dtype)
             elif op == "PRelu":
                 r = torch.clamp(i[0], min=0) + i[1] * torch.clamp(i[0], max=0)
             elif op == "Tile":
@@ -493,7 +531,7 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
             else:
                 raise NotImplementedError(f"oracle: operator {op}")
             env[n.outputs[0]] = r
-    return {k: env[k].numpy() for k in want}
+    return {k: (env[k].to(dtype) if env[k].dtype == torch.bool else env[k]).numpy() for k in want}  # a bool output as 0.0 / 1.0, like the product path
 
 
 def run_model(onnx_bytes: bytes, x: np.ndarray, dtype=torch.float32, outputs=None) -> dict:
@@ -531,4 +569,4 @@ def prune_dead_filter_rows(g: Graph) -> Graph:
         inits[n.inputs[1]] = np.ascontiguousarray(CW[keep])
         if len(n.inputs) > 2 and n.inputs[2] in inits and len(consumers.get(n.inputs[2], [])) == 1:
             inits[n.inputs[2]] = np.ascontiguousarray(inits[n.inputs[2]][keep])
-    return Graph(g.nodes, inits, g.inputs, g.outputs)
+    return Graph(g.nodes, inits, g.inputs, g.outputs, g.opset)

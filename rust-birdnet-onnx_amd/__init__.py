@@ -39,6 +39,7 @@ LIB_PATH = os.environ.get("BN_LIB") or os.path.join(_HERE, "libbirdnet_hip.so") 
 
 BN_MAX_OUTPUTS, BN_MAX_RANK, BN_NAME_LEN = 8, 6, 64
 BN_CTX_DEFAULT, BN_CTX_ALL_OUTPUTS, BN_CTX_NO_GRAPH = 0, 1, 2
+BN_ERR_MODEL_LOAD, BN_ERR_UNSUPPORTED_MODEL, BN_ERR_MODEL_DETECTION, BN_ERR_NO_DEVICE = 6, 7, 8, 9  # bn_status values the harness names
 
 # every symbol include/birdnet_hip.h and include/birdnet_host.h declare
 ENGINE_SYMBOLS = [
@@ -46,7 +47,7 @@ ENGINE_SYMBOLS = [
     "bn_model_device", "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create", "bn_ctx_get_stats", "bn_ctx_input_device",
     "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_submit", "bn_infer_collect", "bn_infer_device",
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels", "bn_ctx_launch_costs",
-    "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe",
+    "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe", "bn_model_survey",
     "bn_recording_create", "bn_recording_create_async", "bn_recording_wait", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
     "bn_infer_windows", "bn_step_windows", "bn_ctx_step_device_rows", "bn_group_create", "bn_group_destroy", "bn_group_size",
     "bn_group_uses_rccl", "bn_group_get_stats", "bn_shard_range", "bn_group_analyze_recording", "bn_group_last_error", "bn_recording_create_resampled", "bn_resample_table", "bn_recording_read_f32", "bn_last_error",
@@ -141,6 +142,7 @@ def _load() -> C.CDLL:
         "bn_step_device": (i32, [vp, vp, sz, sz, i32, C.c_float, i32]),
         "bn_step_results": (i32, [vp, C.POINTER(f32p), C.POINTER(u32p), C.POINTER(f32p), C.POINTER(u32p), C.POINTER(sz)]),
         "bn_plan_describe": (sz, [C.c_char_p, i32, i32, C.c_char_p, sz, C.POINTER(i32)]),
+        "bn_model_survey": (sz, [C.c_char_p, C.c_char_p, sz, C.POINTER(i32)]),
         "bn_recording_create": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
         "bn_recording_create_async": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
         "bn_recording_wait": (i32, [vp]),
@@ -1090,6 +1092,18 @@ def plan_describe(path: str, model_type: int = -1, all_outputs: bool = False) ->
     buf = C.create_string_buffer(n + 1)
     lib.bn_plan_describe(path.encode(), model_type, 1 if all_outputs else 0, buf, n + 1, C.byref(st))
     return buf.value.decode()
+
+
+def model_survey(path: str):
+    """bn_model_survey: (status, text).  Needs no device.  status 0 = every plan accepted, BN_ERR_UNSUPPORTED_MODEL = a plan refused
+    (the text says which node and why); an unreadable file raises."""
+    st = C.c_int32()
+    n = lib.bn_model_survey(path.encode(), None, 0, C.byref(st))
+    if n == 0 and st.value:
+        raise EngineError(st.value)
+    buf = C.create_string_buffer(n + 1)
+    lib.bn_model_survey(path.encode(), buf, n + 1, C.byref(st))
+    return st.value, buf.value.decode()
 
 
 def parse_labels(content: str, csv: bool) -> list:

@@ -1678,6 +1678,78 @@ bn_status bn_step_windows(bn_ctx *c, const bn_recording *r, size_t step_samples,
     return bn_step_device(c, c->d_input, count, top_k, has_min, min_conf, sync);
 }
 
+size_t bn_model_survey(const char *onnx_path, char *buf, size_t cap, bn_status *status) {
+    bn_status dummy;
+    if (!status) status = &dummy;
+    *status = BN_OK;
+    std::string text;
+    char line[1024];
+    try {
+        if (!onnx_path) throw std::runtime_error("null path");
+        OnnxModel om = parse_onnx_file(onnx_path);
+        IoMeta io = read_io_meta(om);
+        auto shape_str = [](const std::vector<int64_t> &s) {
+            std::string r = "[";
+            for (size_t k = 0; k < s.size(); k++) r += (k ? ", " : "") + (s[k] < 0 ? std::string("?") : std::to_string(s[k]));
+            return r + "]";
+        };
+        snprintf(line, sizeof(line), "opset %lld, %zu nodes, %zu initializers\n", (long long)om.opset, om.nodes.size(), om.initializers.size());
+        text += line;
+        text += "input  " + io.input_name + " " + shape_str(io.input_shape) + "\n";
+        for (size_t k = 0; k < io.output_names.size(); k++) text += "output " + std::to_string(k) + " " + io.output_names[k] + " " + shape_str(io.output_shapes[k]) + "\n";
+        bn_model_config cfg{};
+        std::string reason;
+        const bool detected = detect_model_type(io.input_shape, io.output_shapes, -1, cfg, reason);
+        if (detected) {
+            snprintf(line, sizeof(line), "detected model_type=%d sample_rate=%u sample_count=%llu num_species=%llu embedding_dim=%llu logits_output=%d embedding_output=%d\n",
+                     cfg.model_type, cfg.sample_rate, (unsigned long long)cfg.sample_count, (unsigned long long)cfg.num_species,
+                     (unsigned long long)cfg.embedding_dim, cfg.logits_output, cfg.embedding_output);
+            text += line;
+        } else text += "detection FAILED: " + reason + "\n";
+        // operator types: count, and whether the lowering has a rule for the type at all
+        std::map<std::string, std::pair<int, std::string>> hist;
+        for (const auto &nd : om.nodes) {
+            auto &h = hist[nd.op_type];
+            if (h.first++ == 0) h.second = nd.name.empty() ? (nd.outputs.empty() ? std::string("?") : nd.outputs[0]) : nd.name;
+        }
+        int unmapped_types = 0, unmapped_nodes = 0;
+        for (const auto &kv : hist) {
+            const bool ok = op_type_mapped(kv.first);
+            if (!ok) { unmapped_types++; unmapped_nodes += kv.second.first; }
+            snprintf(line, sizeof(line), "op %-24s x%-5d %s%s\n", kv.first.c_str(), kv.second.first, ok ? "mapped" : "NOT MAPPED   first: ", ok ? "" : kv.second.second.c_str());
+            text += line;
+        }
+        snprintf(line, sizeof(line), "unmapped: %d operator types, %d nodes\n", unmapped_types, unmapped_nodes);
+        text += line;
+        // the plan itself (every graph output, so that no refusal hides in a branch the audio path does not read; then the audio path)
+        for (int all = 1; all >= 0; all--) {
+            std::vector<int> wanted;
+            if (all) for (size_t k = 0; k < om.outputs.size(); k++) wanted.push_back((int)k);
+            else if (detected) { wanted.push_back(cfg.logits_output); if (cfg.embedding_output >= 0) wanted.push_back(cfg.embedding_output); }
+            else continue;
+            try {
+                auto p = build_plan(om, wanted);
+                snprintf(line, sizeof(line), "plan (%s): OK, %zu launches, %.4g MMAC/segment on the matrix cores, %.4g on the vector ALU, arena %.3g MB/segment, weights %.3g MB\n",
+                         all ? "every graph output" : "logits + embeddings", p->ops.size(), p->macs_mfma / 1e6, p->macs_valu / 1e6, p->arena_elems * 4.0 / 1e6, p->weight_bytes / 1e6);
+                text += line;
+            } catch (const std::exception &e) {
+                if (*status == BN_OK || !all) *status = BN_ERR_UNSUPPORTED_MODEL;
+                text += std::string("plan (") + (all ? "every graph output" : "logits + embeddings") + "): REFUSED: " + e.what() + "\n";
+                if (!all) (void)fail(BN_ERR_UNSUPPORTED_MODEL, e.what());
+            }
+        }
+    } catch (const std::exception &e) {
+        *status = fail(BN_ERR_MODEL_LOAD, e.what());
+        return 0;
+    }
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, text.size());
+        memcpy(buf, text.data(), n);
+        buf[n] = 0;
+    }
+    return text.size();
+}
+
 size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int32_t all_outputs, char *buf, size_t cap, bn_status *status) {
     bn_status dummy;
     if (!status) status = &dummy;

@@ -64,6 +64,10 @@ struct Val {
     // `gate_storage >= 0` marks "x * gate" not yet applied (the consuming 1x1 conv applies it on load)
     bool is_gate = false;
     int32_t gate_storage = -1;
+    // (round 5) frames * window not yet applied: the constant `win_name` (vals_ key) multiplies along the `win_nu`-th NON-UNIT
+    // dimension; the DFT node that consumes the value folds it into its basis, any other consumer gets apply_window() in get()
+    std::string win_name;
+    int32_t win_nu = -1;
     int64_t numel() const { return prod(dims); }
     bool contiguous() const { return !is_const && strides_equal(row_major(dims)); }
     bool strides_equal(const Dims &s) const {
@@ -99,6 +103,7 @@ class Builder {
             else { v.is_int = true; v.i = t.i; }
             vals_[t.name] = std::move(v);
         }
+        canonicalize_spectrogram_dialects();
         // graph input
         const auto &in = m_.inputs[0];
         if (!in.has_shape || in.shape.size() < 2)
@@ -215,7 +220,26 @@ class Builder {
         auto it = vals_.find(n.inputs[idx]);
         if (it == vals_.end()) unsupported(n, "input '" + n.inputs[idx] + "' is not defined (graph not topologically sorted?)");
         if (it->second.gate_storage >= 0 && !(n.op_type == "Conv" && idx == 0)) it->second = apply_gate(it->second, n.inputs[idx]);
+        if (!it->second.win_name.empty() && !(idx == 0 && (n.op_type == "DFT" || n.op_type == "Unsqueeze" || n.op_type == "Squeeze" || n.op_type == "Reshape" ||
+                                                          n.op_type == "Identity")))
+            it->second = apply_window(it->second, n.inputs[idx]);
         return it->second;
+    }
+    // frames * window as an explicit elementwise launch (fallback when the consumer is not a DFT after all)
+    Val apply_window(const Val &x, const std::string &why) {
+        Val plain = x;
+        plain.win_name.clear();
+        plain.win_nu = -1;
+        const Val &w = vals_.at(x.win_name);
+        int ax = -1, nu = 0;
+        for (size_t k = 0; k < x.dims.size(); k++)
+            if (x.dims[k] != 1 && nu++ == x.win_nu) ax = (int)k;
+        if (ax < 0 || w.numel() != x.dims[ax]) throw UnsupportedModel("internal: pending window of '" + why + "' lost its axis");
+        Val out = new_act(x.dims, strides_for_order(x.dims, phys_order(x)));
+        Dims ws(x.dims.size(), 0);
+        ws[ax] = 1;
+        emit_elt("window.mul:" + why, out, ref_of(plain), plain.strides, batch_stride(plain), Ref{Space::CONSTS, add_const(w.f), 0}, ws, 0, BIN_MUL, ActSpec{});
+        return out;
     }
     // x * gate as an explicit elementwise launch (fallback when the consumer cannot fold the gate)
     Val apply_gate(const Val &x, const std::string &why) {
@@ -453,8 +477,47 @@ class Builder {
         }
         return o;
     }
+    // (round 5) comparison / boolean operators: 0 / 1 integers on the constant side, f32 0.0 / 1.0 on the device side
+    static int compare_code(const std::string &t) {
+        return t == "Greater" ? BIN_GT : t == "Less" ? BIN_LT : t == "GreaterOrEqual" ? BIN_GE : t == "LessOrEqual" ? BIN_LE : t == "Equal" ? BIN_EQ
+             : t == "Xor" ? BIN_NE : t == "bn.SelA" ? BIN_SELA : t == "bn.SelB" ? BIN_SELB : BIN_NONE;
+    }
+    bool fold_compare(const OnnxNode &n, const Val &a, const Val &b) {
+        const std::string &t = n.op_type;
+        const int code = t == "And" ? BIN_MUL : t == "Or" ? BIN_MAX : compare_code(t);
+        if (code == BIN_NONE) return false;
+        Dims od = bcast_dims(a.dims, b.dims);
+        const bool ints = a.is_int && b.is_int;
+        auto pick = [code](auto x, auto y) -> decltype(x) {
+            using T = decltype(x);
+            switch (code) {
+                case BIN_GT: return (T)(x > y);
+                case BIN_LT: return (T)(x < y);
+                case BIN_GE: return (T)(x >= y);
+                case BIN_LE: return (T)(x <= y);
+                case BIN_EQ: return (T)(x == y);
+                case BIN_NE: return (T)(x != y);
+                case BIN_MUL: return (T)((x != 0) && (y != 0));
+                case BIN_MAX: return (T)((x != 0) || (y != 0));
+                case BIN_SELA: return y != 0 ? x : (T)0;
+                default: return y != 0 ? (T)0 : x;  // BIN_SELB
+            }
+        };
+        const bool keeps_type = code == BIN_SELA || code == BIN_SELB;  // a select keeps its data operand's type, a comparison yields 0 / 1
+        if (ints) {
+            define(n.outputs[0], make_const_i(od, bcast_apply<int64_t>(a.dims, a.i, b.dims, b.i, od, [&](int64_t x, int64_t y) { return pick(x, y); })));
+            return true;
+        }
+        std::vector<float> af = a.is_int ? std::vector<float>(a.i.begin(), a.i.end()) : a.f;
+        std::vector<float> bf = b.is_int ? std::vector<float>(b.i.begin(), b.i.end()) : b.f;
+        std::vector<float> of = bcast_apply<float>(a.dims, af, b.dims, bf, od, [&](float x, float y) { return pick(x, y); });
+        if (keeps_type && !a.is_int) define(n.outputs[0], make_const_f(od, of));
+        else define(n.outputs[0], make_const_i(od, std::vector<int64_t>(of.begin(), of.end())));
+        return true;
+    }
     bool fold_binary(const OnnxNode &n, const Val &a, const Val &b) {
         const std::string &t = n.op_type;
+        if (fold_compare(n, a, b)) return true;
         Dims od = bcast_dims(a.dims, b.dims);
         if (a.is_int && b.is_int) {
             std::function<int64_t(int64_t, int64_t)> fn;
@@ -518,6 +581,152 @@ class Builder {
             if (c.is_int) o.i[lin] = c.i[src]; else o.f[lin] = c.f[src];
         }
         return o;
+    }
+
+    // ------------------------------------------------------------- one spelling for the real / imaginary part of a spectrogram (round 5)
+    // Three exporter dialects write "the real part of an STFT" (what BirdNET v2.4 feeds its mel banks):
+    //   (a) Conv1D with the windowed cosine basis as weights -> Transpose                                  (the form every node-level pass below knows)
+    //   (b) STFT(signal, step, window) -> Gather(index c, last axis)                                        (torch.stft exports, opset 17)
+    //   (c) Reshape -> Gather(affine selector) -> Reshape  [tf.signal.frame]  -> Mul(window) -> Unsqueeze -> DFT(onesided) -> Gather(index c)
+    // (b) and (c) are rewritten into (a) here, before liveness and the passes that prune mel-dead bins, merge the mel product and pick the
+    // fold, so that all three spellings reach the same plan.  Only the exact patterns are rewritten (every intermediate has ONE consumer and
+    // is no graph output); anything else keeps its nodes and goes through lower_stft / lower_dft, which map the general case.
+    void canonicalize_spectrogram_dialects() {
+        if (env_int("BN_CANON_SPECTRO", 1) == 0) return;
+        std::map<std::string, int> uses;
+        for (auto &nd : nodes_)
+            for (auto &i : nd.inputs)
+                if (!i.empty()) uses[i]++;
+        for (auto &o : m_.outputs) uses[o.name] += 2;  // a graph output is never an intermediate
+        std::map<std::string, int> producer;
+        for (size_t k = 0; k < nodes_.size(); k++)
+            for (auto &o : nodes_[k].outputs) producer[o] = (int)k;
+        auto cval = [&](const std::string &name) -> const Val * {
+            auto it = vals_.find(name);
+            return it != vals_.end() && it->second.is_const ? &it->second : nullptr;
+        };
+        auto ints = [&](const std::string &name, std::vector<int64_t> &out) {
+            const Val *v = cval(name);
+            if (!v) return false;
+            out = v->is_int ? v->i : std::vector<int64_t>(v->f.begin(), v->f.end());
+            return true;
+        };
+        auto sole_prod = [&](const std::string &t, const char *op) -> int {  // producer of t if it is `op` and t has one use
+            auto it = producer.find(t);
+            if (it == producer.end() || nodes_[it->second].op_type != op || uses[t] != 1) return -1;
+            return it->second;
+        };
+        std::vector<char> dead(nodes_.size(), 0);
+        std::vector<std::vector<OnnxNode>> repl(nodes_.size());
+        int serial = 0;
+        for (size_t gk = 0; gk < nodes_.size(); gk++) {
+            const OnnxNode &pick = nodes_[gk];
+            if (pick.op_type != "Gather" || pick.inputs.size() != 2) continue;
+            std::vector<int64_t> ci;
+            const Val *civ = cval(pick.inputs[1]);
+            if (!civ || civ->numel() != 1 || !civ->dims.empty() || !ints(pick.inputs[1], ci) || (ci[0] != 0 && ci[0] != 1)) continue;
+            const int64_t gax = pick.attr_i("axis", 0);
+            if (gax != 3 && gax != -1) continue;
+            std::string signal;
+            std::vector<float> window;
+            int64_t N = 0, hop = 0;
+            std::vector<int> chain;
+            int k1 = sole_prod(pick.inputs[0], "STFT");
+            if (k1 >= 0) {                                                      // ---- (b)
+                const OnnxNode &st = nodes_[k1];
+                std::vector<int64_t> stepv, lenv;
+                if (st.attr_i("onesided", 1) == 0 || st.inputs.size() < 2 || !ints(st.inputs[1], stepv) || stepv.size() != 1) continue;
+                const Val *w = st.inputs.size() > 2 && !st.inputs[2].empty() ? cval(st.inputs[2]) : nullptr;
+                if (st.inputs.size() > 2 && !st.inputs[2].empty() && (!w || w->is_int)) continue;
+                if (st.inputs.size() > 3 && !st.inputs[3].empty()) { if (!ints(st.inputs[3], lenv) || lenv.size() != 1) continue; N = lenv[0]; }
+                else if (w) N = w->numel();
+                if (N < 2 || (w && w->numel() != N)) continue;
+                if (w) window = w->f;
+                hop = stepv[0];
+                signal = st.inputs[0];
+                chain = {k1};
+            } else if ((k1 = sole_prod(pick.inputs[0], "DFT")) >= 0) {            // ---- (c)
+                const OnnxNode &df = nodes_[k1];
+                if (df.attr_i("onesided", 0) == 0 || df.attr_i("inverse", 0) != 0 || df.inputs.size() != 1) continue;
+                const int64_t dax = df.has("axis") ? df.attr_i("axis", 1) : (m_.opset >= 20 ? -2 : 1);
+                if (dax != 2 && dax != -2) continue;
+                const int ku = sole_prod(df.inputs[0], "Unsqueeze");
+                if (ku < 0) continue;
+                std::vector<int64_t> ax = nodes_[ku].attr_ints("axes");
+                if (ax.empty() && (nodes_[ku].inputs.size() < 2 || !ints(nodes_[ku].inputs[1], ax))) continue;
+                if (ax.size() != 1 || (ax[0] != 3 && ax[0] != -1)) continue;
+                std::string fr = nodes_[ku].inputs[0];
+                chain = {k1, ku};
+                const int km = sole_prod(fr, "Mul");
+                if (km >= 0) {
+                    const OnnxNode &mu = nodes_[km];
+                    const Val *w0 = cval(mu.inputs[0]), *w1 = cval(mu.inputs[1]);
+                    const Val *w = w0 ? w0 : w1;
+                    if (!w || (w0 && w1) || w->is_int) continue;
+                    int nu = 0;
+                    for (auto d : w->dims) nu += d != 1;
+                    if (nu != 1 || w->dims.empty() || w->dims.back() != w->numel()) continue;  // along the frames' last axis
+                    window = w->f;
+                    fr = mu.inputs[w0 ? 1 : 0];
+                    chain.push_back(km);
+                }
+                // tf.signal.frame: Reshape [0|-1, S / sub, sub] -> Gather(axis 1, selector[f][j] = f * h + j) -> Reshape [0|-1, F, L]
+                const int kr2 = sole_prod(fr, "Reshape");
+                if (kr2 < 0) continue;
+                std::vector<int64_t> shp2, shp0;
+                if (!ints(nodes_[kr2].inputs[1], shp2) || shp2.size() != 3) continue;
+                const int kg = sole_prod(nodes_[kr2].inputs[0], "Gather");
+                if (kg < 0 || nodes_[kg].attr_i("axis", 0) != 1) continue;
+                const Val *sel = cval(nodes_[kg].inputs[1]);
+                if (!sel || !sel->is_int || sel->dims.size() != 2) continue;
+                const int kr0 = sole_prod(nodes_[kg].inputs[0], "Reshape");
+                if (kr0 < 0 || !ints(nodes_[kr0].inputs[1], shp0) || shp0.size() != 3) continue;
+                const int64_t F = sel->dims[0], J = sel->dims[1], sub = shp0[2];
+                if (sub < 1 || F < 1 || J < 1 || shp2[1] != F || shp2[2] != J * sub) continue;
+                const int64_t h = F > 1 ? sel->i[(size_t)J] - sel->i[0] : 1;
+                bool affine = sel->i[0] == 0 && h >= 1;
+                for (int64_t f = 0; f < F && affine; f++)
+                    for (int64_t j = 0; j < J && affine; j++) affine = sel->i[(size_t)(f * J + j)] == f * h + j;
+                // (the Conv frames the WHOLE signal: the selector must take every frame that fits)
+                if (!affine || shp0[1] < (F - 1) * h + J || F != (shp0[1] - J) / h + 1) continue;
+                N = J * sub;
+                hop = h * sub;
+                if (!window.empty() && (int64_t)window.size() != N) continue;
+                signal = nodes_[kr0].inputs[0];
+                chain.insert(chain.end(), {kr2, kg, kr0});
+            } else continue;
+            if (hop < 1 || N > 8192) continue;
+            const int64_t bins = N / 2 + 1;
+            Val basis;
+            basis.is_const = true;
+            basis.dims = {bins, 1, N};
+            basis.f.resize((size_t)(bins * N));
+            for (int64_t k = 0; k < bins; k++)
+                for (int64_t t = 0; t < N; t++) {
+                    const double wv = window.empty() ? 1.0 : (double)window[(size_t)t];
+                    const double th = 2.0 * M_PI * (double)((k * t) % N) / (double)N;
+                    basis.f[(size_t)(k * N + t)] = (float)(ci[0] == 0 ? wv * std::cos(th) : -wv * std::sin(th));
+                }
+            const std::string base = "spectro" + std::to_string(serial++) + ":" + pick.outputs[0];
+            vals_[base + "/basis"] = std::move(basis);
+            vals_[base + "/shape"] = make_const_i({3}, {0, 1, -1});
+            OnnxNode rs = synth_node("Reshape", base + "/signal", {signal, base + "/shape"}, base + "/signal");
+            OnnxNode conv = synth_node("Conv", (pick.name.empty() ? pick.outputs[0] : pick.name) + (ci[0] == 0 ? "~re" : "~im"), {base + "/signal", base + "/basis"}, base + "/bank");
+            set_ints(conv, "strides", {hop});
+            set_ints(conv, "kernel_shape", {N});
+            OnnxNode tr = synth_node("Transpose", base + "/t", {base + "/bank"}, pick.outputs[0]);
+            set_ints(tr, "perm", {0, 2, 1});
+            repl[gk] = {rs, conv, tr};
+            dead[gk] = 1;
+            for (int c : chain) dead[(size_t)c] = 1;
+        }
+        if (!serial) return;
+        std::vector<OnnxNode> out;
+        for (size_t k = 0; k < nodes_.size(); k++) {
+            for (auto &r : repl[k]) out.push_back(r);
+            if (!dead[k]) out.push_back(nodes_[k]);
+        }
+        nodes_ = std::move(out);
     }
 
     // ------------------------------------------------------------- pruning
@@ -1284,7 +1493,21 @@ class Builder {
         bool allc = !ins.empty() && all_const(ins);
         if (allc && try_fold(n, ins)) return;
 
-        if (t == "Identity" || t == "Dropout" || (t == "Cast" && !get(n, 0).is_const)) { define(n.outputs[0], get(n, 0)); return; }
+        if (t == "Identity" || t == "Dropout") { define(n.outputs[0], get(n, 0)); return; }
+        if (t == "Cast" && !get(n, 0).is_const) {
+            // activations are f32 whatever the graph calls them: a cast between float types is the value itself, a cast to bool is
+            // x != 0 -> 1, a cast to an integer type truncates toward zero (ONNX Cast) -- both stay f32 numbers
+            const int64_t to = n.attr_i("to", 1);
+            if (to == 1 || to == 10 || to == 11 || to == 16) { define(n.outputs[0], get(n, 0)); return; }
+            if (to == 9) return lower_unary(n, ActSpec{ACT_NEZ, 0, 0});
+            if (to == 2 || to == 3 || to == 4 || to == 5 || to == 6 || to == 7 || to == 12 || to == 13) return lower_unary(n, ActSpec{ACT_TRUNC, 0, 0});
+            unsupported(n, "Cast to element type " + std::to_string(to) + " (strings / complex) is outside the native subset");
+        }
+        if (t == "Not") return lower_unary(n, ActSpec{ACT_AFFINE, -1.0f, 1.0f});  // on a 0 / 1 tensor
+        if (t == "And" || t == "Or" || compare_code(t) != BIN_NONE) return lower_binary(n);
+        if (t == "Where") return lower_where(n);
+        if (t == "Gather" && !get(n, 0).is_const) return lower_gather(n);
+        if (t == "DFT") return lower_dft(n);
         if (t == "Transpose") return lower_transpose(n);
         if (t == "Reshape" || t == "Flatten" || t == "Squeeze" || t == "Unsqueeze") return lower_reshape_like(n);
         if (t == "Slice") return lower_slice(n);
@@ -1306,11 +1529,8 @@ class Builder {
         ActSpec a;
         if (unary_spec(n, a)) return lower_unary(n, a);
         // exporter dialects this path has met but does not map: say what the node is and what to export instead
-        if (t == "DFT") unsupported(n, "DFT nodes are not mapped; export the spectrogram as an STFT node (opset 17, mapped to the framing kernels) or as a Conv with the windowed DFT basis");
         if (t == "Resize" || t == "Upsample") unsupported(n, "resampling of feature maps is outside the native subset (no BirdNET / Perch graph needs it)");
-        if (t == "Where") unsupported(n, "element selection is outside the native subset; express clamps as Clip / Max / Min");
-        if (t == "Equal" || t == "Greater" || t == "Less" || t == "GreaterOrEqual" || t == "LessOrEqual" || t == "Not" || t == "And" || t == "Or")
-            unsupported(n, "boolean tensors computed from activations are outside the native subset");
+        if (t == "Gather" || t == "GatherND" || t == "GatherElements") unsupported(n, "gathers of activations are mapped only where the constant indices are an affine pattern (a strided view: tf.signal.frame's selector)");
         unsupported(n, "operator is outside the native subset");
     }
 
@@ -1544,8 +1764,23 @@ class Builder {
     bool try_fold(const OnnxNode &n, const std::vector<const Val *> &ins) {
         const std::string &t = n.op_type;
         const Val &a = *ins[0];
-        if (ins.size() >= 2 && ins[1] && (t == "Add" || t == "Sub" || t == "Mul" || t == "Div" || t == "Pow" || t == "Max" || t == "Min"))
+        if (ins.size() >= 2 && ins[1] && (t == "Add" || t == "Sub" || t == "Mul" || t == "Div" || t == "Pow" || t == "Max" || t == "Min" ||
+                                          t == "And" || t == "Or" || compare_code(t) != BIN_NONE))
             return fold_binary(n, a, *ins[1]);
+        if (t == "Not") {
+            std::vector<int64_t> o(a.is_int ? a.i.size() : a.f.size());
+            for (size_t k = 0; k < o.size(); k++) o[k] = a.is_int ? a.i[k] == 0 : a.f[k] == 0.0f;
+            define(n.outputs[0], make_const_i(a.dims, o));
+            return true;
+        }
+        if (t == "Where" && ins.size() == 3 && ins[1] && ins[2]) {
+            // Where(cond, x, y) on constants (the exporters' shape arithmetic: Where(Equal(shape, -1), ...)): SelA(x, cond) + SelB(y, cond)
+            const std::string base = "where:" + n.outputs[0];
+            lower(synth_node("bn.SelA", n.name + "/x", {n.inputs[1], n.inputs[0]}, base + "/x"));
+            lower(synth_node("bn.SelB", n.name + "/y", {n.inputs[2], n.inputs[0]}, base + "/y"));
+            lower(synth_node("Add", n.name, {base + "/x", base + "/y"}, n.outputs[0]));
+            return true;
+        }
         if (t == "Identity") { define(n.outputs[0], a); return true; }
         if (t == "Cast") {
             int64_t to = n.attr_i("to", 1);
@@ -1719,10 +1954,16 @@ class Builder {
         for (auto d : nd) if (d != 1) b.push_back(d);
         Val o = v;
         o.dims = nd;
+        Dims vs;
         if (a == b) {
             o.strides.assign(nd.size(), 0);
             size_t j = 0;
             for (size_t k = 0; k < nd.size(); k++) if (nd[k] != 1) o.strides[k] = as[j++];
+        } else if (!v.win_name.empty()) {
+            vals_[n.inputs[0]] = apply_window(v, n.inputs[0]);  // (the non-unit dims change: the window's axis would be lost)
+            return lower_reshape_like(n);
+        } else if (view_reshape(a, as, nd, vs)) {
+            o.strides = vs;  // (round 5) dims that merge / split without moving an element: tf.signal.frame's [frames, L / sub, sub] -> [frames, L]
         } else {
             Val src = v.contiguous() ? v : materialize(v, row_major(v.dims), n.name);
             o = src;
@@ -1730,6 +1971,216 @@ class Builder {
             o.strides = row_major(nd);
         }
         define(n.outputs[0], o);
+    }
+
+    // Strides of `nd` over the same elements as the (non-unit) dims `a` with strides `as`, if one exists without a copy: the old dims are
+    // cut into maximal runs that are contiguous among themselves (stride[k] == dims[k+1] * stride[k+1]); every new non-unit dim must
+    // fall inside one run (row-major inside it).  The usual no-copy reshape rule.
+    static bool view_reshape(const Dims &a, const Dims &as, const Dims &nd, Dims &out) {
+        out.assign(nd.size(), 0);
+        size_t i = 0, j = 0;
+        while (j < nd.size() && nd[j] == 1) j++;
+        while (i < a.size() && j < nd.size()) {
+            // old run [i, e): contiguous among themselves
+            size_t e = i + 1;
+            int64_t run = a[i];
+            // extend the new side until the products match, extending the old run when the new product overshoots
+            size_t j0 = j;
+            int64_t np = nd[j];
+            size_t je = j + 1;
+            while (np != run) {
+                if (np < run) {
+                    while (je < nd.size() && nd[je] == 1) je++;
+                    if (je >= nd.size()) return false;
+                    np *= nd[je++];
+                } else {
+                    if (e >= a.size() || as[e - 1] != a[e] * as[e]) return false;
+                    run *= a[e++];
+                }
+            }
+            // strides of the new dims inside the run: row-major, innermost = the run's last old stride
+            int64_t st = as[e - 1];
+            for (size_t k = je; k-- > j0;) {
+                if (nd[k] == 1) continue;
+                out[k] = st;
+                st *= nd[k];
+            }
+            i = e;
+            j = je;
+            while (j < nd.size() && nd[j] == 1) j++;
+        }
+        return i == a.size() && j == nd.size();
+    }
+
+    // Gather of an activation with CONSTANT indices that form an affine pattern idx[i0, i1, ...] = base + sum_k i_k * step_k: a strided
+    // view, no copy.  This is what framing looks like in a TensorFlow export (tf.signal.frame gathers sub-frames with the selector
+    // frame * (hop / sub) + j); anything that is not affine is refused.
+    void lower_gather(const OnnxNode &n) {
+        const Val &x = get(n, 0);
+        const Val &iv = get(n, 1);
+        if (x.is_const || !iv.is_const) unsupported(n, "Gather is mapped for an activation with constant indices only");
+        int64_t axis = n.attr_i("axis", 0);
+        const int64_t r = (int64_t)x.dims.size() + 1;
+        if (axis < 0) axis += r;
+        if (axis <= 0 || axis >= r) unsupported(n, "Gather along the batch dimension");
+        axis -= 1;
+        const int64_t D = x.dims[axis];
+        std::vector<int64_t> idx = const_ints(n, iv);
+        for (auto &v : idx) { if (v < 0) v += D; if (v < 0 || v >= D) unsupported(n, "Gather index out of range"); }
+        const Dims &id = iv.dims;
+        Dims irs = row_major(id), step(id.size(), 0);
+        const int64_t base = idx.empty() ? 0 : idx[0];
+        for (size_t k = 0; k < id.size(); k++) step[k] = id[k] > 1 ? idx[(size_t)irs[k]] - base : 0;
+        for (size_t lin = 0; lin < idx.size(); lin++) {
+            int64_t want = base, rem = (int64_t)lin;
+            for (size_t k = 0; k < id.size(); k++) { want += (rem / irs[k]) * step[k]; rem %= irs[k]; }
+            if (idx[lin] != want) unsupported(n, "Gather indices are not an affine pattern (only strided views of an activation are mapped; tf.signal.frame's selector is one)");
+        }
+        Val o = x;
+        o.dims.assign(x.dims.begin(), x.dims.begin() + axis);
+        o.strides.assign(x.strides.begin(), x.strides.begin() + axis);
+        for (size_t k = 0; k < id.size(); k++) { o.dims.push_back(id[k]); o.strides.push_back(step[k] * x.strides[axis]); }
+        o.dims.insert(o.dims.end(), x.dims.begin() + axis + 1, x.dims.end());
+        o.strides.insert(o.strides.end(), x.strides.begin() + axis + 1, x.strides.end());
+        o.offset = x.offset + base * x.strides[axis];
+        define(n.outputs[0], o);
+    }
+
+    // Mul(frames, window[L]) whose result reaches a DFT node through nothing but unit-dimension reshapes: leave the window pending on the
+    // value -- lower_dft folds it into its basis, which is what lets the framing kernels (mirror / quarter fold, FFT) recognise the bank
+    bool try_pending_window(const OnnxNode &n, const Val &a, const Val &b) {
+        const Val &x = a.is_const ? b : a, &w = a.is_const ? a : b;
+        if (x.is_const || !w.is_const || w.is_int || !x.win_name.empty() || x.gate_storage >= 0 || wanted_names_.count(n.outputs[0])) return false;
+        const int64_t L = w.numel();
+        if (L < 2) return false;
+        // the window's one non-unit dim, aligned from the right against the full (batched) dims of x
+        int wax = -1;
+        for (size_t k = 0; k < w.dims.size(); k++)
+            if (w.dims[k] != 1) { if (wax >= 0) return false; wax = (int)k; }
+        const int ax = wax + (int)(x.dims.size() + 1) - (int)w.dims.size() - 1;  // per-sample axis of x
+        if (ax < 0 || ax >= (int)x.dims.size() || x.dims[ax] != L) return false;
+        std::string cur = n.outputs[0];
+        for (int hop = 0; hop < 4; hop++) {
+            int c = sole_consumer(cur);
+            if (c < 0 || nodes_[c].inputs.empty() || nodes_[c].inputs[0] != cur) return false;
+            const std::string &ct = nodes_[c].op_type;
+            if (ct == "DFT") {
+                Val o = x;
+                o.win_name = n.inputs[a.is_const ? 0 : 1];
+                o.win_nu = 0;
+                for (int k = 0; k < ax; k++) o.win_nu += x.dims[k] != 1;
+                define(n.outputs[0], o);
+                return true;
+            }
+            if (ct != "Unsqueeze" && ct != "Squeeze" && ct != "Reshape" && ct != "Identity") return false;
+            cur = nodes_[c].outputs[0];
+        }
+        return false;
+    }
+
+    // ONNX DFT (opset 17: attribute axis, default 1; opset 20: input axis, default -2): forward, real input [.., L, 1], optional constant
+    // dft_length N (zero-padded or truncated signal), onesided -> N/2 + 1 bins, output [.., bins, 2].  The frames [F, L] along `axis` are
+    // rows of a framing convolution over the flat view they come from (hop = frame stride / sample stride: overlapping views of a signal
+    // -- tf.signal.frame through lower_gather -- or hop = L for a materialised tensor), exactly like lower_stft: one cos | -sin bank built in
+    // double precision with a pending window folded in, so the mirror / quarter folds and the FFT kernel apply to it like to any bank.
+    void lower_dft(const OnnxNode &n) {
+        Val x = get(n, 0);
+        if (x.is_const) unsupported(n, "DFT of a constant signal");
+        if (n.attr_i("inverse", 0) != 0) unsupported(n, "inverse DFT is outside the native subset (no BirdNET / Perch front end needs it)");
+        const int64_t r = (int64_t)x.dims.size() + 1;
+        if (x.dims.empty() || x.dims.back() == 2) unsupported(n, "complex input (last dimension 2) is outside the native subset; the front ends transform a real signal");
+        if (x.dims.back() != 1) unsupported(n, "input must end in a dimension of 1 (real) per the operator's definition, got per-sample dims " + dims_str(x.dims));
+        int64_t axis = n.has("axis") ? n.attr_i("axis", 1) : (m_.opset >= 20 ? -2 : 1);
+        if (!n.has("axis") && has_input(n, 2)) axis = const_ints(n, get(n, 2)).at(0);
+        if (axis < 0) axis += r;
+        if (axis <= 0 || axis >= r - 1) unsupported(n, "DFT axis must be a signal dimension (not the batch, not the trailing real / imaginary one)");
+        axis -= 1;
+        const int64_t L = x.dims[axis];
+        int64_t N = L;
+        if (has_input(n, 1)) { const Val &dl = get(n, 1); if (!dl.is_const) unsupported(n, "dft_length must be a constant"); N = const_ints(n, dl).at(0); }
+        if (N <= 0) unsupported(n, "dft_length must be positive");
+        const int64_t taps = std::min(L, N);  // a longer transform zero-pads the signal (= fewer taps per basis row), a shorter one truncates it
+        const bool onesided = n.attr_i("onesided", 0) != 0;
+        const int64_t bins = onesided ? N / 2 + 1 : N;
+        if (taps * 2 * bins > ((int64_t)1 << 28)) unsupported(n, "DFT basis too large");
+        // pending window: must lie along the transformed axis and have its length
+        std::vector<float> win;
+        if (!x.win_name.empty()) {
+            int nu = 0;
+            for (int64_t k = 0; k < axis; k++) nu += x.dims[k] != 1;
+            const Val &w = vals_.at(x.win_name);
+            if (nu == x.win_nu && w.numel() == L) win = w.f;
+            else x = apply_window(x, n.inputs[0]);
+            x.win_name.clear();
+            x.win_nu = -1;
+        }
+        // frames: every non-unit dim except `axis` and the trailing 1, merged into one row index with ONE stride if the view allows it
+        Dims lead, lead_s;
+        for (int64_t k = 0; k + 1 < (int64_t)x.dims.size(); k++)
+            if (k != axis && x.dims[k] != 1) { lead.push_back(x.dims[k]); lead_s.push_back(x.strides[k]); }
+        int64_t F = 1;
+        for (auto d : lead) F *= d;
+        int64_t sL = x.strides[axis], sF = lead.empty() ? L * sL : lead_s.back();
+        bool rows_ok = sL > 0 && sF > 0 && sF % sL == 0;
+        for (size_t k = 0; k + 1 < lead.size() && rows_ok; k++) rows_ok = lead_s[k] == lead[k + 1] * lead_s[k + 1];
+        if (!rows_ok) {  // arbitrary view: copy the frames into [lead..., L] row-major, then they are non-overlapping rows
+            Dims keep = x.dims;
+            Val c = materialize(x, row_major(keep), n.name + "/frames");
+            x = c;
+            lead_s.clear();
+            for (int64_t k = 0; k + 1 < (int64_t)x.dims.size(); k++)
+                if (k != axis && x.dims[k] != 1) lead_s.push_back(x.strides[k]);
+            sL = x.strides[axis];
+            sF = lead.empty() ? L * sL : lead_s.back();
+            rows_ok = sL > 0 && sF % sL == 0;
+            for (size_t k = 0; k + 1 < lead.size() && rows_ok; k++) rows_ok = lead_s[k] == lead[k + 1] * lead_s[k + 1];
+            if (!rows_ok) unsupported(n, "DFT axis must be the innermost signal dimension of its frames (transpose the frames first)");
+        }
+        const int64_t hop = sF / sL;
+        Val w;
+        w.is_const = true;
+        w.dims = {2 * bins, 1, taps};
+        w.f.resize((size_t)(2 * bins * taps));
+        for (int64_t k = 0; k < bins; k++)
+            for (int64_t t = 0; t < taps; t++) {
+                const double wv = win.empty() ? 1.0 : (double)win[(size_t)t];
+                const double th = 2.0 * M_PI * (double)((k * t) % N) / (double)N;
+                w.f[(size_t)(k * taps + t)] = (float)(wv * std::cos(th));
+                w.f[(size_t)((bins + k) * taps + t)] = (float)(-wv * std::sin(th));
+            }
+        const std::string base = "dft:" + (n.name.empty() ? n.outputs[0] : n.name);
+        const int64_t span = (F - 1) * hop + taps;
+        Val xv = x;
+        xv.dims = {1, span};
+        xv.strides = {span * sL, sL};
+        vals_[base + "/signal"] = xv;
+        vals_[base + "/basis"] = std::move(w);
+        OnnxNode conv;
+        conv.name = base;
+        conv.op_type = "Conv";
+        conv.inputs = {base + "/signal", base + "/basis"};
+        conv.outputs = {base + "/frames"};
+        set_ints(conv, "strides", {hop});
+        lower_conv(conv);
+        auto yit = vals_.find(base + "/frames");
+        if (yit == vals_.end()) unsupported(n, "internal: the framing conv defined no output");
+        const Val y = yit->second;
+        if (y.is_const || y.dims.size() != 2 || y.dims[0] != 2 * bins || y.dims[1] != F) unsupported(n, "internal: framing conv produced " + dims_str(y.dims));
+        // the node's result: x's dims with `axis` -> bins and the trailing 1 -> 2, as a strided view of the conv's [2 bins, F] output
+        Val out = y;
+        out.dims = x.dims;
+        out.strides.assign(x.dims.size(), 0);
+        int64_t fs = y.strides[1];
+        for (int64_t k = (int64_t)x.dims.size() - 2; k >= 0; k--) {
+            if (k == axis || x.dims[k] == 1) continue;
+            out.strides[k] = fs;
+            fs *= x.dims[k];
+        }
+        out.dims[axis] = bins;
+        out.strides[axis] = y.strides[0];
+        out.dims.back() = 2;
+        out.strides.back() = bins * y.strides[0];
+        define(n.outputs[0], out);
     }
 
     void lower_transpose(const OnnxNode &n) {
@@ -2136,7 +2587,9 @@ class Builder {
                 return;
             }
         }
-        int bin = t == "Add" ? BIN_ADD : t == "Sub" ? BIN_SUB : t == "Mul" ? BIN_MUL : t == "Div" ? BIN_DIV : t == "Pow" ? BIN_POW : t == "Max" ? BIN_MAX : BIN_MIN;
+        if (t == "Mul" && a.is_const != b.is_const && try_pending_window(n, a, b)) return;
+        int bin = t == "Add" ? BIN_ADD : t == "Sub" ? BIN_SUB : t == "Mul" ? BIN_MUL : t == "Div" ? BIN_DIV : t == "Pow" ? BIN_POW : t == "Max" ? BIN_MAX
+                : t == "And" ? BIN_MUL : t == "Or" ? BIN_MAX : compare_code(t) != BIN_NONE ? compare_code(t) : BIN_MIN;
         // scalar constants become parametrised unary ops
         float c;
         if (!a.is_const && const_scalar(b, c)) {
@@ -2154,8 +2607,14 @@ class Builder {
                     else if (c == 1.0f) s = {ACT_AFFINE, 1.0f, 0.0f};
                     else s = {ACT_POW, c, 0};
                     break;
+                case BIN_GT: s = {ACT_GTC, c, 0}; break;
+                case BIN_LT: s = {ACT_LTC, c, 0}; break;
+                case BIN_GE: s = {ACT_GEC, c, 0}; break;
+                case BIN_LE: s = {ACT_LEC, c, 0}; break;
+                case BIN_EQ: s = {ACT_EQC, c, 0}; break;
                 default: ok = false;
             }
+            if (ok && (t == "And" || t == "Or")) ok = false;  // (logic on 0 / 1 tensors takes the general path)
             if (ok) return lower_unary(n, s);
         }
         if (!b.is_const && const_scalar(a, c)) {
@@ -2168,8 +2627,14 @@ class Builder {
                 case BIN_DIV: s = {ACT_RDIV, c, 0}; break;
                 case BIN_MAX: s = {ACT_MAXC, c, 0}; break;
                 case BIN_MIN: s = {ACT_MINC, c, 0}; break;
+                case BIN_GT: s = {ACT_LTC, c, 0}; break;  // c > x
+                case BIN_LT: s = {ACT_GTC, c, 0}; break;
+                case BIN_GE: s = {ACT_LEC, c, 0}; break;
+                case BIN_LE: s = {ACT_GEC, c, 0}; break;
+                case BIN_EQ: s = {ACT_EQC, c, 0}; break;
                 default: ok = false;
             }
+            if (ok && (t == "And" || t == "Or")) ok = false;
             if (ok) {
                 OnnxNode sw = n;
                 std::swap(sw.inputs[0], sw.inputs[1]);
@@ -2218,6 +2683,22 @@ class Builder {
         operand(b, db, rb_, sb, bb);
         emit_elt(t + ":" + n.name, out, ra_, sa, ba, rb_, sb, bb, bin, ActSpec{});
         define(n.outputs[0], out);
+    }
+
+    // Where(cond, x, y) with at least one activation among the three: SelA(x, cond) + SelB(y, cond) -- each half is exactly x or +0
+    // (never x * 0: infinities and NaNs of the unselected branch do not leak), the sum adds a +0; a branch that is the constant 0
+    // drops its half.  The one difference to a true select: a selected -0.0 comes out as +0.0.
+    void lower_where(const OnnxNode &n) {
+        if (n.inputs.size() != 3) unsupported(n, "Where takes three inputs");
+        const Val &x = get(n, 1), &y = get(n, 2);
+        float c;
+        const bool x0 = const_scalar(x, c) && c == 0.0f, y0 = const_scalar(y, c) && c == 0.0f;
+        const std::string base = "where:" + n.outputs[0];
+        if (y0 && !x0) return lower(synth_node("bn.SelA", n.name, {n.inputs[1], n.inputs[0]}, n.outputs[0]));
+        if (x0 && !y0) return lower(synth_node("bn.SelB", n.name, {n.inputs[2], n.inputs[0]}, n.outputs[0]));
+        lower(synth_node("bn.SelA", n.name + "/x", {n.inputs[1], n.inputs[0]}, base + "/x"));
+        lower(synth_node("bn.SelB", n.name + "/y", {n.inputs[2], n.inputs[0]}, base + "/y"));
+        lower(synth_node("Add", n.name, {base + "/x", base + "/y"}, n.outputs[0]));
     }
 
     void lower_batchnorm(const OnnxNode &n) {
@@ -3739,6 +4220,19 @@ class Builder {
 };
 
 }  // namespace
+
+bool op_type_mapped(const std::string &t) {
+    // the operator types Builder::lower / try_fold dispatch on (keep in step with them: tests/test_host_logic.py plans one node of every
+    // type listed here and expects no "outside the native subset" refusal)
+    static const std::set<std::string> known = {
+        "Constant", "ConstantOfShape", "Range", "Shape", "Identity", "Dropout", "Cast", "Transpose", "Reshape", "Flatten", "Squeeze", "Unsqueeze",
+        "Slice", "Concat", "Pad", "Softmax", "LogSoftmax", "Split", "MaxPool", "AveragePool", "Conv", "MatMul", "Gemm", "BatchNormalization",
+        "Add", "Sub", "Mul", "Div", "Pow", "Max", "Min", "GlobalAveragePool", "GlobalMaxPool", "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin",
+        "ReduceProd", "ReduceL2", "ReduceSumSquare", "STFT", "DFT", "Expand", "Tile", "PRelu", "InstanceNormalization", "Relu", "Sigmoid", "Tanh",
+        "Exp", "Log", "Sqrt", "Abs", "Neg", "Reciprocal", "Floor", "Ceil", "Erf", "Softplus", "HardSwish", "HardSigmoid", "LeakyRelu", "Clip",
+        "Greater", "Less", "GreaterOrEqual", "LessOrEqual", "Equal", "Not", "And", "Or", "Xor", "Where", "Gather"};
+    return known.count(t) != 0;
+}
 
 IoMeta read_io_meta(const OnnxModel &m) {
     IoMeta io;

@@ -110,6 +110,9 @@ struct Plan {
 
 // wanted_outputs: graph output indices that must be computed (others are dead code).
 std::unique_ptr<Plan> build_plan(const OnnxModel &m, const std::vector<int> &wanted_outputs);
+// Whether the lowering has a rule for this operator type at all (first-contact survey of a model file: a node of a mapped type can still
+// be refused for its attributes or shapes, which only planning finds out; an unmapped type is refused whatever its attributes).
+bool op_type_mapped(const std::string &op_type);
 // Graph I/O metadata without planning (for detection before the wanted set is known).
 IoMeta read_io_meta(const OnnxModel &m);
 

@@ -43,8 +43,13 @@ def _int(field: int, v: int) -> bytes:
     return _key(field, 0) + _varint(v)
 
 
-def tensor_proto(name: str, arr: np.ndarray) -> bytes:
+def tensor_proto(name: str, arr: np.ndarray, scalar: bool = False) -> bytes:
+    """scalar: write a one-element array with NO dims (rank 0), as exporters write scalar indices / attributes-as-inputs; the default
+    keeps the historical [1] so that the committed synthetic models do not change."""
     arr = np.ascontiguousarray(arr)
+    if scalar:
+        assert arr.size == 1
+        arr = arr.reshape(())
     if arr.dtype == np.float32:
         dt = FLOAT
     elif arr.dtype == np.int64:
@@ -113,9 +118,9 @@ class GraphBuilder:
         self._n += 1
         return f"{hint}_{self._n}"
 
-    def const(self, arr, hint: str = "c") -> str:
+    def const(self, arr, hint: str = "c", scalar: bool = False) -> str:
         name = self.fresh(hint)
-        self.inits.append(tensor_proto(name, np.asarray(arr)))
+        self.inits.append(tensor_proto(name, np.asarray(arr), scalar))
         self.const_values.append((name, hint, np.asarray(arr)))
         return name
 

@@ -179,12 +179,39 @@ def _minmax_normalise(g: GraphBuilder, x: str) -> str:
     return g.node("Mul", [x3, g.const(np.float32(2.0))])
 
 
+def _frames_tf_signal(g: GraphBuilder, x: str, samples: int, n_fft: int, hop: int) -> str:
+    """[B,S] -> [B, frames, n_fft] the way a TensorFlow export writes tf.signal.frame: the signal reshaped into sub-frames of
+    gcd(n_fft, hop) samples, a Gather with the constant selector frame * (hop / sub) + j, and a Reshape that merges the sub-frames."""
+    sub = math.gcd(n_fft, hop)
+    assert samples % sub == 0
+    frames = (samples - n_fft) // hop + 1
+    xs = g.node("Reshape", [x, g.const(np.array([0, samples // sub, sub], dtype=np.int64))])
+    sel = (np.arange(frames, dtype=np.int64)[:, None] * (hop // sub) + np.arange(n_fft // sub, dtype=np.int64)[None, :])
+    gth = g.node("Gather", [xs, g.const(sel)], axis=1)                          # [B, frames, n_fft / sub, sub]
+    return g.node("Reshape", [gth, g.const(np.array([0, frames, n_fft], dtype=np.int64))])
+
+
 def _mel_branch_real(g: GraphBuilder, x3: str, sr: int, n_fft: int, hop: int, n_mels: int, fmin: float,
-                     fmax: float, mag_scale: float) -> str:
-    """[B,S] -> [B,1,n_mels,frames]: real STFT part -> mel -> ^2 -> ^(1/(1+e^mag_scale)) -> flip -> transpose."""
-    u = g.node("Unsqueeze", [x3, g.const(np.array([1], dtype=np.int64))])
-    c = g.node("Conv", [u, g.const(dft_basis(n_fft, "real"), "dft")], kernel_shape=[n_fft], strides=[hop])
-    t = g.node("Transpose", [c], perm=[0, 2, 1])                             # [B, frames, bins]
+                     fmax: float, mag_scale: float, dialect: str = "conv", samples: int = 0) -> str:
+    """[B,S] -> [B,1,n_mels,frames]: real STFT part -> mel -> ^2 -> ^(1/(1+e^mag_scale)) -> flip -> transpose.
+    dialect "conv": the windowed DFT basis as a Conv1D weight (the default).  "dft": what an opset-17+ exporter writes for
+    tf.signal.stft -- tf.signal.frame (Reshape / Gather / Reshape), the periodic Hann window as a Mul, an ONNX DFT node
+    (onesided) and a Gather of its real part.  "stft": one opset-17 STFT node + the same Gather."""
+    if dialect == "conv":
+        u = g.node("Unsqueeze", [x3, g.const(np.array([1], dtype=np.int64))])
+        c = g.node("Conv", [u, g.const(dft_basis(n_fft, "real"), "dft")], kernel_shape=[n_fft], strides=[hop])
+        t = g.node("Transpose", [c], perm=[0, 2, 1])                         # [B, frames, bins]
+    else:
+        n = np.arange(n_fft, dtype=np.float64)
+        hann = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft)).astype(np.float32)
+        if dialect == "dft":
+            fr = _frames_tf_signal(g, x3, samples, n_fft, hop)
+            w = g.node("Mul", [fr, g.const(hann, "window")])
+            u = g.node("Unsqueeze", [w, g.const(np.array([3], dtype=np.int64))])   # [B, frames, n_fft, 1]
+            d = g.node("DFT", [u], axis=2, onesided=1)                              # [B, frames, bins, 2]
+        else:
+            d = g.node("STFT", [x3, g.const(np.array(hop, dtype=np.int64), scalar=True), g.const(hann, "window")], onesided=1)
+        t = g.node("Gather", [d, g.const(np.array(0, dtype=np.int64), scalar=True)], axis=3)  # the real part, [B, frames, bins]
     m = g.node("MatMul", [t, g.const(mel_filterbank(n_fft // 2 + 1, n_mels, sr, fmin, fmax), "mel")])
     p = g.node("Pow", [m, g.const(np.float32(2.0))])
     q = g.node("Pow", [p, g.const(np.float32(1.0 / (1.0 + math.exp(mag_scale))))])
@@ -195,8 +222,10 @@ def _mel_branch_real(g: GraphBuilder, x3: str, sr: int, n_fft: int, hop: int, n_
 
 
 def birdnet_v24(num_species: int = 6522, seed: int = 24, width: float = 1.0, depth: float = 1.0,
-                head: int = 1024, se: bool = True, bn_nodes: bool = True, builder_out: list | None = None) -> bytes:
-    """builder_out: if a list is given, the GraphBuilder is appended to it (tests read the raw constants from it)."""
+                head: int = 1024, se: bool = True, bn_nodes: bool = True, builder_out: list | None = None, front_end: str = "conv") -> bytes:
+    """builder_out: if a list is given, the GraphBuilder is appended to it (tests read the raw constants from it).
+    front_end: "conv" (windowed DFT basis as Conv weights), "dft" (tf.signal.frame + window Mul + ONNX DFT) or "stft" (ONNX STFT):
+    three spellings of the same spectrogram, identical weights behind them."""
     rng = np.random.RandomState(seed)
     g = GraphBuilder("birdnet_v24_synth")
     if builder_out is not None:
@@ -204,8 +233,8 @@ def birdnet_v24(num_species: int = 6522, seed: int = 24, width: float = 1.0, dep
     S, sr = 144000, 48000
     g.add_input("input", [None, S])
     x3 = _minmax_normalise(g, "input")
-    lo = _mel_branch_real(g, x3, sr, 2048, 278, 96, 0.0, 3000.0, 1.23)
-    hi = _mel_branch_real(g, x3, sr, 1024, 280, 96, 500.0, 15000.0, 1.23)
+    lo = _mel_branch_real(g, x3, sr, 2048, 278, 96, 0.0, 3000.0, 1.23, front_end, S)
+    hi = _mel_branch_real(g, x3, sr, 1024, 280, 96, 500.0, 15000.0, 1.23, front_end, S)
     img = g.node("Concat", [lo, hi], axis=1)                                  # [B,2,96,511]
     gamma = np.array([0.02, 0.03], dtype=np.float32)
     img = g.node("BatchNormalization", [img, g.const(gamma), g.const(np.array([-0.5, -0.6], dtype=np.float32)),

@@ -609,3 +609,35 @@ def test_bench_batch_instances_repeat_the_oracle_checked_bits(bn, family, batch,
     # ... and the same rows at the END of the batch (another block / strip / group of every launch), default plan
     l2, e2 = bn.Context(bn.Model(path), batch).infer(np.roll(big, -n, axis=0))
     assert l2[batch - n:].tobytes() == small_l.tobytes() and e2[batch - n:].tobytes() == small_e.tobytes()
+
+
+# ---- the same v2.4 network in the spellings an exporter may choose for its spectrogram ---------------------------
+@pytest.mark.parametrize("front_end", ["dft", "stft"])
+@pytest.mark.parametrize("canon", ["1", "0"])
+def test_v24_front_end_dialects(bn, v24_small, front_end, canon, monkeypatch):
+    """BirdNET v2.4 (reduced width, full-size front end) authored with ONNX DFT nodes behind tf.signal.frame's Reshape / Gather / Reshape
+    and a window Mul ("dft"), or with opset-17 STFT nodes ("stft"), instead of Conv banks: Session::commit_from_file loads any of them
+    (classifier.rs:340-350) and so does the planner.  With the node-level canonicalisation (default) the plan is the Conv dialect's plan,
+    launch for launch; with BN_CANON_SPECTRO=0 the nodes go through lower_dft / lower_stft (cos | -sin banks on the framing kernels, the
+    real half picked by a Gather view).  Both within the suite's tolerance of the oracle -- which evaluates DFT / STFT with torch.fft --
+    with identical top-1, and within it of the Conv dialect's logits."""
+    conv_data, conv_path = v24_small
+    data = synth.birdnet_v24(num_species=500, width=0.5, depth=0.5, head=256, front_end=front_end)  # v24_small with another front end: same seed, same weights
+    path = write_model(data)
+    monkeypatch.setenv("BN_CANON_SPECTRO", canon)
+    desc = bn.plan_describe(path)
+    conv_desc = bn.plan_describe(conv_path)
+    n_launch = lambda d: len([l for l in d.splitlines() if l[:3].strip().isdigit()])
+    if canon == "1":
+        assert n_launch(desc) == n_launch(conv_desc) and "~quarter" in desc and "~re" in desc, desc
+        assert desc.splitlines()[-2].split("macs_mfma=")[1].split()[0] == conv_desc.splitlines()[-2].split("macs_mfma=")[1].split()[0]
+    else:
+        assert ("dft:DFT_" in desc) == (front_end == "dft") and ("stft:STFT_" in desc) == (front_end == "stft"), desc
+    x = synth.synthetic_segments(3, 144000, 48000)
+    x[1] = 0.0
+    got, _ = bn.Context(bn.Model(path), 3).infer(x)
+    ref = onnx_ref.run_model(data, x)["output"]
+    assert_close(got, ref, f"{front_end} dialect, canon={canon}")
+    assert np.array_equal(got.argmax(1), ref.argmax(1))
+    conv_got, _ = bn.Context(bn.Model(conv_path), 3).infer(x)
+    assert_close(got, conv_got, f"{front_end} dialect against the Conv dialect")

@@ -1168,3 +1168,152 @@ def test_prelu_tile_instance_norm(bn):
 
     got, ref = run_both(bn, op_graph(build, [c, h, w]), scale=3.0)
     assert_close(got, ref, "InstanceNormalization + PRelu + Tile")
+
+
+# ---------------------------------------------------------------- exporter dialects (round 5)
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["frames_axis2", "opset20_default_axis", "zero_padded", "truncated", "two_sided", "leading_dims", "transposed_frames"])
+def test_dft_node(bn, case):
+    """ONNX DFT (what an opset-17+ exporter writes for an RFFT front end; classifier.rs:340-350 loads whatever ORT loads) is mapped onto
+    the framing kernels like STFT: frames as rows of a framing convolution with a cos | -sin bank.  Axis as attribute (opset 17) and by
+    default (opset 20: -2), dft_length longer (zero padding) and shorter (truncation) than the frames, two-sided, extra leading
+    dimensions, and frames whose transformed axis is not innermost (copied first) -- raw [.., bins, 2] output against the oracle's
+    torch.fft call."""
+    from gpu_helpers import writer
+    L, F = 256, 120
+    opset = 20 if case == "opset20_default_axis" else 17
+    nfft = {"zero_padded": 320, "truncated": 192}.get(case, L)
+    onesided = 0 if case == "two_sided" else 1
+    bins = nfft // 2 + 1 if onesided else nfft
+
+    g = writer.GraphBuilder(opset=opset)
+    g.add_input("input", [None, 144000])
+    i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+    x = g.node("Slice", ["input", i64(0), i64(F * L), i64(1), i64(1)])
+    if case == "leading_dims":
+        x = g.node("Reshape", [x, i64(-1, 4, F // 4, L, 1)])
+        axis, out_shape = 3, [4, F // 4, bins, 2]
+    elif case == "transposed_frames":
+        x = g.node("Reshape", [x, i64(-1, L, F)])
+        x = g.node("Transpose", [x], perm=[0, 2, 1])                      # [B, F, L] with the samples of a frame F apart
+        x = g.node("Unsqueeze", [x, i64(3)])
+        axis, out_shape = 2, [F, bins, 2]
+    else:
+        x = g.node("Reshape", [x, i64(-1, F, L, 1)])
+        axis, out_shape = 2, [F, bins, 2]
+    ins = [x] + ([g.const(np.array(nfft, dtype=np.int64), scalar=True)] if nfft != L else [])
+    if case == "opset20_default_axis":
+        y = g.node("DFT", ins, onesided=onesided)                            # opset 20: axis is an input, default -2
+    else:
+        y = g.node("DFT", ins, axis=axis, onesided=onesided)
+    g.node("Identity", [y], outputs=["output"])
+    g.add_output("output", [None] + out_shape)
+    data = g.serialize()
+    text = bn.plan_describe(write_model(data))
+    copies = [l for l in text.splitlines() if " copy(" in l and "copy(output" not in l]  # (the graph output itself is copied into its dense layout)
+    assert ("dft:" in text) and (bool(copies) == (case == "transposed_frames")), text
+    got, ref = run_both(bn, data)
+    assert ref.shape[1:] == tuple(out_shape)
+    assert_close(got, ref, f"DFT {case}", atol=2e-4 * np.sqrt(L / 256) * 4, rtol=2e-4)
+
+
+@pytest.mark.gpu
+def test_tf_signal_frame_gather_is_a_view_and_the_window_joins_the_dft_bank(bn):
+    """tf.signal.stft as a TensorFlow export spells it: Reshape into sub-frames of gcd(L, hop) samples, Gather with the constant affine
+    selector, Reshape to [frames, L], Mul by the window, DFT.  The Gather and both reshapes are views (no copy launch), the window is
+    folded into the DFT bank (no multiply launch) and the bank folds like any windowed-DFT bank: ONE or two framing launches in the plan."""
+    L, hop, S = 512, 120, 48000
+    sub = int(np.gcd(L, hop))
+    F = (S - L) // hop + 1
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Slice", [x, i64(0), i64(S), i64(1), i64(1)])
+        xs = g.node("Reshape", [x, i64(0, S // sub, sub)])
+        sel = np.arange(F, dtype=np.int64)[:, None] * (hop // sub) + np.arange(L // sub, dtype=np.int64)[None, :]
+        fr = g.node("Reshape", [g.node("Gather", [xs, g.const(sel)], axis=1), i64(0, F, L)])
+        w = g.node("Mul", [fr, g.const(_hann(L))])
+        return g.node("DFT", [g.node("Unsqueeze", [w, i64(3)])], axis=2, onesided=1)
+
+    data = op_graph(build, [F, L // 2 + 1, 2])
+    text = bn.plan_describe(write_model(data))
+    launches = [l for l in text.splitlines() if l[:3].strip().isdigit()]
+    assert len(launches) <= 3 and not any(" ELT " in l and (("copy(" in l and "copy(output" not in l) or "Mul:" in l or "window.mul" in l) for l in launches), text
+    assert (f"lda={hop} " in text and "fold=" in text) or f" FFT " in text and f"hop={hop} " in text, text  # overlapping rows straight from the signal: folded taps or an FFT
+    got, ref = run_both(bn, data)
+    assert_close(got, ref, "tf.signal.frame + window + DFT", atol=4e-4, rtol=2e-4)
+
+
+@pytest.mark.gpu
+def test_gather_that_is_not_affine_is_refused_and_a_pending_window_is_applied_for_other_consumers(bn):
+    rng = np.random.default_rng(5)
+
+    def bad(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Reshape", [g.node("Slice", [x, i64(0), i64(4000), i64(1), i64(1)]), i64(0, 100, 40)])
+        return g.node("Gather", [x, g.const(np.array([0, 1, 3, 7], dtype=np.int64))], axis=1)
+    with pytest.raises(bn.EngineError):
+        bn.Model(write_model(op_graph(bad, [4, 40])))
+    assert "affine" in bn.last_error()
+
+    # frames * window read by a DFT AND by something else: the window becomes an ordinary multiply
+    L, F = 128, 50
+
+    def both(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Reshape", [g.node("Slice", [x, i64(0), i64(F * L), i64(1), i64(1)]), i64(0, F, L)])
+        w = g.node("Mul", [x, g.const(_hann(L))])
+        d = g.node("DFT", [g.node("Unsqueeze", [w, i64(3)])], axis=2, onesided=1)      # [B, F, 65, 2]
+        e = g.node("ReduceSum", [g.node("Mul", [w, w]), i64(1, 2)], keepdims=1)         # second consumer of the windowed frames: [B, 1, 1]
+        return g.node("Add", [d, g.node("Reshape", [e, i64(0, 1, 1, 1)])])
+    data = op_graph(both, [F, L // 2 + 1, 2])
+    got, ref = run_both(bn, data)
+    assert_close(got, ref, "window with two consumers", atol=4e-4, rtol=2e-4)
+    # strided, negative and scalar indices as views
+    def views(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        x = g.node("Reshape", [g.node("Slice", [x, i64(0), i64(6000), i64(1), i64(1)]), i64(0, 100, 60)])
+        a = g.node("Gather", [x, g.const(np.array([[90, 80], [70, 60], [50, 40]], dtype=np.int64))], axis=1)      # [B, 3, 2, 60], steps -20 / -10
+        b = g.node("Gather", [a, g.const(np.array(-1, dtype=np.int64), scalar=True)], axis=2)                     # [B, 3, 60]
+        return g.node("Gather", [b, g.const(np.arange(5, 60, 11, dtype=np.int64))], axis=2)                       # [B, 3, 5]
+    got, ref = run_both(bn, op_graph(views, [3, 5]))
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_comparisons_logic_where_and_casts(bn):
+    """Greater / Less / Equal / GreaterOrEqual / LessOrEqual against constants and tensors, Not / And / Or / Xor, Where with tensor and
+    constant branches (incl. a branch holding inf where it is NOT selected), Cast to bool / int / float -- "bool" tensors are 0.0 / 1.0
+    on the device; results equal the oracle's torch calls exactly (selection and comparison involve no rounding)."""
+    rng = np.random.default_rng(11)
+    c, n = 6, 500
+    thr = rng.standard_normal((c, 1)).astype(np.float32)
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        f32 = lambda v: g.const(np.array(v, dtype=np.float32))
+        x = g.node("Reshape", [g.node("Slice", [x, i64(0), i64(2 * c * n), i64(1), i64(1)]), i64(0, 2, c, n)])
+        a = g.node("Gather", [x, g.const(np.array(0, dtype=np.int64), scalar=True)], axis=1)        # [B, c, n]
+        b = g.node("Gather", [x, g.const(np.array(1, dtype=np.int64), scalar=True)], axis=1)
+        gt = g.node("Greater", [a, f32(0.25)])
+        lt = g.node("Less", [f32(-0.5), b])                                                         # constant on the left: -0.5 < b
+        ge = g.node("GreaterOrEqual", [a, b])
+        le = g.node("LessOrEqual", [a, g.const(thr)])                                               # per-channel thresholds
+        eq = g.node("Equal", [g.node("Floor", [a]), g.node("Floor", [b])])
+        m1 = g.node("And", [gt, lt])
+        m2 = g.node("Or", [g.node("Not", [ge]), le])
+        m3 = g.node("Xor", [m1, eq])
+        big = g.node("Div", [f32(1.0), g.node("Sub", [a, a])])                                      # 1 / 0 = inf (nan where a is nan): must not leak
+        w1 = g.node("Where", [m1, a, b])
+        w2 = g.node("Where", [m2, f32(0.0), w1])
+        w3 = g.node("Where", [g.node("Cast", [m3], to=9), big, f32(-2.0)])                          # inf selected where m3, else -2
+        w3 = g.node("Where", [m3, f32(7.0), w3])                                                    # ... and every inf replaced again
+        ci = g.node("Cast", [g.node("Mul", [a, f32(3.7)])], to=7)                                   # float -> int64: toward zero
+        cb = g.node("Cast", [g.node("Relu", [b])], to=9)                                            # float -> bool: != 0
+        masks = g.node("Add", [g.node("Cast", [m2], to=1), g.node("Mul", [g.node("Cast", [m3], to=1), f32(2.0)])])
+        outs = [w1, w2, w3, g.node("Cast", [ci], to=1), g.node("Cast", [cb], to=1), masks]
+        return g.node("Concat", [g.node("Unsqueeze", [o, i64(1)]) for o in outs], axis=1)
+    data = op_graph(build, [6, c, n])
+    got, ref = run_both(bn, data)
+    assert np.isfinite(ref).all()
+    assert np.array_equal(got, ref), float(np.abs(got - ref).max())
