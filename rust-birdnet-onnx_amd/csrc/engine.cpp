@@ -188,6 +188,7 @@ class Builder {
             plan_.storages[v.storage].pinned = true;
         }
         fuse_elementwise_chains();
+        pack_bf16x3_weights();
         plan_memory();
         for (auto &op : plan_.ops) {
             (op.mfma ? plan_.macs_mfma : plan_.macs_valu) += op.macs;
@@ -4162,6 +4163,34 @@ class Builder {
     }
 
     // --------------------------------------------------------- memory plan
+    // (round 5) every GEMM the one-tile-per-block LDS-DMA kernel takes gets its weights as three exact bf16 planes (plan_rules.h, pack_w3):
+    // the launch then runs on the bf16 matrix pipe with f32-complete products (gemm_dma3.hip).  Last pass over the descriptors: gate, pooled
+    // epilogue, inline squeeze-excite are all decided.  The f32 copy goes away with it when no other launch reads it.
+    void pack_bf16x3_weights() {
+        auto refs_of = [](PlanOp &op) {
+            std::vector<Ref *> r = {&op.a, &op.b, &op.w, &op.bias, &op.res, &op.scale, &op.w2, &op.bias2};
+            for (auto &e : op.eb) r.push_back(&e);
+            for (auto &e : op.x) r.push_back(&e);
+            return r;
+        };
+        for (auto &op : plan_.ops) {
+            if (op.kind != OpKind::GEMM || op.gemm2.N > 0 || op.gemm.fold || op.gemm.w3 || op.w.space != Space::CONSTS) continue;
+            if (!gemm_b3_shape_ok(op.gemm) && !gemm_dma3_wanted(op.gemm)) continue;
+            const int64_t N = op.gemm.N, K = op.gemm.K;
+            if ((int64_t)plan_.consts[(size_t)op.w.id].size() < op.w.offset + N * K) continue;
+            // BN_GEMM3: 0 = exact-f32 kernel, 1 = the LDS-DMA form everywhere, 2 (default) = the register-staged form wherever it applies
+            const bool b3 = gemm_b3_shape_ok(op.gemm);
+            std::vector<float> img = b3 ? pack_w3f(plan_.consts[(size_t)op.w.id].data() + op.w.offset, N, K) : pack_w3(plan_.consts[(size_t)op.w.id].data() + op.w.offset, N, K);
+            int users = 0;
+            for (auto &o2 : plan_.ops)
+                for (Ref *r : refs_of(o2)) users += r->space == Space::CONSTS && r->id == op.w.id;
+            if (users == 1 && op.w.offset == 0) plan_.consts[(size_t)op.w.id] = std::move(img);
+            else op.w = Ref{Space::CONSTS, add_const(img), 0};
+            op.gemm.w3 = b3 ? 2 : 1;
+            op.weight_bytes += 2.0 * (double)N * (double)((K + 31) / 32 * 32) + 4.0 * (double)N * (double)((K + 31) / 32 * 32 - K);  // 6 bytes per (padded) weight instead of 4
+        }
+    }
+
     void plan_memory() {
         // greedy first-fit over the linear launch order; storages are per-sample extents,
         // rounded to 64 elements so that (offset * max_batch) stays 256-byte aligned.

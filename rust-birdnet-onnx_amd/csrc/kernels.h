@@ -134,6 +134,11 @@ struct GemmDesc {
     // holds  sum_m act(row m) / rows.  Only the LDS-DMA kernel's 48-row tiles with rows == 48 (one block sees every row of the sample for its
     // channels, one wave every row of its channels): the head conv of v2.4 in front of its GlobalAveragePool.
     int32_t gap;
+    // (round 5, planner: pack_bf16x3_weights) W is the layer's weights as three bf16 planes [plane][N][Kp] (Kp = K rounded up to 32, k
+    // permuted inside every 32-deep step; plan_rules.h, pack_w3): the launch takes gemm_dma3_kernel -- f32-complete products from six
+    // bf16 matrix instructions per 32-deep k (gemm_dma3.hip).  Only where gemm_dma_shape is 1 or 2; there is no other kernel for this form.
+    // w3 == 2: the planes in FRAGMENT order (pack_w3f) for the register-staged kernel of the same arithmetic (gemm_b3.hip).
+    int32_t w3;
 };
 inline bool gemm_gap_shape_ok(const GemmDesc &d) { return d.rows == 48 && !d.has_res && !d.npost && !d.out_strided && !d.fold; }
 
@@ -315,6 +320,12 @@ void launch_gemm_fold2(hipStream_t s, const GemmDesc &d, float *C, const float *
 // launch_gemm_dma returns false (nothing launched) when the shape or a pointer's alignment rules it out.  BN_GEMMDMA=0 disables.
 bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W, const float *bias, const float *res,
                      const float *scale, int64_t batch, const SeInline *se = nullptr);
+// the same launches with GemmDesc::w3 (gemm_dma3.hip): W3 = pack_w3's image of the layer's weights
+bool launch_gemm_dma3(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W3, const float *bias, const float *res,
+                      const float *scale, int64_t batch, const SeInline *se = nullptr);
+// GemmDesc::w3 == 2 (gemm_b3.hip): W3F = pack_w3f's fragment-order image; operands through registers, one wave per 16-channel tile
+bool launch_gemm_b3(hipStream_t s, const GemmDesc &d, float *C, const float *A, const float *W3F, const float *bias, const float *res,
+                    const float *scale, int64_t batch);
 // the largest channel count whose excite products a GEMM block computes for itself (BN_SEGEMM_MAXC; 0 = never)
 void launch_conv(hipStream_t s, const ConvDesc &d, float *out, const float *in, const float *w,
                  const float *bias, const float *res, int64_t batch);

@@ -71,6 +71,7 @@ void register_stft_kernels();  // stft.hip
 void register_topk_kernels();  // topk.hip
 void register_gemm_dma_kernels();  // gemm_dma.hip
 void register_mbmap_kernels();     // mbmap.hip
+void register_gemm_dma3_kernels();  // gemm_dma3.hip
 
 bool prepare_device(int dev) {
     if (dev < 0 || dev >= 64) return false;
@@ -83,6 +84,7 @@ bool prepare_device(int dev) {
         register_topk_kernels();
         register_gemm_dma_kernels();
         register_mbmap_kernels();
+        register_gemm_dma3_kernels();
     }
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) return false;
@@ -3316,6 +3318,10 @@ void launch_gemm(hipStream_t s, const GemmDesc &d, float *C, const float *A, con
     if (d.fold && launch_frame_fold(s, d, C, A, W, bias, batch)) return;
     if (d.fold && (d.npost || d.out_strided)) {  // (planner rule E fuses a chain into a folded GEMM only where frame_fold_post_ok holds)
         launch_error("folded framing GEMM with an absorbed chain: the LDS-resident kernel refused the launch and no other kernel carries both");
+        return;
+    }
+    if (d.w3) {  // (round 5) the weights are the planner's three-plane bf16 image: only gemm_dma3_kernel reads that
+        if (!(d.w3 == 2 ? launch_gemm_b3(s, d, C, A, W, bias, res, scale, batch) : launch_gemm_dma3(s, d, C, A, W, bias, res, scale, batch))) launch_error("GEMM with bf16x3 weights: the LDS-DMA kernel refused the launch and no other kernel reads that weight form");
         return;
     }
     if (d.npost || d.out_strided) return launch_gemm_bn<32, false>(s, d, C, A, W, bias, res, scale, total_rows);

@@ -8,6 +8,8 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "kernels.h"
 
@@ -149,6 +151,111 @@ inline int gemm_dma_kslices(const GemmDesc &d, int se_cr = 0) {
         if (!fits) ks = 1;
     }
     return ks;
+}
+
+// ---- the same GEMMs on the bf16 matrix pipe with f32-complete products (gemm_dma3.hip, round 5) ------------------------------------
+// bytes of LDS of a (tile, K-slice count, ring depth) configuration: activations f32 (128 B per row and stage), weights three bf16 planes
+// (192 B per row and stage)
+inline size_t gemm_dma3_lds_bytes(const GemmDesc &d, int mtw, int ntw, int wm, int wn, int ks, int depth, int se_cr = 0) {
+    const int tr = 16 * mtw * wm, bn = 16 * ntw * wn;
+    const int gate_floats = d.has_scale ? (d.K + 1023) / 1024 * 1024 : 0;
+    const int se_floats = d.se_inline ? ((d.K + 3) & ~3) + ((se_cr + 3) & ~3) : 0;
+    return std::max((size_t)ks * depth * ((size_t)tr * 128 + (size_t)bn * 192) + (size_t)(gate_floats + se_floats) * 4,
+                    (size_t)(ks - 1) * wm * wn * mtw * ntw * 256 * sizeof(float));
+}
+// K slices of the layer (they enter the summation order: a property of the SHAPE, never of the batch): deep products run as two
+// interleaved slices through rings of TWO stages each (three would not fit the widest tile), unless even that does not fit
+inline int gemm_dma3_kslices(const GemmDesc &d, int se_cr = 0) {
+    const int force = env_int("BN_GEMM3_KS", 0);
+    int ks = (force == 1 || force == 2) ? force : (d.K >= 192 ? 2 : 1);
+    if (ks == 2) {
+        const size_t cap = 156 * 1024;
+        const bool fits = d.rows % 32 == 0 ? gemm_dma3_lds_bytes(d, 1, 8, 4, 1, 2, 2, se_cr) <= cap : gemm_dma3_lds_bytes(d, 3, 2, 1, 4, 2, 2, se_cr) <= cap;
+        if (!fits) ks = 1;
+    }
+    return ks;
+}
+// which GEMMs take the form: every one-tile-per-block LDS-DMA shape (BN_GEMM3=0 keeps the exact-f32 kernel)
+inline bool gemm_dma3_wanted(const GemmDesc &d) {
+    if (env_int("BN_GEMM3", 1) == 0 || d.w3) return false;
+    const int shape = gemm_dma_shape(d);
+    return shape == 1 || shape == 2;
+}
+// x = hi + mid + lo exactly, each the f32 of a bf16 number: hi = x with its low 16 bits cleared, mid the same of x - hi, lo the rest
+inline void split_bf16x3(float x, uint16_t &hi, uint16_t &mid, uint16_t &lo) {
+    auto top = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); u &= 0xffff0000u; float r; std::memcpy(&r, &u, 4); return r; };
+    auto bits = [](float v) { uint32_t u; std::memcpy(&u, &v, 4); return (uint16_t)(u >> 16); };
+    const float h = top(x), r1 = x - h, m = top(r1), r2 = r1 - m;
+    hi = bits(h); mid = bits(m); lo = bits(r2);
+}
+// The weights [N][K] (K contiguous) as three bf16 planes [plane][N][Kp], Kp = K rounded up to 32, returned in a vector of floats (a bit
+// container: 3 N Kp / 2 of them).  Inside every 32-deep step position 8 q + j holds k offset 4 q + j (j < 4) or 16 + 4 q + (j - 4): the
+// order in which a lane's two 16-byte activation reads (chunks q and 4 + q of the stage row) deliver its eight values.  K % 32 == 16:
+// the kernel's last stage re-reads columns K-32 .. K-1 and multiplies its first half as zeros, so the last step holds column
+// K - 16 + 4 q + (j - 4) at position 8 q + j (j >= 4) and zeros at j < 4.
+inline std::vector<float> pack_w3(const float *W, int64_t N, int64_t K) {
+    const int64_t Kp = (K + 31) & ~(int64_t)31, nfs = K / 32;
+    std::vector<uint16_t> img((size_t)(3 * N * Kp), 0);
+    for (int64_t n = 0; n < N; n++)
+        for (int64_t s = 0; s < Kp / 32; s++)
+            for (int64_t q = 0; q < 4; q++)
+                for (int64_t j = 0; j < 8; j++) {
+                    int64_t k;
+                    if (s < nfs) k = 32 * s + (j < 4 ? 4 * q + j : 16 + 4 * q + (j - 4));
+                    else k = j < 4 ? -1 : K - 16 + 4 * q + (j - 4);
+                    if (k < 0 || k >= K) continue;
+                    uint16_t h, m, l;
+                    split_bf16x3(W[n * K + k], h, m, l);
+                    const size_t at = (size_t)(n * Kp + 32 * s + 8 * q + j);
+                    img[at] = h;
+                    img[(size_t)(N * Kp) + at] = m;
+                    img[(size_t)(2 * N * Kp) + at] = l;
+                }
+    std::vector<float> out((img.size() + 1) / 2, 0.0f);
+    std::memcpy(out.data(), img.data(), img.size() * sizeof(uint16_t));
+    return out;
+}
+
+// ---- ... register-staged (gemm_b3.hip).  Its own shape rule: the kernel walks the batch's row matrix in 8-float chunks and has no
+// staging constraint on K or on the rows of a sample, so it also takes what the LDS-DMA kernels leave to the tiled one -- the expand
+// convs of the late stages (K 80 .. 232, N 480 .. 1392; Perch's K = 136 / 232 are not multiples of 16).  Not where the squeeze-excite
+// products ride in the GEMM's prologue (gemm_dma3_kernel carries those), not below four channel tiles: one wave per 16-channel tile
+// gives a block too few waves there, and those layers (the project convs of the large maps, N = 16 .. 48) are bound by their activation
+// traffic, not by the product.  Per-sample quantities only.
+inline bool gemm_b3_shape_ok(const GemmDesc &d) {
+    if (env_int("BN_GEMM3", 2) < 2) return false;
+    if (d.fold || d.npost || d.out_strided || d.se_inline || d.K % 8 || d.K < 32 || d.N % 4 || d.N <= 48 || !gemm_dma_act_ok(d.act)) return false;
+    if (d.lda % 4 || d.lda < d.K || d.ldc % 4 || d.c_bs % 4 || d.a_bs % 4 || (d.has_res && (d.ldr % 4 || d.r_bs % 4)) || (d.has_scale && d.s_bs % 4)) return false;
+    if (d.gap && !(gemm_gap_shape_ok(d) && d.rows == 48)) return false;
+    if ((int64_t)d.N * d.K >= ((int64_t)1 << 30)) return false;
+    // the expand convs only where the product is big enough to matter; tiny ones keep their kernels (and their bits)
+    return d.K >= 64 || d.has_scale;
+}
+// The weights [N][K] as three bf16 planes in FRAGMENT order: [16-channel tile][K step][plane][lane][8 bf16] -- lane (c, q) of the tile's
+// wave holds k = 32 step + 8 q .. + 7 of channel 16 tile + c, i.e. one coalesced 1-KiB load per (tile, step, plane).  Channels past N
+// and k past K -- including a whole padding step when K / 32 is odd -- are zeros.  Returned in a vector of floats (a bit container).
+inline std::vector<float> pack_w3f(const float *W, int64_t N, int64_t K) {
+    const int64_t nt16 = (N + 15) / 16, nst = ((K + 31) / 32 + 1) & ~(int64_t)1;  // an EVEN number of K steps (the kernel's loop is unrolled by two, unguarded)
+    std::vector<uint16_t> img((size_t)(nt16 * nst * 3 * 64 * 8), 0);
+    for (int64_t t = 0; t < nt16; t++)
+        for (int64_t s = 0; s < nst; s++)
+            for (int64_t lane = 0; lane < 64; lane++) {
+                const int64_t n = 16 * t + (lane & 15), q = lane >> 4;
+                if (n >= N) continue;
+                for (int64_t j = 0; j < 8; j++) {
+                    const int64_t k = 32 * s + 8 * q + j;
+                    if (k >= K) continue;
+                    uint16_t h, m, l;
+                    split_bf16x3(W[n * K + k], h, m, l);
+                    const size_t at = (size_t)((((t * nst + s) * 3) * 64 + lane) * 8 + j);
+                    img[at] = h;
+                    img[at + 64 * 8] = m;
+                    img[at + 2 * 64 * 8] = l;
+                }
+            }
+    std::vector<float> out(img.size() / 2, 0.0f);
+    std::memcpy(out.data(), img.data(), img.size() * sizeof(uint16_t));
+    return out;
 }
 
 // the largest channel count whose excite products a GEMM block computes for itself (BN_SEGEMM_MAXC; 0 = never)
