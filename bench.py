@@ -529,7 +529,9 @@ def main():
         desc = bn.plan_describe(path_for_describe(model_bytes))
         plan_lines = [l for l in desc.splitlines() if l[:3].strip().isdigit()]
         kind_of = [l.split()[1] for l in plan_lines]
-        gemm_kernel_of = [("frame_fold2_kernel" if " kernel=frame_fold2" in l else "frame_fold_kernel" if " kernel=frame_fold" in l else "gemm_dma_kernel" if " kernel=dma" in l else "gemm_splitk_kernel" if " kernel=splitk" in l else "gemm_mfma_kernel")
+        gemm_kernel_of = [("frame_fold2q_kernel" if " kernel=frame_fold2q" in l else "frame_fold2_kernel" if " kernel=frame_fold2" in l else "frame_fold_kernel" if " kernel=frame_fold" in l
+                           else "gemm_b3_kernel" if " kernel=b3" in l else "gemm_dma3_kernel" if " kernel=dma3" in l else "gemm_dma_kernel" if " kernel=dma" in l
+                           else "gemm_splitk_kernel" if " kernel=splitk" in l else "gemm_mfma_kernel")
                           if l.split()[1] == "GEMM" else None for l in plan_lines]
         fam_name = {"GEMM": "gemm_mfma_kernel", "DWCONV": "dwconv_kernel", "CONV": "conv_direct_kernel", "MBCONV": "mbconv_row_kernel",
                     "REDUCE": "reduce_kernel", "ELT": "elt_kernel", "GAP": "gap_partial_kernel", "SEFC": "se_fc_kernel", "POOL": "pool_kernel", "FFT": "stft_kernel"}
@@ -607,6 +609,15 @@ def main():
             roof["pmc_refused"] = stale
         roof.update({"traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                      "kernel": dom_sym[0], "family": dname,
+                     # (round 5) gemm_b3_kernel / gemm_dma3_kernel / frame_fold2q_kernel compute their f32 products as six exact bf16 partial products on the
+                     # bf16 matrix pipe: `achieved` stays ALGORITHMIC f32 flops per second (against the f32 MFMA peak the exact-f32 kernels are held to);
+                     # the bf16 pipe sees six times those flops against its own 2.5 PFLOP/s
+                     "bf16x3": {"symbols": sorted(k_ for k_ in sym if k_ in ("gemm_b3_kernel", "gemm_dma3_kernel", "frame_fold2q_kernel")),
+                                "kernel_is_bf16x3": dom_sym[0] in ("gemm_b3_kernel", "gemm_dma3_kernel", "frame_fold2q_kernel"),
+                                "bf16_pipe_TFLOPs_of_kernel": round(6 * 2.0 * dom_sym[1]["macs"] / (dom_sym[1]["us"] * 1e-6) / 1e12, 1) if dom_sym[0] in ("gemm_b3_kernel", "gemm_dma3_kernel", "frame_fold2q_kernel") else None,
+                                "bf16_pipe_peak_TFLOPs": 2500.0,
+                                "what": "f32 operands split exactly into three bf16 terms, six of nine partial products kept (each exact in f32, the dropped ones < 2^-24 of the product): "
+                                        "error against a double-precision product equal to the exact-f32 kernel's (tools/gemm3_bench); dtype stays f32"},
                      "kernel_alone": {"launches_per_step": dom_sym[1]["launches"], "us_per_step": round(dom_sym[1]["us"], 1), "avg_launch_us": round(dom_sym[1]["us"] / dom_sym[1]["launches"], 2),
                                       "TFLOPs": round(2.0 * dom_sym[1]["macs"] / (dom_sym[1]["us"] * 1e-6) / 1e12, 2),
                                       "frac_mfma_f32": round(2.0 * dom_sym[1]["macs"] / (dom_sym[1]["us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4)},

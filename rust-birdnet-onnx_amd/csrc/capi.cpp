@@ -1788,7 +1788,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                 if (op.gemm2.N > 0) { snprintf(line, sizeof(line), " pair=%dx%d post=%d out_rs=%lld out_cs=%lld", op.gemm2.K, op.gemm2.N, op.gemm2.npost, (long long)op.gemm2.out_rs, (long long)op.gemm2.out_cs); extra += line; }
                 // which of the three matrix kernels the launcher picks (the LDS-resident framing kernel may still fall back to
                 // the generic one at launch: BN_FRAMELDS=0 or a span that does not fit)
-                extra += op.gemm.fold == 2 ? (op.gemm.fold_wpk ? " kernel=frame_fold2p" : " kernel=frame_fold2") : op.gemm.fold ? " kernel=frame_fold" : gemm_dma_shape(op.gemm) == 3 ? " kernel=dma-stream" : op.gemm.w3 == 2 ? " kernel=b3" : op.gemm.w3 ? " kernel=dma3" : gemm_dma_shape(op.gemm) ? " kernel=dma" : (!(op.gemm.npost || op.gemm.out_strided) && gemm_use_splitk(op.gemm) ? " kernel=splitk" : " kernel=tiled");
+                extra += op.gemm.fold == 2 ? (op.gemm.fold_wpk == 2 ? " kernel=frame_fold2q" : op.gemm.fold_wpk ? " kernel=frame_fold2p" : " kernel=frame_fold2") : op.gemm.fold ? " kernel=frame_fold" : gemm_dma_shape(op.gemm) == 3 ? " kernel=dma-stream" : op.gemm.w3 == 2 ? " kernel=b3" : op.gemm.w3 ? " kernel=dma3" : gemm_dma_shape(op.gemm) ? " kernel=dma" : (!(op.gemm.npost || op.gemm.out_strided) && gemm_use_splitk(op.gemm) ? " kernel=splitk" : " kernel=tiled");
                 if (op.gemm.npost || op.gemm.out_strided) {
                     snprintf(line, sizeof(line), " post=%d out_rs=%lld out_cs=%lld", op.gemm.npost, (long long)op.gemm.out_rs, (long long)op.gemm.out_cs);
                     extra += line;

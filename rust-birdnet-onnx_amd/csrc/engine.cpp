@@ -1334,7 +1334,28 @@ class Builder {
         tabs[(size_t)Q] = w[(size_t)Q];
         tabs[(size_t)(K2 + Q)] = 0.0f;
         f.name = "Conv:" + n.name + "~quarter";
-        if (frame_fold2p_ok(f.gemm)) {  // half-height blocks: the filter fragments in the order the waves load them
+        if (frame_fold2q_ok(f.gemm)) {  // (round 5) half-height blocks on the bf16 matrix pipe: three exact bf16 planes per filter element, fragment order
+            const int64_t steps = K2 / 32;
+            std::vector<uint16_t> img((size_t)(N2 * K2 * 3), 0);  // [column group][step][16-wide k group][plane][lane][8]
+            for (int64_t wn = 0; wn < N2 / 32; wn++)
+                for (int64_t ks = 0; ks < steps; ks++)
+                    for (int64_t g = 0; g < 2; g++)
+                        for (int64_t lane = 0; lane < 64; lane++) {
+                            const int64_t lr = lane & 31, lh = lane >> 5;
+                            for (int64_t j = 0; j < 8; j++) {
+                                uint16_t h, m, l;
+                                split_bf16x3(wk[(size_t)((wn * 32 + lr) * K2 + ks * 32 + 16 * g + 8 * lh + j)], h, m, l);
+                                const size_t at = (size_t)(((((wn * steps + ks) * 2 + g) * 3) * 64 + lane) * 8 + j);
+                                img[at] = h;
+                                img[at + 64 * 8] = m;
+                                img[at + 2 * 64 * 8] = l;
+                            }
+                        }
+            std::vector<float> pk(img.size() / 2);
+            std::memcpy(pk.data(), img.data(), img.size() * sizeof(uint16_t));
+            wk.swap(pk);
+            f.gemm.fold_wpk = 2;
+        } else if (frame_fold2p_ok(f.gemm)) {  // half-height blocks: the filter fragments in the order the waves load them
             const int64_t steps = K2 / 32;
             std::vector<float> pk((size_t)(N2 * K2));
             for (int64_t wn = 0; wn < N2 / 32; wn++)

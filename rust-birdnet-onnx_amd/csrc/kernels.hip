@@ -27,6 +27,7 @@
 #include "kernels.h"
 #include "plan_rules.h"
 #include "hip_gate.h"
+#include "bf16x3.h"
 #include "device_common.h"
 
 namespace bn {
@@ -1531,6 +1532,154 @@ __global__ __launch_bounds__(64 * WN, 2) void frame_fold2p_kernel(Frame2Desc d, 
     }
 }
 
+// ---- the quarter fold on the bf16 matrix pipe with f32-complete products (round 5; bf16x3.h has the arithmetic) --------------------
+// frame_fold2p_kernel's structure -- 32 frames per block, their signal span and the two window tables resident in LDS, one wave per
+// 32-column group, filter fragments straight from global memory one step ahead -- with the S / D operand tiles written as three exact
+// bf16 planes each ([buffer][S | D][plane][32 rows][80 B]: 64 B of k + 16 of padding make the b128 fragment reads conflict free) and
+// 2 x 6 v_mfma_f32_32x32x16_bf16 per 32-tap step in place of 16 exact-f32 instructions: 384 instead of 1024 matrix cycles, and the
+// staging arithmetic (fold, window, split: ~35 vector instructions per slot) issues in their shadow instead of beside them.  The
+// planner packs the filters as [column group][step][16-wide k group][plane][lane][8 bf16] (GemmDesc::fold_wpk == 2).  All K / 32 steps
+// are ordinary ones: the tables and the filter rows are zero past tap L / 4.
+// Arithmetic: per output one chain -- steps ascending, per step two 16-deep groups, per group the six partial products smallest terms
+// first.  Other bits than the f32 forms (BN_FRAME2_B3=0 keeps those), the same tolerance of the oracle.
+template <int WN>
+__global__ __launch_bounds__(64 * WN, 2) void frame_fold2q_kernel(Frame2Desc d, float *__restrict__ C, const float *__restrict__ A, const b3_u32x4 *__restrict__ Wq,
+                                                                  const float *__restrict__ bias, const float *__restrict__ wtab, const int32_t *__restrict__ colmap,
+                                                                  FramePre pre) {
+    extern __shared__ __align__(16) float frame_lds[];
+    constexpr int BM = 32, T = 64 * WN, SLOTS = (BM * 16 + T - 1) / T;
+    constexpr uint32_t PITCH = 80, PT = BM * PITCH, BUF = 6 * PT;  // bytes: row pitch, one plane tile, one buffer (S | D x three planes)
+    const int tid = threadIdx.x;
+    float *sig = frame_lds;
+    float *tab = sig + ((d.span + 4 + 3) & ~3);  // [2][K]: wa | wb
+    float *As = tab + 2 * d.K;                   // [2 buffers][S | D][3 planes][32][80 B]
+    const int b = blockIdx.x / d.tiles, rt = blockIdx.x - b * d.tiles;
+    const int row0 = rt * BM;
+    const int rows_here = min(BM, d.rows - row0);
+    const float *src = A + (int64_t)b * d.a_bs + (int64_t)row0 * d.hop;
+    const int count = (rows_here - 1) * d.hop + d.L;
+    frame_load_span(sig, src, count, d.vec4 != 0, tid, T, pre, b);
+    if (tid < 4) sig[count + tid] = 0.0f;
+    for (int i = tid; i < 2 * d.K; i += T) tab[i] = wtab[i];
+    const int nsteps = d.K / GEMM_BK;
+    uint32_t a_fw[SLOTS], a_rv[SLOTS], a_hm[SLOTS], a_hp[SLOTS], a_dst[SLOTS];
+    const uint32_t sig0 = lds_offset_of(sig), as0 = lds_offset_of(As);
+    const int cp = (tid & 15) * 2;
+    uint32_t a_wa = lds_offset_of(tab) + 4u * cp, a_wb = a_wa + 4u * d.K;
+#pragma unroll
+    for (int i = 0; i < SLOTS; i++) {
+        const int p = tid + i * T;
+        const int r = (p >> 4) & (BM - 1);
+        const int re = r < rows_here ? r : rows_here - 1;
+        const uint32_t f = sig0 + 4u * (uint32_t)(re * d.hop);
+        a_fw[i] = f + 4u * cp;
+        a_rv[i] = f + 4u * (d.L - cp - 1);
+        a_hm[i] = f + 4u * (d.L / 2 - cp - 1);
+        a_hp[i] = f + 4u * (d.L / 2 + cp);
+        a_dst[i] = as0 + (uint32_t)r * PITCH + 2u * cp;
+    }
+    constexpr bool LAST_PARTIAL = (BM * 16) % T != 0;
+    const bool last_on = !LAST_PARTIAL || tid + (SLOTS - 1) * T < BM * 16;
+    float2 xf[SLOTS], xr[SLOTS], xm[SLOTS], xp[SLOTS], cwa, cwb;
+    auto load_a = [&]() {
+        cwa = lds_ld2(a_wa); cwb = lds_ld2(a_wb);
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) {
+            xf[i] = make_float2(lds_ld(a_fw[i]), lds_ld(a_fw[i] + 4));
+            xr[i] = make_float2(lds_ld(a_rv[i]), lds_ld(a_rv[i] + 4));
+            xm[i] = make_float2(lds_ld(a_hm[i]), lds_ld(a_hm[i] + 4));
+            xp[i] = make_float2(lds_ld(a_hp[i]), lds_ld(a_hp[i] + 4));
+        }
+    };
+    auto top = [](float v) { return __uint_as_float(__float_as_uint(v) & 0xffff0000u); };
+    auto pack = [](float hi16, float lo16) { return __builtin_amdgcn_perm(__float_as_uint(hi16), __float_as_uint(lo16), 0x07060302u); };
+    auto st32 = [](uint32_t off, uint32_t v) { *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)off = v; };
+    auto finish_a = [&](uint32_t buf_off) {
+#pragma unroll
+        for (int i = 0; i < SLOTS; i++) {
+            if (i < SLOTS - 1 || last_on) {
+                const float a0 = xf[i].x + xr[i].y, a1 = xf[i].y + xr[i].x;
+                const float b0 = xm[i].y + xp[i].x, b1 = xm[i].x + xp[i].y;
+                const float ya0 = cwa.x * a0, ya1 = cwa.y * a1, yb0 = cwb.x * b0, yb1 = cwb.y * b1;
+                const float v[4] = {ya0 + yb0, ya1 + yb1, ya0 - yb0, ya1 - yb1};  // S pair, D pair
+                float r1[4], r2[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    r1[q] = v[q] - top(v[q]);
+                    r2[q] = r1[q] - top(r1[q]);
+                }
+                const uint32_t dst = a_dst[i] + buf_off;
+                st32(dst, pack(v[1], v[0]));
+                st32(dst + PT, pack(r1[1], r1[0]));
+                st32(dst + 2 * PT, pack(r2[1], r2[0]));
+                st32(dst + 3 * PT, pack(v[3], v[2]));
+                st32(dst + 4 * PT, pack(r1[3], r1[2]));
+                st32(dst + 5 * PT, pack(r2[3], r2[2]));
+            }
+            a_fw[i] += 4 * GEMM_BK; a_hp[i] += 4 * GEMM_BK;
+            a_rv[i] -= 4 * GEMM_BK; a_hm[i] -= 4 * GEMM_BK;
+        }
+        a_wa += 4 * GEMM_BK; a_wb += 4 * GEMM_BK;
+    };
+    const int wn = tid >> 6, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int kind = wn * 32 < d.n_even ? 0 : 1;
+    // this wave's filter fragments: [wn][step][g][plane][lane] x 16 bytes
+    const b3_u32x4 *wf = Wq + ((int64_t)wn * nsteps * 6) * 64 + lane;
+    b3_u32x4 w[6], nw[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) w[q] = wf[q * 64];
+    __syncthreads();  // signal span and window tables complete
+    load_a();
+    finish_a(0);
+    __syncthreads();
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    const uint32_t ap0 = as0 + (uint32_t)kind * 3u * PT + (uint32_t)lr * PITCH + 16u * (uint32_t)lh;
+    auto ld128 = [](uint32_t off) { return *(const __attribute__((address_space(3))) b3_u32x4 *)(uintptr_t)off; };
+    auto mm32 = [](const b3_u32x4 &a, const b3_u32x4 &wv, const floatx16 &c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b3_bf16x8, a), __builtin_bit_cast(b3_bf16x8, wv), c, 0, 0, 0);
+    };
+    for (int ks = 0; ks < nsteps; ks++) {
+        const int cur = ks & 1;
+        {  // the fragments of the next step (the last step re-reads its own: loads of this loop are unconditional)
+            const b3_u32x4 *wn_ = wf + (int64_t)min(ks + 1, nsteps - 1) * 384;
+#pragma unroll
+            for (int q = 0; q < 6; q++) nw[q] = wn_[q * 64];
+        }
+        if (ks + 1 < nsteps) load_a();
+        const uint32_t ap = ap0 + (uint32_t)cur * BUF;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const b3_u32x4 ah = ld128(ap + 32u * g), am = ld128(ap + 32u * g + PT), al = ld128(ap + 32u * g + 2 * PT);
+            const b3_u32x4 &wh = w[3 * g], &wm = w[3 * g + 1], &wl = w[3 * g + 2];
+            acc = mm32(ah, wl, acc);
+            acc = mm32(al, wh, acc);
+            acc = mm32(am, wm, acc);
+            acc = mm32(ah, wm, acc);
+            acc = mm32(am, wh, acc);
+            acc = mm32(ah, wh, acc);
+        }
+        if (ks + 1 < nsteps) finish_a((uint32_t)(cur ^ 1) * BUF);
+#pragma unroll
+        for (int q = 0; q < 6; q++) w[q] = nw[q];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    const int col = wn * 32 + lr;
+    const int n = colmap[col];
+    if (n >= 0) {
+        const float bv = d.has_bias ? bias[n] : 0.0f;
+        float *cb = C + (int64_t)b * d.c_bs + (int64_t)row0 * d.ldc + n;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (r < rows_here) cb[(int64_t)r * d.ldc] = acc[reg] + bv;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ small-M GEMM: intra-block split-K
 // When the output has few 128-row tiles (late CNN stages, FC head) the kernel above leaves most
 // CUs idle.  Here a block owns one 32 x BN tile and its 4 waves split K between them (k-steps
@@ -2925,6 +3074,10 @@ void register_kernels_hip() {
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<3>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<4>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2_kernel<5>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2q_kernel<2>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2q_kernel<3>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2q_kernel<4>));
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2q_kernel<5>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2p_kernel<2>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2p_kernel<3>));
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(frame_fold2p_kernel<4>));
@@ -3261,6 +3414,28 @@ void launch_gemm_fold2(hipStream_t s, const GemmDesc &d, float *C, const float *
     f.rows = (int32_t)d.rows; f.N = d.N; f.K = d.K; f.L = d.fold_n; f.hop = (int32_t)d.lda;
     f.n_even = d.fold_ne; f.has_bias = d.has_bias;
     f.a_bs = d.a_bs; f.ldc = d.ldc; f.c_bs = d.c_bs;
+    if (d.fold_wpk == 2) {  // (round 5) the same blocks on the bf16 matrix pipe, filters as three bf16 planes in fragment order (frame_fold2q_kernel)
+        f.tiles = (int32_t)((d.rows + 31) / 32);
+        f.span = 31 * f.hop + f.L;
+        f.vec4 = d.a_bs % 4 == 0 && (32 * (int64_t)f.hop) % 4 == 0 && aligned16(A);
+        const size_t ldsq = frame_fold2q_lds_bytes(d);
+        const dim3 gridq((unsigned)((int64_t)f.tiles * batch));
+        const b3_u32x4 *Wq = reinterpret_cast<const b3_u32x4 *>(W);
+#define FOLD2Q_GO(WN)                                                                                                       \
+    do {                                                                                                                    \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(frame_fold2q_kernel<WN>), ldsq)) {                           \
+            launch_error("quarter-folded framing GEMM: the device refused the dynamic-LDS opt-in");                         \
+            return;                                                                                                         \
+        }                                                                                                                   \
+        hipLaunchKernelGGL(frame_fold2q_kernel<WN>, gridq, dim3(64 * WN), ldsq, s, f, C, A, Wq, bias, wtab, colmap, pre_v); \
+    } while (0)
+        if (d.N == 64) FOLD2Q_GO(2);
+        else if (d.N == 96) FOLD2Q_GO(3);
+        else if (d.N == 128) FOLD2Q_GO(4);
+        else FOLD2Q_GO(5);
+#undef FOLD2Q_GO
+        return;
+    }
     if (d.fold_wpk) {  // half-height blocks, filter fragments packed by the planner (frame_fold2p_kernel)
         f.tiles = (int32_t)((d.rows + 31) / 32);
         f.span = 31 * f.hop + f.L;

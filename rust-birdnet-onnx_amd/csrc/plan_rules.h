@@ -61,6 +61,12 @@ inline size_t frame_fold2p_lds_bytes(const GemmDesc &d) {
     const int64_t span = (int64_t)31 * d.lda + d.fold_n + 4;
     return (size_t)(((span + 3) & ~3) + 2 * d.K + 4 * 32 * GEMM_LD_RULE) * sizeof(float);
 }
+// ... on the bf16 matrix pipe (frame_fold2q_kernel): the operand tiles are three bf16 planes each, rows of 80 bytes
+inline size_t frame_fold2q_lds_bytes(const GemmDesc &d) {
+    const int64_t span = (int64_t)31 * d.lda + d.fold_n + 4;
+    return (size_t)(((span + 3) & ~3) + 2 * d.K) * sizeof(float) + (size_t)2 * 6 * 32 * 80;
+}
+inline bool frame_fold2q_ok(const GemmDesc &d) { return env_int("BN_FRAME2_B3", 1) != 0 && env_int("BN_GEMM3", 2) != 0 && frame_fold2q_lds_bytes(d) <= 80 * 1024; }
 inline bool frame_fold2p_ok(const GemmDesc &d) { return env_int("BN_FRAME2_WPK", 1) != 0 && frame_fold2p_lds_bytes(d) <= 80 * 1024; }
 inline bool frame_fold2_shape_ok(const GemmDesc &d, const float *W) {
     if (env_int("BN_FRAMELDS", 1) == 0 || env_int("BN_CONVFOLD2", 1) == 0) return false;

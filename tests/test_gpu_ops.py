@@ -1317,3 +1317,95 @@ def test_comparisons_logic_where_and_casts(bn):
     got, ref = run_both(bn, data)
     assert np.isfinite(ref).all()
     assert np.array_equal(got, ref), float(np.abs(got - ref).max())
+
+
+# ---------------------------------------------------------------- GEMMs on the bf16 matrix pipe with f32-complete products (round 5)
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,h,w,cout,act,kernel", [
+    (240, 6, 32, 80, "relu", "b3"),      # a late project-conv shape: 192 rows per sample, 15 K steps padded to 16
+    (672, 6, 32, 112, None, "b3"),       # K = 672: 21 steps + the zero padding step; seven channel tiles = seven waves
+    (1152, 3, 16, 320, "silu", "b3"),    # 48 rows per sample: row tiles span samples; three channel blocks of 7 / 7 / 6 tiles
+    (136, 8, 32, 816, "silu", "b3"),     # an expand conv the tiled kernel used to keep: K % 16 == 8, N = 51 tiles
+    (80, 5, 16, 100, "relu", "b3"),      # 80 rows per sample (no multiple of 32), N = 100: a partial last channel tile
+    (144, 8, 16, 40, None, "dma3"),      # narrow project conv: the LDS-DMA form, K % 32 == 16 (half step)
+    (256, 4, 16, 24, "relu", "dma3"),
+])
+def test_gemm_bf16x3_forms_against_the_oracle_and_the_exact_f32_kernels(bn, cin, h, w, cout, act, kernel, monkeypatch):
+    """1x1 convs that take gemm_b3_kernel / gemm_dma3_kernel (exact three-way bf16 split of both operands, six partial products on the
+    bf16 matrix pipe): the plan names the kernel, the result agrees with the oracle far inside the suite's tolerance -- to a few f32
+    roundings of the sum, like the exact-f32 kernel the same layer gets under BN_GEMM3=0 -- and does not depend on the row tile, the batch
+    it rides in or its position in the batch (bit for bit)."""
+    rng0 = np.random.default_rng(cin + cout)
+    wa = (rng0.standard_normal((cin, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+    wt = (rng0.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+    wb = (rng0.standard_normal((8, cout, 1, 1)) / np.sqrt(cout)).astype(np.float32)
+
+    def build(g, xin):  # 1x1 (brings the map into the channels-last layout) -> the conv under test, dense in and out -> 1x1 down to 8 channels
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        y = g.node("Reshape", [g.node("Slice", [xin, i64(0), i64(cin * h * w), i64(1), i64(1)]), i64(-1, cin, h, w)])
+        y = g.node("Conv", [y, g.const(wa)], kernel_shape=[1, 1])
+        y = g.node("Conv", [y, g.const(wt), g.const(rng0.standard_normal(cout).astype(np.float32))], kernel_shape=[1, 1])
+        if act == "relu":
+            y = g.node("Relu", [y])
+        elif act == "silu":
+            y = g.node("Mul", [y, g.node("Sigmoid", [y])])
+        return g.node("Conv", [y, g.const(wb)], kernel_shape=[1, 1])
+    data = op_graph(build, [8, h, w])
+    path = write_model(data)
+    text = bn.plan_describe(path)
+    under_test = [l for l in text.splitlines() if f" K={cin} N={cout} " in l]
+    assert len(under_test) == 1 and f"kernel={kernel}" in under_test[0], text
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((5, 144000))).astype(np.float32)
+    ref = onnx_ref.run_model(data, x)["output"].reshape(5, -1)
+    got = bn.Context(bn.Model(path), 5).infer(x)[0].reshape(5, -1).copy()
+    scale = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 2e-5 * scale, (np.abs(got - ref).max(), scale)
+    monkeypatch.setenv("BN_GEMM3", "0")
+    assert "kernel=b3" not in bn.plan_describe(path) and "kernel=dma3" not in bn.plan_describe(path)
+    f32 = bn.Context(bn.Model(path), 5).infer(x)[0].reshape(5, -1).copy()
+    monkeypatch.delenv("BN_GEMM3")
+    assert np.abs(f32 - ref).max() <= 2e-5 * scale
+    assert np.abs(got - f32).max() <= 2e-5 * scale
+    # the tile and the batch do not enter the arithmetic
+    one = np.concatenate([bn.Context(bn.Model(path), 1).infer(x[i:i + 1])[0].reshape(1, -1) for i in (0, 4)])
+    assert one.tobytes() == got[[0, 4]].tobytes()
+    if kernel == "b3":
+        for mt in ("2", "4", "8"):
+            monkeypatch.setenv("BN_GEMMB3_MT", mt)
+            alt = bn.Context(bn.Model(path), 5).infer(x)[0].reshape(5, -1)
+            assert alt.tobytes() == got.tobytes(), mt
+        monkeypatch.delenv("BN_GEMMB3_MT")
+    big = np.tile(x, (7, 1))[:33]
+    many = bn.Context(bn.Model(path), 33).infer(big)[0].reshape(33, -1)
+    assert many[:5].tobytes() == got.tobytes() and many[30:33].tobytes() == got[[0, 1, 2]].tobytes()
+
+
+@pytest.mark.gpu
+def test_bf16x3_split_is_exact_and_the_weight_images_round_trip(bn):
+    """The arithmetic's premise, on the host packer the planner uses (through the plan's constants nothing is observable, so the check runs
+    on numpy's restatement of the same three masks / subtractions): x == hi + mid + lo exactly for every finite f32, each term a bf16
+    number; and the device agrees with it -- a GEMM whose weights are powers of two times ones reproduces its input sums exactly."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(100000).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, 100000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 3.4e38, 1.2e-30], dtype=np.float32)])
+    x = x[(np.abs(x) >= np.float32(1e-30)) | (x == 0)]  # (below 2^-100 the third term leaves bf16's normal range: not activations)
+    top = lambda v: (v.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+    hi = top(x); r1 = x - hi; mid = top(r1); lo = r1 - mid
+    assert np.array_equal(hi + mid + lo, x) and np.array_equal((lo.view(np.uint32) & np.uint32(0xffff)), np.zeros_like(lo.view(np.uint32)))
+    # identity-like product: out[n] = x[k == n] * 2^-3 (exact in every arithmetic that keeps 24 bits)
+    cin = cout = 128
+
+    def build(g, xin):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        y = g.node("Reshape", [g.node("Slice", [xin, i64(0), i64(cin * 64), i64(1), i64(1)]), i64(-1, cin, 8, 8)])
+        eye = lambda f: g.const((np.eye(cin, dtype=np.float32) * np.float32(f)).reshape(cout, cin, 1, 1))
+        y = g.node("Conv", [y, eye(1.0)], kernel_shape=[1, 1])        # into the channels-last layout
+        y = g.node("Conv", [y, eye(0.125)], kernel_shape=[1, 1])      # dense in, dense out: the bf16x3 kernel
+        return g.node("Conv", [y, eye(2.0)], kernel_shape=[1, 1])     # (its output view is the graph's NCHW: the tiled f32 kernel)
+    data = op_graph(build, [cout, 8, 8])
+    assert bn.plan_describe(write_model(data)).count("kernel=b3") == 2
+    xs = (rng.standard_normal((2, 144000)) * 3.0).astype(np.float32)
+    got = bn.Context(bn.Model(write_model(data)), 2).infer(xs)[0].reshape(2, -1)
+    want = (xs[:, :cin * 64] * np.float32(0.25))
+    assert np.array_equal(got, want)
