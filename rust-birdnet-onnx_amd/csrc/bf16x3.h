@@ -32,6 +32,10 @@ __device__ __forceinline__ void split3(const b3_floatx4 &a, const b3_floatx4 &b,
 __device__ __forceinline__ b3_floatx4 mm_bf16(const b3_u32x4 &w, const b3_u32x4 &x, const b3_floatx4 &acc) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b3_bf16x8, w), __builtin_bit_cast(b3_bf16x8, x), acc, 0, 0, 0);
 }
+typedef float b3_floatx16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ b3_floatx16 mm32_bf16(const b3_u32x4 &a, const b3_u32x4 &b, const b3_floatx16 &acc) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b3_bf16x8, a), __builtin_bit_cast(b3_bf16x8, b), acc, 0, 0, 0);
+}
 // the six partial products of one 16 x 16 tile and 32-deep k, smallest terms first (fixed order: part of every output's arithmetic)
 __device__ __forceinline__ b3_floatx4 mm6(const b3_u32x4 &wh, const b3_u32x4 &wm, const b3_u32x4 &wl, const b3_u32x4 &xh, const b3_u32x4 &xm,
                                           const b3_u32x4 &xl, b3_floatx4 a) {

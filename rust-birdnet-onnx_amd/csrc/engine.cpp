@@ -1490,6 +1490,7 @@ class Builder {
         if (!force && !tr && util < 0.7) return;
         m.row_mode = 1;
         m.row_tr = tr ? 1 : 0;
+        m.row_b3 = (env_int("BN_MBROW_B3", 1) != 0 && env_int("BN_GEMM3", 2) != 0 && m.k1 == 0 && m.Cin % 8 == 0) ? 1 : 0;
         const int rows_k = tr ? m.OW : m.OH, cols_k = tr ? m.OH : m.OW;  // the kernel's output rows / columns
         // band height: a band of toh output rows expands (toh - 1) s + k halo rows, so taller bands recompute less (12 rows of a
         // 5x5 block: 16 halo rows instead of 2 x 10) -- what several contexts sharing the chip pay for; a block with one or two

@@ -16,7 +16,9 @@
 //     coalesced 1-KiB load per (tile, step, plane), PF steps ahead, no LDS, no barrier;
 //   * activations: each thread loads 8 consecutive k of one row (32 B; a wave covers 16 rows x 128 B), multiplies the squeeze-excite
 //     gate in (f32), splits ONCE for the whole block and writes the three bf16 planes to LDS ([plane][row][64 B], 16-byte chunk c of
-//     row r in slot c ^ ((r >> 2) & 3): conflict-free b128 writes and fragment reads); double-buffered, ONE raw barrier per K step;
+//     row r in slot c ^ (-(r >> 2) & 3): ds_read_b128 is served in four NON-contiguous 16-lane groups -- {0-3, 12-15, 20-27}, ... -- so a
+//     fragment read puts rows {0-3, 12-15} at chunk q and rows {4-11} at chunk q ^ 1 on the bank row at once; the first layout, c ^ ((r >> 2) & 3),
+//     was 2-way conflicted, PMC 41 - 44 % of the LDS cycles); double-buffered, ONE raw barrier per K step;
 //   * a block is TR = 16 MT rows of the BATCH's row matrix (tiles may span samples: the gate is per row) x NW channel tiles, one wave
 //     per channel tile: 6 MT matrix instructions, 3 MT fragment reads and 3 weight loads per wave and K step.
 //
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__r
         const int64_t b = g / d.rows, m = g - b * d.rows;
         xsrc[j] = A + b * d.a_bs + m * d.lda;
         gsrc[j] = GATED ? scale + b * d.s_bs : nullptr;
-        wofs[j] = row * 64 + 16 * (kc[j] ^ ((row >> 2) & 3));
+        wofs[j] = row * 64 + 16 * (kc[j] ^ ((0 - (row >> 2)) & 3));
     }
     const int t16 = min((int)blockIdx.y * NW + wave, nt16 - 1);  // this wave's channel tile (a padding wave repeats the last one, stores nothing)
     const u32x4 *wsrc = W3F + (int64_t)t16 * nst * 192 + lane;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__r
     floatx4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const int aoff = lc * 64 + 16 * (lq ^ ((lc >> 2) & 3));
+    const int aoff = lc * 64 + 16 * (lq ^ ((0 - (lc >> 2)) & 3));
     auto compute = [&](int u, int buf) {
         const char *ab = lds + buf * BUF_BYTES + aoff;
 #pragma unroll

@@ -79,7 +79,8 @@ __device__ __forceinline__ floatx4 mm(const u32x4 &w, const u32x4 &x, const floa
 // MTW x NTW 16x16 tiles per wave, WM x WN waves per K slice, KS K slices (slice ks takes the 32-deep K steps ks, ks + KS, ...
 // through a ring of D stages of its own), block = 64 WM WN KS threads, tile = (16 MTW WM) rows x (16 NTW WN) channels.
 // Stage image (bytes): [TR rows x 128: f32 activations, chunk c of row r in slot c ^ ((r >> 1) & 7)]
-//                      [3 planes x BN rows x 64: bf16 weights, chunk c of row r in slot c ^ ((r >> 2) & 3)]
+//                      [3 planes x BN rows x 64: bf16 weights, chunk c of row r in slot c ^ (-(r >> 2) & 3): conflict free for ds_read_b128's
+//                       four non-contiguous 16-lane groups (gemm_b3.hip has the derivation)]
 // GATE as in gemm_dma_kernel: 0 plain, 1 gate read from memory, 2 gate computed in the prologue from the squeeze partial sums.
 template <int MTW, int NTW, int WM, int WN, int KS, int D, int GATE>
 __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma3_kernel(GemmDesc d, float *__restrict__ C, const float *__restrict__ A, const uint16_t *__restrict__ W3,
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma3_kernel(GemmDesc d
         } else {
             const int pw = p - XP, plane = pw / WPP, rblk = pw - plane * WPP;
             const int r16 = lane >> 2;
-            const int chunk = (lane & 3) ^ ((r16 >> 2) & 3);
+            const int chunk = (lane & 3) ^ ((0 - (r16 >> 2)) & 3);
             int grow = n0 + 16 * rblk + r16;
             grow = grow < d.N ? grow : d.N - 1;
             off[j] = ((uint32_t)plane * (uint32_t)d.N + (uint32_t)grow) * (uint32_t)Kp + 8u * (uint32_t)chunk;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_dma3_kernel(GemmDesc d
 #pragma unroll
     for (int nt = 0; nt < NTW; nt++) {
         const int r = (wn * NTW + nt) * 16 + lc;
-        woff[nt] = X_BYTES + r * 64 + 16 * (lq ^ ((lc >> 2) & 3));
+        woff[nt] = X_BYTES + r * 64 + 16 * (lq ^ ((0 - (lc >> 2)) & 3));
     }
 
     // one 32-deep K step of the stage at sb.  kcol: first column of the stage (gate index); TAIL: the stage holds columns K-32 .. K-1

@@ -199,6 +199,9 @@ struct MbDesc {
     // each, squeeze sums partial per band: tiles_y = bands), the kernel's rows are the map's columns, floats per input / filter row
     // in LDS (Cin rounded up to 16: the planner pads w1's rows to it, the missing input chunks are read from a page of zeros)
     int32_t map_bands, map_tr, cin_pad;
+    // (round 5) row-streaming form: the expand conv on the bf16 matrix pipe with f32-complete products (bf16x3.h): 1x1 expands with
+    // Cin % 8 == 0; decided by the planner (BN_MBROW_B3, BN_GEMM3), part of the block's arithmetic like any kernel choice
+    int32_t row_b3;
 };
 // MaxPool / AveragePool over an NHWC tensor (1-D pooling = H == 1).
 struct PoolDesc {

@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include "bf16x3.h"
 #include "device_common.h"
 #include "kernels.h"
 #include "plan_rules.h"
@@ -112,15 +113,19 @@ __device__ __forceinline__ void row_act_t(int act, float p0, float p1, float (&v
 // Waves per SIMD the instance is compiled for: two (256 registers each) wherever everything fits; the instances whose live state does not
 // (5 x 5 windows with SiLU / run-time activations or five and more K groups; run-time activations with six K groups or an im2col stem) get
 // one wave's 512 registers instead of spilling to scratch memory -- tests/test_build_hygiene.py keeps the build free of scratch
-template <int K, int NG, int S, bool IM2COL, int ACT>
+template <int K, int NG, int S, bool IM2COL, int ACT, bool B3 = false>
 constexpr int mbrow_waves_per_simd() {
+    if (B3 && K == 5 && NG >= 5) return 1;  // (three filter planes + the split's temporaries: 36 - 40 bytes of scratch at 256 registers)
     if (K == 5 && (ACT != ACT_RELU || (S == 1 && NG >= 5))) return 1;
     if (ACT != ACT_RELU && ACT != ACT_SILU && (NG >= 6 || IM2COL)) return 1;
     if (IM2COL && ACT == ACT_SILU && NG >= 4) return 1;
     return 2;
 }
-template <int K, int S, int NG, bool IM2COL, int ACT, bool TR = false>
-__global__ __launch_bounds__(256, (mbrow_waves_per_simd<K, NG, S, IM2COL, ACT>())) void mbconv_row_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
+// B3 (round 5): the expand conv as six exact-bf16 partial products per 16-deep k group on the bf16 matrix pipe (bf16x3.h) -- 1x1 expands with
+// Cin % 8 == 0 only.  Lane (pixel lr, lh) then feeds k = 16 G + 8 lh .. + 7 of group G (two float4 loads, split in registers: ~44 vector
+// instructions per group and halo row, which issue in the matrix instructions' shadow), the filters are split once per unit.
+template <int K, int S, int NG, bool IM2COL, int ACT, bool TR = false, bool B3 = false>
+__global__ __launch_bounds__(256, (mbrow_waves_per_simd<K, NG, S, IM2COL, ACT, B3>())) void mbconv_row_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                             const float *__restrict__ w1, const float *__restrict__ b1,
                                                             const float *__restrict__ w2, const float *__restrict__ b2,
                                                             float *__restrict__ gap, int total_units) {
@@ -152,12 +157,28 @@ __global__ __launch_bounds__(256, (mbrow_waves_per_simd<K, NG, S, IM2COL, ACT>()
     const int xm = 16 * ((lr >> 2) & 1) + 4 * (lr >> 3) + (lr & 3);
     const int ixc = min(max(ix0 + xm, 0), d.W - 1);  // clamped: the loads never leave the row, masked columns are zeroed after the act
     constexpr int ngr = NG;                           // K groups: the launcher picks the instance with NG == ceil(Cin / 8)
-    float4 bw[NG];
+    static_assert(!B3 || !IM2COL, "the bf16 form is for 1x1 expands");
+    constexpr int NG16 = (NG + 1) / 2;        // B3: 16-deep k groups; an odd NG leaves the last group's upper half (lh == 1) as padding
+    constexpr bool B3_PAD = B3 && (NG & 1);
+    float4 bw[B3 ? 1 : NG];
+    b3_u32x4 bwh[B3 ? NG16 : 1], bwm[B3 ? NG16 : 1], bwl[B3 ? NG16 : 1];
     {
         const int n = min(ch * 32 + lr, d.C - 1);
-        const float *wr = w1 + (int64_t)n * (ngr * 8) + 4 * lh;
+        if constexpr (B3) {
+            const float *wr = w1 + (int64_t)n * (ngr * 8);
 #pragma unroll
-        for (int g = 0; g < NG; g++) bw[g] = *reinterpret_cast<const float4 *>(wr + 8 * g);
+            for (int G = 0; G < NG16; G++) {
+                const bool pad = B3_PAD && G == NG16 - 1 && lh == 1;
+                const float *p = wr + (pad ? 0 : 16 * G + 8 * lh);
+                b3_floatx4 lo4 = *reinterpret_cast<const b3_floatx4 *>(p), hi4 = *reinterpret_cast<const b3_floatx4 *>(p + 4);
+                if (pad) lo4 = hi4 = b3_floatx4{0.f, 0.f, 0.f, 0.f};
+                split3(lo4, hi4, bwh[G], bwm[G], bwl[G]);
+            }
+        } else {
+            const float *wr = w1 + (int64_t)n * (ngr * 8) + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < NG; g++) bw[g] = *reinterpret_cast<const float4 *>(wr + 8 * g);
+        }
     }
     // ---- accumulator / depthwise role: lane (c, lh) owns channel cg, halo pixels 16*lh .. 16*lh + 15
     const int cg = ch * 32 + lr;
@@ -239,11 +260,13 @@ __global__ __launch_bounds__(256, (mbrow_waves_per_simd<K, NG, S, IM2COL, ACT>()
     // step one map row)
     const int64_t a_rs = tr ? (int64_t)d.Cin : (int64_t)d.W * d.Cin;   // floats per input row
     const int a_px = tr ? d.H * d.Cin : d.Cin;                          // floats per input column step
-    const unsigned a_lane4 = 4u * (unsigned)(ixc * a_px + 4 * lh);            // byte offset of this lane's pixel + K half within the row
+    const unsigned a_lane4 = 4u * (unsigned)(ixc * a_px + (B3 ? 8 : 4) * lh);  // byte offset of this lane's pixel + K half within the row
     const unsigned a_last4 = a_lane4 + (pad_lane ? 0u : 32u * (NG - 1));  // channel-padding lanes re-read group 0 (then zeroed)
-    float4 abuf[2][NG];
+    constexpr int NA = B3 ? 2 * NG16 : NG;  // float4 operands per halo row and lane
+    const bool b3_pad_lane = B3_PAD && lh == 1;
+    float4 abuf[2][NA];
 #pragma unroll
-    for (int g = 0; g < NG; g++) abuf[0][g] = abuf[1][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < NA; g++) abuf[0][g] = abuf[1][g] = make_float4(0.f, 0.f, 0.f, 0.f);
     // operands of halo row J (clamped into the image: rows outside it are zeroed after the expansion)
 #define MBROW_LOAD_A(dst, J)                                                                                                    \
     do {                                                                                                                        \
@@ -272,6 +295,16 @@ __global__ __launch_bounds__(256, (mbrow_waves_per_simd<K, NG, S, IM2COL, ACT>()
                     }                                                                                                           \
                     dst[g] = make_float4(v_[0], v_[1], v_[2], v_[3]);                                                           \
                 }                                                                                                               \
+            }                                                                                                                   \
+        } else if constexpr (B3) { /* k = 16 G + 8 lh .. + 7: two float4 per group; a padded upper half re-reads group 0 and is zeroed */ \
+            const char *prow_ = reinterpret_cast<const char *>(xin + (int64_t)iy_ * a_rs);                                      \
+            _Pragma("unroll") for (int G = 0; G < NG16; G++) {                                                                  \
+                const unsigned o_ = a_lane4 + ((G == NG16 - 1 && b3_pad_lane) ? 0u : 64u * G);                                  \
+                dst[2 * G] = *reinterpret_cast<const float4 *>(prow_ + o_);                                                     \
+                dst[2 * G + 1] = *reinterpret_cast<const float4 *>(prow_ + o_ + 16);                                            \
+            }                                                                                                                   \
+            if (B3_PAD) {                                                                                                       \
+                if (b3_pad_lane) dst[2 * NG16 - 2] = dst[2 * NG16 - 1] = make_float4(0.f, 0.f, 0.f, 0.f);                       \
             }                                                                                                                   \
         } else {                                                                                                                \
             const char *prow_ = reinterpret_cast<const char *>(xin + (int64_t)iy_ * a_rs); /* wave-uniform row base */          \
@@ -313,11 +346,25 @@ __global__ __launch_bounds__(256, (mbrow_waves_per_simd<K, NG, S, IM2COL, ACT>()
             acc = bvec;                                                                                                         \
             break;                                                                                                              \
         }                                                                                                                       \
-        _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                                        \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].x, bw[g].x, g == 0 ? bvec : acc, 0, 0, 0);                          \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].y, bw[g].y, acc, 0, 0, 0);                                          \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].z, bw[g].z, acc, 0, 0, 0);                                          \
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].w, bw[g].w, acc, 0, 0, 0);                                          \
+        if constexpr (B3) {                                                                                                     \
+            _Pragma("unroll") for (int G = 0; G < NG16; G++) {                                                                  \
+                b3_u32x4 xh_, xm_, xl_;                                                                                         \
+                split3(b3_floatx4{A[2 * G].x, A[2 * G].y, A[2 * G].z, A[2 * G].w},                                              \
+                       b3_floatx4{A[2 * G + 1].x, A[2 * G + 1].y, A[2 * G + 1].z, A[2 * G + 1].w}, xh_, xm_, xl_);              \
+                acc = mm32_bf16(xh_, bwl[G], G == 0 ? bvec : acc);                                                              \
+                acc = mm32_bf16(xl_, bwh[G], acc);                                                                              \
+                acc = mm32_bf16(xm_, bwm[G], acc);                                                                              \
+                acc = mm32_bf16(xh_, bwm[G], acc);                                                                              \
+                acc = mm32_bf16(xm_, bwh[G], acc);                                                                              \
+                acc = mm32_bf16(xh_, bwh[G], acc);                                                                              \
+            }                                                                                                                   \
+        } else {                                                                                                                \
+            _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                                    \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].x, bw[g].x, g == 0 ? bvec : acc, 0, 0, 0);                      \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].y, bw[g].y, acc, 0, 0, 0);                                      \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].z, bw[g].z, acc, 0, 0, 0);                                      \
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[g].w, bw[g].w, acc, 0, 0, 0);                                      \
+            }                                                                                                                   \
         }                                                                                                                       \
     } while (0)
     // activation of the expanded row J into slot SLOT (+ masks, + the neighbouring half's first EXT values)
@@ -467,9 +514,22 @@ static void launch_mbconv_row_impl(hipStream_t s, const MbDesc &d, float *out, c
         else hipLaunchKernelGGL((mbconv_row_kernel<K, S, NG, IM, -1>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
     } while (0)
 #endif
+    // (round 5) the expand on the bf16 matrix pipe: the planner's choice (MbDesc::row_b3), 1x1 expands with whole 8-channel groups
+#define ROW_LAUNCH3(K, S, NG)                                                                                                              \
+    do {                                                                                                                                   \
+        if (actc == ACT_RELU) hipLaunchKernelGGL((mbconv_row_kernel<K, S, NG, false, ACT_RELU, false, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
+        else if (actc == ACT_SILU) hipLaunchKernelGGL((mbconv_row_kernel<K, S, NG, false, ACT_SILU, false, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
+        else hipLaunchKernelGGL((mbconv_row_kernel<K, S, NG, false, -1, false, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
+    } while (0)
 #define ROW_NG(K, S)                                    \
     do {                                                \
-        if (ng <= 2) ROW_LAUNCH(K, S, 2, false);        \
+        if (d.row_b3 && d.Cin % 8 == 0) {               \
+            if (ng <= 2) ROW_LAUNCH3(K, S, 2);          \
+            else if (ng == 3) ROW_LAUNCH3(K, S, 3);     \
+            else if (ng == 4) ROW_LAUNCH3(K, S, 4);     \
+            else if (ng == 5) ROW_LAUNCH3(K, S, 5);     \
+            else ROW_LAUNCH3(K, S, 6);                  \
+        } else if (ng <= 2) ROW_LAUNCH(K, S, 2, false); \
         else if (ng == 3) ROW_LAUNCH(K, S, 3, false);   \
         else if (ng == 4) ROW_LAUNCH(K, S, 4, false);   \
         else if (ng == 5) ROW_LAUNCH(K, S, 5, false);   \
@@ -512,6 +572,7 @@ static void launch_mbconv_row_impl(hipStream_t s, const MbDesc &d, float *out, c
 #undef ROW_NG_T
 #undef ROW_LAUNCH_T
 #undef ROW_NG
+#undef ROW_LAUNCH3
 #undef ROW_LAUNCH
 }
 

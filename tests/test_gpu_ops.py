@@ -841,9 +841,16 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
             assert ("tiles=1x1" in desc) == (variant == "map" or (oh <= (8 if stride == 1 else 4) and ow <= (16 if stride == 1 else 8)))
         got, ref = run_both(bn, data)
         if variant == "row":
+            # (round 5) the default row kernel runs its expand on the bf16 matrix pipe where Cin % 8 == 0 (bf16x3: other bits, the oracle's
+            # tolerance -- asserted at the end); its exact-f32 form (BN_MBROW_B3=0) is the one that repeats the tiled kernel's bits
+            os.environ["BN_MBROW_B3"] = "0"
+            f32row, _ = run_both(bn, data)
             os.environ["BN_MBROW"] = "0"
             tiled, _ = run_both(bn, data)
-            assert np.array_equal(got.view(np.uint32), tiled.view(np.uint32)), "row-streaming kernel differs from the tiled kernel"
+            del os.environ["BN_MBROW_B3"]
+            os.environ["BN_MBROW"] = "force"
+            assert np.array_equal(f32row.view(np.uint32), tiled.view(np.uint32)), "row-streaming kernel differs from the tiled kernel"
+            assert np.abs(got - f32row).max() <= 2e-5 * np.abs(ref).max()
             if k == 3:
                 # ... and streaming along the map's COLUMNS (round 3: tall narrow maps; the depthwise taps then meet in (kx, ky)
                 # order, so the bits may differ from the tiled kernel's: checked against the oracle)
@@ -852,8 +859,8 @@ def test_fused_expand_depthwise(bn, cin, h, w, cmid, k, stride, act, variant):
                 got_t, _ = run_both(bn, data)
                 assert_close(got_t, ref, f"mbconv[row, transposed] {cin}->{cmid} k{k} s{stride}")
     finally:
-        for key in ("BN_MBFUSE", "BN_MBMAP", "BN_MBMAP_MAXHW", "BN_MBPIPE", "BN_MBROW", "BN_MBROW_TOH", "BN_MBROW_TR"):
-            del os.environ[key]
+        for key in ("BN_MBFUSE", "BN_MBMAP", "BN_MBMAP_MAXHW", "BN_MBPIPE", "BN_MBROW", "BN_MBROW_TOH", "BN_MBROW_TR", "BN_MBROW_B3"):
+            os.environ.pop(key, None)
     assert_close(got, ref, f"mbconv[{variant}] {cin}->{cmid} k{k} s{stride}")
 
 
@@ -938,11 +945,12 @@ def test_pipelined_mbconv_is_bit_identical_to_the_plain_kernel(bn):
         os.environ["BN_MBPIPE"] = mode
         os.environ["BN_MBROW"] = row
         os.environ["BN_MBFUSE"] = "force"
+        os.environ["BN_MBROW_B3"] = "0"   # (the exact-f32 form of the row kernel: the one whose bits the tiled kernels repeat)
         try:
             assert "MBCONV" in bn.plan_describe(write_model(data))
             outs.append(run_both(bn, data, batch=3)[0].copy())
         finally:
-            del os.environ["BN_MBPIPE"], os.environ["BN_MBFUSE"], os.environ["BN_MBROW"]
+            del os.environ["BN_MBPIPE"], os.environ["BN_MBFUSE"], os.environ["BN_MBROW"], os.environ["BN_MBROW_B3"]
     assert outs[0].tobytes() == outs[1].tobytes() == outs[2].tobytes()
 
 
