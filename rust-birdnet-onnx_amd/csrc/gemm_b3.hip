@@ -23,7 +23,9 @@
 //     per channel tile: 6 MT matrix instructions, 3 MT fragment reads and 3 weight loads per wave and K step.
 //
 // Arithmetic: an output element is one accumulation chain -- K steps ascending, inside a step the six partial products in mm6's order
-// -- independent of the tile shape, the batch and the prefetch depth.  Same bits as gemm_dma3_kernel's K-slice-free form; other bits
+// -- independent of the tile shape, the batch and the prefetch depth.  (Measured and dropped, tools/gemm3_bench: four K steps of prefetch
+// instead of two -- 217 -> 238 us over the models' shapes at batch 32, 514 -> 631 us at batch 128; two K steps per barrier -- 224 -> 246 us over the models' shapes at batch 32, 523 ->
+// 662 us at batch 128; 128-row tiles -- slower at every size.)  Same bits as gemm_dma3_kernel's K-slice-free form; other bits
 // than the exact-f32 kernels (another summation order, the dropped 2^-24 terms), inside the same tolerance of the oracle.
 #include <hip/hip_runtime.h>
 
@@ -53,11 +55,11 @@ __device__ __forceinline__ void gb_act(int act, float p0, float p1, float (&v)[N
 }
 
 // MT 16-row tiles per block (every wave multiplies all of them), NW waves = NW 16-channel tiles
-template <int MT, int NW, bool GATED>
+template <int MT, int NW, bool GATED, int PF>
 __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__restrict__ C, const float *__restrict__ A, const u32x4 *__restrict__ W3F,
                                                            const float *__restrict__ bias, const float *__restrict__ res, const float *__restrict__ scale,
-                                                           int64_t total_rows, int nt16, int nst) {
-    constexpr int PF = 2;  // K steps of both operands in flight (four measured no faster and spills at the wide tiles)
+                                                           int64_t total_rows, int nt16, int nst4, int nst) {
+    static_assert(PF == 2 || PF == 4, "K steps of both operands in flight");
     constexpr int TR = 16 * MT, T = 64 * NW, SLOTS = 4 * TR, XS = (SLOTS + T - 1) / T;
     constexpr int PLANE_BYTES = TR * 64, BUF_BYTES = 3 * PLANE_BYTES;
     extern __shared__ __align__(1024) float gb_lds[];
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__r
         wofs[j] = row * 64 + 16 * (kc[j] ^ ((0 - (row >> 2)) & 3));
     }
     const int t16 = min((int)blockIdx.y * NW + wave, nt16 - 1);  // this wave's channel tile (a padding wave repeats the last one, stores nothing)
-    const u32x4 *wsrc = W3F + (int64_t)t16 * nst * 192 + lane;
+    const u32x4 *wsrc = W3F + (int64_t)t16 * nst4 * 192 + lane;  // (the planes hold nst4 = a multiple of four K steps per tile, zeros past K)
 
     floatx4 xr[PF][XS][2], gr[PF][XS][2];
     u32x4 wr[PF][3];
@@ -159,21 +161,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__r
     // i.e. one L2 round trip per K step (seen in the first build's ISA; 0.6 us per step).  The re-loaded last step and the planes written
     // behind the last step are never read.
     const int last = nst - 1;
-    load_x(0, 0);
-    load_w(0, 0);
-    load_x(1, 1);
-    load_w(1, 1);
-    write_x(0, 0, 0);
-    load_x(min(2, last), 0);
-    sync();
-    for (int i0 = 0; i0 < nst; i0 += 2) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < PF; u++) {
+        load_x(min(u, last), u);
+        load_w(min(u, last), u);
+    }
+    write_x(0, 0, 0);
+    load_x(min(PF, last), 0);
+    sync();
+    for (int i0 = 0; i0 < nst; i0 += PF) {  // (nst is a multiple of PF: the launcher pads the run with zero steps the planes hold)
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
             const int i = i0 + u;
-            write_x(min(i + 1, last), u ^ 1, u ^ 1);  // the other buffer: every wave is past its reads of step i - 1 (previous barrier)
-            load_x(min(i + 3, last), u ^ 1);
-            compute(u, u);
-            load_w(min(i + 2, last), u);
+            const int u1 = (u + 1) % PF;
+            write_x(min(i + 1, last), u1, (u + 1) & 1);  // the other buffer: every wave is past its reads of step i - 1 (previous barrier)
+            load_x(min(i + 1 + PF, last), u1);
+            __builtin_amdgcn_sched_barrier(0);  // (keeps the prefetch in front of the products: left alone the compiler sinks it behind them)
+            compute(u, u & 1);
+            load_w(min(i + PF, last), u);
             sync();
         }
     }
@@ -220,12 +225,15 @@ inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) 
 
 template <int MT, int NW>
 void launch_b3(hipStream_t s, const GemmDesc &d, float *C, const float *A, const u32x4 *W3F, const float *bias, const float *res, const float *scale,
-               int64_t total_rows, int nt16, int nst, int nb) {
+               int64_t total_rows, int nt16, int nst4, int nb) {
     constexpr int TR = 16 * MT;
     dim3 grid((unsigned)((total_rows + TR - 1) / TR), (unsigned)nb);
     const size_t lds = 2 * 3 * (size_t)TR * 64;
-    if (d.has_scale) hipLaunchKernelGGL((gemm_b3_kernel<MT, NW, true>), grid, dim3(64 * NW), lds, s, d, C, A, W3F, bias, res, scale, total_rows, nt16, nst);
-    else hipLaunchKernelGGL((gemm_b3_kernel<MT, NW, false>), grid, dim3(64 * NW), lds, s, d, C, A, W3F, bias, res, scale, total_rows, nt16, nst);
+    const int nst = (d.K + 31) / 32;
+    // two K steps of both operands in flight (PF = 4 is instantiable: measured slower at every size, tools/gemm3_bench)
+    const int nrun = (nst + 1) & ~1;
+    if (d.has_scale) hipLaunchKernelGGL((gemm_b3_kernel<MT, NW, true, 2>), grid, dim3(64 * NW), lds, s, d, C, A, W3F, bias, res, scale, total_rows, nt16, nst4, nrun);
+    else hipLaunchKernelGGL((gemm_b3_kernel<MT, NW, false, 2>), grid, dim3(64 * NW), lds, s, d, C, A, W3F, bias, res, scale, total_rows, nt16, nst4, nrun);
 }
 
 }  // namespace
@@ -236,7 +244,7 @@ bool launch_gemm_b3(hipStream_t s, const GemmDesc &d, float *C, const float *A, 
                     int64_t batch) {
     if (d.w3 != 2 || d.fold || d.npost || d.out_strided || d.se_inline || d.K % 8 || d.lda % 4 || d.N % 4 || (d.gap && d.rows != 48)) return false;
     if (!al16(A) || !al16(W3F) || !al16(C) || (d.has_res && !al16(res)) || (d.has_bias && !al16(bias)) || (d.has_scale && !al16(scale))) return false;
-    const int nt16 = (d.N + 15) / 16, nst = ((d.K + 31) / 32 + 1) & ~1;  // (an even number of K steps: pack_w3f pads with a zero step)
+    const int nt16 = (d.N + 15) / 16, nst = ((d.K + 31) / 32 + 3) & ~3;  // (the planes' steps per tile: pack_w3f pads to a multiple of four)
     const int nb = (nt16 + 7) / 8;                 // channel blocks of at most 8 tiles (128 channels), evenly sized
     const int nw = (nt16 + nb - 1) / nb;           // waves = channel tiles per block
     const int64_t total_rows = batch * d.rows;
@@ -248,13 +256,10 @@ bool launch_gemm_b3(hipStream_t s, const GemmDesc &d, float *C, const float *A, 
     const int force_mt = env_int("BN_GEMMB3_MT", 0);  // tests / experiments
     int mt = (total_rows + 63) / 64 * nb >= cus ? 4 : 2;
     if (d.gap) mt = 3;
-    else if (force_mt == 2 || force_mt == 3 || force_mt == 4 || force_mt == 8) mt = force_mt;
+    else if (force_mt == 2 || force_mt == 3 || force_mt == 4) mt = force_mt;
 #define GB_GO(MT)                                                                                          \
     do {                                                                                                   \
-        switch (nw) {                                                                                      \
-            case 1: launch_b3<MT, 1>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb); break;   \
-            case 2: launch_b3<MT, 2>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb); break;   \
-            case 3: launch_b3<MT, 3>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb); break;   \
+        switch (nw) { /* N > 48 (gemm_b3_shape_ok) => at least four channel tiles per block */             \
             case 4: launch_b3<MT, 4>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb); break;   \
             case 5: launch_b3<MT, 5>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb); break;   \
             case 6: launch_b3<MT, 6>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb); break;   \
@@ -262,9 +267,9 @@ bool launch_gemm_b3(hipStream_t s, const GemmDesc &d, float *C, const float *A, 
             default: launch_b3<MT, 8>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb); break;  \
         }                                                                                                  \
     } while (0)
+    if (nw < 4) return false;
     if (mt == 2) GB_GO(2);
     else if (mt == 3) GB_GO(3);
-    else if (mt == 8) GB_GO(8);
     else GB_GO(4);
 #undef GB_GO
     return true;

@@ -542,8 +542,21 @@ static void launch_mbconv_row_impl(hipStream_t s, const MbDesc &d, float *out, c
         else if (actc == ACT_SILU) hipLaunchKernelGGL((mbconv_row_kernel<3, S, NG, false, ACT_SILU, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
         else hipLaunchKernelGGL((mbconv_row_kernel<3, S, NG, false, -1, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
     } while (0)
+#define ROW_LAUNCH_T3(S, NG)                                                                                                               \
+    do {                                                                                                                                   \
+        if (actc == ACT_RELU) hipLaunchKernelGGL((mbconv_row_kernel<3, S, NG, false, ACT_RELU, true, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
+        else if (actc == ACT_SILU) hipLaunchKernelGGL((mbconv_row_kernel<3, S, NG, false, ACT_SILU, true, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
+        else hipLaunchKernelGGL((mbconv_row_kernel<3, S, NG, false, -1, true, true>), grid, dim3(256), 0, s, d, out, in, w1, b1, w2, b2, gap, (int)total); \
+    } while (0)
 #define ROW_NG_T(S)                             \
     do {                                        \
+        if (d.row_b3 && d.Cin % 8 == 0) {       \
+            if (ng <= 2) ROW_LAUNCH_T3(S, 2);   \
+            else if (ng == 3) ROW_LAUNCH_T3(S, 3); \
+            else if (ng == 4) ROW_LAUNCH_T3(S, 4); \
+            else if (ng == 5) ROW_LAUNCH_T3(S, 5); \
+            else ROW_LAUNCH_T3(S, 6);           \
+        } else                                  \
         if (ng <= 2) ROW_LAUNCH_T(S, 2);        \
         else if (ng == 3) ROW_LAUNCH_T(S, 3);   \
         else if (ng == 4) ROW_LAUNCH_T(S, 4);   \
@@ -570,6 +583,7 @@ static void launch_mbconv_row_impl(hipStream_t s, const MbDesc &d, float *out, c
     else if (d.k == 5 && d.s == 1) ROW_NG(5, 1);
     else ROW_NG(5, 2);
 #undef ROW_NG_T
+#undef ROW_LAUNCH_T3
 #undef ROW_LAUNCH_T
 #undef ROW_NG
 #undef ROW_LAUNCH3

@@ -234,14 +234,15 @@ inline bool gemm_b3_shape_ok(const GemmDesc &d) {
     if (d.lda % 4 || d.lda < d.K || d.ldc % 4 || d.c_bs % 4 || d.a_bs % 4 || (d.has_res && (d.ldr % 4 || d.r_bs % 4)) || (d.has_scale && d.s_bs % 4)) return false;
     if (d.gap && !(gemm_gap_shape_ok(d) && d.rows == 48)) return false;
     if ((int64_t)d.N * d.K >= ((int64_t)1 << 30)) return false;
+    if (d.rows < 8) return false;  // one row per sample (the FC heads): a GEMV bound by its weight bytes -- 4 B per weight beat 6, the split-K kernel keeps it
     // the expand convs only where the product is big enough to matter; tiny ones keep their kernels (and their bits)
     return d.K >= 64 || d.has_scale;
 }
 // The weights [N][K] as three bf16 planes in FRAGMENT order: [16-channel tile][K step][plane][lane][8 bf16] -- lane (c, q) of the tile's
 // wave holds k = 32 step + 8 q .. + 7 of channel 16 tile + c, i.e. one coalesced 1-KiB load per (tile, step, plane).  Channels past N
-// and k past K -- including a whole padding step when K / 32 is odd -- are zeros.  Returned in a vector of floats (a bit container).
+// and k past K -- including up to three whole padding steps -- are zeros.  Returned in a vector of floats (a bit container).
 inline std::vector<float> pack_w3f(const float *W, int64_t N, int64_t K) {
-    const int64_t nt16 = (N + 15) / 16, nst = ((K + 31) / 32 + 1) & ~(int64_t)1;  // an EVEN number of K steps (the kernel's loop is unrolled by two, unguarded)
+    const int64_t nt16 = (N + 15) / 16, nst = ((K + 31) / 32 + 3) & ~(int64_t)3;  // a multiple of FOUR K steps (the kernel's loop is unrolled by its prefetch depth, unguarded)
     std::vector<uint16_t> img((size_t)(nt16 * nst * 3 * 64 * 8), 0);
     for (int64_t t = 0; t < nt16; t++)
         for (int64_t s = 0; s < nst; s++)

@@ -1379,7 +1379,7 @@ def test_gemm_bf16x3_forms_against_the_oracle_and_the_exact_f32_kernels(bn, cin,
     one = np.concatenate([bn.Context(bn.Model(path), 1).infer(x[i:i + 1])[0].reshape(1, -1) for i in (0, 4)])
     assert one.tobytes() == got[[0, 4]].tobytes()
     if kernel == "b3":
-        for mt in ("2", "4", "8"):
+        for mt in ("2", "4", "3"):  # rows per block: 32, 64, 48
             monkeypatch.setenv("BN_GEMMB3_MT", mt)
             alt = bn.Context(bn.Model(path), 5).infer(x)[0].reshape(5, -1)
             assert alt.tobytes() == got.tobytes(), mt
