@@ -3961,6 +3961,43 @@ class Builder {
                 changed = true;
             }
         }
+        // (round 5) the zero-padded copy of the signal a padded framing conv reads (pad_copy: one fill + one copy launch) in the STFT's span
+        // load: where the only reader of that copy is an FFT launch, the launch reads the signal itself and zero-fills the positions that
+        // fall into the padding (FftDesc::pad_l, in_len).  Perch's front end: two launches and a round trip of the signal less.
+        changed = env_int("BN_STFT_PAD", 1) != 0;
+        while (changed) {
+            changed = false;
+            auto users = users_of();
+            for (size_t e = 0; e + 2 < plan_.ops.size() && !changed; e++) {
+                const PlanOp &fill = plan_.ops[e], &copy = plan_.ops[e + 1];
+                if (fill.kind != OpKind::ELT || copy.kind != OpKind::ELT || fill.name.rfind("pad.fill:", 0) != 0 || copy.name.rfind("pad.copy:", 0) != 0) continue;
+                if (fill.out.space != Space::ARENA || copy.out.space != Space::ARENA || fill.out.id != copy.out.id || fill.out.offset != 0 || plan_.storages[fill.out.id].pinned) continue;
+                const EltDesc &fd = fill.elt, &cd = copy.elt;
+                if (fd.nd != 1 || cd.nd != 1 || fd.nstages != 1 || cd.nstages != 1 || cd.so[0] != 1 || cd.sa[0] != 1) continue;
+                if (fd.st[0].bin != BIN_NONE || fd.st[0].act != ACT_NONE || cd.st[0].bin != BIN_NONE || cd.st[0].act != ACT_NONE) continue;
+                if (fill.a.space != Space::CONSTS || plan_.consts[(size_t)fill.a.id].empty() || plan_.consts[(size_t)fill.a.id][(size_t)fill.a.offset] != 0.0f) continue;
+                if (copy.a.space != Space::ARENA && copy.a.space != Space::INPUT) continue;
+                const auto &u = users[fill.out.id];
+                if (u.size() != 3 || u[0] != (int)e || u[1] != (int)e + 1) continue;
+                PlanOp &f = plan_.ops[(size_t)u[2]];
+                if (f.kind != OpKind::FFT || f.fft.in_len != 0 || f.fft.npre != 0 || f.a.space != Space::ARENA || f.a.id != fill.out.id || f.a.offset != 0) continue;
+                if (f.fft.a_bs != fd.bo || (int64_t)(f.fft.frames - 1) * f.fft.hop + f.fft.L > fd.per_sample || copy.out.offset + cd.per_sample > fd.per_sample) continue;
+                if (cd.per_sample >= ((int64_t)1 << 30) || copy.out.offset >= ((int64_t)1 << 30)) continue;
+                std::vector<Ref *> refs;
+                all_refs(f, refs);
+                int reads = 0;
+                for (Ref *r : refs) reads += (r->space == Space::ARENA && r->id == fill.out.id) ? 1 : 0;
+                if (reads != 1) continue;
+                f.a = copy.a;
+                f.fft.a_bs = cd.ba;
+                f.fft.pad_l = (int32_t)copy.out.offset;
+                f.fft.in_len = (int32_t)cd.per_sample;
+                f.bytes -= 4.0 * (double)(fd.per_sample - cd.per_sample);
+                f.name = "pad+" + f.name;
+                plan_.ops.erase(plan_.ops.begin() + (long)e, plan_.ops.begin() + (long)e + 2);
+                changed = true;
+            }
+        }
     }
 
     // (K, round 4) GlobalAveragePool behind a 1x1 conv whose 48 rows per sample sit in one block of the LDS-DMA GEMM (48-row tiles): the

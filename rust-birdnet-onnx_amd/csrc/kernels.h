@@ -383,6 +383,9 @@ struct FftDesc {
     // 16 ceil(nout/16) + 8: whole bin groups, and = 8 mod 16 makes the ds_read_b128 fragment reads conflict free)
     int32_t mel_mode, mel_groups, spec_stride;
     int32_t otab_planar;  // 1: the untangle table is stored as planes [nout][4] | [nout][2] | [nout][4 (power mode)] instead of rows
+    // (round 5, planner: absorb_pad_into_fft) the frames are cut from the ZERO-PADDED signal [pad_l zeros | in_len samples | zeros]: the
+    // span load reads sample p - pad_l for padded position p and 0 outside [0, in_len); in_len == 0: no padding (a_bs >= the span)
+    int32_t pad_l, in_len;
 };
 struct StftPtrs {
     float *out;

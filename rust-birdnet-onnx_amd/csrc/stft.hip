@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
     // (macros, not lambdas: a by-reference closure would put the staged registers into scratch memory)
     float4 sr[SPAN_R];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const int tpb = d.tpb, frames = d.frames, L = d.L, a_vec4 = d.a_vec4;
+    const int tpb = d.tpb, frames = d.frames, L = d.L, a_vec4 = d.a_vec4, pad_l = d.pad_l, in_len = d.in_len;
     const int64_t a_bs = d.a_bs;
 #define BN_TILE_GEOM(TILE)                                              \
     const int64_t b = (TILE) / tiles_per_sample;                        \
@@ -327,13 +327,26 @@ __global__ __launch_bounds__(NW * 64) void stft_kernel(FftDesc d, StftPtrs p, in
 #define BN_ISSUE_SPAN(TILE)                                                                                              \
     do {                                                                                                                 \
         BN_TILE_GEOM(TILE)                                                                                               \
-        const float *src = p.in + b * a_bs + (int64_t)t0 * hop;                                                          \
+        const float *src = p.in + b * a_bs + (int64_t)t0 * hop - pad_l;                                                  \
         const int n4 = (count + 3) >> 2;                                                                                 \
+        /* zero-padded signal (planner: absorb_pad_into_fft): a tile that touches the padding loads element by element */ \
+        const int lo_ = t0 * hop - pad_l;                                                                                \
+        const bool edge_ = in_len > 0 && (lo_ < 0 || lo_ + 4 * n4 > in_len);                                             \
         _Pragma("unroll") for (int k = 0; k < SPAN_R; k++) {                                                             \
             int c = tid + k * NW * 64;                                                                                   \
             c = c < n4 ? c : n4 - 1;                                                                                     \
             if (dbg & 32) {                                                                                              \
                 sr[k] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                 \
+            } else if (edge_) {                                                                                          \
+                const int e = lo_ + 4 * c;                                                                               \
+                const float *sx = p.in + b * a_bs;                                                                       \
+                float v_[4];                                                                                             \
+                _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                          \
+                    const int r_ = e + j;                                                                                \
+                    const float x_ = sx[min(max(r_, 0), in_len - 1)];                                                    \
+                    v_[j] = (r_ >= 0 && r_ < in_len) ? x_ : 0.0f;                                                        \
+                }                                                                                                        \
+                sr[k] = make_float4(v_[0], v_[1], v_[2], v_[3]);                                                         \
             } else if (a_vec4) {                                                                                         \
                 sr[k] = reinterpret_cast<const float4 *>(src)[c];                                                        \
             } else { /* unaligned rows: element loads, the last chunk clamped element by element */                     \
@@ -620,7 +633,8 @@ void launch_stft(hipStream_t s, const FftDesc &d, const StftPtrs &p, int64_t bat
     // float4 span loads need 16-byte aligned tile starts (base pointer, batch stride, a tile's first sample) and must
     // not run past the sample row: the last chunk of a span is rounded up to 4 floats
     dd.a_vec4 = (reinterpret_cast<uintptr_t>(p.in) & 15u) == 0 && d.a_bs % 4 == 0 && ((int64_t)d.tpb * d.hop) % 4 == 0 &&
-                (int64_t)(d.frames - 1) * d.hop + d.L + 3 <= d.a_bs;
+                (d.in_len > 0 ? d.pad_l % 4 == 0  // (padded: interior tiles lie inside the sample row by construction, edge tiles load by element)
+                              : (int64_t)(d.frames - 1) * d.hop + d.L + 3 <= d.a_bs);
     const int tps = (d.frames + d.tpb - 1) / d.tpb;
     const int64_t total = (int64_t)tps * batch;
     const int ncu = device_cu_count();  // asked once per device by prepare_device(), never inside a stream capture
