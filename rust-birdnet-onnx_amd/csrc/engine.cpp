@@ -3238,6 +3238,7 @@ class Builder {
                 const bool map_off = getenv("BN_DWMAP") && std::string(getenv("BN_DWMAP")) == "0";
                 if (!map_off && kh == kw && strides[0] == strides[1] && H * W <= 768) {
                     d.tiled = 2;
+                    d.mapt = env_int("BN_DWMAPT", 1) != 0 ? 1 : 0;
                     d.nblk = 1;
                 }
             }

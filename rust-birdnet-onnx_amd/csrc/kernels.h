@@ -167,6 +167,9 @@ struct DwDesc {
     // squeeze of a following squeeze-excite: per-block channel sums -> gap[b][nblk][C]
     int32_t has_gap;
     int64_t gap_bs;
+    // (round 5) tiled == 2: take the instance with the map size at compile time (dwconv_mapt_kernel) where one exists -- the planner's
+    // choice (BN_DWMAPT), same values as dwconv_map_kernel
+    int32_t mapt;
 };
 
 // Fused MBConv front half: expand 1x1 conv (+bias+act) -> depthwise KxK (+bias+act) [+ SE squeeze],

@@ -2873,6 +2873,104 @@ __global__ __launch_bounds__(256) void dwconv_map_kernel(DwDesc d, float *__rest
     if (d.has_gap && tail.on) se_tail(tail, b, gap + b * d.gap_bs, dmsm);
 }
 
+// ---- the same launch with the MAP SIZE AT COMPILE TIME (round 5): dwconv_map_kernel is vector-ALU bound on its bookkeeping -- PMC, Perch's
+// 32 x 8 x 816 5x5 launches: 37.1 M vector instructions for 10.4 M multiply-adds, i.e. exactly the launch's 60 us at full issue rate --
+// because with run-time H / W every input value carries a bounds check and an address computation.  Here the slab sits in LDS WITH its
+// zero padding ([H + K - 1][W + K - 1][32 channels]), a lane group owns a band of R output rows x CW output columns, and every (input
+// element, tap) -> output relation is resolved at compile time: the loads are ds_reads at immediate offsets from one per-lane base, every
+// input element of the band is read once, nothing is predicated.  Multiply-adds per output in dwconv_map_kernel's order (bias, then taps
+// (ky, kx) ascending); the padding's zeros are multiplied where dwconv_map_kernel skips them, which changes no value.
+// Lane groups: (OH / R) * (OW / CW) == 8.  grid (ceil(C/32), batch), 256 threads.
+template <int K, int S, int H, int W, int R, int CW>
+__global__ __launch_bounds__(256) void dwconv_mapt_kernel(DwDesc d, float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, float *__restrict__ gap, SeTail tail) {
+    constexpr int PT = (K - 1) / 2, OH = (H + 2 * PT - K) / S + 1, OW = (W + 2 * PT - K) / S + 1;
+    constexpr int HP = H + K - 1, WP = W + K - 1, HW = H * W;
+    constexpr int IR = (R - 1) * S + K, IC = (CW - 1) * S + K;  // input rows / columns a band reads
+    static_assert(OH % R == 0 && OW % CW == 0 && (OH / R) * (OW / CW) == 8, "eight lane groups cover the output map");
+    extern __shared__ __align__(16) float dmsm[];
+    float *In = dmsm;                 // [HP][WP][32]
+    float *red = dmsm + HP * WP * 32; // [8][32]
+    const int c0 = blockIdx.x * 32;
+    const int64_t b = blockIdx.y;
+    const int tid = threadIdx.x;
+    // the padding frame: zero (rows above / below, columns left / right of the map)
+    for (int i = tid; i < HP * WP * 8; i += 256) {
+        const int q = i & 7, px = i >> 3, y = px / WP, x = px - y * WP;
+        if (y < PT || y >= PT + H || x < PT || x >= PT + W) *reinterpret_cast<float4 *>(In + px * 32 + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    {
+        const int cq = tid & 7, p0 = tid >> 3;
+        const bool qok = c0 + cq * 4 < d.C;
+        const float *ip = in + b * d.in_bs + c0 + (qok ? cq * 4 : 0);
+        for (int pb = p0; pb < HW; pb += 32 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int p = pb + i * 32;
+                v[i] = *reinterpret_cast<const float4 *>(ip + (int64_t)(p < HW ? p : HW - 1) * d.C);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int p = pb + i * 32;
+                const int y = p / W, x = p - y * W;
+                if (p < HW) *reinterpret_cast<float4 *>(In + ((y + PT) * WP + x + PT) * 32 + cq * 4) = qok ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    const int c = tid & 31, g8 = tid >> 5;
+    const int cg = c0 + c;
+    const bool cact = cg < d.C;
+    const int cc = cact ? cg : d.C - 1;
+    float wd[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; q++) wd[q] = w[q * d.C + cc];
+    const float bz = d.has_bias ? bias[cc] : 0.0f;
+    __syncthreads();
+    constexpr int NCS = OW / CW;  // column strips
+    const int oy0 = (g8 / NCS) * R, ox0 = (g8 % NCS) * CW;
+    const float *base = In + ((oy0 * S) * WP + ox0 * S) * 32 + c;  // padded coordinates: output (oy, ox) reads rows oy S .. + K - 1, columns ox S .. + K - 1
+    float ov[R * CW];
+#pragma unroll
+    for (int q = 0; q < R * CW; q++) ov[q] = bz;
+#pragma unroll
+    for (int iy = 0; iy < IR; iy++)
+#pragma unroll
+        for (int ix = 0; ix < IC; ix++) {
+            const float v = base[(iy * WP + ix) * 32];
+#pragma unroll
+            for (int ky = 0; ky < K; ky++)
+#pragma unroll
+                for (int kx = 0; kx < K; kx++)
+                    if (iy - ky >= 0 && (iy - ky) % S == 0 && (iy - ky) / S < R && ix - kx >= 0 && (ix - kx) % S == 0 && (ix - kx) / S < CW)
+                        ov[((iy - ky) / S) * CW + (ix - kx) / S] = fmaf(v, wd[ky * K + kx], ov[((iy - ky) / S) * CW + (ix - kx) / S]);
+        }
+    act_array<R * CW>(d.act, d.p0, d.p1, ov);
+    float sum = 0.0f;
+    if (cact) {
+        float *ob = out + b * d.out_bs + cg;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+#pragma unroll
+            for (int q = 0; q < CW; q++) {
+                ob[((int64_t)(oy0 + r) * OW + ox0 + q) * d.C] = ov[r * CW + q];
+                sum += ov[r * CW + q];
+            }
+    }
+    if (d.has_gap) {
+        float *gap_sample = gap + b * d.gap_bs;
+        red[g8 * 32 + c] = sum;
+        __syncthreads();
+        if (g8 == 0 && cact) {
+            float t = red[c];
+#pragma unroll
+            for (int y = 1; y < 8; y++) t += red[y * 32 + c];
+            se_store(gap_sample + cg, t);
+        }
+        if (tail.on) se_tail(tail, b, gap_sample, dmsm);
+    }
+}
+
 // Fused expand + depthwise for a SMALL feature map (H*W <= 768): one block = (32 mid channels,
 // one sample), no halo, nothing recomputed.
 //   1. the 32 expand filters of the block go to LDS (Ws[32][K+pad], zero K padding)
@@ -3098,6 +3196,11 @@ void register_kernels_hip() {
     register_dynamic_lds_kernel(reinterpret_cast<const void *>(KERNEL<5, 2, true>));
     BN_REG_KS(mbconv_map_kernel)
     BN_REG_KS(dwconv_map_kernel)
+#define BN_REG_DWT(K, S, H, W, R, CW) register_dynamic_lds_kernel(reinterpret_cast<const void *>(dwconv_mapt_kernel<K, S, H, W, R, CW>));
+    BN_REG_DWT(3, 1, 32, 8, 4, 8) BN_REG_DWT(5, 1, 32, 8, 4, 8) BN_REG_DWT(5, 2, 32, 8, 2, 4) BN_REG_DWT(3, 2, 32, 8, 2, 4)
+    BN_REG_DWT(3, 1, 16, 4, 2, 4) BN_REG_DWT(5, 1, 16, 4, 2, 4)
+    BN_REG_DWT(3, 1, 8, 32, 1, 32) BN_REG_DWT(5, 1, 8, 32, 1, 32) BN_REG_DWT(5, 2, 8, 32, 1, 8) BN_REG_DWT(3, 2, 8, 32, 1, 8)
+#undef BN_REG_DWT
     BN_REG_KSI(mbconv_pipe_kernel)
     BN_REG_KSI(mbconv_expand_dw_kernel)
 #undef BN_REG_KS
@@ -3641,6 +3744,34 @@ void launch_dwconv(hipStream_t s, const DwDesc &d, float *out, const float *in, 
         tail.nblocks = (d.C + 31) / 32;
         size_t lds = ((size_t)d.H * d.W * 32 + 256) * sizeof(float);
         if (tail.on) lds = std::max(lds, se_tail_lds_bytes(tail.se));
+        // (round 5) the map sizes of the late stages of BirdNET v3.0 (8 x 32) and Perch (32 x 8, 16 x 4) at compile time
+#define DWT_LAUNCH(K, S, H, W, R, CW)                                                                                                             \
+    do {                                                                                                                                         \
+        size_t ldst = ((size_t)(H + K - 1) * (W + K - 1) * 32 + 256) * sizeof(float);                                                            \
+        if (tail.on) ldst = std::max(ldst, se_tail_lds_bytes(tail.se));                                                                          \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void *>(dwconv_mapt_kernel<K, S, H, W, R, CW>), ldst)) { launch_error("kernel needs more LDS than the device grants"); break; } \
+        hipLaunchKernelGGL((dwconv_mapt_kernel<K, S, H, W, R, CW>), grid, dim3(256), ldst, s, d, out, in, w, bias, gap, tail);                   \
+        return;                                                                                                                                  \
+    } while (0)
+        if (d.mapt && d.kh == d.kw && d.sh == d.sw && d.dh == 1 && d.dw == 1 && d.pt == (d.kh - 1) / 2 && d.pl == (d.kw - 1) / 2 &&
+            d.OH == (d.H + 2 * d.pt - d.kh) / d.sh + 1 && d.OW == (d.W + 2 * d.pl - d.kw) / d.sw + 1) {
+            const int k = d.kw, st = d.sw;
+            if (d.H == 32 && d.W == 8) {
+                if (k == 3 && st == 1) DWT_LAUNCH(3, 1, 32, 8, 4, 8);
+                if (k == 5 && st == 1) DWT_LAUNCH(5, 1, 32, 8, 4, 8);
+                if (k == 5 && st == 2) DWT_LAUNCH(5, 2, 32, 8, 2, 4);
+                if (k == 3 && st == 2) DWT_LAUNCH(3, 2, 32, 8, 2, 4);
+            } else if (d.H == 16 && d.W == 4) {
+                if (k == 3 && st == 1) DWT_LAUNCH(3, 1, 16, 4, 2, 4);
+                if (k == 5 && st == 1) DWT_LAUNCH(5, 1, 16, 4, 2, 4);
+            } else if (d.H == 8 && d.W == 32) {
+                if (k == 3 && st == 1) DWT_LAUNCH(3, 1, 8, 32, 1, 32);
+                if (k == 5 && st == 1) DWT_LAUNCH(5, 1, 8, 32, 1, 32);
+                if (k == 5 && st == 2) DWT_LAUNCH(5, 2, 8, 32, 1, 8);
+                if (k == 3 && st == 2) DWT_LAUNCH(3, 2, 8, 32, 1, 8);
+            }
+        }
+#undef DWT_LAUNCH
 #define DWM_LAUNCH(K, S)                                                                                                                           \
     do {                                                                                                                                         \
         if (!ensure_dynamic_lds(reinterpret_cast<const void *>(dwconv_map_kernel<K, S>), lds)) { launch_error("kernel needs more LDS than the device grants"); break; } \
