@@ -1,7 +1,7 @@
 // f32 as three exact bf16 terms, device side (gemm_dma3.hip, gemm_b3.hip): x = hi + mid + lo with hi = x's top 8 significand bits (the f32
 // with its low 16 bits cleared), mid the same of the remainder x - hi (exact), lo = x - hi - mid (at most 8 significant bits are left: a
 // bf16 number).  The six partial products kept by the kernels (everything but mid lo, lo mid, lo lo) are each exact in f32; the dropped
-// ones are below 2^-24 |x w| each.  Host side and the weight packers: plan_rules.h (split_bf16x3, pack_w3, pack_w3f).
+// ones sum to less than 2^-21 |x w| in the worst case, 2^-24 |x w| in the root mean square (|mid| < 2^-7 |x|, |lo| < 2^-15 |x|).  Host side and the weight packers: plan_rules.h (split_bf16x3, pack_w3, pack_w3f).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -7,9 +7,11 @@
 // of three bf16 numbers -- hi = its top 8 significand bits (the f32 with the low 16 bits cleared), mid = the same of the remainder
 // x - hi (exact), lo = x - hi - mid (8 significant bits left: a bf16 number) -- so
 //     x w = (xh + xm + xl)(wh + wm + wl) = xh wh + xh wm + xm wh + xm wm + xh wl + xl wh   + [xm wl + xl wm + xl wl]
-// and the six products kept here are each EXACT in the accumulator's f32 (8 x 8 significand bits); the three dropped ones are below
-// 2^-24 |x w| each.  A product therefore carries a relative error <= 3 x 2^-24 before accumulation -- the size of ONE f32 rounding,
-// which the exact-f32 instruction commits per product as well (it rounds x w + acc); sums are f32 either way.  Six bf16 instructions of
+// and the six products kept here are each EXACT in the accumulator's f32 (8 x 8 significand bits); of the three dropped ones
+// xm wl and xl wm are below 2^-22 |x w| each (|mid| < 2^-7 |x|, |lo| < 2^-15 |x|) and xl wl below 2^-30 |x w|.  A product therefore carries
+// a relative error below 2^-21 in the worst case and 2^-24 in the root mean square (tests/test_host_logic.py restates the arithmetic in
+// numpy) -- the size of the rounding the exact-f32 instruction commits per product as well (it rounds x w + acc); sums are f32 either way,
+// and the measured error of a K-deep dot product against double precision equals the exact-f32 kernel's (tools/gemm3_bench).  Six bf16 instructions of
 // 32-deep k replace eight f32 instructions of 4-deep k per 16 x 16 tile and K step: 96 against 256 matrix cycles, and the split's
 // vector instructions (two AND, two SUB, 1.5 PERM per activation value) issue in the matrix instructions' shadow instead of beside them.
 // Weights are split once, by the planner (plan_rules.h, pack_w3): three bf16 planes [plane][N][Kp], k permuted inside every 32-deep step

@@ -466,3 +466,52 @@ def test_tile_of_a_real_dimension_is_refused(bn, tmp_path):
     with pytest.raises(bn.EngineError) as e:
         bn.plan_describe(str(p))
     assert "'Tile_1'" in str(e.value) and "only size-1 dimensions" in str(e.value)
+
+
+# ---------------------------------------------------------------- round 5: planner-side facts that need no device
+def test_spectrogram_dialects_reach_one_plan(bn, tmp_path, monkeypatch):
+    """BirdNET v2.4 authored with Conv banks, with tf.signal.frame + window Mul + ONNX DFT, and with opset-17 STFT nodes: after the
+    node-level canonicalisation the three files plan to the same launches (kind, kernel, shape and multiply-adds of every launch); with
+    BN_CANON_SPECTRO=0 the DFT / STFT nodes are lowered directly instead (framing kernels over the strided view of the signal: no
+    Gather / Reshape copy of the frames)."""
+    def plan(fe):
+        p = tmp_path / f"{fe}.onnx"
+        p.write_bytes(synth.birdnet_v24(num_species=300, width=0.25, depth=0.25, head=128, front_end=fe))
+        return bn.plan_describe(str(p))
+    def shape(d):
+        rows = [l.split() for l in d.splitlines() if l[:3].strip().isdigit()]
+        return [(r[1], [t for t in r[3:] if not t.startswith("bytes=")]) for r in rows], d.splitlines()[-2]
+    plans = {fe: plan(fe) for fe in ("conv", "dft", "stft")}
+    assert shape(plans["conv"]) == shape(plans["dft"]) == shape(plans["stft"])
+    assert "~re~quarter" in plans["dft"] and "~re~quarter" in plans["stft"] and "kernel=frame_fold2q" in plans["conv"]
+    monkeypatch.setenv("BN_CANON_SPECTRO", "0")
+    for fe in ("dft", "stft"):
+        d = plan(fe)
+        first = [l for l in d.splitlines() if " GEMM " in l][0]
+        assert ("dft:DFT_" in d) == (fe == "dft") and ("stft:STFT_" in d) == (fe == "stft"), d
+        assert "lda=278" in first and "pre=4" in first and "copy(Gather" not in d and "copy(Reshape" not in d, d
+
+
+def test_bf16x3_error_bound_of_the_six_kept_products():
+    """The arithmetic of csrc/bf16x3.h restated in numpy: x = hi + mid + lo exactly (three bf16 terms), the six kept partial products are
+    each exact in f32 (8 x 8 significand bits), and what they leave out of x w (mid x lo, lo x mid, lo x lo) is below 2^-21 |x w| in the worst
+    case (|mid| < 2^-7 |x|, |lo| < 2^-15 |x|) and 2^-24 |x w| in the root mean square -- the size of one f32 rounding per product."""
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-8, 8, 200000))).astype(np.float32)
+    w = (rng.standard_normal(200000) * np.exp(rng.uniform(-8, 8, 200000))).astype(np.float32)
+    top = lambda v: (v.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
+    def split(v):
+        h = top(v); r1 = v - h; m = top(r1); l = r1 - m
+        assert np.array_equal(h + m + l, v) and not (l.view(np.uint32) & np.uint32(0xffff)).any()
+        return h.astype(np.float64), m.astype(np.float64), l.astype(np.float64)
+    xh, xm, xl = split(x)
+    wh, wm, wl = split(w)
+    kept = [wl * xh, wh * xl, wm * xm, wm * xh, wh * xm, wh * xh]
+    for t in kept:  # each kept product is an f32 number
+        assert np.array_equal(t.astype(np.float32).astype(np.float64), t)
+    exact = x.astype(np.float64) * w.astype(np.float64)
+    missing = np.abs(exact - sum(kept))
+    assert (np.abs(xm) < 2.0 ** -7 * np.abs(xh)).all() and (np.abs(xl) < 2.0 ** -15 * np.abs(xh)).all()
+    rel = missing / np.abs(exact)
+    assert rel.max() <= 2.0 ** -21 and np.sqrt((rel ** 2).mean()) <= 1.1 * 2.0 ** -24
+    assert np.array_equal(xm * wl + xl * wm + xl * wl, exact - sum(kept))
