@@ -321,6 +321,44 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
                      "Floor": torch.floor, "Ceil": torch.ceil, "Erf": torch.erf, "Reciprocal": torch.reciprocal}[op](i[0])
             elif op == "Softplus":
                 r = F.softplus(i[0])
+            elif op in ("Elu", "Selu", "Celu", "ThresholdedRelu", "Softsign", "Mish", "Gelu", "Sign", "Round", "Sin", "Cos"):
+                x = i[0]
+                if op == "Elu":
+                    r = torch.where(x > 0, x, float(a.get("alpha", 1.0)) * (torch.exp(x) - 1.0))
+                elif op == "Selu":
+                    al, ga = float(a.get("alpha", 1.6732632423543772)), float(a.get("gamma", 1.0507009873554805))
+                    r = ga * torch.where(x > 0, x, al * (torch.exp(x) - 1.0))
+                elif op == "Celu":
+                    al = float(a.get("alpha", 1.0))
+                    r = torch.clamp(x, min=0.0) + torch.clamp(al * (torch.exp(x / al) - 1.0), max=0.0)
+                elif op == "ThresholdedRelu":
+                    r = torch.where(x > float(a.get("alpha", 1.0)), x, torch.zeros_like(x))
+                elif op == "Softsign":
+                    r = x / (1.0 + torch.abs(x))
+                elif op == "Mish":
+                    r = x * torch.tanh(F.softplus(x))
+                elif op == "Gelu":
+                    ap = a.get("approximate", b"none")
+                    ap = ap.decode() if isinstance(ap, bytes) else ap
+                    r = F.gelu(x, approximate="tanh" if ap == "tanh" else "none")
+                else:
+                    r = {"Sign": torch.sign, "Round": torch.round, "Sin": torch.sin, "Cos": torch.cos}[op](x)
+            elif op in ("Sum", "Mean"):
+                r = i[0]
+                for t in i[1:]:
+                    r = r + t
+                if op == "Mean":
+                    r = r / float(len(i))
+            elif op == "Size":
+                r = torch.tensor(int(i[0].numel()), dtype=torch.int64)
+            elif op == "LayerNormalization":
+                ax = int(a.get("axis", -1)) % i[0].dim()
+                dims = list(range(ax, i[0].dim()))
+                mu = i[0].mean(dim=dims, keepdim=True)
+                d = i[0] - mu
+                r = d / torch.sqrt((d * d).mean(dim=dims, keepdim=True) + float(a.get("epsilon", 1e-5))) * i[1]
+                if len(i) > 2 and i[2] is not None:
+                    r = r + i[2]
             elif op in ("Identity", "Dropout"):
                 r = i[0]
             elif op == "Cast":
@@ -407,7 +445,8 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
                         e = min(max(e, -1), d - 1)
                         idx[ax] = slice(s, None if e < 0 else e, st)
                 r = torch.from_numpy(np.ascontiguousarray(arr[tuple(idx)]))
-            elif op in ("ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "ReduceProd", "ReduceL2", "ReduceSumSquare"):
+            elif op in ("ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "ReduceProd", "ReduceL2", "ReduceSumSquare", "ReduceL1",
+                        "ReduceLogSum", "ReduceLogSumExp"):
                 ax = _axes(n, env, 1)
                 keep = bool(a.get("keepdims", 1))
                 xx = i[0]
@@ -425,6 +464,12 @@ def run_graph(g: Graph, x: np.ndarray, dtype=torch.float32, outputs=None) -> dic
                         r = r.prod(dim=d, keepdim=keep)
                 elif op == "ReduceL2":
                     r = (xx * xx).sum(dim=ax, keepdim=keep).sqrt()
+                elif op == "ReduceL1":
+                    r = xx.abs().sum(dim=ax, keepdim=keep)
+                elif op == "ReduceLogSum":
+                    r = xx.sum(dim=ax, keepdim=keep).log()
+                elif op == "ReduceLogSumExp":
+                    r = torch.logsumexp(xx, dim=ax, keepdim=keep)
                 else:
                     r = (xx * xx).sum(dim=ax, keepdim=keep)
             elif op in ("Softmax", "LogSoftmax"):

@@ -74,6 +74,7 @@ __device__ __forceinline__ float act_apply(int act, float x, float p0, float p1)
         case ACT_EQC: return x == p0 ? 1.0f : 0.0f;
         case ACT_NEZ: return x != 0.0f ? 1.0f : 0.0f;
         case ACT_TRUNC: return truncf(x);
+        case ACT_ROUND: return rintf(x);
         default: return x;
     }
 }
@@ -116,6 +117,7 @@ __device__ __forceinline__ void act_array_all(int act, float p0, float p1, float
         case ACT_EQC: map_array<N>(v, [=](float x) { return x == p0 ? 1.0f : 0.0f; }); return;
         case ACT_NEZ: map_array<N>(v, [](float x) { return x != 0.0f ? 1.0f : 0.0f; }); return;
         case ACT_TRUNC: map_array<N>(v, [](float x) { return truncf(x); }); return;
+        case ACT_ROUND: map_array<N>(v, [](float x) { return rintf(x); }); return;
         default: return;
     }
 }

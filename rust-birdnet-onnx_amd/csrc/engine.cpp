@@ -1513,6 +1513,12 @@ class Builder {
         for (size_t k = 0; k < n.inputs.size(); k++) ins.push_back(n.inputs[k].empty() ? nullptr : &get(n, k));
         if (t == "Constant") { lower_constant(n); return; }
         if (t == "Shape") { lower_shape(n); return; }
+        if (t == "Size") {
+            const Val &v = get(n, 0);
+            if (!v.is_const) unsupported(n, "Size of an activation depends on the batch size, which a plan does not fix");
+            define(n.outputs[0], make_const_i({}, {v.numel()}));
+            return;
+        }
         bool allc = !ins.empty() && all_const(ins);
         if (allc && try_fold(n, ins)) return;
 
@@ -1543,6 +1549,7 @@ class Builder {
         if (t == "MatMul" || t == "Gemm") return lower_matmul(n);
         if (t == "BatchNormalization") return lower_batchnorm(n);
         if (t == "Add" || t == "Sub" || t == "Mul" || t == "Div" || t == "Pow" || t == "Max" || t == "Min") return lower_binary(n);
+        if (lower_composite(n)) return;
         if (t == "GlobalAveragePool" || t == "GlobalMaxPool" || t.rfind("Reduce", 0) == 0) return lower_reduce(n);
         if (t == "STFT") return lower_stft(n);
         if (t == "Expand") return lower_expand(n);
@@ -1653,6 +1660,160 @@ class Builder {
         a.type = 2;
         a.i = v;
         nd.attrs[key] = a;
+    }
+
+    // Operators written out as the operators above (round 5): the pieces go through the elementwise / reduction lowering, so they fuse into
+    // their neighbours like hand-written graphs of the same arithmetic.  ONNX defines each of these by exactly this formula.
+    bool lower_composite(const OnnxNode &n) {
+        const std::string &t = n.op_type;
+        if (n.outputs.empty() || n.inputs.empty()) return false;
+        const std::string base = "cmp:" + n.outputs[0];
+        const std::string &x = n.inputs[0];
+        int seq = 0;
+        auto step = [&](const char *op, std::vector<std::string> ins, bool last = false) {
+            const std::string out = last ? n.outputs[0] : base + "/" + std::to_string(seq);
+            lower(synth_node(op, last ? n.name : n.name + "/" + std::to_string(seq), std::move(ins), out));
+            seq++;
+            return out;
+        };
+        auto k = [&](float v) { return synth_const(base + "/c" + std::to_string(seq++), {1}, {v}); };
+        auto reduce = [&](const char *op, const std::string &in, bool last) {
+            const std::string out = last ? n.outputs[0] : base + "/" + std::to_string(seq);
+            OnnxNode r = synth_node(op, last ? n.name : n.name + "/" + std::to_string(seq), {in}, out);
+            seq++;
+            if (n.has("axes")) set_ints(r, "axes", n.attr_ints("axes"));
+            else if (has_input(n, 1)) r.inputs.push_back(n.inputs[1]);
+            set_int(r, "keepdims", n.attr_i("keepdims", 1));
+            if (n.has("noop_with_empty_axes")) set_int(r, "noop_with_empty_axes", n.attr_i("noop_with_empty_axes", 0));
+            lower(r);
+            return out;
+        };
+        if (t == "Elu" || t == "Selu" || t == "Celu") {
+            // max(x, 0) + alpha (exp(min(x, 0) / a) - 1), a = alpha for Celu and 1 otherwise; Selu scales the sum by gamma
+            const float alpha = n.attr_f("alpha", t == "Selu" ? 1.67326319217681884765625f : 1.0f);
+            const float gamma = t == "Selu" ? n.attr_f("gamma", 1.05070102214813232421875f) : 1.0f;
+            std::string neg = step("Min", {x, k(0.0f)});
+            if (t == "Celu") neg = step("Div", {neg, k(alpha)});
+            neg = step("Exp", {neg});
+            neg = step("Mul", {neg, k(alpha * gamma)});
+            neg = step("Sub", {neg, k(alpha * gamma)});
+            std::string pos = step("Relu", {x});
+            if (gamma != 1.0f) pos = step("Mul", {pos, k(gamma)});
+            step("Add", {pos, neg}, true);
+            return true;
+        }
+        if (t == "ThresholdedRelu") {
+            const std::string m = step("Greater", {x, k(n.attr_f("alpha", 1.0f))});
+            step("Where", {m, x, k(0.0f)}, true);
+            return true;
+        }
+        if (t == "Softsign") {
+            std::string d = step("Abs", {x});
+            d = step("Add", {d, k(1.0f)});
+            step("Div", {x, d}, true);
+            return true;
+        }
+        if (t == "Mish") {
+            std::string d = step("Softplus", {x});
+            d = step("Tanh", {d});
+            step("Mul", {x, d}, true);
+            return true;
+        }
+        if (t == "Gelu") {
+            std::string g;
+            if (n.attr_s("approximate", "none") == "tanh") {
+                g = step("Mul", {x, x});
+                g = step("Mul", {g, x});
+                g = step("Mul", {g, k(0.044715f)});
+                g = step("Add", {g, x});
+                g = step("Mul", {g, k(0.797884583473205566406250f)});
+                g = step("Tanh", {g});
+            } else {
+                g = step("Mul", {x, k(0.707106769084930419921875f)});
+                g = step("Erf", {g});
+            }
+            g = step("Mul", {g, k(0.5f)});
+            g = step("Add", {g, k(0.5f)});
+            step("Mul", {x, g}, true);
+            return true;
+        }
+        if (t == "Sign") {
+            const std::string p = step("Greater", {x, k(0.0f)}), m = step("Less", {x, k(0.0f)});
+            step("Sub", {p, m}, true);
+            return true;
+        }
+        if (t == "Sum" || t == "Mean") {
+            std::string acc = x;
+            const size_t cnt = n.inputs.size();
+            if (cnt == 1) { lower(synth_node("Identity", n.name, {x}, n.outputs[0])); return true; }
+            for (size_t j = 1; j < cnt; j++) acc = step("Add", {acc, n.inputs[j]}, t == "Sum" && j + 1 == cnt);
+            if (t == "Mean") step("Div", {acc, k((float)cnt)}, true);
+            return true;
+        }
+        if (t == "ReduceL1") {
+            reduce("ReduceSum", step("Abs", {x}), true);
+            return true;
+        }
+        if (t == "ReduceLogSum") {
+            step("Log", {reduce("ReduceSum", x, false)}, true);
+            return true;
+        }
+        if (t == "ReduceLogSumExp") {
+            // log(sum(exp(x - m))) + m with m the maximum over the same axes: the form that cannot overflow (what ORT computes)
+            OnnxNode mx = synth_node("ReduceMax", n.name + "/max", {x}, base + "/max");
+            if (n.has("axes")) set_ints(mx, "axes", n.attr_ints("axes"));
+            else if (has_input(n, 1)) mx.inputs.push_back(n.inputs[1]);
+            set_int(mx, "keepdims", 1);
+            lower(mx);
+            std::string e = step("Sub", {x, base + "/max"});
+            e = step("Exp", {e});
+            e = reduce("ReduceSum", e, false);
+            e = step("Log", {e});
+            std::string m = base + "/max";
+            if (n.attr_i("keepdims", 1) == 0) {
+                OnnxNode m2 = synth_node("ReduceMax", n.name + "/max0", {x}, base + "/max0");
+                if (n.has("axes")) set_ints(m2, "axes", n.attr_ints("axes"));
+                else if (has_input(n, 1)) m2.inputs.push_back(n.inputs[1]);
+                set_int(m2, "keepdims", 0);
+                lower(m2);
+                m = base + "/max0";
+            }
+            step("Add", {e, m}, true);
+            return true;
+        }
+        if (t == "LayerNormalization") {
+            // over the dimensions from `axis` to the last: (x - mean) / sqrt(var + eps) * Scale + B; the optional Mean / InvStdDev outputs
+            // are training-side and not produced here
+            if (n.outputs.size() > 1 && (!n.outputs[1].empty() || (n.outputs.size() > 2 && !n.outputs[2].empty())))
+                unsupported(n, "the Mean / InvStdDev outputs of LayerNormalization are not produced");
+            const Val &xv = get(n, 0);
+            if (xv.is_const) return false;
+            const int64_t r = (int64_t)xv.dims.size() + 1;
+            int64_t axis = n.attr_i("axis", -1);
+            if (axis < 0) axis += r;
+            if (axis <= 0 || axis >= r) unsupported(n, "LayerNormalization over the batch dimension");
+            std::vector<int64_t> axes;
+            for (int64_t a = axis; a < r; a++) axes.push_back(a);
+            auto mean_of = [&](const std::string &in) {
+                const std::string out = base + "/" + std::to_string(seq);
+                OnnxNode m = synth_node("ReduceMean", n.name + "/" + std::to_string(seq), {in}, out);
+                seq++;
+                set_ints(m, "axes", axes);
+                set_int(m, "keepdims", 1);
+                lower(m);
+                return out;
+            };
+            const std::string d = step("Sub", {x, mean_of(x)});
+            std::string v = mean_of(step("Mul", {d, d}));
+            v = step("Add", {v, k(n.attr_f("epsilon", 1e-5f))});
+            v = step("Sqrt", {v});
+            v = step("Div", {d, v});
+            const bool has_b = has_input(n, 2);
+            v = step("Mul", {v, n.inputs[1]}, !has_b);
+            if (has_b) step("Add", {v, n.inputs[2]}, true);
+            return true;
+        }
+        return false;
     }
 
     // PRelu(x, slope) = max(x, 0) + slope * min(x, 0); one slope for everything is LeakyRelu
@@ -2534,6 +2695,7 @@ class Builder {
         else if (t == "Reciprocal") a.act = ACT_RECIP;
         else if (t == "Floor") a.act = ACT_FLOOR;
         else if (t == "Ceil") a.act = ACT_CEIL;
+        else if (t == "Round") a.act = ACT_ROUND;
         else if (t == "Erf") a.act = ACT_ERF;
         else if (t == "Softplus") a.act = ACT_SOFTPLUS;
         else if (t == "HardSwish") a.act = ACT_HSWISH;
@@ -4319,7 +4481,9 @@ bool op_type_mapped(const std::string &t) {
         "Add", "Sub", "Mul", "Div", "Pow", "Max", "Min", "GlobalAveragePool", "GlobalMaxPool", "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin",
         "ReduceProd", "ReduceL2", "ReduceSumSquare", "STFT", "DFT", "Expand", "Tile", "PRelu", "InstanceNormalization", "Relu", "Sigmoid", "Tanh",
         "Exp", "Log", "Sqrt", "Abs", "Neg", "Reciprocal", "Floor", "Ceil", "Erf", "Softplus", "HardSwish", "HardSigmoid", "LeakyRelu", "Clip",
-        "Greater", "Less", "GreaterOrEqual", "LessOrEqual", "Equal", "Not", "And", "Or", "Xor", "Where", "Gather"};
+        "Greater", "Less", "GreaterOrEqual", "LessOrEqual", "Equal", "Not", "And", "Or", "Xor", "Where", "Gather", "Elu", "Selu", "Celu",
+        "ThresholdedRelu", "Softsign", "Mish", "Gelu", "Sign", "Round", "Sum", "Mean", "Size", "ReduceL1", "ReduceLogSum", "ReduceLogSumExp",
+        "LayerNormalization"};
     return known.count(t) != 0;
 }
 

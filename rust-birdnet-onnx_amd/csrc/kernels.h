@@ -45,6 +45,7 @@ enum Act : int32_t {
     ACT_EQC,       // x == p0 ? 1 : 0
     ACT_NEZ,       // x != 0 ? 1 : 0   (Cast to bool)
     ACT_TRUNC,     // toward zero       (Cast to an integer type; values stay f32)
+    ACT_ROUND,     // to nearest, ties to even (ONNX Round)
 };
 
 enum BinOp : int32_t { BIN_NONE = 0, BIN_ADD, BIN_SUB, BIN_MUL, BIN_DIV, BIN_POW, BIN_MAX, BIN_MIN,

@@ -1327,6 +1327,43 @@ def test_comparisons_logic_where_and_casts(bn):
     assert np.array_equal(got, ref), float(np.abs(got - ref).max())
 
 
+@pytest.mark.gpu
+def test_operators_lowered_as_compositions(bn):
+    """Elu / Selu / Celu / ThresholdedRelu / Softsign / Mish / Gelu (both forms) / Sign / Round / Sum / Mean / ReduceL1 / ReduceLogSum /
+    ReduceLogSumExp / LayerNormalization: written out by the planner as the operators it already maps (engine.cpp lower_composite), checked
+    against the oracle's torch calls; the inputs span both signs, exact ties for Round and magnitudes at which a naive log-sum-exp
+    overflows."""
+    c, n = 5, 400
+    rng = np.random.default_rng(21)
+    scale = rng.standard_normal((n,)).astype(np.float32)
+    bias = rng.standard_normal((n,)).astype(np.float32)
+
+    def build(g, x):
+        i64 = lambda *v: g.const(np.array(v, dtype=np.int64))
+        f32 = lambda v: g.const(np.array(v, dtype=np.float32))
+        x = g.node("Reshape", [g.node("Slice", [x, i64(0), i64(2 * c * n), i64(1), i64(1)]), i64(0, 2, c, n)])
+        a = g.node("Gather", [x, g.const(np.array(0, dtype=np.int64), scalar=True)], axis=1)        # [B, c, n]
+        b = g.node("Gather", [x, g.const(np.array(1, dtype=np.int64), scalar=True)], axis=1)
+        outs = [g.node("Elu", [a], alpha=0.7), g.node("Selu", [a]), g.node("Celu", [b], alpha=1.5), g.node("ThresholdedRelu", [a], alpha=0.3),
+                g.node("Softsign", [b]), g.node("Mish", [a]), g.node("Gelu", [a]), g.node("Gelu", [b], approximate="tanh"), g.node("Sign", [a]),
+                g.node("Round", [g.node("Mul", [g.node("Round", [g.node("Mul", [a, f32(4.0)])]), f32(0.5)])]),   # multiples of 0.5: every other one a tie
+                g.node("Sum", [a, b, a]), g.node("Mean", [a, b, b, a]),
+                g.node("LayerNormalization", [a, g.const(scale), g.const(bias)], axis=-1, epsilon=1e-4),
+                g.node("LayerNormalization", [b, g.const(np.ones((c, n), dtype=np.float32))], axis=1)]
+        full = g.node("Concat", [g.node("Unsqueeze", [o, i64(1)]) for o in outs], axis=1)             # [B, 14, c, n]
+        big = g.node("Mul", [a, f32(60.0)])                                                           # exp(60 * 3) overflows f32
+        red = [g.node("ReduceL1", [a, i64(2)], keepdims=1), g.node("ReduceLogSum", [g.node("Abs", [b]), i64(2)], keepdims=1),
+               g.node("ReduceLogSumExp", [big, i64(2)], keepdims=1),
+               g.node("Unsqueeze", [g.node("ReduceLogSumExp", [b], axes=[2], keepdims=0), i64(2)])]
+        small = g.node("Concat", [g.node("Unsqueeze", [o, i64(1)]) for o in red], axis=1)             # [B, 4, c, 1]
+        return g.node("Concat", [full, g.node("Mul", [small, g.const(np.ones((n,), dtype=np.float32))])], axis=1)
+    data = op_graph(build, [18, c, n])
+    got, ref = run_both(bn, data)
+    assert np.isfinite(ref).all()
+    assert_close(got, ref, "composite operators", atol=2e-5, rtol=2e-5)
+    assert np.array_equal(got[:, 8:10], ref[:, 8:10])    # Sign and Round involve no rounding of their own
+
+
 # ---------------------------------------------------------------- GEMMs on the bf16 matrix pipe with f32-complete products (round 5)
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,h,w,cout,act,kernel", [

@@ -515,3 +515,49 @@ def test_bf16x3_error_bound_of_the_six_kept_products():
     rel = missing / np.abs(exact)
     assert rel.max() <= 2.0 ** -21 and np.sqrt((rel ** 2).mean()) <= 1.1 * 2.0 ** -24
     assert np.array_equal(xm * wl + xl * wm + xl * wl, exact - sum(kept))
+
+
+@pytest.mark.parametrize("op,kwargs,extra", [
+    ("Elu", {"alpha": 0.5}, 0), ("Selu", {}, 0), ("Celu", {"alpha": 2.0}, 0), ("ThresholdedRelu", {}, 0), ("Softsign", {}, 0), ("Mish", {}, 0),
+    ("Gelu", {}, 0), ("Gelu", {"approximate": "tanh"}, 0), ("Sign", {}, 0), ("Round", {}, 0), ("Sum", {}, 2), ("Mean", {}, 1),
+    ("ReduceL1", {"axes": [1], "keepdims": 1}, 0), ("ReduceLogSum", {"axes": [1], "keepdims": 1}, 0), ("ReduceLogSumExp", {"axes": [1], "keepdims": 1}, 0),
+    ("LayerNormalization", {"axis": -1}, 1),
+])
+def test_operators_written_out_by_the_planner_plan_without_refusal(bn, tmp_path, op, kwargs, extra):
+    """Round 5: operators the planner writes out as the ones it maps (engine.cpp lower_composite) -- each plans as ELT / REDUCE launches
+    carrying the node's name, and the first-contact survey lists the type as mapped."""
+    g = writer.GraphBuilder()
+    g.add_input("input", [None, 144000])
+    ins = ["input"] + [g.const(np.ones((1,), dtype=np.float32)) for _ in range(extra)]
+    y = g.node(op, ins, **kwargs)
+    if op.startswith("Reduce"):
+        y = g.node("Mul", [y, g.const(np.ones((144000,), dtype=np.float32))])
+    g.node("Identity", [y], outputs=["output"])
+    g.add_output("output", [None, 144000])
+    p = tmp_path / "m.onnx"
+    p.write_bytes(g.serialize())
+    text = bn.plan_describe(str(p))
+    assert f"{op}_" in text and "TOTAL launches=" in text, text
+    status, survey = bn.model_survey(str(p))
+    assert status == 0 and "unmapped" not in survey.split(op)[1].splitlines()[0], survey
+
+
+def test_size_of_an_activation_is_refused_and_of_a_constant_folds(bn, tmp_path):
+    g = writer.GraphBuilder()
+    g.add_input("input", [None, 144000])
+    s = g.node("Size", [g.const(np.ones((3, 5), dtype=np.float32))])
+    y = g.node("Mul", ["input", g.node("Cast", [s], to=1)])
+    g.node("Identity", [y], outputs=["output"])
+    g.add_output("output", [None, 144000])
+    p = tmp_path / "m.onnx"
+    p.write_bytes(g.serialize())
+    assert "p0=15" in bn.plan_describe(str(p)) or "ELT" in bn.plan_describe(str(p))
+    g = writer.GraphBuilder()
+    g.add_input("input", [None, 144000])
+    y = g.node("Mul", ["input", g.node("Cast", [g.node("Size", ["input"])], to=1)])
+    g.node("Identity", [y], outputs=["output"])
+    g.add_output("output", [None, 144000])
+    p.write_bytes(g.serialize())
+    with pytest.raises(bn.EngineError) as e:
+        bn.plan_describe(str(p))
+    assert "depends on the batch" in str(e.value)
