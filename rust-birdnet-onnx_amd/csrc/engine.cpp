@@ -3498,7 +3498,7 @@ class Builder {
                 // Whole-map form with the INPUT resident in LDS (mbmap.hip, round 3): one block = one sample's map x a group of
                 // mid channels, input fetched once per block by LDS-DMA, no staging on the vector ALU.  Default wherever a
                 // configuration fits (192- and 48-pixel maps); BN_MBMAP2=0 disables.
-                int map2 = 0;
+                int map2 = 0, map_b3 = 0;
                 MbmapShape mshape;
                 if (producer0) {
                     MbDesc q{};
@@ -3507,6 +3507,7 @@ class Builder {
                     q.act1 = pe.gemm.act; q.act2 = act.act; q.in_bs = pe.gemm.a_bs;
                     mshape = mbmap_shape(q);
                     map2 = mshape.cfg;
+                    map_b3 = mbmap_b3_steps(q, mshape);
                 }
                 const bool whole_map = map2 != 0 || (!map_off && H * W <= map_maxhw);
                 const bool producer = producer0 && (map2 != 0 || pe.gemm.K <= (whole_map ? 256 : maxk));
@@ -3539,6 +3540,9 @@ class Builder {
                         for (int64_t nn = 0; nn < Cin; nn++)
                             for (int64_t k = 0; k < Kc; k++) wpk[nn * KP + k] = w0[pe.w.offset + nn * Kc + k];
                         mb.w = Ref{Space::CONSTS, add_const(wpk), 0};
+                    } else if (whole_map && map2 && map_b3) {
+                        // mbmap.hip's bf16x3 form: the filters in the order of its LDS chunk image (plan_rules.h)
+                        mb.w = Ref{Space::CONSTS, add_const(pack_mbmap_w3f(plan_.consts[pe.w.id].data() + pe.w.offset, Cin, pe.gemm.K)), 0};
                     } else if (whole_map) {
                         mb.w = pe.w;  // [C][Cin] as the GEMM had it
                     } else {
@@ -3566,6 +3570,7 @@ class Builder {
                         halo = (double)H * W;
                         if (map2) {
                             m.map_bands = mshape.bands; m.map_tr = mshape.tr; m.cin_pad = mshape.cin_pad;
+                            m.map_b3 = map_b3;
                             m.tiles_y = mshape.bands;  // ... per band
                             // expand work performed: every band expands the 6 rows it loads (the rows two bands share twice), over the padded k
                             if (mshape.bands > 1) halo = (double)mshape.bands * 6.0 * (double)(mshape.tr ? H : W);

@@ -206,6 +206,7 @@ struct MbDesc {
     // (round 5) row-streaming form: the expand conv on the bf16 matrix pipe with f32-complete products (bf16x3.h): 1x1 expands with
     // Cin % 8 == 0; decided by the planner (BN_MBROW_B3, BN_GEMM3), part of the block's arithmetic like any kernel choice
     int32_t row_b3;
+    int32_t map_b3;    // small-map kernel: 32-deep bf16x3 steps per wave (plan_rules.h mbmap_b3_steps), 0 = exact-f32 expand
 };
 // MaxPool / AveragePool over an NHWC tensor (1-D pooling = H == 1).
 struct PoolDesc {

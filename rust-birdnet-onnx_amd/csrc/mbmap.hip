@@ -41,6 +41,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "bf16x3.h"
 #include "device_common.h"
 #include "kernels.h"
 #include "plan_rules.h"
@@ -114,6 +115,17 @@ __device__ __forceinline__ void mm_copy_in(float *lds_dst, const float *gsrc, co
     }
 }
 
+// bf16x3 form (NSW > 0): the filter chunk is stored by the planner in FRAGMENT ORDER (plan_rules.h pack_mbmap_w3f) -- piece (tile, step)
+// = 128 chunks of 16 bytes, [h][q][c]: channel 16 tile + c, k = 32 step + 16 h + 4 q .. + 3 -- so the copy of a chunk is one dense block
+// (1 KiB per wave instruction, whole cache lines) and a wave's fragment of a step is two lane-linear, conflict-free ds_read_b128.  (A
+// first version gathered the pieces from the [C][K] rows on the source side of the copy: 16 half-used lines per instruction, and the
+// launch skeleton -- everything but expand and depthwise -- went from 7.6 to 13.6 us at batch 32.)
+template <int NWAVES>
+__device__ __forceinline__ void mm_copy_w3(float *lds_dst, const float *gsrc, int npieces, int wave, int lane) {
+    for (int i = wave; i < 2 * npieces; i += NWAVES)
+        __builtin_amdgcn_global_load_lds(MM_GLB_PTR(gsrc + i * 256 + lane * 4), MM_LDS_PTR(lds_dst + i * 256), 16, 0, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void mm_act(int act, float p0, float p1, float (&v)[N]) {
     if (act == ACT_RELU) map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); });
@@ -126,14 +138,30 @@ __device__ __forceinline__ void mm_act(int act, float p0, float p1, float (&v)[N
 // the expand are split between two sets of waves whose partial tiles are added through the chunk image -- twice the
 // waves for the same LDS, used where a map of 48 pixels gives four waves too little to hide anything); the map has
 // exactly H W = 16 MW WM pixels, a chunk 16 NW WN channels
-template <int K, int S, int MW, int NW, int WM, int WN, int KSP, int H, int W, bool SWZ16, int NB = 1, int HM = H>
+//
+// NSW > 0 (round 5): the expand on the BF16 matrix pipe with f32-complete products (bf16x3.h).  A wave keeps the three bf16 planes of ITS
+// pixels' input rows in registers for the whole block (MW NSW fragments of 32-deep k, read from an LDS image that exists only during the
+// prologue, split once), the planner stores the filters in fragment order (pack_mbmap_w3f: a chunk is one dense copy) and a filter
+// fragment is split as it is read -- 44 vector instructions against the 6 MW matrix instructions it feeds, on the other pipe.  NSW =
+// 32-deep steps per wave (all of them, or this K slice's half).  Arithmetic per expanded value: bias + steps ascending, inside a step the
+// six partial products in bf16x3.h's fixed order; the depthwise half is unchanged.
+// MEASURED (tools/mbmap_phases.py, v2.4 at batch 32, one context; exact-f32 -> bf16x3): the expand phase of the 6 x 32 x 112 launch
+// 9.1 -> 4.5 us, of the 3 x 16 x 192 one 7.5 -> 3.2 us; the launches 24.1 -> 22.0 and 18.3 -> 16.4 us -- the prologue grew by 2.2 us
+// (the split of the block's input: 96 values per lane, 5.5 vector instructions each, both waves of a SIMD), which three chunks per
+// block do not amortise well; marginal cost of the ten launches per 32 more segments 106 -> 76 us; four contexts 64.6 -> 65.7 k
+// segments/s (v3.0 at batch 64: 53.6 -> 54.5 k).  More chunks per block (BN_MBMAP2_NCH=6) buy another 1.5 % with four contexts and
+// cost 130 us of the one-context chain: not taken.
+template <int K, int S, int MW, int NW, int WM, int WN, int KSP, int H, int W, bool SWZ16, int NB = 1, int HM = H, int NSW = 0>
 __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in,
                                                                    const float *__restrict__ w1, const float *__restrict__ b1,
                                                                    const float *__restrict__ w2, const float *__restrict__ b2,
                                                                    float *__restrict__ gap, int nch, uint32_t inv_ch, const float *__restrict__ zpage) {
     constexpr int WPS = WM * WN, NWAVES = WPS * KSP, T = 64 * NWAVES, HW = 16 * MW * WM, NC = 16 * NW * WN, NG = T / NC;
+    constexpr bool B3 = NSW > 0;
+    constexpr int NST = NSW * KSP;  // 32-deep k steps of the whole product (B3)
     static_assert(H * W == HW, "the band is exactly the pixels of the wave tiles");
-    static_assert(KSP == 1 || (KSP == 2 && SWZ16), "the K split walks the 4-group blocks of the SWZ16 layout");
+    static_assert(KSP == 1 || (KSP == 2 && (SWZ16 || B3)), "the K split walks the 4-group blocks of the SWZ16 layout");
+    static_assert(MW * NSW <= 12, "the input planes of a wave: 12 registers per fragment");
     static_assert((W & (W - 1)) == 0 && NB >= 1 && NB <= 2 && (NB > 1 || HM == H), "bands: one or two, of a map HM rows high");
     constexpr int PT = (K - 1) / 2;  // padding on every side (checked by mbmap_shape)
     constexpr int OHM = (HM + 2 * PT - K) / S + 1, OH = OHM / NB, OW = (W + 2 * PT - K) / S + 1;  // OH: output rows of ONE band
@@ -144,9 +172,9 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
     extern __shared__ __align__(1024) float mm_lds[];
     const int Cin = d.cin_pad, CH = Cin >> 2;             // floats / chunks per LDS row (the padded k; == d.Cin unless the planner padded)
     const int tr = d.map_tr;
-    float *Xs = mm_lds;                                   // [HW][Cin]
-    float *Ws = Xs + mm_kib(HW * Cin);                    // [2][NC][Cin]
-    const int wsz = mm_kib(NC * Cin);
+    float *Xs = mm_lds;                                   // [HW][Cin]                      (B3: absent)
+    float *Ws = B3 ? mm_lds : Xs + mm_kib(HW * Cin);      // [2][NC][Cin]                   (B3: [2][NC / 16][NST][128 chunks])
+    const int wsz = B3 ? mm_kib(NC * 32 * NST) : mm_kib(NC * Cin);
     float *Es = Ws + 2 * wsz;                             // [H][WP][EP], columns < PT and >= PT + W stay zero
     float *red = Es + mm_kib(H * WP * EP);                // [NG][NC]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -160,9 +188,45 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
     const int cbase = blockIdx.x * nch * NC;              // first mid channel of this block
     const int nchunks = min(nch, (d.C - cbase + NC - 1) / NC);
 
+    if (d.dbg & 32) return;  // (tools/mbmap_phases.py: the cost of the empty launch)
     // ---- prologue: the sample's input and the first filter chunk on their way, the padding of the chunk image zeroed
-    mm_copy_in<NWAVES, SWZ16, W, HM>(Xs, in + b * d.in_bs, zpage, HW, CH, d.Cin >> 2, d.Cin, inv_ch, gy0, tr, wave, lane);
-    mm_copy<NWAVES, SWZ16>(Ws, w1 + (int64_t)cbase * Cin, min(NC, d.C - cbase), CH, inv_ch, wave, lane);
+    b3_u32x4 xh[B3 ? MW : 1][B3 ? NSW : 1], xm[B3 ? MW : 1][B3 ? NSW : 1], xl[B3 ? MW : 1][B3 ? NSW : 1];
+    floatx4 raw[B3 ? MW : 1][B3 ? NSW : 1][2];
+    if constexpr (B3) {
+        // The sample's input goes through LDS once: the f32 form's dense copy (whole cache lines, 1 KiB per wave instruction) into an image
+        // that ALIASES the second filter buffer, the chunk image and the squeeze partials -- it is dead before any of them is written.
+        // Lane (c, q) of fragment (mt, s) then reads k groups 2 s' and 2 s' + 1 (s' = kh NSW + s) of pixel 16 (wm MW + mt) + c exactly as the
+        // f32 form reads them (same swizzle, conflict free): its eight values are k = 32 s' + 4 q .. + 3 and 32 s' + 16 + 4 q .. + 3 -- the k
+        // order inside a step is free as long as the filters follow it (pack_mbmap_w3f does).  (Loading the fragments straight from global
+        // memory -- one pixel row per lane -- cost 3 us per launch: 64 separate 16-byte requests per instruction.)
+        float *Xi = mm_lds + wsz;
+        mm_copy_in<NWAVES, SWZ16, W, HM>(Xi, in + b * d.in_bs, zpage, HW, CH, d.Cin >> 2, d.Cin, inv_ch, gy0, tr, wave, lane);
+        mm_copy_w3<NWAVES>(Ws, w1 + (int64_t)(cbase / 16) * (NST * 512), NC / 16 * NST, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int G16 = Cin >> 4;
+#pragma unroll
+        for (int mt = 0; mt < MW; mt++) {
+            const int m = (wm * MW + mt) * 16 + (lane & 15);
+            const int sw = mm_swz<SWZ16>(m);
+#pragma unroll
+            for (int st = 0; st < NSW; st++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int g = 2 * (kh * NSW + st) + h;
+                    const int off = SWZ16 ? m * Cin + 64 * (g >> 2) + 16 * ((g & 3) ^ (sw >> 2)) + 4 * ((lane >> 4) ^ (sw & 3))
+                                          : m * Cin + 16 * g + 4 * ((lane >> 4) ^ sw);
+                    raw[mt][st][h] = (g < G16 && !(d.dbg & 8)) ? *reinterpret_cast<const floatx4 *>(Xi + off) : floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave has its fragments: the image's space is free for the chunk image and the filter ring
+        asm volatile("" ::: "memory");
+    } else {
+        mm_copy_in<NWAVES, SWZ16, W, HM>(Xs, in + b * d.in_bs, zpage, HW, CH, d.Cin >> 2, d.Cin, inv_ch, gy0, tr, wave, lane);
+        mm_copy<NWAVES, SWZ16>(Ws, w1 + (int64_t)cbase * Cin, min(NC, d.C - cbase), CH, inv_ch, wave, lane);
+    }
     // the K - 1 padding columns of every row of the chunk image are zero and stay zero (the expand writes the interior)
     for (int i = tid; i < H * (K - 1) * (EP / 4); i += T) {
         const int q4 = i % (EP / 4), pc = (i / (EP / 4)) % (K - 1), y = i / ((EP / 4) * (K - 1));
@@ -203,12 +267,14 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
         floatx4 bias4[NW];
         float wd[K * K], bz;
     };
-    auto fetch = [&](ChunkConst &cc_, int c0) {
+    auto fetch_bias = [&](ChunkConst &cc_, int c0) {
 #pragma unroll
         for (int nt = 0; nt < NW; nt++) {
             const int n = c0 + (wn * NW + nt) * 16 + 4 * lq;
             cc_.bias4[nt] = (d.has_bias1 && kh == 0 && n < d.C) ? *reinterpret_cast<const floatx4 *>(b1 + n) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto fetch_dw = [&](ChunkConst &cc_, int c0) {
         // (uniform base + unsigned 32-bit lane offset: the form the compiler can issue as a scalar-base load -- with a signed index it
         // sign-extended and added 64 bits on the vector ALU for every tap, 110 of the chunk's 800 vector instructions)
         const unsigned cl = (unsigned)min(c0 + c, d.C - 1);
@@ -216,22 +282,44 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
         for (int q = 0; q < K * K; q++) cc_.wd[q] = (w2 + (size_t)(tr ? (q % K) * K + q / K : q) * (size_t)d.C)[cl];  // kernel tap (ky, kx) = map tap (kx, ky) when transposed
         cc_.bz = d.has_bias2 ? b2[cl] : 0.0f;
     };
+    // f32 form: everything one chunk ahead.  bf16x3 form: the expand bias one chunk ahead, the depthwise constants of a chunk at ITS start
+    // (they are first used behind the expand phase, which hides the loads just as well) -- one set of K K + 1 registers instead of two
+    // beside the input planes
+    auto fetch = [&](ChunkConst &cc_, int c0) {
+        fetch_bias(cc_, c0);
+        if constexpr (!B3) fetch_dw(cc_, c0);
+    };
     ChunkConst nxt;
     fetch(nxt, cbase);
+    if constexpr (B3) {  // the split of the input fragments runs while the chunk constants requested above are on their way
+#pragma unroll
+        for (int mt = 0; mt < MW; mt++)
+#pragma unroll
+            for (int st = 0; st < NSW; st++) {
+                if (d.dbg & 16) {
+                    xh[mt][st] = xm[mt][st] = xl[mt][st] = __builtin_bit_cast(b3_u32x4, raw[mt][st][0] + raw[mt][st][1]);
+                } else {
+                    split3(raw[mt][st][0], raw[mt][st][1], xh[mt][st], xm[mt][st], xl[mt][st]);
+                }
+            }
+    }
     // the first filter chunk and the input have landed, the padding is written
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    if (d.dbg & 64) return;  // (... of launch + prologue)
     for (int ch = 0; ch < nchunks; ch++) {
         const int c0 = cbase + ch * NC;
         float *Wc = Ws + (ch & 1) * wsz;
-        const ChunkConst cur = nxt;
+        ChunkConst cur = nxt;
+        if constexpr (B3) fetch_dw(cur, c0);
         const int cg = c0 + c;
         const bool cact = cg < d.C;
         // the next chunk's filters and constants start moving now (that filter buffer was last read two barriers ago)
         if (ch + 1 < nchunks) {
-            mm_copy<NWAVES, SWZ16>(Ws + ((ch + 1) & 1) * wsz, w1 + (int64_t)(c0 + NC) * Cin, min(NC, d.C - c0 - NC), CH, inv_ch, wave, lane);
+            if constexpr (B3) mm_copy_w3<NWAVES>(Ws + ((ch + 1) & 1) * wsz, w1 + (int64_t)((c0 + NC) / 16) * (NST * 512), NC / 16 * NST, wave, lane);
+            else mm_copy<NWAVES, SWZ16>(Ws + ((ch + 1) & 1) * wsz, w1 + (int64_t)(c0 + NC) * Cin, min(NC, d.C - c0 - NC), CH, inv_ch, wave, lane);
             fetch(nxt, c0 + NC);
         }
         floatx4 acc[MW][NW];
@@ -258,6 +346,23 @@ __global__ __launch_bounds__(64 * WM * WN * KSP) void mbmap_kernel(MbDesc d, flo
                     for (int mt = 0; mt < MW; mt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][j], xf[mt][j], acc[mt][nt], 0, 0, 0);
         };
         if (d.dbg & 1) {
+        } else if constexpr (B3) {
+            // step s, channel tile nt: the filter fragment (two lane-linear reads, fetched one fragment ahead), split, six products per pixel tile
+            floatx4 wr[2][2];
+            auto rdw = [&](floatx4 (&r)[2], int f) {  // f = st * NW + nt, compile time at every call site
+                const float *wb = Wc + (((wn * NW + f % NW) * NST + kh * NSW + f / NW) * 128 + lane) * 4;
+                r[0] = *reinterpret_cast<const floatx4 *>(wb);
+                r[1] = *reinterpret_cast<const floatx4 *>(wb + 256);
+            };
+            rdw(wr[0], 0);
+#pragma unroll
+            for (int f = 0; f < NSW * NW; f++) {
+                if (f + 1 < NSW * NW) rdw(wr[(f + 1) & 1], f + 1);
+                b3_u32x4 wh, wmid, wl;
+                split3(wr[f & 1][0], wr[f & 1][1], wh, wmid, wl);
+#pragma unroll
+                for (int mt = 0; mt < MW; mt++) acc[mt][f % NW] = mm6(wh, wmid, wl, xh[mt][f / NW], xm[mt][f / NW], xl[mt][f / NW], acc[mt][f % NW]);
+            }
         } else if constexpr (SWZ16) {
             // G % 4 == 0: one 256-byte block of four groups per trip; this slice takes NGG of them, two at a time
             for (int g = 0; g < G; g += 4) {
@@ -420,17 +525,24 @@ int mbmap_chunks_per_block(const MbDesc &d, const MbmapShape &sh, int64_t batch)
 }
 
 void register_mbmap_kernels() {
-#define MM_REG(K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM) \
-    register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM>));
-#define MM_REG_KS(MW, NW, WM, WN, KSP, H, W, SW, NB, HM)                                                     \
-    MM_REG(3, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM) MM_REG(5, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM) \
-    MM_REG(3, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM) MM_REG(5, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM)
-    MM_REG_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6)
-    MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6)
-    MM_REG_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3)
-    MM_REG(3, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4) MM_REG(5, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4)
-    MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false, 2, 8)                                                          // cfg 5: 8 x 32 in two bands
-    MM_REG(3, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4) MM_REG(5, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4)  // cfg 6
+#define MM_REG(K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW) \
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW>));
+#define MM_REG_KS(MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW)                                                          \
+    MM_REG(3, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW) MM_REG(5, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW) \
+    MM_REG(3, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW) MM_REG(5, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW)
+    MM_REG_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6, 0)
+    MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6, 0)
+    MM_REG_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3, 0)
+    MM_REG(3, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4, 0) MM_REG(5, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4, 0)
+    MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false, 2, 8, 0)                                                          // cfg 5: 8 x 32 in two bands
+    MM_REG(3, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4, 0) MM_REG(5, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4, 0)  // cfg 6
+    // bf16x3 expand (plan_rules.h mbmap_b3_steps)
+    MM_REG_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6, 2) MM_REG_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6, 3)
+    MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6, 3) MM_REG_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6, 4)
+    MM_REG_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3, 2) MM_REG_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3, 3) MM_REG_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3, 4)
+    MM_REG(3, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4, 2) MM_REG(5, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4, 2)
+    MM_REG(3, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4, 3) MM_REG(5, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4, 3)
+    MM_REG(3, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4, 4) MM_REG(5, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4, 4)
 #undef MM_REG_KS
 #undef MM_REG
 }
@@ -442,37 +554,55 @@ bool launch_mbmap(hipStream_t s, const MbDesc &d, float *out, const float *in, c
     if (!sh.cfg || !mm_al16(in) || !mm_al16(w1) || !mm_al16(b1) || !zpage) return false;
     // the plan was built under the same rules: a descriptor whose padding / transposition / bands disagree with them is refused
     if (d.cin_pad != sh.cin_pad || d.map_tr != sh.tr || d.map_bands != sh.bands) return false;
+    const int nsw = d.map_b3;
+    if (nsw && nsw != mbmap_b3_steps(d, sh)) return false;
     MbDesc dd = d;
     dd.dbg = getenv("BN_MM_DBG") ? atoi(getenv("BN_MM_DBG")) : 0;
     const int nch = mbmap_chunks_per_block(d, sh, batch);
+    const int nst = nsw * (sh.cfg >= 3 ? 2 : 1);
     const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(sh.cin_pad / 4)) + 1u;  // slot -> row of the swizzled copies
     MbDesc lds_d = d;  // LDS sizes: padded rows, the kernel's geometry (transposed maps: H <-> W), a band's rows
     lds_d.Cin = sh.cin_pad;
     if (sh.tr) std::swap(lds_d.H, lds_d.W);
     if (sh.bands > 1) lds_d.H = 6;
-#define MM_GO(K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM)                                                                                    \
+#define MM_GO(K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW)                                                                                \
     do {                                                                                                                              \
         constexpr int NC = 16 * NW * WN;                                                                                              \
         dim3 grid((unsigned)((d.C + nch * NC - 1) / (nch * NC)), (unsigned)batch, (unsigned)NB);                                      \
-        const size_t lds_ = mbmap_lds_bytes(lds_d, MW, NW, WM, WN, KSP);                                                              \
-        hipLaunchKernelGGL((mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM>), grid, dim3(64 * WM * WN * KSP), lds_, s, dd, out, in, w1, b1, w2, b2, \
-                           gap, nch, inv_ch, zpage);                                                                                  \
+        const size_t lds_ = NSW ? mbmap_lds_bytes_b3(lds_d, nst, NW, WM, WN, KSP) : mbmap_lds_bytes(lds_d, MW, NW, WM, WN, KSP);      \
+        hipLaunchKernelGGL((mbmap_kernel<K, S, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW>), grid, dim3(64 * WM * WN * KSP), lds_, s, dd, out, in, w1, \
+                           b1, w2, b2, gap, nch, inv_ch, zpage);                                                                      \
     } while (0)
-#define MM_GO_KS(MW, NW, WM, WN, KSP, H, W, SW, NB, HM)                                    \
-    do {                                                                                  \
-        if (d.k == 3 && d.s == 1) MM_GO(3, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM);      \
-        else if (d.k == 5 && d.s == 1) MM_GO(5, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM); \
-        else if (d.k == 3) MM_GO(3, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM);             \
-        else MM_GO(5, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM);                           \
+#define MM_GO_KS(MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW)                                    \
+    do {                                                                                       \
+        if (d.k == 3 && d.s == 1) MM_GO(3, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW);      \
+        else if (d.k == 5 && d.s == 1) MM_GO(5, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW); \
+        else if (d.k == 3) MM_GO(3, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW);             \
+        else MM_GO(5, 2, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW);                           \
     } while (0)
-    if (sh.cfg == 1) MM_GO_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6);
-    else if (sh.cfg == 2) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6);
-    else if (sh.cfg == 3) MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3);
-    else if (sh.cfg == 4 && d.k == 3) MM_GO(3, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4);
-    else if (sh.cfg == 4) MM_GO(5, 1, 2, 1, 2, 2, 2, 4, 16, true, 1, 4);
-    else if (sh.cfg == 5) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false, 2, 8);
-    else if (d.k == 3) MM_GO(3, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4);
-    else MM_GO(5, 1, 2, 1, 2, 2, 1, 4, 16, false, 1, 4);
+#define MM_GO_K31(MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW)                     \
+    do {                                                                         \
+        if (d.k == 3) MM_GO(3, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW);    \
+        else MM_GO(5, 1, MW, NW, WM, WN, KSP, H, W, SW, NB, HM, NSW);             \
+    } while (0)
+    if (nsw) {
+        if (sh.cfg == 1 && nsw == 2) MM_GO_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6, 2);
+        else if (sh.cfg == 1) MM_GO_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6, 3);
+        else if (sh.cfg == 2 && nsw == 3) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6, 3);
+        else if (sh.cfg == 2) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6, 4);
+        else if (sh.cfg == 3 && nsw == 2) MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3, 2);
+        else if (sh.cfg == 3 && nsw == 3) MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3, 3);
+        else if (sh.cfg == 3) MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3, 4);
+        else if (nsw == 2) MM_GO_K31(2, 1, 2, 2, 2, 4, 16, true, 1, 4, 2);
+        else if (nsw == 3) MM_GO_K31(2, 1, 2, 2, 2, 4, 16, true, 1, 4, 3);
+        else MM_GO_K31(2, 1, 2, 2, 2, 4, 16, true, 1, 4, 4);
+    } else if (sh.cfg == 1) MM_GO_KS(3, 2, 4, 2, 1, 6, 32, false, 1, 6, 0);
+    else if (sh.cfg == 2) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false, 1, 6, 0);
+    else if (sh.cfg == 3) MM_GO_KS(3, 1, 1, 4, 2, 3, 16, true, 1, 3, 0);
+    else if (sh.cfg == 4) MM_GO_K31(2, 1, 2, 2, 2, 4, 16, true, 1, 4, 0);
+    else if (sh.cfg == 5) MM_GO_KS(3, 1, 4, 2, 1, 6, 32, false, 2, 8, 0);
+    else MM_GO_K31(2, 1, 2, 2, 1, 4, 16, false, 1, 4, 0);
+#undef MM_GO_K31
 #undef MM_GO_KS
 #undef MM_GO
     return true;

@@ -369,6 +369,42 @@ inline MbmapShape mbmap_shape(const MbDesc &d) {
 }
 inline int mbmap_config(const MbDesc &d) { return mbmap_shape(d).cfg; }
 
+// The small-map kernel's expand on the bf16 matrix pipe (mbmap.hip, NSW > 0): 32-deep k steps per wave, or 0 where the f32 form stays.
+// Compiled: cfg 1 with 2 / 3 steps (Cin <= 96), cfg 2 with 3 / 4 (Cin <= 128), cfg 3 / 4 (two K slices) with 2 / 3 / 4 per slice
+// (Cin = 128 / 192 / 256).  BN_MBMAP_B3=0 (or BN_GEMM3=0) keeps the exact-f32 instruction.
+inline int mbmap_b3_steps(const MbDesc &d, const MbmapShape &sh) {
+    if (!sh.cfg || sh.cfg > 4 || sh.tr || sh.bands != 1 || sh.cin_pad != d.Cin || d.Cin % 8) return 0;
+    if (env_int("BN_MBMAP_B3", 1) == 0 || env_int("BN_GEMM3", 2) == 0) return 0;
+    const int nst = (d.Cin + 31) / 32, ksp = sh.cfg >= 3 ? 2 : 1;
+    if (nst % ksp) return 0;
+    const int nsw = nst / ksp;
+    const bool ok = sh.cfg == 1 ? (nsw == 2 || nsw == 3) : sh.cfg == 2 ? (nsw == 3 || nsw == 4) : (nsw >= 2 && nsw <= 4);
+    return ok ? nsw : 0;
+}
+// the expand filters [C][K] in the order that form's filter chunk has in LDS: [tile of 16 channels][32-deep step][h][q][c][4 floats] holds
+// channel 16 tile + c, k = 32 step + 16 h + 4 q .. + 3 (the k order of the kernel's input fragments; zeros past C and K; tiles padded to whole 64-channel chunks), so a chunk is ONE dense
+// block of memory for the global -> LDS copy and a wave's fragment of a step is two lane-linear 16-byte reads
+inline std::vector<float> pack_mbmap_w3f(const float *w, int64_t C, int64_t K) {
+    const int64_t nst = (K + 31) / 32, tiles = (C + 63) / 64 * 4;
+    std::vector<float> out((size_t)(tiles * nst * 512), 0.0f);
+    for (int64_t t = 0; t < tiles; t++)
+        for (int64_t st = 0; st < nst; st++)
+            for (int64_t h = 0; h < 2; h++)
+                for (int64_t q = 0; q < 4; q++)
+                    for (int64_t c = 0; c < 16; c++)
+                        for (int64_t j = 0; j < 4; j++) {
+                            const int64_t row = 16 * t + c, k = 32 * st + 16 * h + 4 * q + j;
+                            if (row < C && k < K) out[(size_t)((((t * nst + st) * 128) + h * 64 + q * 16 + c) * 4 + j)] = w[row * K + k];
+                        }
+    return out;
+}
+inline size_t mbmap_lds_bytes_b3(const MbDesc &d, int nst, int nw, int wm, int wn, int ksp) {  // d in the kernel's geometry (H, W, k)
+    // two filter buffers + chunk image + squeeze partials; the input image of the prologue lies over everything behind the first buffer
+    const int nc = 16 * nw * wn, ng = 64 * wm * wn * ksp / nc, wsz = mm_kib(nc * 32 * nst);
+    const int ring = 2 * wsz + mm_kib(d.H * (d.W + d.k - 1) * (nc + 4)) + ng * nc, pro = wsz + mm_kib(d.H * d.W * d.Cin);
+    return (size_t)(ring > pro ? ring : pro) * sizeof(float);
+}
+
 // ---- FFT front end (stft.hip) -------------------------------------------------------------------------------------
 // LDS carve-up (floats), shared by the kernel and stft_lds_bytes.  Table regions are whole KiB: the asynchronous
 // global -> LDS copies write 1 KiB per wave instruction.
