@@ -1809,7 +1809,7 @@ size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int3
                          op.mb.row_mode ? op.mb.toh : 0, op.mb.row_mode && op.mb.row_tr ? "(columns)" : "");
                 extra = line;
                 if (op.mb.whole_map == 2) {  // mbmap.hip: configuration, bands, transposition, padded k
-                    snprintf(line, sizeof(line), " map=cfg%d%s%s%s kpad=%d", mbmap_config(op.mb), op.mb.map_bands > 1 ? ",bands" : "", op.mb.map_tr ? ",transposed" : "", op.mb.map_b3 ? ",b3" : "", op.mb.cin_pad);
+                    snprintf(line, sizeof(line), " map=cfg%d%s%s%s kpad=%d", mbmap_config(op.mb), op.mb.map_bands > 1 ? ",bands" : "", op.mb.map_tr ? ",transposed" : "", op.mb.map_ws ? ",ws" : op.mb.map_b3 ? ",b3" : "", op.mb.cin_pad);
                     extra += line;
                 }
             } else if (op.kind == OpKind::POOL) {

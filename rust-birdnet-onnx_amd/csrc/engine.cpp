@@ -3498,7 +3498,7 @@ class Builder {
                 // Whole-map form with the INPUT resident in LDS (mbmap.hip, round 3): one block = one sample's map x a group of
                 // mid channels, input fetched once per block by LDS-DMA, no staging on the vector ALU.  Default wherever a
                 // configuration fits (192- and 48-pixel maps); BN_MBMAP2=0 disables.
-                int map2 = 0, map_b3 = 0;
+                int map2 = 0, map_b3 = 0, map_ws = 0;
                 MbmapShape mshape;
                 if (producer0) {
                     MbDesc q{};
@@ -3508,6 +3508,7 @@ class Builder {
                     mshape = mbmap_shape(q);
                     map2 = mshape.cfg;
                     map_b3 = mbmap_b3_steps(q, mshape);
+                    map_ws = mbmap_ws_steps(q, mshape);
                 }
                 const bool whole_map = map2 != 0 || (!map_off && H * W <= map_maxhw);
                 const bool producer = producer0 && (map2 != 0 || pe.gemm.K <= (whole_map ? 256 : maxk));
@@ -3570,7 +3571,7 @@ class Builder {
                         halo = (double)H * W;
                         if (map2) {
                             m.map_bands = mshape.bands; m.map_tr = mshape.tr; m.cin_pad = mshape.cin_pad;
-                            m.map_b3 = map_b3;
+                            m.map_b3 = map_b3; m.map_ws = map_ws;
                             m.tiles_y = mshape.bands;  // ... per band
                             // expand work performed: every band expands the 6 rows it loads (the rows two bands share twice), over the padded k
                             if (mshape.bands > 1) halo = (double)mshape.bands * 6.0 * (double)(mshape.tr ? H : W);

@@ -206,6 +206,7 @@ struct MbDesc {
     // (round 5) row-streaming form: the expand conv on the bf16 matrix pipe with f32-complete products (bf16x3.h): 1x1 expands with
     // Cin % 8 == 0; decided by the planner (BN_MBROW_B3, BN_GEMM3), part of the block's arithmetic like any kernel choice
     int32_t row_b3;
+    int32_t map_ws;    // 6 x 32 maps: the wave-specialised kernel (mbmap_ws.hip) with this many 32-deep steps, 0 = mbmap.hip
     int32_t map_b3;    // small-map kernel: 32-deep bf16x3 steps per wave (plan_rules.h mbmap_b3_steps), 0 = exact-f32 expand
 };
 // MaxPool / AveragePool over an NHWC tensor (1-D pooling = H == 1).
@@ -235,6 +236,8 @@ void launch_mbconv_row(hipStream_t s, const MbDesc &d, float *out, const float *
                        const float *b2, float *gap, int64_t batch);
 // whole-map form with the input resident in LDS (mbmap.hip): configuration this block takes (0 = none; per-sample
 // quantities only), and the launch (false = not eligible, nothing launched)
+bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
+                     float *gap, int64_t batch, int nch);
 bool launch_mbmap(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
                   float *gap, int64_t batch);
 struct SeTail;

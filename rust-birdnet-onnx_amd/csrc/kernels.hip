@@ -72,6 +72,7 @@ void register_stft_kernels();  // stft.hip
 void register_topk_kernels();  // topk.hip
 void register_gemm_dma_kernels();  // gemm_dma.hip
 void register_mbmap_kernels();     // mbmap.hip
+void register_mbmap_ws_kernels();  // mbmap_ws.hip
 void register_gemm_dma3_kernels();  // gemm_dma3.hip
 
 bool prepare_device(int dev) {
@@ -85,6 +86,7 @@ bool prepare_device(int dev) {
         register_topk_kernels();
         register_gemm_dma_kernels();
         register_mbmap_kernels();
+        register_mbmap_ws_kernels();
         register_gemm_dma3_kernels();
     }
     int cur = -1;

@@ -1,0 +1,315 @@
+// Fused MBConv front half for the 6 x 32 maps, WAVE-SPECIALISED (round 5): expand 1x1 conv (+bias+act) on the bf16 matrix pipe (bf16x3.h)
+// and depthwise K x K (+bias+act) + squeeze sums on the vector ALU run in the SAME phase, on different waves and different chunks.
+//
+// mbmap.hip walks a block's channel chunks in two phases per chunk -- every wave expands, barrier, every wave runs the depthwise window,
+// barrier -- so the matrix pipe idles through the depthwise phase and the vector ALU through the expand (tools/mbmap_phases.py: of the
+// 22 us of the 6 x 32 x 112 launch at batch 32, 4.5 are expand, 5.3 depthwise, 4.8 the loop's waits and barriers).  Here a block is
+// eight waves of two kinds:
+//   * waves 0-3 (one per SIMD) EXPAND chunk p: each owns three pixel tiles (48 of the map's 192 pixels) and both 16-channel tiles of
+//     the 32-channel chunk; the three bf16 planes of its pixels' input rows sit in registers for the whole block (read from an LDS
+//     image that exists only in the prologue, split once), the filter chunk arrives in fragment order by LDS-DMA (pack_mbmap_w3f;
+//     these waves issue the copy of chunk p + 1 at the start of phase p and are the only ones that wait for it -- they store nothing to
+//     memory, so their vmcnt wait never includes a result store's round trip) and is split as it is read; the activated tiles go
+//     into chunk image p mod 2;
+//   * waves 4-7 (the other wave of each SIMD) run the DEPTHWISE window of chunk p - 1 from chunk image (p - 1) mod 2: lane = channel,
+//     lane group = strip of output columns over all rows, exactly mbmap.hip's phase (same taps, same order, same bits), with eight lane
+//     groups instead of sixteen; they store the results and the squeeze sums.
+// One barrier per phase; nchunks + 1 phases.  The matrix instructions of one wave and the vector instructions of the other share a
+// SIMD's issue but not its pipes.
+// MEASURED (tools/mbmap_phases.py ... 0 BN_MBMAP_WS; v2.4, one context, mbmap.hip's bf16x3 form -> this kernel): the 6 x 32 x 112 launches
+// 22.2 -> 20.6 us at batch 32 and 60.0 -> 47.4 us at batch 128 (marginal cost per 32 segments 12.6 -> 8.9 us; the exact-f32 form: 16),
+// the 6 x 32 x 80 ones 14.2 -> 14.1 and 33.2 -> 28.6 us; four contexts +1 %.  A phase is now bound by the vector ALU alone: the
+// depthwise taps (600 FMA per lane and chunk), the two SiLU's transcendentals and the 352 instructions of the filter split share it;
+// the matrix pipe is busy for a third of the phase.
+//
+// Arithmetic per value: identical to mbmap.hip's bf16x3 form (expand = bias + 32-deep steps ascending, six partial products per step
+// in bf16x3.h's order; depthwise = bias2 + taps ascending): the same result bits.  The squeeze sum of a channel adds the partials of
+// EIGHT column strips (in strip order) where mbmap.hip's 32-channel configuration adds sixteen -- the same terms, associated differently;
+// against its 64-channel configuration (eight strips as well) everything is bit-identical (tests/test_gpu_ops.py).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "bf16x3.h"
+#include "device_common.h"
+#include "kernels.h"
+#include "plan_rules.h"
+
+namespace bn {
+namespace {
+
+#include "mbmap_common.h"
+
+template <int K, int S, int NSW>
+__global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w1,
+                                                       const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+                                                       float *__restrict__ gap, int nch, uint32_t inv_ch, const float *__restrict__ zpage) {
+    constexpr int H = 6, W = 32, HW = H * W, NC = 32, MW = 3, NW = 2, EWV = 4, TD = 256, NGD = TD / NC;
+    constexpr int PT = (K - 1) / 2, OH = (H + 2 * PT - K) / S + 1, OW = (W + 2 * PT - K) / S + 1;
+    static_assert(OW % NGD == 0, "one strip of output columns per lane group");
+    constexpr int PPG = OW / NGD, IWS = (PPG - 1) * S + K, WP = W + K - 1, EP = NC + 4;
+    constexpr int WSZ = NC * 32 * NSW, ESZ = mm_kib(H * WP * EP), RSZ = NGD * NC;
+    extern __shared__ __align__(1024) float ws_lds[];
+    float *Ws = ws_lds;                 // [2][NC / 16][NSW][128 chunks of 16 bytes]
+    float *Es = Ws + 2 * WSZ;           // [2][H][WP][EP], columns < PT and >= PT + W stay zero
+    float *red = Es + 2 * ESZ;          // [2][NGD][NC]
+    float *Xi = ws_lds + WSZ;           // prologue only: the input image [HW][Cin], over everything behind the first filter buffer
+    const int Cin = d.Cin, CH = Cin >> 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool expander = wave < EWV;   // (wave-uniform)
+    const int lc = lane & 15, lq = lane >> 4;
+    const int64_t b = blockIdx.y;
+    const int cbase = blockIdx.x * nch * NC;
+    const int nchunks = min(nch, (d.C - cbase + NC - 1) / NC);
+
+    // ---- prologue, all waves: the sample's input image and the first filter chunk
+    mm_copy_in<8, false, W, H>(Xi, in + b * d.in_bs, zpage, HW, CH, CH, Cin, inv_ch, 0, 0, wave, lane);
+    mm_copy_w3<8>(Ws, w1 + (int64_t)(cbase / 16) * (NSW * 512), (NC / 16) * NSW, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    floatx4 raw[MW][NSW][2];
+    if (expander) {
+        // lane (c, q) of fragment (mt, s): k groups 2 s and 2 s + 1 of pixel 16 (3 wave + mt) + c, read as mbmap.hip's f32 form reads them
+        const int G16 = Cin >> 4;
+#pragma unroll
+        for (int mt = 0; mt < MW; mt++) {
+            const int m = (wave * MW + mt) * 16 + lc;
+            const int sw = mm_swz<false>(m);
+#pragma unroll
+            for (int st = 0; st < NSW; st++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int g = 2 * st + h;
+                    raw[mt][st][h] = g < G16 ? *reinterpret_cast<const floatx4 *>(Xi + m * Cin + 16 * g + 4 * (lq ^ sw)) : floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the image's space is free
+    asm volatile("" ::: "memory");
+    // the K - 1 padding columns of every row of both chunk images are zero and stay zero
+    for (int i = tid; i < 2 * H * (K - 1) * (EP / 4); i += 512) {
+        const int q4 = i % (EP / 4), pc = (i / (EP / 4)) % (K - 1), y = (i / ((EP / 4) * (K - 1))) % H, im = i / ((EP / 4) * (K - 1) * H);
+        const int xcol = pc < PT ? pc : W + pc;
+        *reinterpret_cast<floatx4 *>(Es + im * ESZ + (y * WP + xcol) * EP + 4 * q4) = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    if (expander) {
+        // =================================================================== expand waves
+        b3_u32x4 xh[MW][NSW], xm[MW][NSW], xl[MW][NSW];
+        int epix[MW];
+#pragma unroll
+        for (int mt = 0; mt < MW; mt++) {
+            const int m = (wave * MW + mt) * 16 + lc;
+            const int y = m / W, x = m - y * W;
+            epix[mt] = (y * WP + x + PT) * EP;
+        }
+        auto fetch_bias = [&](floatx4 (&bz)[NW], int c0) {
+#pragma unroll
+            for (int nt = 0; nt < NW; nt++) {
+                const int n = c0 + nt * 16 + 4 * lq;
+                bz[nt] = (d.has_bias1 && n < d.C) ? *reinterpret_cast<const floatx4 *>(b1 + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        floatx4 nbias[NW];
+        fetch_bias(nbias, cbase);
+#pragma unroll
+        for (int mt = 0; mt < MW; mt++)
+#pragma unroll
+            for (int st = 0; st < NSW; st++) split3(raw[mt][st][0], raw[mt][st][1], xh[mt][st], xm[mt][st], xl[mt][st]);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        for (int p = 0; p < nchunks; p++) {
+            const int c0 = cbase + p * NC;
+            const float *Wc = Ws + (p & 1) * WSZ;
+            float *Ec = Es + (p & 1) * ESZ;
+            floatx4 acc[MW][NW];
+#pragma unroll
+            for (int mt = 0; mt < MW; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NW; nt++) acc[mt][nt] = nbias[nt];
+            if (p + 1 < nchunks) {  // (that filter buffer was last read in phase p - 1)
+                mm_copy_w3<EWV>(Ws + ((p + 1) & 1) * WSZ, w1 + (int64_t)((c0 + NC) / 16) * (NSW * 512), (NC / 16) * NSW, wave, lane);
+                fetch_bias(nbias, c0 + NC);
+            }
+            floatx4 wr[2][2];
+            auto rdw = [&](floatx4 (&r)[2], int f) {  // f = st * NW + nt, compile time at every call site
+                const float *wb = Wc + (((f % NW) * NSW + f / NW) * 128 + lane) * 4;
+                r[0] = *reinterpret_cast<const floatx4 *>(wb);
+                r[1] = *reinterpret_cast<const floatx4 *>(wb + 256);
+            };
+            rdw(wr[0], 0);
+#pragma unroll
+            for (int f = 0; f < NSW * NW; f++) {
+                if (f + 1 < NSW * NW) rdw(wr[(f + 1) & 1], f + 1);
+                b3_u32x4 wh, wmid, wl;
+                split3(wr[f & 1][0], wr[f & 1][1], wh, wmid, wl);
+#pragma unroll
+                for (int mt = 0; mt < MW; mt++) acc[mt][f % NW] = mm6(wh, wmid, wl, xh[mt][f / NW], xm[mt][f / NW], xl[mt][f / NW], acc[mt][f % NW]);
+            }
+            float v[MW * NW * 4];
+#pragma unroll
+            for (int mt = 0; mt < MW; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NW; nt++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[(mt * NW + nt) * 4 + i] = acc[mt][nt][i];
+            mm_act<MW * NW * 4>(d.act1, d.p0_1, d.p1_1, v);
+#pragma unroll
+            for (int mt = 0; mt < MW; mt++)
+#pragma unroll
+                for (int nt = 0; nt < NW; nt++)
+                    *reinterpret_cast<floatx4 *>(Ec + epix[mt] + nt * 16 + 4 * lq) =
+                        floatx4{v[(mt * NW + nt) * 4], v[(mt * NW + nt) * 4 + 1], v[(mt * NW + nt) * 4 + 2], v[(mt * NW + nt) * 4 + 3]};
+            // chunk image p is complete, filter chunk p + 1 has landed (only loads are outstanding on these waves)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        return;  // (a finished wave leaves the work-group's barrier count: the depthwise waves' last barrier is among themselves)
+    }
+
+    // ======================================================================= depthwise waves
+    const int td = tid - 64 * EWV;
+    const int c = td % NC, grp = td / NC;
+    const int ox0 = grp * PPG;
+    struct DwConst {
+        float wd[K * K], bz;
+    };
+    auto fetch_dw = [&](DwConst &cc_, int c0) {
+        const unsigned cl = (unsigned)min(c0 + c, d.C - 1);
+#pragma unroll
+        for (int q = 0; q < K * K; q++) cc_.wd[q] = (w2 + (size_t)q * (size_t)d.C)[cl];
+        cc_.bz = d.has_bias2 ? b2[cl] : 0.0f;
+    };
+    DwConst nxt;
+    fetch_dw(nxt, cbase);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // (the prologue's third barrier)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // phase 0: the first chunk image is being written
+    asm volatile("" ::: "memory");
+    auto flush_gap = [&](int q) {  // the squeeze sums of chunk q, complete per (sample, channel): its partials were written a barrier ago
+        const int cgq = cbase + q * NC + c;
+        if (d.has_gap && grp == 0 && cgq < d.C) {
+            const float *r = red + (q & 1) * RSZ;
+            float t = r[c];
+#pragma unroll
+            for (int y = 1; y < NGD; y++) t += r[y * NC + c];
+            gap[b * d.gap_bs + cgq] = t;
+        }
+    };
+    for (int q = 0; q < nchunks; q++) {
+        const int c0 = cbase + q * NC;
+        const float *Ec = Es + (q & 1) * ESZ;
+        const DwConst cur = nxt;
+        if (q + 1 < nchunks) fetch_dw(nxt, c0 + NC);
+        if (q > 0) flush_gap(q - 1);
+        const int cg = c0 + c;
+        const bool cact = cg < d.C;
+        float sum = 0.0f;
+        {
+            float ov[OH][PPG];
+#pragma unroll
+            for (int oy = 0; oy < OH; oy++)
+#pragma unroll
+                for (int x = 0; x < PPG; x++) ov[oy][x] = cur.bz;
+            const float *rp0 = Ec + (ox0 * S) * EP + c;
+#pragma unroll
+            for (int iy = 0; iy < H; iy++) {
+                bool used = false;  // (compile time) an image row no output reaches is not read
+#pragma unroll
+                for (int ky = 0; ky < K; ky++) {
+                    const int t = iy + PT - ky;
+                    used = used || (t >= 0 && t % S == 0 && t / S < OH);
+                }
+                if (!used) continue;
+                float val[IWS];
+#pragma unroll
+                for (int ix = 0; ix < IWS; ix++) val[ix] = rp0[(iy * WP + ix) * EP];
+#pragma unroll
+                for (int ky = 0; ky < K; ky++) {
+                    const int t = iy + PT - ky;  // = oy * S for the output row this (image row, tap row) pair feeds
+                    if (t >= 0 && t % S == 0 && t / S < OH) {
+#pragma unroll
+                        for (int x = 0; x < PPG; x++)
+#pragma unroll
+                            for (int kx = 0; kx < K; kx++) ov[t / S][x] = fmaf(val[x * S + kx], cur.wd[ky * K + kx], ov[t / S][x]);
+                    }
+                }
+            }
+            float *ob = out + b * d.out_bs;
+            const unsigned o_cs = (unsigned)d.C, o_rs = (unsigned)(OW * d.C);
+            const unsigned olane = (unsigned)cg + (unsigned)ox0 * o_cs;
+#pragma unroll
+            for (int oy = 0; oy < OH; oy++) {
+                float r[PPG];
+#pragma unroll
+                for (int x = 0; x < PPG; x++) r[x] = ov[oy][x];
+                mm_act<PPG>(d.act2, d.p0_2, d.p1_2, r);
+                if (cact) {
+#pragma unroll
+                    for (int x = 0; x < PPG; x++) {
+                        (ob + (size_t)((unsigned)oy * o_rs + (unsigned)x * o_cs))[olane] = r[x];
+                        sum += r[x];
+                    }
+                }
+            }
+        }
+        if (d.has_gap) red[(q & 1) * RSZ + grp * NC + c] = sum;
+        // ends phase q + 1: this chunk image is read, the partials are written (LDS only: the result stores stay in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    flush_gap(nchunks - 1);
+}
+
+}  // namespace
+
+size_t mbmap_ws_lds_bytes(const MbDesc &d, int nsw) {
+    const int wsz = 32 * 32 * nsw, esz = mm_kib(6 * (32 + d.k - 1) * 36), ring = 2 * wsz + 2 * esz + 2 * 8 * 32, pro = wsz + mm_kib(192 * d.Cin);
+    return (size_t)std::max(ring, pro) * sizeof(float);
+}
+
+void register_mbmap_ws_kernels() {
+#define WS_REG(K, S, NSW) register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_ws_kernel<K, S, NSW>));
+#define WS_REG_KS(NSW) WS_REG(3, 1, NSW) WS_REG(5, 1, NSW) WS_REG(3, 2, NSW) WS_REG(5, 2, NSW)
+    WS_REG_KS(2) WS_REG_KS(3) WS_REG_KS(4)
+#undef WS_REG_KS
+#undef WS_REG
+}
+
+// d.map_ws = 32-deep steps (plan_rules.h mbmap_ws_steps); w1 = pack_mbmap_w3f's image
+bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
+                     float *gap, int64_t batch, int nch) {
+    const int nsw = d.map_ws;
+    const float *zpage = device_zero_page();
+    if (nsw < 2 || nsw > 4 || !zpage || d.H != 6 || d.W != 32 || d.Cin % 16 || (d.Cin + 31) / 32 != nsw) return false;
+    const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(d.Cin / 4)) + 1u;
+    const size_t lds = mbmap_ws_lds_bytes(d, nsw);
+    dim3 grid((unsigned)((d.C + nch * 32 - 1) / (nch * 32)), (unsigned)batch, 1);
+#define WS_GO(K, S, NSW) hipLaunchKernelGGL((mbmap_ws_kernel<K, S, NSW>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage)
+#define WS_GO_KS(NSW)                             \
+    do {                                          \
+        if (d.k == 3 && d.s == 1) WS_GO(3, 1, NSW); \
+        else if (d.k == 5 && d.s == 1) WS_GO(5, 1, NSW); \
+        else if (d.k == 3) WS_GO(3, 2, NSW);      \
+        else WS_GO(5, 2, NSW);                    \
+    } while (0)
+    if (nsw == 2) WS_GO_KS(2);
+    else if (nsw == 3) WS_GO_KS(3);
+    else WS_GO_KS(4);
+#undef WS_GO_KS
+#undef WS_GO
+    return true;
+}
+
+}  // namespace bn

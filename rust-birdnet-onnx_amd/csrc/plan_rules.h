@@ -398,6 +398,12 @@ inline std::vector<float> pack_mbmap_w3f(const float *w, int64_t C, int64_t K) {
                         }
     return out;
 }
+// ... and for the 6 x 32 maps (cfg 1 / 2) the wave-specialised kernel (mbmap_ws.hip: expand of chunk p and depthwise of chunk p - 1 in the
+// same phase, chunks of 32 channels): 32-deep steps of the whole product, or 0.  BN_MBMAP_WS=0 keeps mbmap.hip.
+inline int mbmap_ws_steps(const MbDesc &d, const MbmapShape &sh) {
+    if (mbmap_b3_steps(d, sh) == 0 || sh.cfg > 2 || env_int("BN_MBMAP_WS", 1) == 0) return 0;
+    return (d.Cin + 31) / 32;
+}
 inline size_t mbmap_lds_bytes_b3(const MbDesc &d, int nst, int nw, int wm, int wn, int ksp) {  // d in the kernel's geometry (H, W, k)
     // two filter buffers + chunk image + squeeze partials; the input image of the prologue lies over everything behind the first buffer
     const int nc = 16 * nw * wn, ng = 64 * wm * wn * ksp / nc, wsz = mm_kib(nc * 32 * nst);

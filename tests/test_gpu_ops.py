@@ -956,11 +956,11 @@ def test_pipelined_mbconv_is_bit_identical_to_the_plain_kernel(bn):
 
 # (last column: what the default plan runs the block on -- an mbmap.hip configuration (plan_rules.h, mbmap_shape) or None = GEMM + depthwise)
 @pytest.mark.parametrize("cin,h,w,cmid,k,stride,expect", [
-    (80, 6, 32, 480, 3, 1, "cfg1,b3 "), (112, 6, 32, 672, 5, 2, "cfg2,b3 "), (192, 3, 16, 1152, 5, 1, "cfg3,b3 "),
+    (80, 6, 32, 480, 3, 1, "cfg1,ws "), (112, 6, 32, 672, 5, 2, "cfg2,ws "), (192, 3, 16, 1152, 5, 1, "cfg3,b3 "),
     (192, 4, 16, 1152, 5, 1, "cfg4,b3 "), (192, 4, 16, 1152, 3, 1, "cfg4,b3 "), (192, 4, 16, 600, 5, 2, None),
     # round 5 -- the expand on the bf16 pipe: every compiled step count (Cin = 48 / 80: 1.5 / 2.5 steps, the half step zero-filled; 112: 3.5;
     # 128 / 256 in two K slices), ragged channel counts (a partial last chunk), Cin = 16 (half a step: stays on the exact-f32 form)
-    (48, 6, 32, 288, 5, 1, "cfg1,b3 "), (112, 6, 32, 672, 5, 1, "cfg2,b3 "), (112, 6, 32, 600, 3, 1, "cfg2,b3 "), (128, 3, 16, 776, 3, 2, "cfg3,b3 "),
+    (48, 6, 32, 288, 5, 1, "cfg1,ws "), (112, 6, 32, 672, 5, 1, "cfg2,ws "), (112, 6, 32, 600, 3, 1, "cfg2,ws "), (80, 6, 32, 40, 3, 2, "cfg1,ws "), (128, 3, 16, 776, 3, 2, "cfg3,b3 "),
     (256, 3, 16, 1536, 5, 1, None), (128, 4, 16, 768, 5, 1, "cfg4,b3 "), (256, 4, 16, 520, 3, 1, "cfg4,b3 "), (16, 6, 32, 96, 3, 1, "cfg1 "),
     (20, 5, 7, 72, 3, 1, None), (40, 12, 40, 100, 3, 2, None),
     # round 4 -- BirdNET v3.0's 8 x 32 stage in two bands (all four window / stride instances, both swizzle classes) ...
@@ -1030,16 +1030,28 @@ def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride, expec
         assert ("MBCONV" in desc) == (expect is not None) and (expect is None or "map=" + expect in desc + " "), desc
         got2, _ = run_both(bn, data, batch=3)
         assert_close(got2, ref, f"default plan {cin}->{cmid} k{k} s{stride}")
-        if expect and ",b3" in expect:
+        if expect and (",b3" in expect or ",ws" in expect):
             # the exact-f32 expand of the same configuration (BN_MBMAP_B3=0), and the bits of the bf16x3 form do not depend on the batch a
             # segment rides in (chunks per block follow the batch)
             os.environ["BN_MBMAP_B3"] = "0"
             try:
-                assert "map=" + expect.replace(",b3", "") in bn.plan_describe(write_model(data)) + " "
+                assert "map=" + expect.replace(",b3", "").replace(",ws", "") in bn.plan_describe(write_model(data)) + " "
                 got4, _ = run_both(bn, data, batch=3)
             finally:
                 del os.environ["BN_MBMAP_B3"]
             assert_close(got4, ref, f"exact-f32 expand {cin}->{cmid} k{k} s{stride}")
+            if ",ws" in expect:
+                # the wave-specialised kernel and mbmap.hip's bf16x3 form: the same expanded / depthwise bits; the squeeze sums add the column
+                # strips' partials in 8 lane groups where mbmap.hip's 32-channel configuration has 16 (another association of the same terms)
+                os.environ["BN_MBMAP_WS"] = "0"
+                try:
+                    assert "map=" + expect.replace(",ws", ",b3") in bn.plan_describe(write_model(data)) + " "
+                    got5, _ = run_both(bn, data, batch=3)
+                finally:
+                    del os.environ["BN_MBMAP_WS"]
+                assert np.abs(got5 - got2).max() <= 2e-6 * np.abs(got2).max()
+                if "cfg1" in expect:  # (64-channel chunks there: 8 lane groups as well)
+                    assert np.array_equal(got5.view(np.uint32), got2.view(np.uint32))
             one = run_both(bn, data, batch=1)[0][:1]
             many, _ = run_both(bn, data, batch=9)
             assert np.array_equal(one.view(np.uint32), many[:1].view(np.uint32)) and np.array_equal(got2.view(np.uint32), many[:3].view(np.uint32))

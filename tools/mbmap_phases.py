@@ -1,6 +1,6 @@
 """Phase timings of the small-map MBConv launches (mbmap.hip): one context, per launch, with the kernel's debug switches (BN_MM_DBG bit 1 =
-no expand, 2 = no depthwise, 4 = no result stores) under both expand forms (BN_MBMAP_B3).  Each configuration runs in a child process (the
-switches are read at plan / launch time).  usage: python tools/mbmap_phases.py [v24|v30] [batch]"""
+no expand, 2 = no depthwise, 4 = no result stores) under both expand forms (BN_MBMAP_B3, or the switch named as the fourth argument).  Each configuration runs in a child process (the
+switches are read at plan / launch time).  usage: python tools/mbmap_phases.py [v24|v30] [batch] [dbg,dbg,...] [switch]"""
 import importlib, json, os, subprocess, sys, tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,15 +23,17 @@ if __name__ == "__main__":
     model = sys.argv[1] if len(sys.argv) > 1 else "v24"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     DBGS = (sys.argv[3].split(",") if len(sys.argv) > 3 else ["0", "1", "2", "3", "4"])
+    SWITCH = sys.argv[4] if len(sys.argv) > 4 else "BN_MBMAP_B3"
     table = {}
     for b3 in ("1", "0"):
         for dbg in DBGS:
-            env = dict(os.environ, BN_MBMAP_B3=b3, BN_MM_DBG=dbg)
+            env = dict(os.environ, BN_MM_DBG=dbg)
+            env[SWITCH] = b3
             r = subprocess.run([sys.executable, __file__, "--child", model, str(batch)], env=env, capture_output=True, text=True, timeout=300)
             if r.returncode != 0:
                 print(r.stderr[-2000:]); sys.exit(1)
             table[(b3, dbg)] = json.loads(r.stdout.strip().splitlines()[-1])
     names = [n for n, _ in table[("1", DBGS[0])]]
-    print(f"{'launch':34s} " + " ".join(f"b3={b}/dbg={d}" for b in "10" for d in DBGS))
+    print(f"{'launch':34s} " + f"{SWITCH}: " + " ".join(f"{b}/dbg={d}" for b in "10" for d in DBGS))
     for i, n in enumerate(names):
         print(f"{n[:34]:34s} " + " ".join(f"{table[(b, d)][i][1]:11.1f}" for b in "10" for d in DBGS))
