@@ -78,6 +78,13 @@ __device__ __forceinline__ void mm_copy_w3(float *lds_dst, const float *gsrc, in
         __builtin_amdgcn_global_load_lds(MM_GLB_PTR(gsrc + i * 256 + lane * 4), MM_LDS_PTR(lds_dst + i * 256), 16, 0, 0);
 }
 
+// dense copy of `kib` KiB, piece i by wave i % NWAVES
+template <int NWAVES>
+__device__ __forceinline__ void mm_copy_lin(float *lds_dst, const float *gsrc, int kib, int wave, int lane) {
+    for (int i = wave; i < kib; i += NWAVES)
+        __builtin_amdgcn_global_load_lds(MM_GLB_PTR(gsrc + i * 256 + lane * 4), MM_LDS_PTR(lds_dst + i * 256), 16, 0, 0);
+}
+
 template <int N>
 __device__ __forceinline__ void mm_act(int act, float p0, float p1, float (&v)[N]) {
     if (act == ACT_RELU) map_array<N>(v, [](float x) { return fmaxf(x, 0.0f); });

@@ -7,9 +7,9 @@
 // eight waves of two kinds:
 //   * waves 0-3 (one per SIMD) EXPAND chunk p: each owns three pixel tiles (48 of the map's 192 pixels) and both 16-channel tiles of
 //     the 32-channel chunk; the three bf16 planes of its pixels' input rows sit in registers for the whole block (read from an LDS
-//     image that exists only in the prologue, split once), the filter chunk arrives in fragment order by LDS-DMA (pack_mbmap_w3f;
+//     image that exists only in the prologue, split once), the filter chunk arrives as bf16 planes in fragment order by LDS-DMA (pack_mbmap_w3p;
 //     these waves issue the copy of chunk p + 1 at the start of phase p and are the only ones that wait for it -- they store nothing to
-//     memory, so their vmcnt wait never includes a result store's round trip) and is split as it is read; the activated tiles go
+//     memory, so their vmcnt wait never includes a result store's round trip); the activated tiles go
 //     into chunk image p mod 2;
 //   * waves 4-7 (the other wave of each SIMD) run the DEPTHWISE window of chunk p - 1 from chunk image (p - 1) mod 2: lane = channel,
 //     lane group = strip of output columns over all rows, exactly mbmap.hip's phase (same taps, same order, same bits), with eight lane
@@ -18,9 +18,10 @@
 // SIMD's issue but not its pipes.
 // MEASURED (tools/mbmap_phases.py ... 0 BN_MBMAP_WS; v2.4, one context, mbmap.hip's bf16x3 form -> this kernel): the 6 x 32 x 112 launches
 // 22.2 -> 20.6 us at batch 32 and 60.0 -> 47.4 us at batch 128 (marginal cost per 32 segments 12.6 -> 8.9 us; the exact-f32 form: 16),
-// the 6 x 32 x 80 ones 14.2 -> 14.1 and 33.2 -> 28.6 us; four contexts +1 %.  A phase is now bound by the vector ALU alone: the
-// depthwise taps (600 FMA per lane and chunk), the two SiLU's transcendentals and the 352 instructions of the filter split share it;
-// the matrix pipe is busy for a third of the phase.
+// the 6 x 32 x 80 ones 14.2 -> 14.1 and 33.2 -> 28.6 us; four contexts +1 %.  A phase was then bound by the vector ALU alone -- the
+// depthwise taps (600 FMA per lane and chunk), the two SiLU's transcendentals and 352 instructions of filter split -- so the split
+// moved to the planner (pack_mbmap_w3p): the 112-channel launches 20.0 / 45.8 us (marginal 8.6), four contexts 65.3 -> 66.8 k
+// segments/s (+2.3 % over mbmap.hip's bf16x3 form, 0.478 - 0.481 ms per step).
 //
 // Arithmetic per value: identical to mbmap.hip's bf16x3 form (expand = bias + 32-deep steps ascending, six partial products per step
 // in bf16x3.h's order; depthwise = bias2 + taps ascending): the same result bits.  The squeeze sum of a channel adds the partials of
@@ -51,9 +52,9 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     constexpr int PT = (K - 1) / 2, OH = (H + 2 * PT - K) / S + 1, OW = (W + 2 * PT - K) / S + 1;
     static_assert(OW % NGD == 0, "one strip of output columns per lane group");
     constexpr int PPG = OW / NGD, IWS = (PPG - 1) * S + K, WP = W + K - 1, EP = NC + 4;
-    constexpr int WSZ = NC * 32 * NSW, ESZ = mm_kib(H * WP * EP), RSZ = NGD * NC;
+    constexpr int WSZ = (NC / 16) * NSW * 3 * 256, ESZ = mm_kib(H * WP * EP), RSZ = NGD * NC;
     extern __shared__ __align__(1024) float ws_lds[];
-    float *Ws = ws_lds;                 // [2][NC / 16][NSW][128 chunks of 16 bytes]
+    float *Ws = ws_lds;                 // [2][NC / 16][NSW][3 planes][64 lanes][8 bf16]
     float *Es = Ws + 2 * WSZ;           // [2][H][WP][EP], columns < PT and >= PT + W stay zero
     float *red = Es + 2 * ESZ;          // [2][NGD][NC]
     float *Xi = ws_lds + WSZ;           // prologue only: the input image [HW][Cin], over everything behind the first filter buffer
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
 
     // ---- prologue, all waves: the sample's input image and the first filter chunk
     mm_copy_in<8, false, W, H>(Xi, in + b * d.in_bs, zpage, HW, CH, CH, Cin, inv_ch, 0, 0, wave, lane);
-    mm_copy_w3<8>(Ws, w1 + (int64_t)(cbase / 16) * (NSW * 512), (NC / 16) * NSW, wave, lane);
+    mm_copy_lin<8>(Ws, w1 + (int64_t)(cbase / 16) * (NSW * 768), WSZ / 256, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -136,23 +137,22 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
 #pragma unroll
                 for (int nt = 0; nt < NW; nt++) acc[mt][nt] = nbias[nt];
             if (p + 1 < nchunks) {  // (that filter buffer was last read in phase p - 1)
-                mm_copy_w3<EWV>(Ws + ((p + 1) & 1) * WSZ, w1 + (int64_t)((c0 + NC) / 16) * (NSW * 512), (NC / 16) * NSW, wave, lane);
+                mm_copy_lin<EWV>(Ws + ((p + 1) & 1) * WSZ, w1 + (int64_t)((c0 + NC) / 16) * (NSW * 768), WSZ / 256, wave, lane);
                 fetch_bias(nbias, c0 + NC);
             }
-            floatx4 wr[2][2];
-            auto rdw = [&](floatx4 (&r)[2], int f) {  // f = st * NW + nt, compile time at every call site
-                const float *wb = Wc + (((f % NW) * NSW + f / NW) * 128 + lane) * 4;
-                r[0] = *reinterpret_cast<const floatx4 *>(wb);
-                r[1] = *reinterpret_cast<const floatx4 *>(wb + 256);
+            b3_u32x4 wr[2][3];
+            auto rdw = [&](b3_u32x4 (&r)[3], int f) {  // f = st * NW + nt, compile time at every call site: the three planes of the fragment
+                const float *wb = Wc + (((f % NW) * NSW + f / NW) * 3 * 64 + lane) * 4;
+#pragma unroll
+                for (int pp = 0; pp < 3; pp++) r[pp] = *reinterpret_cast<const b3_u32x4 *>(wb + pp * 256);
             };
             rdw(wr[0], 0);
 #pragma unroll
             for (int f = 0; f < NSW * NW; f++) {
                 if (f + 1 < NSW * NW) rdw(wr[(f + 1) & 1], f + 1);
-                b3_u32x4 wh, wmid, wl;
-                split3(wr[f & 1][0], wr[f & 1][1], wh, wmid, wl);
 #pragma unroll
-                for (int mt = 0; mt < MW; mt++) acc[mt][f % NW] = mm6(wh, wmid, wl, xh[mt][f / NW], xm[mt][f / NW], xl[mt][f / NW], acc[mt][f % NW]);
+                for (int mt = 0; mt < MW; mt++)
+                    acc[mt][f % NW] = mm6(wr[f & 1][0], wr[f & 1][1], wr[f & 1][2], xh[mt][f / NW], xm[mt][f / NW], xl[mt][f / NW], acc[mt][f % NW]);
             }
             float v[MW * NW * 4];
 #pragma unroll
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
 }  // namespace
 
 size_t mbmap_ws_lds_bytes(const MbDesc &d, int nsw) {
-    const int wsz = 32 * 32 * nsw, esz = mm_kib(6 * (32 + d.k - 1) * 36), ring = 2 * wsz + 2 * esz + 2 * 8 * 32, pro = wsz + mm_kib(192 * d.Cin);
+    const int wsz = 2 * nsw * 3 * 256, esz = mm_kib(6 * (32 + d.k - 1) * 36), ring = 2 * wsz + 2 * esz + 2 * 8 * 32, pro = wsz + mm_kib(192 * d.Cin);
     return (size_t)std::max(ring, pro) * sizeof(float);
 }
 
@@ -287,7 +287,7 @@ void register_mbmap_ws_kernels() {
 #undef WS_REG
 }
 
-// d.map_ws = 32-deep steps (plan_rules.h mbmap_ws_steps); w1 = pack_mbmap_w3f's image
+// d.map_ws = 32-deep steps (plan_rules.h mbmap_ws_steps); w1 = pack_mbmap_w3p's image
 bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
                      float *gap, int64_t batch, int nch) {
     const int nsw = d.map_ws;

@@ -404,6 +404,27 @@ inline int mbmap_ws_steps(const MbDesc &d, const MbmapShape &sh) {
     if (mbmap_b3_steps(d, sh) == 0 || sh.cfg > 2 || env_int("BN_MBMAP_WS", 1) == 0) return 0;
     return (d.Cin + 31) / 32;
 }
+// the same filters as three bf16 planes for mbmap_ws.hip, whose expand waves share their SIMD's vector ALU with the depthwise waves and
+// should not spend it on splitting filters: [tile][step][plane hi | mid | lo][lane (q, c)][8 bf16], element e of lane (q, c) = k
+// 32 step + 16 (e / 4) + 4 q + e % 4 -- a fragment is three lane-linear 16-byte reads.  Returned in floats (a bit container).
+inline std::vector<float> pack_mbmap_w3p(const float *w, int64_t C, int64_t K) {
+    const int64_t nst = (K + 31) / 32, tiles = (C + 63) / 64 * 4;
+    std::vector<uint16_t> img((size_t)(tiles * nst * 3 * 64 * 8), 0);
+    for (int64_t t = 0; t < tiles; t++)
+        for (int64_t st = 0; st < nst; st++)
+            for (int64_t q = 0; q < 4; q++)
+                for (int64_t c = 0; c < 16; c++)
+                    for (int64_t e = 0; e < 8; e++) {
+                        const int64_t row = 16 * t + c, k = 32 * st + 16 * (e / 4) + 4 * q + e % 4;
+                        if (row >= C || k >= K) continue;
+                        uint16_t pl[3];
+                        split_bf16x3(w[row * K + k], pl[0], pl[1], pl[2]);
+                        for (int64_t pp = 0; pp < 3; pp++) img[(size_t)(((((t * nst + st) * 3 + pp) * 64) + q * 16 + c) * 8 + e)] = pl[pp];
+                    }
+    std::vector<float> out(img.size() / 2);
+    std::memcpy(out.data(), img.data(), img.size() * 2);
+    return out;
+}
 inline size_t mbmap_lds_bytes_b3(const MbDesc &d, int nst, int nw, int wm, int wn, int ksp) {  // d in the kernel's geometry (H, W, k)
     // two filter buffers + chunk image + squeeze partials; the input image of the prologue lies over everything behind the first buffer
     const int nc = 16 * nw * wn, ng = 64 * wm * wn * ksp / nc, wsz = mm_kib(nc * 32 * nst);
