@@ -551,7 +551,8 @@ def main():
         dname, d = dom
         # the same launches by the kernel FUNCTION that runs them (the symbols rocprofv3 lists): `roofline.kernel` is the symbol with the
         # most device time inside the dominant family, `roofline.family` the family label the PMC summaries are keyed by
-        symbol_of = [(gk_ if gk_ else ("mbmap_kernel" if k == "MBCONV" and " map=cfg" in line else fam_name[k])) for gk_, k, line in zip(gemm_kernel_of, kind_of, plan_lines)]
+        symbol_of = [(gk_ if gk_ else (("mbmap_ws_kernel" if ",ws " in line else "mbmap_kernel") if k == "MBCONV" and " map=cfg" in line else fam_name[k]))
+                     for gk_, k, line in zip(gemm_kernel_of, kind_of, plan_lines)]
         sym = {}
         for (name, us, macs, byts), sn, k, line in zip(rows, symbol_of, kind_of, plan_lines):
             fname = "mbmap_kernel" if k == "MBCONV" and " map=cfg" in line else fam_name[k]

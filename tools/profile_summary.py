@@ -24,7 +24,7 @@ from collections import defaultdict
 def family(name):
     n = name.replace("bn::(anonymous namespace)::", "")
     for key, fam in (("gemm_mfma_kernel", "gemm_mfma_kernel"), ("gemm_splitk_kernel", "gemm_mfma_kernel"), ("gemm_dma_kernel", "gemm_mfma_kernel"), ("gemm_dma3_kernel", "gemm_mfma_kernel"), ("gemm_b3_kernel", "gemm_mfma_kernel"), ("frame_fold2q_kernel", "gemm_mfma_kernel"), ("frame_fold_kernel", "gemm_mfma_kernel"), ("frame_fold2_kernel", "gemm_mfma_kernel"), ("frame_fold2p_kernel", "gemm_mfma_kernel"), ("frame_foldh_kernel", "gemm_mfma_kernel"),
-                     ("mbconv_", "mbconv_row_kernel"), ("mbmap_kernel", "mbmap_kernel"),
+                     ("mbconv_", "mbconv_row_kernel"), ("mbmap_kernel", "mbmap_kernel"), ("mbmap_ws_kernel", "mbmap_kernel"),
                      ("dwconv_", "dwconv_kernel"), ("conv_small", "conv_direct_kernel"), ("conv_direct", "conv_direct_kernel"),
                      ("stft_kernel", "stft_kernel"), ("se_fc", "se_fc_kernel"), ("gap_partial", "gap_partial_kernel"), ("elt_", "elt_kernel"), ("reduce_", "reduce_kernel"), ("minmax_chunks", "reduce_kernel"),
                      ("topk", "topk_kernel")):
