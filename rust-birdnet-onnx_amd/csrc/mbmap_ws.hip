@@ -73,35 +73,37 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    floatx4 raw[MW][NSW][2];
-    if (expander) {
-        // lane (c, q) of fragment (mt, s): k groups 2 s and 2 s + 1 of pixel 16 (3 wave + mt) + c, read as mbmap.hip's f32 form reads them
-        const int G16 = Cin >> 4;
-#pragma unroll
-        for (int mt = 0; mt < MW; mt++) {
-            const int m = (wave * MW + mt) * 16 + lc;
-            const int sw = mm_swz<false>(m);
-#pragma unroll
-            for (int st = 0; st < NSW; st++)
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int g = 2 * st + h;
-                    raw[mt][st][h] = g < G16 ? *reinterpret_cast<const floatx4 *>(Xi + m * Cin + 16 * g + 4 * (lq ^ sw)) : floatx4{0.f, 0.f, 0.f, 0.f};
-                }
+    // (from here the two kinds of waves run separate code -- the barriers pair up: 2 more in the prologue, then one per phase)
+    auto zero_padding = [&]() {  // the K - 1 padding columns of every row of both chunk images are zero and stay zero
+        for (int i = tid; i < 2 * H * (K - 1) * (EP / 4); i += 512) {
+            const int q4 = i % (EP / 4), pc = (i / (EP / 4)) % (K - 1), y = (i / ((EP / 4) * (K - 1))) % H, im = i / ((EP / 4) * (K - 1) * H);
+            const int xcol = pc < PT ? pc : W + pc;
+            *reinterpret_cast<floatx4 *>(Es + im * ESZ + (y * WP + xcol) * EP + 4 * q4) = floatx4{0.f, 0.f, 0.f, 0.f};
         }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // the image's space is free
-    asm volatile("" ::: "memory");
-    // the K - 1 padding columns of every row of both chunk images are zero and stay zero
-    for (int i = tid; i < 2 * H * (K - 1) * (EP / 4); i += 512) {
-        const int q4 = i % (EP / 4), pc = (i / (EP / 4)) % (K - 1), y = (i / ((EP / 4) * (K - 1))) % H, im = i / ((EP / 4) * (K - 1) * H);
-        const int xcol = pc < PT ? pc : W + pc;
-        *reinterpret_cast<floatx4 *>(Es + im * ESZ + (y * WP + xcol) * EP + 4 * q4) = floatx4{0.f, 0.f, 0.f, 0.f};
-    }
-
+    };
     if (expander) {
         // =================================================================== expand waves
+        // lane (c, q) of fragment (mt, s): k groups 2 s and 2 s + 1 of pixel 16 (3 wave + mt) + c, read as mbmap.hip's f32 form reads them
+        floatx4 raw[MW][NSW][2];
+        {
+            const int G16 = Cin >> 4;
+#pragma unroll
+            for (int mt = 0; mt < MW; mt++) {
+                const int m = (wave * MW + mt) * 16 + lc;
+                const int sw = mm_swz<false>(m);
+#pragma unroll
+                for (int st = 0; st < NSW; st++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int g = 2 * st + h;
+                        raw[mt][st][h] = g < G16 ? *reinterpret_cast<const floatx4 *>(Xi + m * Cin + 16 * g + 4 * (lq ^ sw)) : floatx4{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // the image's space is free
+        asm volatile("" ::: "memory");
+        zero_padding();
         b3_u32x4 xh[MW][NSW], xm[MW][NSW], xl[MW][NSW];
         int epix[MW];
 #pragma unroll
@@ -177,6 +179,9 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     }
 
     // ======================================================================= depthwise waves
+    __builtin_amdgcn_s_barrier();  // (the expand waves have read their input fragments: the image's space is free)
+    asm volatile("" ::: "memory");
+    zero_padding();
     const int td = tid - 64 * EWV;
     const int c = td % NC, grp = td / NC;
     const int ox0 = grp * PPG;
@@ -216,6 +221,9 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
         const bool cact = cg < d.C;
         float sum = 0.0f;
         {
+            // (Two output columns per instruction -- v_pk_fma_f32 on pairs read from LDS with ds_read2, bit-identical chains -- measured no
+            // faster: 20.0 -> 20.3 us at batch 32, 45.8 -> 47.9 at batch 128 for the 112-channel launches.  The phase is not bound by the FMA
+            // issue rate; the scalar form with its 8 reads per image row stays.)
             float ov[OH][PPG];
 #pragma unroll
             for (int oy = 0; oy < OH; oy++)
