@@ -1,4 +1,4 @@
-// Fused MBConv front half for the 6 x 32 maps, WAVE-SPECIALISED (round 5): expand 1x1 conv (+bias+act) on the bf16 matrix pipe (bf16x3.h)
+// Fused MBConv front half for the small maps (6 x 32; 3 x 16 and 4 x 16 with Cin = 128 / 192), WAVE-SPECIALISED (round 5): expand 1x1 conv (+bias+act) on the bf16 matrix pipe (bf16x3.h)
 // and depthwise K x K (+bias+act) + squeeze sums on the vector ALU run in the SAME phase, on different waves and different chunks.
 //
 // mbmap.hip walks a block's channel chunks in two phases per chunk -- every wave expands, barrier, every wave runs the depthwise window,
@@ -21,7 +21,9 @@
 // the 6 x 32 x 80 ones 14.2 -> 14.1 and 33.2 -> 28.6 us; four contexts +1 %.  A phase was then bound by the vector ALU alone -- the
 // depthwise taps (600 FMA per lane and chunk), the two SiLU's transcendentals and 352 instructions of filter split -- so the split
 // moved to the planner (pack_mbmap_w3p): the 112-channel launches 20.0 / 45.8 us (marginal 8.6), four contexts 65.3 -> 66.8 k
-// segments/s (+2.3 % over mbmap.hip's bf16x3 form, 0.478 - 0.481 ms per step).
+// segments/s (+2.3 % over mbmap.hip's bf16x3 form, 0.478 - 0.481 ms per step).  The 3 x 16 / 4 x 16 instances (one channel tile and two
+// pixel tiles per expand wave, all K steps: no K slices to add up): v2.4's four launches 17.2 -> 15.5 us at batch 32, 40 -> 37 at
+// batch 128, four contexts unchanged; v3.0's four 4 x 16 launches at batch 64 136 -> 103 us, 55.1 -> 56.2 k segments/s.
 //
 // Arithmetic per value: identical to mbmap.hip's bf16x3 form (expand = bias + 32-deep steps ascending, six partial products per step
 // in bf16x3.h's order; depthwise = bias2 + taps ascending): the same result bits.  The squeeze sum of a channel adds the partials of
@@ -44,11 +46,17 @@ namespace {
 
 #include "mbmap_common.h"
 
-template <int K, int S, int NSW>
+// H x W = 6 x 32: an expand wave owns three pixel tiles and both channel tiles of a chunk.  3 x 16 and 4 x 16 (Cin % 64 == 0; round 5, the
+// maps mbmap.hip walks with two K slices): an expand wave owns ONE channel tile and two pixel tiles (tiles 0-1 or 2-3; the 48-pixel map
+// has no tile 3), so its input planes are 2 NSW fragments -- NSW up to 6 (Cin = 192) in 144 registers.
+template <int K, int S, int NSW, int H, int W>
 __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w1,
                                                        const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
                                                        float *__restrict__ gap, int nch, uint32_t inv_ch, const float *__restrict__ zpage) {
-    constexpr int H = 6, W = 32, HW = H * W, NC = 32, MW = 3, NW = 2, EWV = 4, TD = 256, NGD = TD / NC;
+    constexpr bool SMALL = W == 16;
+    constexpr int HW = H * W, NT = HW / 16, NC = 32, MW = SMALL ? 2 : 3, NW = SMALL ? 1 : 2, EWV = 4, TD = 256, NGD = TD / NC;
+    static_assert((H == 6 && W == 32) || ((H == 3 || H == 4) && W == 16), "compiled map sizes");
+    static_assert(MW * NSW <= 12, "the input planes of an expand wave: 12 registers per fragment");
     constexpr int PT = (K - 1) / 2, OH = (H + 2 * PT - K) / S + 1, OW = (W + 2 * PT - K) / S + 1;
     static_assert(OW % NGD == 0, "one strip of output columns per lane group");
     constexpr int PPG = OW / NGD, IWS = (PPG - 1) * S + K, WP = W + K - 1, EP = NC + 4;
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     const int nchunks = min(nch, (d.C - cbase + NC - 1) / NC);
 
     // ---- prologue, all waves: the sample's input image and the first filter chunk
-    mm_copy_in<8, false, W, H>(Xi, in + b * d.in_bs, zpage, HW, CH, CH, Cin, inv_ch, 0, 0, wave, lane);
+    mm_copy_in<8, SMALL, W, H>(Xi, in + b * d.in_bs, zpage, HW, CH, CH, Cin, inv_ch, 0, 0, wave, lane);
     mm_copy_lin<8>(Ws, w1 + (int64_t)(cbase / 16) * (NSW * 768), WSZ / 256, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -83,20 +91,22 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     };
     if (expander) {
         // =================================================================== expand waves
-        // lane (c, q) of fragment (mt, s): k groups 2 s and 2 s + 1 of pixel 16 (3 wave + mt) + c, read as mbmap.hip's f32 form reads them
+        // lane (c, q) of fragment (mt, s): k groups 2 s and 2 s + 1 of pixel 16 (mt0 + mt) + c, read as mbmap.hip's f32 form reads them
+        const int nt0 = SMALL ? (wave & 1) : 0, mt0 = SMALL ? 2 * (wave >> 1) : 3 * wave;  // (wave-uniform)
         floatx4 raw[MW][NSW][2];
         {
             const int G16 = Cin >> 4;
 #pragma unroll
             for (int mt = 0; mt < MW; mt++) {
-                const int m = (wave * MW + mt) * 16 + lc;
-                const int sw = mm_swz<false>(m);
+                const int m = min(mt0 + mt, NT - 1) * 16 + lc;  // (a tile past the map repeats the last one: never multiplied, never stored)
+                const int sw = mm_swz<SMALL>(m);
 #pragma unroll
                 for (int st = 0; st < NSW; st++)
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const int g = 2 * st + h;
-                        raw[mt][st][h] = g < G16 ? *reinterpret_cast<const floatx4 *>(Xi + m * Cin + 16 * g + 4 * (lq ^ sw)) : floatx4{0.f, 0.f, 0.f, 0.f};
+                        const int off = SMALL ? m * Cin + 64 * (g >> 2) + 16 * ((g & 3) ^ (sw >> 2)) + 4 * (lq ^ (sw & 3)) : m * Cin + 16 * g + 4 * (lq ^ sw);
+                        raw[mt][st][h] = g < G16 ? *reinterpret_cast<const floatx4 *>(Xi + off) : floatx4{0.f, 0.f, 0.f, 0.f};
                     }
             }
         }
@@ -108,14 +118,14 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
         int epix[MW];
 #pragma unroll
         for (int mt = 0; mt < MW; mt++) {
-            const int m = (wave * MW + mt) * 16 + lc;
+            const int m = min(mt0 + mt, NT - 1) * 16 + lc;
             const int y = m / W, x = m - y * W;
-            epix[mt] = (y * WP + x + PT) * EP;
+            epix[mt] = (y * WP + x + PT) * EP + nt0 * 16;
         }
         auto fetch_bias = [&](floatx4 (&bz)[NW], int c0) {
 #pragma unroll
             for (int nt = 0; nt < NW; nt++) {
-                const int n = c0 + nt * 16 + 4 * lq;
+                const int n = c0 + (nt0 + nt) * 16 + 4 * lq;
                 bz[nt] = (d.has_bias1 && n < d.C) ? *reinterpret_cast<const floatx4 *>(b1 + n) : floatx4{0.f, 0.f, 0.f, 0.f};
             }
         };
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
             }
             b3_u32x4 wr[2][3];
             auto rdw = [&](b3_u32x4 (&r)[3], int f) {  // f = st * NW + nt, compile time at every call site: the three planes of the fragment
-                const float *wb = Wc + (((f % NW) * NSW + f / NW) * 3 * 64 + lane) * 4;
+                const float *wb = Wc + (((nt0 + f % NW) * NSW + f / NW) * 3 * 64 + lane) * 4;
 #pragma unroll
                 for (int pp = 0; pp < 3; pp++) r[pp] = *reinterpret_cast<const b3_u32x4 *>(wb + pp * 256);
             };
@@ -154,7 +164,8 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
                 if (f + 1 < NSW * NW) rdw(wr[(f + 1) & 1], f + 1);
 #pragma unroll
                 for (int mt = 0; mt < MW; mt++)
-                    acc[mt][f % NW] = mm6(wr[f & 1][0], wr[f & 1][1], wr[f & 1][2], xh[mt][f / NW], xm[mt][f / NW], xl[mt][f / NW], acc[mt][f % NW]);
+                    if (NT % MW == 0 || mt0 + mt < NT)  // (wave-uniform; compile-time true for the maps whose tiles divide evenly)
+                        acc[mt][f % NW] = mm6(wr[f & 1][0], wr[f & 1][1], wr[f & 1][2], xh[mt][f / NW], xm[mt][f / NW], xl[mt][f / NW], acc[mt][f % NW]);
             }
             float v[MW * NW * 4];
 #pragma unroll
@@ -168,7 +179,8 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
             for (int mt = 0; mt < MW; mt++)
 #pragma unroll
                 for (int nt = 0; nt < NW; nt++)
-                    *reinterpret_cast<floatx4 *>(Ec + epix[mt] + nt * 16 + 4 * lq) =
+                    if (NT % MW == 0 || mt0 + mt < NT)
+                        *reinterpret_cast<floatx4 *>(Ec + epix[mt] + nt * 16 + 4 * lq) =
                         floatx4{v[(mt * NW + nt) * 4], v[(mt * NW + nt) * 4 + 1], v[(mt * NW + nt) * 4 + 2], v[(mt * NW + nt) * 4 + 3]};
             // chunk image p is complete, filter chunk p + 1 has landed (only loads are outstanding on these waves)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -283,14 +295,16 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
 }  // namespace
 
 size_t mbmap_ws_lds_bytes(const MbDesc &d, int nsw) {
-    const int wsz = 2 * nsw * 3 * 256, esz = mm_kib(6 * (32 + d.k - 1) * 36), ring = 2 * wsz + 2 * esz + 2 * 8 * 32, pro = wsz + mm_kib(192 * d.Cin);
+    const int wsz = 2 * nsw * 3 * 256, esz = mm_kib(d.H * (d.W + d.k - 1) * 36), ring = 2 * wsz + 2 * esz + 2 * 8 * 32, pro = wsz + mm_kib(d.H * d.W * d.Cin);
     return (size_t)std::max(ring, pro) * sizeof(float);
 }
 
 void register_mbmap_ws_kernels() {
-#define WS_REG(K, S, NSW) register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_ws_kernel<K, S, NSW>));
-#define WS_REG_KS(NSW) WS_REG(3, 1, NSW) WS_REG(5, 1, NSW) WS_REG(3, 2, NSW) WS_REG(5, 2, NSW)
-    WS_REG_KS(2) WS_REG_KS(3) WS_REG_KS(4)
+#define WS_REG(K, S, NSW, H, W) register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_ws_kernel<K, S, NSW, H, W>));
+#define WS_REG_KS(NSW, H, W) WS_REG(3, 1, NSW, H, W) WS_REG(5, 1, NSW, H, W) WS_REG(3, 2, NSW, H, W) WS_REG(5, 2, NSW, H, W)
+    WS_REG_KS(2, 6, 32) WS_REG_KS(3, 6, 32) WS_REG_KS(4, 6, 32)
+    WS_REG_KS(4, 3, 16) WS_REG_KS(6, 3, 16)
+    WS_REG(3, 1, 4, 4, 16) WS_REG(5, 1, 4, 4, 16) WS_REG(3, 1, 6, 4, 16) WS_REG(5, 1, 6, 4, 16)
 #undef WS_REG_KS
 #undef WS_REG
 }
@@ -300,21 +314,33 @@ bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in
                      float *gap, int64_t batch, int nch) {
     const int nsw = d.map_ws;
     const float *zpage = device_zero_page();
-    if (nsw < 2 || nsw > 4 || !zpage || d.H != 6 || d.W != 32 || d.Cin % 16 || (d.Cin + 31) / 32 != nsw) return false;
+    const bool big = d.H == 6 && d.W == 32, small3 = d.H == 3 && d.W == 16, small4 = d.H == 4 && d.W == 16;
+    if (!zpage || d.Cin % 16 || (d.Cin + 31) / 32 != nsw) return false;
+    if (!(big ? (nsw >= 2 && nsw <= 4) : ((small3 || (small4 && d.s == 1)) && d.Cin % 64 == 0 && (nsw == 4 || nsw == 6)))) return false;
     const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(d.Cin / 4)) + 1u;
     const size_t lds = mbmap_ws_lds_bytes(d, nsw);
     dim3 grid((unsigned)((d.C + nch * 32 - 1) / (nch * 32)), (unsigned)batch, 1);
-#define WS_GO(K, S, NSW) hipLaunchKernelGGL((mbmap_ws_kernel<K, S, NSW>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage)
-#define WS_GO_KS(NSW)                             \
-    do {                                          \
-        if (d.k == 3 && d.s == 1) WS_GO(3, 1, NSW); \
-        else if (d.k == 5 && d.s == 1) WS_GO(5, 1, NSW); \
-        else if (d.k == 3) WS_GO(3, 2, NSW);      \
-        else WS_GO(5, 2, NSW);                    \
+#define WS_GO(K, S, NSW, H, W) hipLaunchKernelGGL((mbmap_ws_kernel<K, S, NSW, H, W>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage)
+#define WS_GO_KS(NSW, H, W)                                  \
+    do {                                                     \
+        if (d.k == 3 && d.s == 1) WS_GO(3, 1, NSW, H, W);    \
+        else if (d.k == 5 && d.s == 1) WS_GO(5, 1, NSW, H, W); \
+        else if (d.k == 3) WS_GO(3, 2, NSW, H, W);           \
+        else WS_GO(5, 2, NSW, H, W);                         \
     } while (0)
-    if (nsw == 2) WS_GO_KS(2);
-    else if (nsw == 3) WS_GO_KS(3);
-    else WS_GO_KS(4);
+    if (big) {
+        if (nsw == 2) WS_GO_KS(2, 6, 32);
+        else if (nsw == 3) WS_GO_KS(3, 6, 32);
+        else WS_GO_KS(4, 6, 32);
+    } else if (small3) {
+        if (nsw == 4) WS_GO_KS(4, 3, 16);
+        else WS_GO_KS(6, 3, 16);
+    } else {
+        if (nsw == 4 && d.k == 3) WS_GO(3, 1, 4, 4, 16);
+        else if (nsw == 4) WS_GO(5, 1, 4, 4, 16);
+        else if (d.k == 3) WS_GO(3, 1, 6, 4, 16);
+        else WS_GO(5, 1, 6, 4, 16);
+    }
 #undef WS_GO_KS
 #undef WS_GO
     return true;

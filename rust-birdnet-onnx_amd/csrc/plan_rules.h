@@ -399,10 +399,13 @@ inline std::vector<float> pack_mbmap_w3f(const float *w, int64_t C, int64_t K) {
     return out;
 }
 // ... and for the 6 x 32 maps (cfg 1 / 2) the wave-specialised kernel (mbmap_ws.hip: expand of chunk p and depthwise of chunk p - 1 in the
-// same phase, chunks of 32 channels): 32-deep steps of the whole product, or 0.  BN_MBMAP_WS=0 keeps mbmap.hip.
+// same phase, chunks of 32 channels): 32-deep steps of the whole product, or 0.  BN_MBMAP_WS=0 keeps mbmap.hip; BN_MBMAP_WS_SMALL=0 keeps it for
+// the 3 x 16 / 4 x 16 maps only.
 inline int mbmap_ws_steps(const MbDesc &d, const MbmapShape &sh) {
-    if (mbmap_b3_steps(d, sh) == 0 || sh.cfg > 2 || env_int("BN_MBMAP_WS", 1) == 0) return 0;
-    return (d.Cin + 31) / 32;
+    if (mbmap_b3_steps(d, sh) == 0 || env_int("BN_MBMAP_WS", 1) == 0) return 0;
+    const int nst = (d.Cin + 31) / 32;
+    if (sh.cfg <= 2) return nst;                                               // 6 x 32: 2 .. 4 steps (mbmap_b3_steps)
+    return (env_int("BN_MBMAP_WS_SMALL", 1) != 0 && (nst == 4 || nst == 6)) ? nst : 0;  // 3 x 16 / 4 x 16: Cin = 128 / 192
 }
 // the same filters as three bf16 planes for mbmap_ws.hip, whose expand waves share their SIMD's vector ALU with the depthwise waves and
 // should not spend it on splitting filters: [tile][step][plane hi | mid | lo][lane (q, c)][8 bf16], element e of lane (q, c) = k

@@ -956,12 +956,12 @@ def test_pipelined_mbconv_is_bit_identical_to_the_plain_kernel(bn):
 
 # (last column: what the default plan runs the block on -- an mbmap.hip configuration (plan_rules.h, mbmap_shape) or None = GEMM + depthwise)
 @pytest.mark.parametrize("cin,h,w,cmid,k,stride,expect", [
-    (80, 6, 32, 480, 3, 1, "cfg1,ws "), (112, 6, 32, 672, 5, 2, "cfg2,ws "), (192, 3, 16, 1152, 5, 1, "cfg3,b3 "),
-    (192, 4, 16, 1152, 5, 1, "cfg4,b3 "), (192, 4, 16, 1152, 3, 1, "cfg4,b3 "), (192, 4, 16, 600, 5, 2, None),
+    (80, 6, 32, 480, 3, 1, "cfg1,ws "), (112, 6, 32, 672, 5, 2, "cfg2,ws "), (192, 3, 16, 1152, 5, 1, "cfg3,ws "),
+    (192, 4, 16, 1152, 5, 1, "cfg4,ws "), (192, 4, 16, 1152, 3, 1, "cfg4,ws "), (192, 4, 16, 600, 5, 2, None),
     # round 5 -- the expand on the bf16 pipe: every compiled step count (Cin = 48 / 80: 1.5 / 2.5 steps, the half step zero-filled; 112: 3.5;
     # 128 / 256 in two K slices), ragged channel counts (a partial last chunk), Cin = 16 (half a step: stays on the exact-f32 form)
-    (48, 6, 32, 288, 5, 1, "cfg1,ws "), (112, 6, 32, 672, 5, 1, "cfg2,ws "), (112, 6, 32, 600, 3, 1, "cfg2,ws "), (80, 6, 32, 40, 3, 2, "cfg1,ws "), (128, 3, 16, 776, 3, 2, "cfg3,b3 "),
-    (256, 3, 16, 1536, 5, 1, None), (128, 4, 16, 768, 5, 1, "cfg4,b3 "), (256, 4, 16, 520, 3, 1, "cfg4,b3 "), (16, 6, 32, 96, 3, 1, "cfg1 "),
+    (48, 6, 32, 288, 5, 1, "cfg1,ws "), (112, 6, 32, 672, 5, 1, "cfg2,ws "), (112, 6, 32, 600, 3, 1, "cfg2,ws "), (80, 6, 32, 40, 3, 2, "cfg1,ws "), (128, 3, 16, 776, 3, 2, "cfg3,ws "), (192, 3, 16, 200, 5, 2, "cfg3,ws "),
+    (256, 3, 16, 1536, 5, 1, None), (128, 4, 16, 768, 5, 1, "cfg4,ws "), (256, 4, 16, 520, 3, 1, "cfg4,b3 "), (16, 6, 32, 96, 3, 1, "cfg1 "),
     (20, 5, 7, 72, 3, 1, None), (40, 12, 40, 100, 3, 2, None),
     # round 4 -- BirdNET v3.0's 8 x 32 stage in two bands (all four window / stride instances, both swizzle classes) ...
     (80, 8, 32, 480, 3, 1, "cfg5,bands "), (112, 8, 32, 672, 5, 1, "cfg5,bands "), (112, 8, 32, 672, 5, 2, "cfg5,bands "), (80, 8, 32, 252, 3, 2, "cfg5,bands "),
@@ -1047,8 +1047,12 @@ def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride, expec
                 try:
                     assert "map=" + expect.replace(",ws", ",b3") in bn.plan_describe(write_model(data)) + " "
                     got5, _ = run_both(bn, data, batch=3)
+                    if "cfg3" in expect or "cfg4" in expect:  # the small maps have a switch of their own
+                        os.environ["BN_MBMAP_WS"], os.environ["BN_MBMAP_WS_SMALL"] = "1", "0"
+                        assert "map=" + expect.replace(",ws", ",b3") in bn.plan_describe(write_model(data)) + " "
                 finally:
                     del os.environ["BN_MBMAP_WS"]
+                    os.environ.pop("BN_MBMAP_WS_SMALL", None)
                 assert np.abs(got5 - got2).max() <= 2e-6 * np.abs(got2).max()
                 if "cfg1" in expect:  # (64-channel chunks there: 8 lane groups as well)
                     assert np.array_equal(got5.view(np.uint32), got2.view(np.uint32))
