@@ -164,6 +164,7 @@ struct bn_ctx {
     size_t h_out_elems = 0;
     size_t device_bytes = 0;
     bool holds_model = false;  // counted in model->refs (set once creation succeeded)
+    bool counted = false;      // counted in the device's live-context count (kernels.h device_context_count)
     bool in_flight = false;  // a cancelled/timed-out run may still be executing
     size_t last_batch = 0;
     // top-K scratch
@@ -697,12 +698,15 @@ bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));  // arena zeroed before anyone captures or launches
+    bn::device_context_count_add(m->device, 1);
+    c->counted = true;
     *out = c.release();
     return BN_OK;
 }
 
 void bn_ctx_destroy(bn_ctx *c) {
     if (!c) return;
+    if (c->counted) bn::device_context_count_add(c->model->device, -1);
     (void)bn::use_device(c->model->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->graphs) (void)gated::GraphExecDestroy(kv.second);

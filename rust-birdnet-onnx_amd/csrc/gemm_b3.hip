@@ -252,9 +252,12 @@ bool launch_gemm_b3(hipStream_t s, const GemmDesc &d, float *C, const float *A, 
     // rows per block (it does not enter the arithmetic): a pooled epilogue needs the sample's 48 rows in one block; otherwise 64-row tiles
     // once they give every CU a block (half the weight traffic of 32-row tiles), 32-row tiles below that -- the launch is then a chain of
     // K steps per block, and twice the blocks is the only parallelism left (tools/gemm3_bench sweeps: 128-row tiles lose at every size)
+    // That is the rule for ONE context on the device.  With several in flight the launch shares the CUs, the blocks of other launches are
+    // the parallelism, and the weight traffic decides: 64-row tiles throughout gain 1.9 % on the v2.4 step with four contexts (68.8 -> 70.1 k
+    // segments/s) and cost the one-context chain 65 us -- so they are taken as soon as a second live context exists (kernels.h).
     const int64_t cus = device_cu_count();
     const int force_mt = env_int("BN_GEMMB3_MT", 0);  // tests / experiments
-    int mt = (total_rows + 63) / 64 * nb >= cus ? 4 : 2;
+    int mt = (device_context_count() > 1 || (total_rows + 63) / 64 * nb >= cus) ? 4 : 2;
     if (d.gap) mt = 3;
     else if (force_mt == 2 || force_mt == 3 || force_mt == 4) mt = force_mt;
 #define GB_GO(MT)                                                                                          \

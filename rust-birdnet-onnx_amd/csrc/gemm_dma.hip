@@ -667,7 +667,7 @@ bool launch_gemm_dma(hipStream_t s, const GemmDesc &d, float *C, const float *A,
     // not by any launch's own latency (three contexts already reach 94 % of four), so the efficient tile wins even when
     // one launch alone leaves CUs idle: measured 54.6 k -> 55.5 k segments/s against a threshold of 192 blocks.
     // BN_GEMMDMA_MINBLOCKS moves the line.
-    const int64_t min_blocks = getenv("BN_GEMMDMA_MINBLOCKS") ? atoll(getenv("BN_GEMMDMA_MINBLOCKS")) : 64;
+    const int64_t min_blocks = getenv("BN_GEMMDMA_MINBLOCKS") ? atoll(getenv("BN_GEMMDMA_MINBLOCKS")) : (device_context_count() > 1 ? 1 : 64);  // (a shared device: the efficient tile always, +0.7 %)
 #define GD_GO(MTW, NTW, WM, WN)                                                                  \
     do {                                                                                         \
         if (ks == 2) launch_cfg<MTW, NTW, WM, WN, 2, 3>(s, d, C, A, W, bias, res, scale, batch, se); \

@@ -410,7 +410,7 @@ bool launch_gemm_dma3(hipStream_t s, const GemmDesc &d, float *C, const float *A
     if (d.se_inline && !se) return false;
     const uint16_t *W3 = reinterpret_cast<const uint16_t *>(W3f);
     const int ks = gemm_dma3_kslices(d, se ? se->se.Cr : 0);  // decided for the layer (it enters the summation order), not for the tile
-    const int64_t min_blocks = getenv("BN_GEMMDMA_MINBLOCKS") ? atoll(getenv("BN_GEMMDMA_MINBLOCKS")) : 64;
+    const int64_t min_blocks = getenv("BN_GEMMDMA_MINBLOCKS") ? atoll(getenv("BN_GEMMDMA_MINBLOCKS")) : (device_context_count() > 1 ? 1 : 64);  // (a shared device: the efficient tile always, +0.7 %)
 #define G3_GO(MTW, NTW, WM, WN)                                                                      \
     do {                                                                                             \
         if (ks == 2) launch_cfg3<MTW, NTW, WM, WN, 2, 2>(s, d, C, A, W3, bias, res, scale, batch, se); \

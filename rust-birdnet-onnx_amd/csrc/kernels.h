@@ -429,6 +429,8 @@ void note_launch_device(int dev);
 // launch-time check only (no runtime call): true when `bytes` fits and the thread's launch device was prepared
 bool ensure_dynamic_lds(const void *kernel, size_t bytes);
 int device_cu_count();
+void device_context_count_add(int dev, int delta);  // capi.cpp: a context was created (+1) / destroyed (-1) on the device
+int device_context_count();                        // live contexts on the launching thread's device (>= 1)
 const float *device_zero_page();  // 4 KiB of zeros on the thread's launch device (allocated by prepare_device)
 size_t topk_lds_bytes(int64_t n, int64_t k);
 

@@ -145,6 +145,17 @@ const float *device_zero_page() {
         if (m & (1ull << d)) return g_zero_page[d].load(std::memory_order_relaxed);
     return nullptr;
 }
+// live inference contexts per device (capi.cpp counts them): kernels whose grid is a trade between one launch's latency and the work per
+// block (mbmap.hip's chunks per block) size it for a device that is SHARED when several contexts keep batches in flight
+static std::atomic<int> g_ctx_count[64];
+void device_context_count_add(int dev, int delta) {
+    if (dev >= 0 && dev < 64) g_ctx_count[dev].fetch_add(delta, std::memory_order_relaxed);
+}
+int device_context_count() {
+    const int dev = t_launch_dev;
+    const int n = (dev >= 0 && dev < 64) ? g_ctx_count[dev].load(std::memory_order_relaxed) : 1;
+    return n < 1 ? 1 : n;
+}
 int device_cu_count() {
     const uint64_t m = g_prepared_mask.load(std::memory_order_acquire);
     const int dev = t_launch_dev;

@@ -432,12 +432,19 @@ inline bool mm_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15
 // one -- the blocks are LDS-bound to one per CU, so more blocks than CUs means a second round (measured, batch 32:
 // 1152 channels as 288 blocks 32 us, as 192 blocks 25 us) and fewer blocks amortise the input fetch better.  The
 // grouping does not enter the arithmetic (squeeze sums are complete per channel inside a block).
+// "Every CU" is the device's when ONE context runs on it.  With several contexts in flight a launch gets a share of the CUs and runs
+// its blocks in rounds anyway, while every block pays the prologue (with the bf16x3 forms: input image, fragment reads, the split -- 40 %
+// of a block at three chunks); sized for HALF the CUs the v2.4 step with four contexts gains 5 % (65.5 -> 68.6 k segments/s; a third:
+// 68.7 k, a quarter: 69.0 k) and one launch alone loses 30 % (160 -> 209 us for the ten launches; a third: 255 us) -- so the share is 2
+// as soon as a second live context exists on the device (capi.cpp counts them; BN_MBMAP_SHARE=n fixes it, 1 = the latency form).
 int mbmap_chunks_per_block(const MbDesc &d, const MbmapShape &sh, int64_t batch) {
     const int force = getenv("BN_MBMAP2_NCH") ? atoi(getenv("BN_MBMAP2_NCH")) : 0;
     const int nc = (!d.map_ws && (sh.cfg == 1 || sh.cfg == 3)) ? 64 : 32;
     const int chunks = (d.C + nc - 1) / nc;
     if (force > 0) return std::min(force, chunks);
-    const int64_t ncu = device_cu_count();
+    const int share_env = getenv("BN_MBMAP_SHARE") ? atoi(getenv("BN_MBMAP_SHARE")) : 0;
+    const int share = share_env > 0 ? share_env : std::min(device_context_count(), 2);
+    const int64_t ncu = std::max<int64_t>(1, device_cu_count() / share);
     return (int)std::max<int64_t>(1, std::min<int64_t>(chunks, (chunks * batch * sh.bands + ncu - 1) / ncu));
 }
 
