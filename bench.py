@@ -249,13 +249,24 @@ def main():
     kernel_rows, kernel_rows4 = None, None
     if rank == 0:
         ctxs[0].infer(bufs[0].cpu().numpy())  # puts a real batch into the context's own input buffer
-        ctxs[0].time_kernels(B)  # (first pass: warm-up of the per-launch events, not counted)
+        # Launches whose grid is a trade between one launch's latency and the work per block come in two forms (bn_set_sharing_mode): the
+        # per-launch table of `roofline` -- one context ALONE on the device -- is timed in the form a lone context runs (what `--streams 1`
+        # runs, comparable with earlier rounds); the form the timed region runs with several contexts alive is timed next to it
+        # (`roofline.shared_forms`; `saturated` and the marginal costs are of that form).
+        def _timed_rows(npass):
+            ctxs[0].time_kernels(B)  # (first pass: warm-up of the per-launch events, not counted)
+            acc = ctxs[0].time_kernels(B)
+            for _ in range(npass - 1):
+                acc = [(a[0], a[1] + b[1], a[2], a[3]) for a, b in zip(acc, ctxs[0].time_kernels(B))]
+            return [(n_, us / float(npass), m_, by_) for n_, us, m_, by_ in acc]
         NPASS = 12
-        kernel_rows = ctxs[0].time_kernels(B)
-        for _ in range(NPASS - 1):  # average of NPASS passes
-            more = ctxs[0].time_kernels(B)
-            kernel_rows = [(a[0], a[1] + b[1], a[2], a[3]) for a, b in zip(kernel_rows, more)]
-        kernel_rows = [(n_, us / float(NPASS), m_, by_) for n_, us, m_, by_ in kernel_rows]
+        bn.set_sharing_mode(bn.SHARING_ALONE)
+        kernel_rows = _timed_rows(NPASS)
+        kernel_rows_shared = None
+        if len(ctxs) > 1:
+            bn.set_sharing_mode(bn.SHARING_SHARED)
+            kernel_rows_shared = _timed_rows(6)
+        bn.set_sharing_mode(bn.SHARING_AUTO)
         # (the same passes at four times the batch -- `roofline.saturated` -- run BEHIND the timed steps since round 4: measured on one box,
         # `--steps 20 --warmup 5` reads 58.9-59.0 k with that leg in front of the timed region and 60.8-61.3 k without it (tools/ab_legs.sh);
         # the timed steps' own ramp-up is what the passes above are for, a fifth context of 1.4 GB is not part of the workload)
@@ -275,6 +286,7 @@ def main():
     drain(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    bn.set_sharing_mode(bn.SHARING_ALONE)  # (the legs behind the timed region -- own buffer, host to host, one segment -- run the default forms)
     for j in range(max(0, args.steps - S_), args.steps):  # the last S_ steps were consumed by drain()
         done_ms.append(ev_base.elapsed_time(ev_pool[j % (2 * S_)]))
     done_ms = np.array(sorted(done_ms))
@@ -315,12 +327,14 @@ def main():
             for c in ctxs:
                 c.synchronize()
 
+        bn.set_sharing_mode(bn.SHARING_SHARED if len(ctxs) > 1 else bn.SHARING_ALONE)  # (the timed region's forms)
         run_own(2 * S_)
         fence()
         t_own = time.perf_counter()
         run_own(args.steps)
         fence()
         d_own = time.perf_counter() - t_own
+        bn.set_sharing_mode(bn.SHARING_ALONE)
         if use_dist:
             t = torch.tensor([d_own], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -402,6 +416,7 @@ def main():
             "global_batch": B * world,
             "segments_per_gpu_per_step": B,
             "streams_per_gpu": max(1, args.streams),
+            "sharing_mode": "shared" if max(1, args.streams) > 1 else "alone",
             "num_species": int(N),
             "x_realtime": round(value * SEC, 1),
             "parallelism": f"segment-sharded x{world}" + ((f" + RCCL all-gather of logits (one collective per {S_} steps)" if args.backend == "nccl" else f" + {args.backend} all-gather of logits on the host (rehearsal backend)") if world > 1 else ""),
@@ -642,6 +657,7 @@ def main():
             if args.no_saturated:
                 raise RuntimeError("skipped (--no-saturated)")
             big = bn.Context(model, 4 * B)
+            bn.set_sharing_mode(bn.SHARING_SHARED if kernel_rows_shared is not None else bn.SHARING_ALONE)
             big.infer(np.concatenate([bufs[0].cpu().numpy()] * 4))
             big.time_kernels(4 * B)
             kernel_rows4 = big.time_kernels(4 * B)
@@ -650,7 +666,10 @@ def main():
             kernel_rows4 = [(n_, us / 6.0, m_, by_) for n_, us, m_, by_ in kernel_rows4]
             big.close()
             del big
+            bn.set_sharing_mode(bn.SHARING_ALONE)
             rows4 = kernel_rows4
+            rows_alone = rows
+            rows = kernel_rows_shared if kernel_rows_shared is not None else rows  # (the marginal costs: both batch sizes in the timed region's form)
             if rows4 is None:
                 raise RuntimeError("not measured")
             if len(rows4) == len(rows):
@@ -666,7 +685,16 @@ def main():
                                      "all_launches_marginal_us_per_batch": round(all_marg, 1),
                                      "what": f"the same launches timed at batch {4 * B} on one context, and (t({4 * B}) - t({B})) / 3 = the cost of one more batch of {B} "
                                              "once the chip is full -- the regime the concurrent contexts of the headline number run in"}
+                if kernel_rows_shared is not None:
+                    roof["shared_forms"] = {"family_us_alone": round(us1, 1), "frac_alone": round(2 * macs1 / (us1 * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                                            "device_us_per_step_sum_of_launches": round(sum(r[1] for r in rows), 1),
+                                            "what": "the grids the launches take while several contexts are alive on the device (bn_set_sharing_mode: 64-row GEMM tiles, "
+                                                    "twice the chunks per small-map MBConv block) -- what the timed region runs; `frac`, `achieved` and the per-launch "
+                                                    "table above are of the form one context ALONE runs; `saturated` is of this form"}
+            rows = rows_alone
         except Exception as e:  # noqa: BLE001 -- informational block only
+            bn.set_sharing_mode(bn.SHARING_ALONE)
+            rows = kernel_rows
             roof["saturated"] = {"error": str(e)[:200]}
         out["roofline"] = roof
         out["whole_path_frac_mfma_f32"] = round(roof["flops_performed_per_segment"] * value / world / 1e12 / MFMA_F32_PEAK_TF, 4)

@@ -412,6 +412,18 @@ size_t bn_group_last_error(char *buf, size_t cap);
  * and the native path.  *status: BN_OK, BN_ERR_UNSUPPORTED_MODEL (a plan was refused) or BN_ERR_MODEL_LOAD (unreadable file).
  * Returns the number of bytes the full text needs (excluding the NUL). */
 size_t bn_model_survey(const char *onnx_path, char *buf, size_t cap, bn_status *status);
+
+/* How launches size their grids where a choice exists between one launch's latency and the work per block (chunks per block of the
+ * small-map MBConv kernels, row tiles of the 1x1-conv GEMMs).  BN_SHARING_ALONE (default): for a device the launch has to itself -- the
+ * lowest latency of one batch.  BN_SHARING_SHARED: for a device whose CUs are shared by several batches in flight -- the reference's way
+ * to throughput is several BatchInferenceContexts (classifier.rs:826-867); a launch then gets a share of the CUs whatever its grid, and
+ * bigger blocks amortise their prologues and weight traffic (BirdNET v2.4, four contexts: +7 % segments/s; one batch alone: +13 % time).
+ * BN_SHARING_AUTO: SHARED while more than one context is alive on the device.  Results do not depend on the mode (bit for bit);
+ * process-wide; graphs captured under one form are re-captured under the other.  No ort counterpart: ORT has no such notion. */
+#define BN_SHARING_AUTO (-1)
+#define BN_SHARING_ALONE 0
+#define BN_SHARING_SHARED 1
+void bn_set_sharing_mode(int32_t mode);
 size_t bn_plan_describe(const char *onnx_path, int32_t model_type_override, int32_t all_outputs,
                         char *buf, size_t cap, bn_status *status);
 

@@ -47,7 +47,7 @@ ENGINE_SYMBOLS = [
     "bn_model_device", "bn_model_io_info", "bn_model_get_config", "bn_model_get_cost", "bn_detect_model_type", "bn_ctx_create", "bn_ctx_get_stats", "bn_ctx_input_device",
     "bn_ctx_destroy", "bn_ctx_max_batch", "bn_ctx_device_bytes", "bn_infer", "bn_infer_submit", "bn_infer_collect", "bn_infer_device",
     "bn_ctx_output_device", "bn_ctx_read_output", "bn_ctx_synchronize", "bn_ctx_stream", "bn_ctx_time_kernels", "bn_ctx_launch_costs",
-    "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe", "bn_model_survey",
+    "bn_topk", "bn_topk_device", "bn_topk_host", "bn_step_device", "bn_step_results", "bn_plan_describe", "bn_model_survey", "bn_set_sharing_mode",
     "bn_recording_create", "bn_recording_create_async", "bn_recording_wait", "bn_recording_free", "bn_recording_samples", "bn_chunk_count", "bn_recording_windows",
     "bn_infer_windows", "bn_step_windows", "bn_ctx_step_device_rows", "bn_group_create", "bn_group_destroy", "bn_group_size",
     "bn_group_uses_rccl", "bn_group_get_stats", "bn_shard_range", "bn_group_analyze_recording", "bn_group_last_error", "bn_recording_create_resampled", "bn_resample_table", "bn_recording_read_f32", "bn_last_error",
@@ -143,6 +143,7 @@ def _load() -> C.CDLL:
         "bn_step_results": (i32, [vp, C.POINTER(f32p), C.POINTER(u32p), C.POINTER(f32p), C.POINTER(u32p), C.POINTER(sz)]),
         "bn_plan_describe": (sz, [C.c_char_p, i32, i32, C.c_char_p, sz, C.POINTER(i32)]),
         "bn_model_survey": (sz, [C.c_char_p, C.c_char_p, sz, C.POINTER(i32)]),
+        "bn_set_sharing_mode": (None, [i32]),
         "bn_recording_create": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
         "bn_recording_create_async": (i32, [i32, vp, sz, i32, C.POINTER(vp)]),
         "bn_recording_wait": (i32, [vp]),
@@ -1092,6 +1093,15 @@ def plan_describe(path: str, model_type: int = -1, all_outputs: bool = False) ->
     buf = C.create_string_buffer(n + 1)
     lib.bn_plan_describe(path.encode(), model_type, 1 if all_outputs else 0, buf, n + 1, C.byref(st))
     return buf.value.decode()
+
+
+SHARING_AUTO, SHARING_ALONE, SHARING_SHARED = -1, 0, 1
+
+
+def set_sharing_mode(mode: int) -> None:
+    """bn_set_sharing_mode: grids sized for a device of the caller's own (0, the default), a shared one (1), or by the number of live
+    contexts (-1).  Results are bit-identical in every mode."""
+    lib.bn_set_sharing_mode(int(mode))
 
 
 def model_survey(path: str):

@@ -336,7 +336,8 @@ bn_status enqueue_plan(bn_ctx *c, const float *d_in, size_t batch, const volatil
         d_in = c->d_input;
     }
     if (use_graph) {
-        bn_ctx::GraphKey key{batch, nullptr};
+        // (the grids of some launches depend on whether the device is shared, kernels.h: one graph per form)
+        bn_ctx::GraphKey key{batch, bn::device_context_count() > 1 ? reinterpret_cast<const float *>(uintptr_t(1)) : nullptr};
         auto it = c->graphs.find(key);
         if (it == c->graphs.end()) {
             hipGraph_t g = nullptr;
@@ -645,6 +646,8 @@ bn_status bn_detect_model_type(const int64_t *in_shape, size_t in_rank, const in
 }
 
 static bn_status ensure_step_block(bn_ctx *c, size_t k);
+
+void bn_set_sharing_mode(int32_t mode) { bn::device_sharing_mode(mode); }
 
 bn_status bn_ctx_create(bn_model *m, size_t max_batch, uint32_t flags, bn_ctx **out) {
     if (!m || !out) return fail(BN_ERR_INVALID_ARG, "null argument");

@@ -430,7 +430,8 @@ void note_launch_device(int dev);
 bool ensure_dynamic_lds(const void *kernel, size_t bytes);
 int device_cu_count();
 void device_context_count_add(int dev, int delta);  // capi.cpp: a context was created (+1) / destroyed (-1) on the device
-int device_context_count();                        // live contexts on the launching thread's device (>= 1)
+int device_context_count();                        // live contexts on the launching thread's device (>= 1; bn_set_sharing_mode overrides: 1 / >= 2)
+void device_sharing_mode(int mode);
 const float *device_zero_page();  // 4 KiB of zeros on the thread's launch device (allocated by prepare_device)
 size_t topk_lds_bytes(int64_t n, int64_t k);
 

@@ -151,10 +151,14 @@ static std::atomic<int> g_ctx_count[64];
 void device_context_count_add(int dev, int delta) {
     if (dev >= 0 && dev < 64) g_ctx_count[dev].fetch_add(delta, std::memory_order_relaxed);
 }
+static std::atomic<int> g_sharing_mode{0};  // bn_set_sharing_mode: 0 = alone (default), 1 = shared, -1 = by the count of live contexts
+void device_sharing_mode(int mode) { g_sharing_mode.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 int device_context_count() {
     const int dev = t_launch_dev;
-    const int n = (dev >= 0 && dev < 64) ? g_ctx_count[dev].load(std::memory_order_relaxed) : 1;
-    return n < 1 ? 1 : n;
+    int n = (dev >= 0 && dev < 64) ? g_ctx_count[dev].load(std::memory_order_relaxed) : 1;
+    n = n < 1 ? 1 : n;
+    const int mode = g_sharing_mode.load(std::memory_order_relaxed);
+    return mode == 0 ? 1 : (mode == 1 && n < 2 ? 2 : n);
 }
 int device_cu_count() {
     const uint64_t m = g_prepared_mask.load(std::memory_order_acquire);

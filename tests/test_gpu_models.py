@@ -98,6 +98,35 @@ def test_v24_batch_composition_does_not_change_results(bn, v24_small):
     assert a.tobytes() == b.tobytes() == c.tobytes()   # deterministic: same kernels, same per-sample order
 
 
+def test_sharing_modes_change_grids_not_bits(bn, v24_full):
+    """bn_set_sharing_mode: the forms for a device of the launch's own, for a shared device and by the count of live contexts give the same
+    bytes (full-size v2.4: small-map MBConv blocks with more chunks, 64-row GEMM tiles, the LDS-DMA GEMMs' larger tile), each form is
+    captured as its own graph, and the default is the form for a device of its own."""
+    data, path = v24_full
+    m = bn.Model(path)
+    x = synth.synthetic_segments(24, 144000, 48000)
+    ctx = bn.Context(m, 24)
+    base = ctx.infer(x)[0].copy()
+    g0 = ctx.stats()["instantiates"]
+    try:
+        bn.set_sharing_mode(bn.SHARING_SHARED)
+        shared = ctx.infer(x)[0].copy()
+        assert ctx.stats()["instantiates"] == g0 + 1          # a graph of its own for the other form
+        assert ctx.infer(x)[0].tobytes() == shared.tobytes() and ctx.stats()["instantiates"] == g0 + 1
+        bn.set_sharing_mode(bn.SHARING_AUTO)
+        other = bn.Context(m, 24)                           # a second live context: AUTO = the shared form
+        auto2 = ctx.infer(x)[0].copy()
+        assert ctx.stats()["instantiates"] == g0 + 1
+        other.close()
+        auto1 = ctx.infer(x)[0].copy()                      # alone again: the first graph
+        assert ctx.stats()["instantiates"] == g0 + 1
+    finally:
+        bn.set_sharing_mode(bn.SHARING_ALONE)
+    assert base.tobytes() == shared.tobytes() == auto2.tobytes() == auto1.tobytes()
+    ref = onnx_ref.run_model(data, x[:3])["output"]
+    assert np.abs(base[:3] - ref).max() <= 2e-4 + 2e-4 * np.abs(ref).max()
+
+
 def test_v24_full_size_model(bn, v24_full):
     data, path = v24_full
     clf = bn.Classifier.builder().model_path(path).labels(labels(6522)).with_rocm().build()

@@ -128,7 +128,7 @@ def test_structs_and_constants_agree():
             want.append((fname, ty))
         assert got == want, sname
         assert "#[repr(C)]\n#[derive(Clone, Copy)]\npub struct %s {" % sname in rust
-    consts = dict(re.findall(r"pub const (BN_\w+): \w+ = (\d+);", rust))
+    consts = dict(re.findall(r"pub const (BN_\w+): \w+ = (-?\d+);", rust))
     for _, items in gen.enums(text):
         for k, v in items:
             assert consts[k] == str(v), k

@@ -30,12 +30,12 @@ def strip_comments(text: str) -> str:
 
 
 def defines(text: str) -> dict:
-    """{name: (value, rust type)}: `0u`-suffixed values are the u32 context flags, BN_PCM_* the i32 `format` argument, the ABI version is
+    """{name: (value, rust type)}: `0u`-suffixed values are the u32 context flags, BN_PCM_* / BN_SHARING_* i32 arguments, the ABI version is
     compared with bn_abi_version()'s i32, everything else sizes an array"""
     out = {}
-    for m in re.finditer(r"^#define\s+(BN_[A-Z_0-9]+)\s+(\d+)(u?)\b", text, flags=re.M):
+    for m in re.finditer(r"^#define\s+(BN_[A-Z_0-9]+)\s+\(?(-?\d+)\)?(u?)(?=\s|$)", text, flags=re.M):
         k = m.group(1)
-        out[k] = (int(m.group(2)), "u32" if m.group(3) else "i32" if k == "BN_ABI_VERSION" or k.startswith("BN_PCM_") else "usize")
+        out[k] = (int(m.group(2)), "u32" if m.group(3) else "i32" if k == "BN_ABI_VERSION" or k.startswith(("BN_PCM_", "BN_SHARING_")) else "usize")
     return out
 
 
