@@ -3,7 +3,7 @@
 (bn_ctx_time_kernels), next to the time of the launch alone at B.  The marginal figure is what a launch costs once the
 chip is full -- the regime the concurrent contexts of the headline number run in.
 
-    python tools/marginal_table.py [--batch 32] [--model v24|v30|perch] [--reps 6]"""
+    python tools/marginal_table.py [--batch 32] [--model v24|v30|perch] [--reps 6] [--shared]"""
 import argparse
 import importlib
 import os
@@ -36,12 +36,14 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--model", default="v24")
     ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--shared", action="store_true", help="the launches' forms for a shared device (bn_set_sharing_mode)")
     a = ap.parse_args()
     blob = {"v24": synth.birdnet_v24, "v30": synth.birdnet_v30, "perch": synth.perch_v2}[a.model]()
     with tempfile.NamedTemporaryFile(suffix=".onnx", delete=False) as f:
         f.write(blob)
         path = f.name
     model = bn.Model(path)
+    bn.set_sharing_mode(bn.SHARING_SHARED if a.shared else bn.SHARING_ALONE)
     one = timed(model, a.batch, a.reps)
     four = timed(model, 4 * a.batch, a.reps)
     os.unlink(path)
