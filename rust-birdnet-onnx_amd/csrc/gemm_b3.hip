@@ -54,8 +54,10 @@ __device__ __forceinline__ void gb_act(int act, float p0, float p1, float (&v)[N
     else if (act == ACT_HSIGMOID) map_array<N>(v, [=](float x) { return fminf(fmaxf(p0 * x + p1, 0.0f), 1.0f); });
 }
 
-// MT 16-row tiles per block (every wave multiplies all of them), NW waves = NW 16-channel tiles
-template <int MT, int NW, bool GATED, int PF>
+// MT 16-row tiles per block (every wave multiplies all of them), NW waves of NTW 16-channel tiles each.  NTW = 2 (round 5, the large
+// products of v3.0 / Perch): an activation fragment read from LDS feeds twelve matrix instructions instead of six -- with one tile per wave
+// the eight waves of a block read 96 KB of planes per K step for 768 matrix cycles per SIMD: exactly the LDS pipe's 768 cycles.
+template <int MT, int NW, bool GATED, int PF, int NTW = 1>
 __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__restrict__ C, const float *__restrict__ A, const u32x4 *__restrict__ W3F,
                                                            const float *__restrict__ bias, const float *__restrict__ res, const float *__restrict__ scale,
                                                            int64_t total_rows, int nt16, int nst4, int nst) {
@@ -90,11 +92,13 @@ __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__r
         gsrc[j] = GATED ? scale + b * d.s_bs : nullptr;
         wofs[j] = row * 64 + 16 * (kc[j] ^ ((0 - (row >> 2)) & 3));
     }
-    const int t16 = min((int)blockIdx.y * NW + wave, nt16 - 1);  // this wave's channel tile (a padding wave repeats the last one, stores nothing)
-    const u32x4 *wsrc = W3F + (int64_t)t16 * nst4 * 192 + lane;  // (the planes hold nst4 = a multiple of four K steps per tile, zeros past K)
+    const u32x4 *wsrc[NTW];  // this wave's channel tiles (a padding tile repeats the last one, stores nothing)
+#pragma unroll
+    for (int jt = 0; jt < NTW; jt++)
+        wsrc[jt] = W3F + (int64_t)min(((int)blockIdx.y * NW + wave) * NTW + jt, nt16 - 1) * nst4 * 192 + lane;  // (nst4 K steps per tile, zeros past K)
 
     floatx4 xr[PF][XS][2], gr[PF][XS][2];
-    u32x4 wr[PF][3];
+    u32x4 wr[PF][NTW][3];
     auto load_x = [&](int s, int u) {
 #pragma unroll
         for (int j = 0; j < XS; j++) {
@@ -110,7 +114,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__r
     };
     auto load_w = [&](int s, int u) {
 #pragma unroll
-        for (int p = 0; p < 3; p++) wr[u][p] = wsrc[(s * 3 + p) * 64];
+        for (int jt = 0; jt < NTW; jt++)
+#pragma unroll
+            for (int p = 0; p < 3; p++) wr[u][jt][p] = wsrc[jt][(s * 3 + p) * 64];
     };
     auto write_x = [&](int s, int u, int buf) {
 #pragma unroll
@@ -135,9 +141,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__r
         }
     };
 
-    floatx4 acc[MT];
+    floatx4 acc[MT][NTW];
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int jt = 0; jt < NTW; jt++) acc[mt][jt] = floatx4{0.f, 0.f, 0.f, 0.f};
     const int aoff = lc * 64 + 16 * (lq ^ ((0 - (lc >> 2)) & 3));
     auto compute = [&](int u, int buf) {
         const char *ab = lds + buf * BUF_BYTES + aoff;
@@ -146,7 +154,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__r
             const u32x4 ah = *reinterpret_cast<const u32x4 *>(ab + mt * 1024);
             const u32x4 am = *reinterpret_cast<const u32x4 *>(ab + mt * 1024 + PLANE_BYTES);
             const u32x4 al = *reinterpret_cast<const u32x4 *>(ab + mt * 1024 + 2 * PLANE_BYTES);
-            acc[mt] = mm6(wr[u][0], wr[u][1], wr[u][2], ah, am, al, acc[mt]);
+#pragma unroll
+            for (int jt = 0; jt < NTW; jt++) acc[mt][jt] = mm6(wr[u][jt][0], wr[u][jt][1], wr[u][jt][2], ah, am, al, acc[mt][jt]);
         }
     };
     auto sync = [&]() {
@@ -183,47 +192,50 @@ __global__ __launch_bounds__(64 * NW) void gemm_b3_kernel(GemmDesc d, float *__r
         }
     }
 
-    // ---- epilogue: lane (lc, lq) holds channels n .. n + 3 of row lc of each m-tile
-    const int n = ((int)blockIdx.y * NW + wave) * 16 + 4 * lq;
-    if (n >= d.N) return;  // (a padding wave / the padding lanes of the last tile)
-    const floatx4 bv = d.has_bias ? *reinterpret_cast<const floatx4 *>(bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
-    float v[MT * 4];
+    // ---- epilogue: lane (lc, lq) holds channels n .. n + 3 of row lc of each m-tile, per channel tile
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[mt * 4 + i] = acc[mt][i] + bv[i];
-    gb_act<MT * 4>(d.act, d.p0, d.p1, v);
-    if (d.gap) {  // (launcher: TR == rows, one block per sample) the sample's mean over its rows: m-tiles ascending, then a fixed butterfly over the 16 rows
-        floatx4 sm = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int jt = 0; jt < NTW; jt++) {
+        const int n = (((int)blockIdx.y * NW + wave) * NTW + jt) * 16 + 4 * lq;
+        if (n >= d.N) continue;  // (a padding tile / the padding lanes of the last tile)
+        const floatx4 bv = d.has_bias ? *reinterpret_cast<const floatx4 *>(bias + n) : floatx4{0.f, 0.f, 0.f, 0.f};
+        float v[MT * 4];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) sm[i] += v[mt * 4 + i];
+            for (int i = 0; i < 4; i++) v[mt * 4 + i] = acc[mt][jt][i] + bv[i];
+        gb_act<MT * 4>(d.act, d.p0, d.p1, v);
+        if (d.gap) {  // (launcher: TR == rows, one block per sample) the sample's mean over its rows: m-tiles ascending, then a fixed butterfly over the 16 rows
+            floatx4 sm = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1)
+            for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) sm[i] += __shfl_xor(sm[i], o);
-        if (lc == 0) {
-            const float rows = (float)TR;
-            *reinterpret_cast<floatx4 *>(C + (int64_t)blockIdx.x * d.c_bs + n) = floatx4{sm[0] / rows, sm[1] / rows, sm[2] / rows, sm[3] / rows};
+                for (int i = 0; i < 4; i++) sm[i] += v[mt * 4 + i];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+                for (int i = 0; i < 4; i++) sm[i] += __shfl_xor(sm[i], o);
+            if (lc == 0) {
+                const float rows = (float)TR;
+                *reinterpret_cast<floatx4 *>(C + (int64_t)blockIdx.x * d.c_bs + n) = floatx4{sm[0] / rows, sm[1] / rows, sm[2] / rows, sm[3] / rows};
+            }
+            continue;
         }
-        return;
-    }
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        const int64_t g = row0 + mt * 16 + lc;
-        if (g < total_rows) {
-            const int64_t b = g / d.rows, m = g - b * d.rows;
-            floatx4 o = floatx4{v[mt * 4], v[mt * 4 + 1], v[mt * 4 + 2], v[mt * 4 + 3]};
-            if (d.has_res) o += *reinterpret_cast<const floatx4 *>(res + b * d.r_bs + m * d.ldr + n);
-            *reinterpret_cast<floatx4 *>(C + b * d.c_bs + m * d.ldc + n) = o;
+        for (int mt = 0; mt < MT; mt++) {
+            const int64_t g = row0 + mt * 16 + lc;
+            if (g < total_rows) {
+                const int64_t b = g / d.rows, m = g - b * d.rows;
+                floatx4 o = floatx4{v[mt * 4], v[mt * 4 + 1], v[mt * 4 + 2], v[mt * 4 + 3]};
+                if (d.has_res) o += *reinterpret_cast<const floatx4 *>(res + b * d.r_bs + m * d.ldr + n);
+                *reinterpret_cast<floatx4 *>(C + b * d.c_bs + m * d.ldc + n) = o;
+            }
         }
     }
 }
 
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <int MT, int NW>
+template <int MT, int NW, int NTW = 1>
 void launch_b3(hipStream_t s, const GemmDesc &d, float *C, const float *A, const u32x4 *W3F, const float *bias, const float *res, const float *scale,
                int64_t total_rows, int nt16, int nst4, int nb) {
     constexpr int TR = 16 * MT;
@@ -232,8 +244,8 @@ void launch_b3(hipStream_t s, const GemmDesc &d, float *C, const float *A, const
     const int nst = (d.K + 31) / 32;
     // two K steps of both operands in flight (PF = 4 is instantiable: measured slower at every size, tools/gemm3_bench)
     const int nrun = (nst + 1) & ~1;
-    if (d.has_scale) hipLaunchKernelGGL((gemm_b3_kernel<MT, NW, true, 2>), grid, dim3(64 * NW), lds, s, d, C, A, W3F, bias, res, scale, total_rows, nt16, nst4, nrun);
-    else hipLaunchKernelGGL((gemm_b3_kernel<MT, NW, false, 2>), grid, dim3(64 * NW), lds, s, d, C, A, W3F, bias, res, scale, total_rows, nt16, nst4, nrun);
+    if (d.has_scale) hipLaunchKernelGGL((gemm_b3_kernel<MT, NW, true, 2, NTW>), grid, dim3(64 * NW), lds, s, d, C, A, W3F, bias, res, scale, total_rows, nt16, nst4, nrun);
+    else hipLaunchKernelGGL((gemm_b3_kernel<MT, NW, false, 2, NTW>), grid, dim3(64 * NW), lds, s, d, C, A, W3F, bias, res, scale, total_rows, nt16, nst4, nrun);
 }
 
 }  // namespace
@@ -271,6 +283,20 @@ bool launch_gemm_b3(hipStream_t s, const GemmDesc &d, float *C, const float *A, 
         }                                                                                                  \
     } while (0)
     if (nw < 4) return false;
+    // two channel tiles per wave: the large products (64-row tiles, at least 16 channel tiles, enough blocks to fill the device twice over)
+    const int ntw_env = env_int("BN_GEMMB3_NTW", 0);
+    if (mt == 4 && !d.gap && nt16 >= 16 && ntw_env != 1 && (ntw_env == 2 || (total_rows + 63) / 64 * ((nt16 + 15) / 16) >= 2 * cus)) {
+        const int nb2 = (nt16 + 15) / 16;                  // channel blocks of at most 16 tiles (256 channels), evenly sized, two tiles per wave
+        const int nw2 = ((nt16 + nb2 - 1) / nb2 + 1) / 2;  // waves per block
+        switch (nw2) {
+            case 4: launch_b3<4, 4, 2>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb2); return true;
+            case 5: launch_b3<4, 5, 2>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb2); return true;
+            case 6: launch_b3<4, 6, 2>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb2); return true;
+            case 7: launch_b3<4, 7, 2>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb2); return true;
+            case 8: launch_b3<4, 8, 2>(s, d, C, A, W, bias, res, scale, total_rows, nt16, nst, nb2); return true;
+            default: break;  // (fewer than eight tiles per block cannot happen with nt16 >= 16)
+        }
+    }
     if (mt == 2) GB_GO(2);
     else if (mt == 3) GB_GO(3);
     else GB_GO(4);
