@@ -406,7 +406,7 @@ def main():
         "step_done_ms": [round(float(v), 3) for v in done_ms] if (len(done_ms) <= 64 or args.dump_steps) else None,  # completion time of every timed step since the start of the timed region (short runs only)
         "higher_is_better": True,
         "protocol": "r4-own-buffer" if args.own_buffer else "r4-rotating-input",  # r4-rotating-input: a fresh device batch per step, one D2D copy inside the timed region (BENCH_r01-r03: own-buffer)
-        "pre_warmup_device_passes": 13 if rank == 0 else 0,  # per-launch HIP-event timing passes (roofline leg) that run before the W warm-up steps
+        "pre_warmup_device_passes": (13 + (7 if max(1, args.streams) > 1 else 0)) if rank == 0 else 0,  # per-launch HIP-event timing passes (roofline leg: 13 in the default forms, 7 in the shared ones) that run before the W warm-up steps
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
