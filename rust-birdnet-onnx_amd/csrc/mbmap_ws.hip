@@ -1,4 +1,4 @@
-// Fused MBConv front half for the small maps (6 x 32; 3 x 16 and 4 x 16 with Cin = 128 / 192), WAVE-SPECIALISED (round 5): expand 1x1 conv (+bias+act) on the bf16 matrix pipe (bf16x3.h)
+// Fused MBConv front half for the small maps (6 x 32; 8 x 32 in two bands; 3 x 16 and 4 x 16 with Cin = 128 / 192), WAVE-SPECIALISED (round 5): expand 1x1 conv (+bias+act) on the bf16 matrix pipe (bf16x3.h)
 // and depthwise K x K (+bias+act) + squeeze sums on the vector ALU run in the SAME phase, on different waves and different chunks.
 //
 // mbmap.hip walks a block's channel chunks in two phases per chunk -- every wave expands, barrier, every wave runs the depthwise window,
@@ -23,7 +23,9 @@
 // moved to the planner (pack_mbmap_w3p): the 112-channel launches 20.0 / 45.8 us (marginal 8.6), four contexts 65.3 -> 66.8 k
 // segments/s (+2.3 % over mbmap.hip's bf16x3 form, 0.478 - 0.481 ms per step).  The 3 x 16 / 4 x 16 instances (one channel tile and two
 // pixel tiles per expand wave, all K steps: no K slices to add up): v2.4's four launches 17.2 -> 15.5 us at batch 32, 40 -> 37 at
-// batch 128, four contexts unchanged; v3.0's four 4 x 16 launches at batch 64 136 -> 103 us, 55.1 -> 56.2 k segments/s.
+// batch 128, four contexts unchanged; v3.0's four 4 x 16 launches at batch 64 136 -> 103 us, 55.1 -> 56.2 k segments/s.  The banded 8 x 32
+// instances replace v3.0's six expand GEMM + depthwise pairs (the exact-f32 banded form of round 4 had lost to them): 651 + 130 us of GEMM and
+// depthwise launches become 488 + 206 us of GEMM and small-map launches, 56.0 -> 58.7 k segments/s; v3.0 runs no separate depthwise launch.
 //
 // Arithmetic per value: identical to mbmap.hip's bf16x3 form (expand = bias + 32-deep steps ascending, six partial products per step
 // in bf16x3.h's order; depthwise = bias2 + taps ascending): the same result bits.  The squeeze sum of a channel adds the partials of
@@ -49,7 +51,10 @@ namespace {
 // H x W = 6 x 32: an expand wave owns three pixel tiles and both channel tiles of a chunk.  3 x 16 and 4 x 16 (Cin % 64 == 0; round 5, the
 // maps mbmap.hip walks with two K slices): an expand wave owns ONE channel tile and two pixel tiles (tiles 0-1 or 2-3; the 48-pixel map
 // has no tile 3), so its input planes are 2 NSW fragments -- NSW up to 6 (Cin = 192) in 144 registers.
-template <int K, int S, int NSW, int H, int W>
+// NB = 2, HM = 8 (BirdNET v3.0's 8 x 32 stage): the map is cut into two bands of OHM / 2 output rows, a band is a block of its own
+// (blockIdx.z) over the H = 6 REAL map rows its outputs reach (first row gy0 clamped into the map, mbmap.hip's scheme: which image row
+// feeds which output row through which tap row is compile time per band); the squeeze sums are partial per band.
+template <int K, int S, int NSW, int H, int W, int NB = 1, int HM = H>
 __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w1,
                                                        const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
                                                        float *__restrict__ gap, int nch, uint32_t inv_ch, const float *__restrict__ zpage) {
@@ -57,7 +62,8 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     constexpr int HW = H * W, NT = HW / 16, NC = 32, MW = SMALL ? 2 : 3, NW = SMALL ? 1 : 2, EWV = 4, TD = 256, NGD = TD / NC;
     static_assert((H == 6 && W == 32) || ((H == 3 || H == 4) && W == 16), "compiled map sizes");
     static_assert(MW * NSW <= 12, "the input planes of an expand wave: 12 registers per fragment");
-    constexpr int PT = (K - 1) / 2, OH = (H + 2 * PT - K) / S + 1, OW = (W + 2 * PT - K) / S + 1;
+    constexpr int PT = (K - 1) / 2, OHM = (HM + 2 * PT - K) / S + 1, OH = OHM / NB, OW = (W + 2 * PT - K) / S + 1;  // OH: output rows of ONE band
+    static_assert(NB == 1 ? HM == H : (NB == 2 && H == 6 && W == 32 && OHM % 2 == 0), "bands: two, of six rows, of a map HM rows high");
     static_assert(OW % NGD == 0, "one strip of output columns per lane group");
     constexpr int PPG = OW / NGD, IWS = (PPG - 1) * S + K, WP = W + K - 1, EP = NC + 4;
     constexpr int WSZ = (NC / 16) * NSW * 3 * 256, ESZ = mm_kib(H * WP * EP), RSZ = NGD * NC;
@@ -72,11 +78,13 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     const bool expander = wave < EWV;   // (wave-uniform)
     const int lc = lane & 15, lq = lane >> 4;
     const int64_t b = blockIdx.y;
+    const int band = NB > 1 ? (int)blockIdx.z : 0;                          // (block-uniform)
+    const int gy0 = NB > 1 ? min(max(band * OH * S - PT, 0), HM - H) : 0;   // first map row of the band's image
     const int cbase = blockIdx.x * nch * NC;
     const int nchunks = min(nch, (d.C - cbase + NC - 1) / NC);
 
     // ---- prologue, all waves: the sample's input image and the first filter chunk
-    mm_copy_in<8, SMALL, W, H>(Xi, in + b * d.in_bs, zpage, HW, CH, CH, Cin, inv_ch, 0, 0, wave, lane);
+    mm_copy_in<8, SMALL, W, HM>(Xi, in + b * d.in_bs, zpage, HW, CH, CH, Cin, inv_ch, gy0, 0, wave, lane);
     mm_copy_lin<8>(Ws, w1 + (int64_t)(cbase / 16) * (NSW * 768), WSZ / 256, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
             float t = r[c];
 #pragma unroll
             for (int y = 1; y < NGD; y++) t += r[y * NC + c];
-            gap[b * d.gap_bs + cgq] = t;
+            gap[b * d.gap_bs + (int64_t)band * d.C + cgq] = t;
         }
     };
     for (int q = 0; q < nchunks; q++) {
@@ -232,7 +240,8 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
         const int cg = c0 + c;
         const bool cact = cg < d.C;
         float sum = 0.0f;
-        {
+        auto dw_phase = [&](auto roff_c) {
+            constexpr int ROFF = decltype(roff_c)::value;  // image row of output row oy through tap row ky: oy * S + ky - ROFF
             // (Two output columns per instruction -- v_pk_fma_f32 on pairs read from LDS with ds_read2, bit-identical chains -- measured no
             // faster: 20.0 -> 20.3 us at batch 32, 45.8 -> 47.9 at batch 128 for the 112-channel launches.  The phase is not bound by the FMA
             // issue rate; the scalar form with its 8 reads per image row stays.)
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
                 bool used = false;  // (compile time) an image row no output reaches is not read
 #pragma unroll
                 for (int ky = 0; ky < K; ky++) {
-                    const int t = iy + PT - ky;
+                    const int t = iy + ROFF - ky;
                     used = used || (t >= 0 && t % S == 0 && t / S < OH);
                 }
                 if (!used) continue;
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
                 for (int ix = 0; ix < IWS; ix++) val[ix] = rp0[(iy * WP + ix) * EP];
 #pragma unroll
                 for (int ky = 0; ky < K; ky++) {
-                    const int t = iy + PT - ky;  // = oy * S for the output row this (image row, tap row) pair feeds
+                    const int t = iy + ROFF - ky;  // = oy * S for the output row this (image row, tap row) pair feeds
                     if (t >= 0 && t % S == 0 && t / S < OH) {
 #pragma unroll
                         for (int x = 0; x < PPG; x++)
@@ -277,11 +286,18 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
                 if (cact) {
 #pragma unroll
                     for (int x = 0; x < PPG; x++) {
-                        (ob + (size_t)((unsigned)oy * o_rs + (unsigned)x * o_cs))[olane] = r[x];
+                        (ob + (size_t)((unsigned)(band * OH + oy) * o_rs + (unsigned)x * o_cs))[olane] = r[x];
                         sum += r[x];
                     }
                 }
             }
+        };
+        if constexpr (NB == 1) {
+            dw_phase(std::integral_constant<int, PT>{});
+        } else {
+            constexpr int G1 = (OH * S - PT) < 0 ? 0 : ((OH * S - PT) > HM - H ? HM - H : (OH * S - PT));  // gy0 of band 1
+            if (band == 0) dw_phase(std::integral_constant<int, PT>{});
+            else dw_phase(std::integral_constant<int, PT + G1 - OH * S>{});
         }
         if (d.has_gap) red[(q & 1) * RSZ + grp * NC + c] = sum;
         // ends phase q + 1: this chunk image is read, the partials are written (LDS only: the result stores stay in flight)
@@ -301,10 +317,13 @@ size_t mbmap_ws_lds_bytes(const MbDesc &d, int nsw) {
 
 void register_mbmap_ws_kernels() {
 #define WS_REG(K, S, NSW, H, W) register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_ws_kernel<K, S, NSW, H, W>));
+#define WS_REGB(K, S, NSW) register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_ws_kernel<K, S, NSW, 6, 32, 2, 8>));
 #define WS_REG_KS(NSW, H, W) WS_REG(3, 1, NSW, H, W) WS_REG(5, 1, NSW, H, W) WS_REG(3, 2, NSW, H, W) WS_REG(5, 2, NSW, H, W)
     WS_REG_KS(2, 6, 32) WS_REG_KS(3, 6, 32) WS_REG_KS(4, 6, 32)
     WS_REG_KS(4, 3, 16) WS_REG_KS(6, 3, 16)
     WS_REG(3, 1, 4, 4, 16) WS_REG(5, 1, 4, 4, 16) WS_REG(3, 1, 6, 4, 16) WS_REG(5, 1, 6, 4, 16)
+    WS_REGB(3, 1, 3) WS_REGB(5, 1, 3) WS_REGB(3, 2, 3) WS_REGB(5, 2, 3) WS_REGB(3, 1, 4) WS_REGB(5, 1, 4) WS_REGB(3, 2, 4) WS_REGB(5, 2, 4)  // 8 x 32 in two bands
+#undef WS_REGB
 #undef WS_REG_KS
 #undef WS_REG
 }
@@ -314,12 +333,14 @@ bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in
                      float *gap, int64_t batch, int nch) {
     const int nsw = d.map_ws;
     const float *zpage = device_zero_page();
-    const bool big = d.H == 6 && d.W == 32, small3 = d.H == 3 && d.W == 16, small4 = d.H == 4 && d.W == 16;
+    const bool big = d.H == 6 && d.W == 32, small3 = d.H == 3 && d.W == 16, small4 = d.H == 4 && d.W == 16, banded = d.H == 8 && d.W == 32 && d.map_bands == 2;
     if (!zpage || d.Cin % 16 || (d.Cin + 31) / 32 != nsw) return false;
-    if (!(big ? (nsw >= 2 && nsw <= 4) : ((small3 || (small4 && d.s == 1)) && d.Cin % 64 == 0 && (nsw == 4 || nsw == 6)))) return false;
+    if (!(big ? (nsw >= 2 && nsw <= 4) : banded ? (nsw == 3 || nsw == 4) : ((small3 || (small4 && d.s == 1)) && d.Cin % 64 == 0 && (nsw == 4 || nsw == 6)))) return false;
     const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(d.Cin / 4)) + 1u;
-    const size_t lds = mbmap_ws_lds_bytes(d, nsw);
-    dim3 grid((unsigned)((d.C + nch * 32 - 1) / (nch * 32)), (unsigned)batch, 1);
+    MbDesc ld = d;  // LDS sizes follow the block's image: a band's six rows
+    if (banded) ld.H = 6;
+    const size_t lds = mbmap_ws_lds_bytes(ld, nsw);
+    dim3 grid((unsigned)((d.C + nch * 32 - 1) / (nch * 32)), (unsigned)batch, banded ? 2u : 1u);
 #define WS_GO(K, S, NSW, H, W) hipLaunchKernelGGL((mbmap_ws_kernel<K, S, NSW, H, W>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage)
 #define WS_GO_KS(NSW, H, W)                                  \
     do {                                                     \
@@ -328,7 +349,20 @@ bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in
         else if (d.k == 3) WS_GO(3, 2, NSW, H, W);           \
         else WS_GO(5, 2, NSW, H, W);                         \
     } while (0)
-    if (big) {
+    if (banded) {
+#define WS_GOB(K, S, NSW) hipLaunchKernelGGL((mbmap_ws_kernel<K, S, NSW, 6, 32, 2, 8>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage)
+#define WS_GOB_KS(NSW)                               \
+    do {                                             \
+        if (d.k == 3 && d.s == 1) WS_GOB(3, 1, NSW); \
+        else if (d.k == 5 && d.s == 1) WS_GOB(5, 1, NSW); \
+        else if (d.k == 3) WS_GOB(3, 2, NSW);        \
+        else WS_GOB(5, 2, NSW);                      \
+    } while (0)
+        if (nsw == 3) WS_GOB_KS(3);
+        else WS_GOB_KS(4);
+#undef WS_GOB_KS
+#undef WS_GOB
+    } else if (big) {
         if (nsw == 2) WS_GO_KS(2, 6, 32);
         else if (nsw == 3) WS_GO_KS(3, 6, 32);
         else WS_GO_KS(4, 6, 32);

@@ -346,6 +346,11 @@ inline MbmapShape mbmap_shape(const MbDesc &d) {
     const size_t cap = 160 * 1024;
     const int cls = sh.cin_pad % 64;
     const bool c1648 = cls == 16 || cls == 48;
+    // round 5: the 8 x 32 map in two bands is taken by DEFAULT where the wave-specialised kernel serves it (mbmap_ws.hip: not transposed,
+    // 3 or 4 steps of 32, no padded k) -- the exact-f32 banded form stays opt-in
+    const int nst_ws = (d.Cin + 31) / 32;
+    const bool ws_bands = !r4 && !sh.tr && c1648 && (nst_ws == 3 || nst_ws == 4) && env_int("BN_MBMAP_WS", 1) != 0 && env_int("BN_MBMAP_WS_BANDS", 1) != 0 &&
+                          env_int("BN_MBMAP_B3", 1) != 0 && env_int("BN_GEMM3", 2) != 0;
     // (the row swizzle each configuration is compiled with: see mm_swz)
     if (R == 6 && Wc == 32 && c1648) {
         if (mbmap_lds_bytes(p, 3, 2, 4, 2) <= cap) sh.cfg = 1;
@@ -356,7 +361,7 @@ inline MbmapShape mbmap_shape(const MbDesc &d) {
         if (mbmap_lds_bytes(p, 2, 1, 2, 2, 2) <= cap) sh.cfg = 4;  // 32-channel chunks (Cin = 192: two filter chunks of 64 would not fit), eight waves
     } else if (r4 && R == 4 && Wc == 16 && c1648 && d.s == 1) {
         if (mbmap_lds_bytes(p, 2, 1, 2, 2, 1) <= cap) sh.cfg = 6;
-    } else if (r4 && R == 8 && Wc == 32 && env_int("BN_MBMAP_BANDS", 1) != 0) {
+    } else if ((r4 || ws_bands) && R == 8 && Wc == 32 && env_int("BN_MBMAP_BANDS", 1) != 0) {
         // rows whose length is 0 or 32 mod 64 floats (Perch: Cin = 96) would meet the fragment reads' bank pattern: one more k group
         // of zeros moves them into a class the compiled swizzle serves (96 -> 112: a sixth more expand work, still ahead of the
         // GEMM + depthwise pair it replaces)
@@ -402,8 +407,11 @@ inline std::vector<float> pack_mbmap_w3f(const float *w, int64_t C, int64_t K) {
 // same phase, chunks of 32 channels): 32-deep steps of the whole product, or 0.  BN_MBMAP_WS=0 keeps mbmap.hip; BN_MBMAP_WS_SMALL=0 keeps it for
 // the 3 x 16 / 4 x 16 maps only.
 inline int mbmap_ws_steps(const MbDesc &d, const MbmapShape &sh) {
-    if (mbmap_b3_steps(d, sh) == 0 || env_int("BN_MBMAP_WS", 1) == 0) return 0;
+    if (env_int("BN_MBMAP_WS", 1) == 0 || env_int("BN_MBMAP_B3", 1) == 0 || env_int("BN_GEMM3", 2) == 0) return 0;
     const int nst = (d.Cin + 31) / 32;
+    if (sh.cfg == 5)  // 8 x 32 in two bands of six rows: the 6 x 32 kernel per band
+        return (!sh.tr && sh.bands == 2 && sh.cin_pad == d.Cin && d.Cin % 16 == 0 && (nst == 3 || nst == 4) && env_int("BN_MBMAP_WS_BANDS", 1) != 0) ? nst : 0;
+    if (mbmap_b3_steps(d, sh) == 0) return 0;
     if (sh.cfg <= 2) return nst;                                               // 6 x 32: 2 .. 4 steps (mbmap_b3_steps)
     return (env_int("BN_MBMAP_WS_SMALL", 1) != 0 && (nst == 4 || nst == 6)) ? nst : 0;  // 3 x 16 / 4 x 16: Cin = 128 / 192
 }
