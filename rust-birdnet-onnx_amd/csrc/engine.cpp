@@ -3533,7 +3533,10 @@ class Builder {
                     mb.a = pe.a;
                     // expand filters repacked for the kernel: [C][KW] rows = Cin weights | zeros, KW = Cin rounded up to
                     // 8-wide K groups (the bias starts the accumulators)
-                    if (whole_map && map2 && mshape.cin_pad != pe.gemm.K) {
+                    if (whole_map && map2 && map_ws) {
+                        // mbmap_ws.hip: the filters as bf16 planes in fragment order (plan_rules.h)
+                        mb.w = Ref{Space::CONSTS, add_const(pack_mbmap_w3p(plan_.consts[pe.w.id].data() + pe.w.offset, Cin, pe.gemm.K)), 0};
+                    } else if (whole_map && map2 && mshape.cin_pad != pe.gemm.K) {
                         // mbmap.hip with padded k: the filter rows get the zeros the input rows get from the zero page
                         const int64_t Kc = pe.gemm.K, KP = mshape.cin_pad;
                         const std::vector<float> &w0 = plan_.consts[pe.w.id];
@@ -3541,9 +3544,6 @@ class Builder {
                         for (int64_t nn = 0; nn < Cin; nn++)
                             for (int64_t k = 0; k < Kc; k++) wpk[nn * KP + k] = w0[pe.w.offset + nn * Kc + k];
                         mb.w = Ref{Space::CONSTS, add_const(wpk), 0};
-                    } else if (whole_map && map2 && map_ws) {
-                        // mbmap_ws.hip: the filters as bf16 planes in fragment order (plan_rules.h)
-                        mb.w = Ref{Space::CONSTS, add_const(pack_mbmap_w3p(plan_.consts[pe.w.id].data() + pe.w.offset, Cin, pe.gemm.K)), 0};
                     } else if (whole_map && map2 && map_b3) {
                         // mbmap.hip's bf16x3 form: the filters in the order of its LDS chunk image (plan_rules.h)
                         mb.w = Ref{Space::CONSTS, add_const(pack_mbmap_w3f(plan_.consts[pe.w.id].data() + pe.w.offset, Cin, pe.gemm.K)), 0};

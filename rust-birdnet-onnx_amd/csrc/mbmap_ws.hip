@@ -26,6 +26,9 @@
 // batch 128, four contexts unchanged; v3.0's four 4 x 16 launches at batch 64 136 -> 103 us, 55.1 -> 56.2 k segments/s.  The banded 8 x 32
 // instances replace v3.0's six expand GEMM + depthwise pairs (the exact-f32 banded form of round 4 had lost to them): 651 + 130 us of GEMM and
 // depthwise launches become 488 + 206 us of GEMM and small-map launches, 56.0 -> 58.7 k segments/s; v3.0 runs no separate depthwise launch.
+// TRANSPOSED bands (d.map_tr: the kernel's rows are the map's columns) with the input rows padded to whole 16-wide groups in LDS (d.cin_pad)
+// serve Perch's ten 32 x 8 blocks (K = 96, and K = 136 in five steps: 252 registers): GEMM 2926 -> 2256 us, depthwise 793 -> 319 us,
+// small-map launches + 718 us of its 5.5 ms chain; 23.2 -> 24.8 k segments/s at batch 128; 100 -> 90 launches.
 //
 // Arithmetic per value: identical to mbmap.hip's bf16x3 form (expand = bias + 32-deep steps ascending, six partial products per step
 // in bf16x3.h's order; depthwise = bias2 + taps ascending): the same result bits.  The squeeze sum of a channel adds the partials of
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     constexpr bool SMALL = W == 16;
     constexpr int HW = H * W, NT = HW / 16, NC = 32, MW = SMALL ? 2 : 3, NW = SMALL ? 1 : 2, EWV = 4, TD = 256, NGD = TD / NC;
     static_assert((H == 6 && W == 32) || ((H == 3 || H == 4) && W == 16), "compiled map sizes");
-    static_assert(MW * NSW <= 12, "the input planes of an expand wave: 12 registers per fragment");
+    static_assert(MW * NSW <= 15, "the input planes of an expand wave: 12 registers per fragment");
     constexpr int PT = (K - 1) / 2, OHM = (HM + 2 * PT - K) / S + 1, OH = OHM / NB, OW = (W + 2 * PT - K) / S + 1;  // OH: output rows of ONE band
     static_assert(NB == 1 ? HM == H : (NB == 2 && H == 6 && W == 32 && OHM % 2 == 0), "bands: two, of six rows, of a map HM rows high");
     static_assert(OW % NGD == 0, "one strip of output columns per lane group");
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     float *Es = Ws + 2 * WSZ;           // [2][H][WP][EP], columns < PT and >= PT + W stay zero
     float *red = Es + 2 * ESZ;          // [2][NGD][NC]
     float *Xi = ws_lds + WSZ;           // prologue only: the input image [HW][Cin], over everything behind the first filter buffer
-    const int Cin = d.Cin, CH = Cin >> 2;
+    const int Cin = d.cin_pad, CH = Cin >> 2;  // floats / chunks per row of the input image (the padded k: chunks past d.Cin come from the page of zeros)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool expander = wave < EWV;   // (wave-uniform)
@@ -84,7 +87,8 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     const int nchunks = min(nch, (d.C - cbase + NC - 1) / NC);
 
     // ---- prologue, all waves: the sample's input image and the first filter chunk
-    mm_copy_in<8, SMALL, W, HM>(Xi, in + b * d.in_bs, zpage, HW, CH, CH, Cin, inv_ch, gy0, 0, wave, lane);
+    const int tr = d.map_tr;  // (run time) the kernel's rows are the map's columns: input gather, tap order and output address follow
+    mm_copy_in<8, SMALL, W, HM>(Xi, in + b * d.in_bs, zpage, HW, CH, d.Cin >> 2, d.Cin, inv_ch, gy0, tr, wave, lane);
     mm_copy_lin<8>(Ws, w1 + (int64_t)(cbase / 16) * (NSW * 768), WSZ / 256, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     auto fetch_dw = [&](DwConst &cc_, int c0) {
         const unsigned cl = (unsigned)min(c0 + c, d.C - 1);
 #pragma unroll
-        for (int q = 0; q < K * K; q++) cc_.wd[q] = (w2 + (size_t)q * (size_t)d.C)[cl];
+        for (int q = 0; q < K * K; q++) cc_.wd[q] = (w2 + (size_t)(tr ? (q % K) * K + q / K : q) * (size_t)d.C)[cl];  // kernel tap (ky, kx) = map tap (kx, ky) when transposed
         cc_.bz = d.has_bias2 ? b2[cl] : 0.0f;
     };
     DwConst nxt;
@@ -275,7 +279,8 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
                 }
             }
             float *ob = out + b * d.out_bs;
-            const unsigned o_cs = (unsigned)d.C, o_rs = (unsigned)(OW * d.C);
+            // output element (row, column) of the kernel's geometry: + row * o_rs + column * o_cs floats (transposed: the map's (x, y))
+            const unsigned o_cs = tr ? (unsigned)(OHM * d.C) : (unsigned)d.C, o_rs = tr ? (unsigned)d.C : (unsigned)(OW * d.C);
             const unsigned olane = (unsigned)cg + (unsigned)ox0 * o_cs;
 #pragma unroll
             for (int oy = 0; oy < OH; oy++) {
@@ -323,6 +328,7 @@ void register_mbmap_ws_kernels() {
     WS_REG_KS(4, 3, 16) WS_REG_KS(6, 3, 16)
     WS_REG(3, 1, 4, 4, 16) WS_REG(5, 1, 4, 4, 16) WS_REG(3, 1, 6, 4, 16) WS_REG(5, 1, 6, 4, 16)
     WS_REGB(3, 1, 3) WS_REGB(5, 1, 3) WS_REGB(3, 2, 3) WS_REGB(5, 2, 3) WS_REGB(3, 1, 4) WS_REGB(5, 1, 4) WS_REGB(3, 2, 4) WS_REGB(5, 2, 4)  // 8 x 32 in two bands
+    WS_REGB(3, 1, 5) WS_REGB(5, 1, 5) WS_REGB(3, 2, 5) WS_REGB(5, 2, 5)                                                                      // (Perch: K = 136)
 #undef WS_REGB
 #undef WS_REG_KS
 #undef WS_REG
@@ -333,12 +339,16 @@ bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in
                      float *gap, int64_t batch, int nch) {
     const int nsw = d.map_ws;
     const float *zpage = device_zero_page();
-    const bool big = d.H == 6 && d.W == 32, small3 = d.H == 3 && d.W == 16, small4 = d.H == 4 && d.W == 16, banded = d.H == 8 && d.W == 32 && d.map_bands == 2;
-    if (!zpage || d.Cin % 16 || (d.Cin + 31) / 32 != nsw) return false;
-    if (!(big ? (nsw >= 2 && nsw <= 4) : banded ? (nsw == 3 || nsw == 4) : ((small3 || (small4 && d.s == 1)) && d.Cin % 64 == 0 && (nsw == 4 || nsw == 6)))) return false;
-    const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(d.Cin / 4)) + 1u;
+    // (the kernel's geometry: a transposed map's rows are its columns)
+    const int kh_ = d.map_tr ? d.W : d.H, kw_ = d.map_tr ? d.H : d.W;
+    const bool banded = kh_ == 8 && kw_ == 32 && d.map_bands == 2;
+    const bool big = !d.map_tr && d.H == 6 && d.W == 32, small3 = !d.map_tr && d.H == 3 && d.W == 16, small4 = !d.map_tr && d.H == 4 && d.W == 16;
+    if (!zpage || d.cin_pad % 16 || d.Cin % 4 || d.cin_pad < d.Cin || (d.Cin + 31) / 32 != nsw || (d.map_tr && !banded)) return false;
+    if (!(big ? (nsw >= 2 && nsw <= 4) : banded ? (nsw >= 3 && nsw <= 5) : ((small3 || (small4 && d.s == 1)) && d.Cin % 64 == 0 && (nsw == 4 || nsw == 6)))) return false;
+    const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(d.cin_pad / 4)) + 1u;
     MbDesc ld = d;  // LDS sizes follow the block's image: a band's six rows
-    if (banded) ld.H = 6;
+    ld.Cin = d.cin_pad;
+    if (banded) { ld.H = 6; ld.W = 32; }
     const size_t lds = mbmap_ws_lds_bytes(ld, nsw);
     dim3 grid((unsigned)((d.C + nch * 32 - 1) / (nch * 32)), (unsigned)batch, banded ? 2u : 1u);
 #define WS_GO(K, S, NSW, H, W) hipLaunchKernelGGL((mbmap_ws_kernel<K, S, NSW, H, W>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage)
@@ -359,7 +369,8 @@ bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in
         else WS_GOB(5, 2, NSW);                      \
     } while (0)
         if (nsw == 3) WS_GOB_KS(3);
-        else WS_GOB_KS(4);
+        else if (nsw == 4) WS_GOB_KS(4);
+        else WS_GOB_KS(5);
 #undef WS_GOB_KS
 #undef WS_GOB
     } else if (big) {

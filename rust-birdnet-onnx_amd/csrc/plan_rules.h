@@ -336,10 +336,15 @@ inline MbmapShape mbmap_shape(const MbDesc &d) {
     if (!mbconv_row_act_supported(d.act1) || !mbconv_row_act_supported(d.act2)) return none;
     // the kernel's geometry: R rows x Wc columns, Wc in {32, 16}; a tall narrow map is walked transposed
     int R = d.H, Wc = d.W;
-    if (r4 && d.W < 16 && (d.H == 32 || d.H == 16)) { R = d.W; Wc = d.H; sh.tr = 1; }
+    // round 5: a 32 x 8 map is walked transposed by DEFAULT where the banded wave-specialised kernel serves it (Perch: K = 96 / 136 -> 3 / 5
+    // steps of 32; any K % 16 == 0 -- its fragment reads happen once per block, so no padded k for the bank pattern)
+    const int nst_ws = (d.Cin + 31) / 32;
+    const bool ws_on = env_int("BN_MBMAP_WS", 1) != 0 && env_int("BN_MBMAP_WS_BANDS", 1) != 0 && env_int("BN_MBMAP_B3", 1) != 0 && env_int("BN_GEMM3", 2) != 0;
+    const bool ws_tr = !r4 && ws_on && d.W == 8 && d.H == 32 && d.Cin % 8 == 0 && nst_ws >= 3 && nst_ws <= 5 && env_int("BN_MBMAP_WS_TR", 1) != 0;
+    if ((r4 && d.W < 16 && (d.H == 32 || d.H == 16)) || ws_tr) { R = d.W; Wc = d.H; sh.tr = 1; }
     if (Wc % 4) return none;
     sh.cin_pad = (d.Cin + 15) & ~15;
-    if (!r4 && sh.cin_pad != d.Cin) return none;
+    if (!r4 && !ws_tr && sh.cin_pad != d.Cin) return none;
     MbDesc p = d;
     p.Cin = sh.cin_pad;  // LDS sizes follow the padded rows
     p.H = R; p.W = Wc;
@@ -348,9 +353,7 @@ inline MbmapShape mbmap_shape(const MbDesc &d) {
     const bool c1648 = cls == 16 || cls == 48;
     // round 5: the 8 x 32 map in two bands is taken by DEFAULT where the wave-specialised kernel serves it (mbmap_ws.hip: not transposed,
     // 3 or 4 steps of 32, no padded k) -- the exact-f32 banded form stays opt-in
-    const int nst_ws = (d.Cin + 31) / 32;
-    const bool ws_bands = !r4 && !sh.tr && c1648 && (nst_ws == 3 || nst_ws == 4) && env_int("BN_MBMAP_WS", 1) != 0 && env_int("BN_MBMAP_WS_BANDS", 1) != 0 &&
-                          env_int("BN_MBMAP_B3", 1) != 0 && env_int("BN_GEMM3", 2) != 0;
+    const bool ws_bands = !r4 && ws_on && (ws_tr || (!sh.tr && d.Cin % 16 == 0 && (nst_ws == 3 || nst_ws == 4)));
     // (the row swizzle each configuration is compiled with: see mm_swz)
     if (R == 6 && Wc == 32 && c1648) {
         if (mbmap_lds_bytes(p, 3, 2, 4, 2) <= cap) sh.cfg = 1;
@@ -361,7 +364,9 @@ inline MbmapShape mbmap_shape(const MbDesc &d) {
         if (mbmap_lds_bytes(p, 2, 1, 2, 2, 2) <= cap) sh.cfg = 4;  // 32-channel chunks (Cin = 192: two filter chunks of 64 would not fit), eight waves
     } else if (r4 && R == 4 && Wc == 16 && c1648 && d.s == 1) {
         if (mbmap_lds_bytes(p, 2, 1, 2, 2, 1) <= cap) sh.cfg = 6;
-    } else if ((r4 || ws_bands) && R == 8 && Wc == 32 && env_int("BN_MBMAP_BANDS", 1) != 0) {
+    } else if (ws_bands && R == 8 && Wc == 32) {
+        sh.cfg = 5; sh.bands = 2;  // (mbmap_ws.hip: its LDS carve-up fits for every K it is compiled for; no padded k)
+    } else if (r4 && R == 8 && Wc == 32 && env_int("BN_MBMAP_BANDS", 1) != 0) {
         // rows whose length is 0 or 32 mod 64 floats (Perch: Cin = 96) would meet the fragment reads' bank pattern: one more k group
         // of zeros moves them into a class the compiled swizzle serves (96 -> 112: a sixth more expand work, still ahead of the
         // GEMM + depthwise pair it replaces)
@@ -410,7 +415,8 @@ inline int mbmap_ws_steps(const MbDesc &d, const MbmapShape &sh) {
     if (env_int("BN_MBMAP_WS", 1) == 0 || env_int("BN_MBMAP_B3", 1) == 0 || env_int("BN_GEMM3", 2) == 0) return 0;
     const int nst = (d.Cin + 31) / 32;
     if (sh.cfg == 5)  // 8 x 32 in two bands of six rows: the 6 x 32 kernel per band
-        return (!sh.tr && sh.bands == 2 && sh.cin_pad == d.Cin && d.Cin % 16 == 0 && (nst == 3 || nst == 4) && env_int("BN_MBMAP_WS_BANDS", 1) != 0) ? nst : 0;
+        return (sh.bands == 2 && (sh.tr || sh.cin_pad == d.Cin) && sh.cin_pad % 16 == 0 && nst >= 3 && nst <= (sh.tr ? 5 : 4) && env_int("BN_MBMAP_WS_BANDS", 1) != 0 &&
+                (!sh.tr || env_int("BN_MBMAP_WS_TR", 1) != 0)) ? nst : 0;
     if (mbmap_b3_steps(d, sh) == 0) return 0;
     if (sh.cfg <= 2) return nst;                                               // 6 x 32: 2 .. 4 steps (mbmap_b3_steps)
     return (env_int("BN_MBMAP_WS_SMALL", 1) != 0 && (nst == 4 || nst == 6)) ? nst : 0;  // 3 x 16 / 4 x 16: Cin = 128 / 192
