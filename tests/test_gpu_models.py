@@ -560,9 +560,9 @@ def test_round3_kernels_switched_off_and_on_against_the_oracle(bn, v24_full, mon
 # reach (the 5 x 5 SiLU row-kernel instances at one wave per SIMD, Perch's 40-channel stem, its K = 24 project conv, the
 # column-streaming blocks at 125 x 32, v3.0's 8 x 32 / 4 x 16 maps) met the oracle nowhere; permutation / duplicate-row
 # properties cannot see a deterministic wrong answer.  Each switch set names the kernel family a disagreement would belong to.
-FULL_SIZE_ENVS = [{}, {"BN_MBMAP_WS": "0", "BN_GEMMB3_NTW": "1"}, {"BN_MBROW": "0", "BN_GEMMDMA": "0"}, {"BN_MBMAP2": "0"}, {"BN_MBROW_TR": "0"}, {"BN_STFT": "0"}, {"BN_GEMMDMA": "2"}, {"BN_MBMAP3": "1"},
+FULL_SIZE_ENVS = [{}, {"BN_MBMAP_WS_BANDS": "0"}, {"BN_MBMAP_WS": "0", "BN_GEMMB3_NTW": "1"}, {"BN_MBROW": "0", "BN_GEMMDMA": "0"}, {"BN_MBMAP2": "0"}, {"BN_MBROW_TR": "0"}, {"BN_STFT": "0"}, {"BN_GEMMDMA": "2"}, {"BN_MBMAP3": "1"},
                   {"BN_GEMM3": "0"}, {"BN_GEMM3": "1"}, {"BN_STFT_PAD": "0", "BN_MBROW_B3": "0", "BN_DWMAPT": "0", "BN_MBMAP_B3": "0"}]
-FULL_SIZE_IDS = ["default", "two_phase_small_map_kernel_one_tile_per_gemm_wave", "tiled_mbconv_and_gemm", "no_small_map_kernels", "no_column_streaming", "matrix_front_end", "dma_gemm_everywhere",
+FULL_SIZE_IDS = ["default", "no_banded_small_map_kernels", "two_phase_small_map_kernel_one_tile_per_gemm_wave", "tiled_mbconv_and_gemm", "no_small_map_kernels", "no_column_streaming", "matrix_front_end", "dma_gemm_everywhere",
                   "round4_small_map_kernels", "exact_f32_gemms", "bf16x3_lds_dma_form_everywhere", "padded_copy_launches_f32_row_and_map_expand_runtime_size_depthwise"]
 
 
