@@ -28,7 +28,9 @@
 // depthwise launches become 488 + 206 us of GEMM and small-map launches, 56.0 -> 58.7 k segments/s; v3.0 runs no separate depthwise launch.
 // TRANSPOSED bands (d.map_tr: the kernel's rows are the map's columns) with the input rows padded to whole 16-wide groups in LDS (d.cin_pad)
 // serve Perch's ten 32 x 8 blocks (K = 96, and K = 136 in five steps: 252 registers): GEMM 2926 -> 2256 us, depthwise 793 -> 319 us,
-// small-map launches + 718 us of its 5.5 ms chain; 23.2 -> 24.8 k segments/s at batch 128; 100 -> 90 launches.
+// small-map launches + 718 us of its 5.5 ms chain; 23.2 -> 24.8 k segments/s at batch 128; 100 -> 90 launches.  Its six 16 x 4 blocks with
+// K = 232 take the one-pixel-tile-per-wave form (EM = 2): GEMM - 270 us, depthwise - 150 us, small-map launches + 375 us; 24.25 -> 24.8 k on
+// one box; 84 launches, two depthwise launches left (3 % of the chain).
 //
 // Arithmetic per value: identical to mbmap.hip's bf16x3 form (expand = bias + 32-deep steps ascending, six partial products per step
 // in bf16x3.h's order; depthwise = bias2 + taps ascending): the same result bits.  The squeeze sum of a channel adds the partials of
@@ -57,12 +59,14 @@ namespace {
 // NB = 2, HM = 8 (BirdNET v3.0's 8 x 32 stage): the map is cut into two bands of OHM / 2 output rows, a band is a block of its own
 // (blockIdx.z) over the H = 6 REAL map rows its outputs reach (first row gy0 clamped into the map, mbmap.hip's scheme: which image row
 // feeds which output row through which tap row is compile time per band); the squeeze sums are partial per band.
-template <int K, int S, int NSW, int H, int W, int NB = 1, int HM = H>
+// EM = 2 (Perch's 16 x 4 maps, walked transposed as 4 x 16, K = 232 in eight steps): an expand wave owns ONE pixel tile and both channel
+// tiles -- 96 registers of input planes at eight steps -- and the input image takes the four-chunk swizzle (SWZ16 = false: K % 64 != 0).
+template <int K, int S, int NSW, int H, int W, int NB = 1, int HM = H, int EM = (W == 16 ? 1 : 0), bool SWZ16 = (W == 16)>
 __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restrict__ out, const float *__restrict__ in, const float *__restrict__ w1,
                                                        const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
                                                        float *__restrict__ gap, int nch, uint32_t inv_ch, const float *__restrict__ zpage) {
-    constexpr bool SMALL = W == 16;
-    constexpr int HW = H * W, NT = HW / 16, NC = 32, MW = SMALL ? 2 : 3, NW = SMALL ? 1 : 2, EWV = 4, TD = 256, NGD = TD / NC;
+    constexpr int HW = H * W, NT = HW / 16, NC = 32, MW = EM == 0 ? 3 : (EM == 1 ? 2 : 1), NW = EM == 1 ? 1 : 2, EWV = 4, TD = 256, NGD = TD / NC;
+    static_assert(EM == 0 ? W == 32 : (W == 16 && (EM == 1 || NT <= 4)), "tile ownership of the expand waves");
     static_assert((H == 6 && W == 32) || ((H == 3 || H == 4) && W == 16), "compiled map sizes");
     static_assert(MW * NSW <= 15, "the input planes of an expand wave: 12 registers per fragment");
     constexpr int PT = (K - 1) / 2, OHM = (HM + 2 * PT - K) / S + 1, OH = OHM / NB, OW = (W + 2 * PT - K) / S + 1;  // OH: output rows of ONE band
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
 
     // ---- prologue, all waves: the sample's input image and the first filter chunk
     const int tr = d.map_tr;  // (run time) the kernel's rows are the map's columns: input gather, tap order and output address follow
-    mm_copy_in<8, SMALL, W, HM>(Xi, in + b * d.in_bs, zpage, HW, CH, d.Cin >> 2, d.Cin, inv_ch, gy0, tr, wave, lane);
+    mm_copy_in<8, SWZ16, W, HM>(Xi, in + b * d.in_bs, zpage, HW, CH, d.Cin >> 2, d.Cin, inv_ch, gy0, tr, wave, lane);
     mm_copy_lin<8>(Ws, w1 + (int64_t)(cbase / 16) * (NSW * 768), WSZ / 256, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -104,20 +108,20 @@ __global__ __launch_bounds__(512) void mbmap_ws_kernel(MbDesc d, float *__restri
     if (expander) {
         // =================================================================== expand waves
         // lane (c, q) of fragment (mt, s): k groups 2 s and 2 s + 1 of pixel 16 (mt0 + mt) + c, read as mbmap.hip's f32 form reads them
-        const int nt0 = SMALL ? (wave & 1) : 0, mt0 = SMALL ? 2 * (wave >> 1) : 3 * wave;  // (wave-uniform)
+        const int nt0 = EM == 1 ? (wave & 1) : 0, mt0 = EM == 0 ? 3 * wave : (EM == 1 ? 2 * (wave >> 1) : wave);  // (wave-uniform)
         floatx4 raw[MW][NSW][2];
         {
             const int G16 = Cin >> 4;
 #pragma unroll
             for (int mt = 0; mt < MW; mt++) {
                 const int m = min(mt0 + mt, NT - 1) * 16 + lc;  // (a tile past the map repeats the last one: never multiplied, never stored)
-                const int sw = mm_swz<SMALL>(m);
+                const int sw = mm_swz<SWZ16>(m);
 #pragma unroll
                 for (int st = 0; st < NSW; st++)
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         const int g = 2 * st + h;
-                        const int off = SMALL ? m * Cin + 64 * (g >> 2) + 16 * ((g & 3) ^ (sw >> 2)) + 4 * (lq ^ (sw & 3)) : m * Cin + 16 * g + 4 * (lq ^ sw);
+                        const int off = SWZ16 ? m * Cin + 64 * (g >> 2) + 16 * ((g & 3) ^ (sw >> 2)) + 4 * (lq ^ (sw & 3)) : m * Cin + 16 * g + 4 * (lq ^ sw);
                         raw[mt][st][h] = g < G16 ? *reinterpret_cast<const floatx4 *>(Xi + off) : floatx4{0.f, 0.f, 0.f, 0.f};
                     }
             }
@@ -329,6 +333,8 @@ void register_mbmap_ws_kernels() {
     WS_REG(3, 1, 4, 4, 16) WS_REG(5, 1, 4, 4, 16) WS_REG(3, 1, 6, 4, 16) WS_REG(5, 1, 6, 4, 16)
     WS_REGB(3, 1, 3) WS_REGB(5, 1, 3) WS_REGB(3, 2, 3) WS_REGB(5, 2, 3) WS_REGB(3, 1, 4) WS_REGB(5, 1, 4) WS_REGB(3, 2, 4) WS_REGB(5, 2, 4)  // 8 x 32 in two bands
     WS_REGB(3, 1, 5) WS_REGB(5, 1, 5) WS_REGB(3, 2, 5) WS_REGB(5, 2, 5)                                                                      // (Perch: K = 136)
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_ws_kernel<3, 1, 8, 4, 16, 1, 4, 2, false>));  // 4 x 16, K = 232 / 256 (Perch, transposed)
+    register_dynamic_lds_kernel(reinterpret_cast<const void *>(mbmap_ws_kernel<5, 1, 8, 4, 16, 1, 4, 2, false>));
 #undef WS_REGB
 #undef WS_REG_KS
 #undef WS_REG
@@ -342,13 +348,15 @@ bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in
     // (the kernel's geometry: a transposed map's rows are its columns)
     const int kh_ = d.map_tr ? d.W : d.H, kw_ = d.map_tr ? d.H : d.W;
     const bool banded = kh_ == 8 && kw_ == 32 && d.map_bands == 2;
-    const bool big = !d.map_tr && d.H == 6 && d.W == 32, small3 = !d.map_tr && d.H == 3 && d.W == 16, small4 = !d.map_tr && d.H == 4 && d.W == 16;
-    if (!zpage || d.cin_pad % 16 || d.Cin % 4 || d.cin_pad < d.Cin || (d.Cin + 31) / 32 != nsw || (d.map_tr && !banded)) return false;
-    if (!(big ? (nsw >= 2 && nsw <= 4) : banded ? (nsw >= 3 && nsw <= 5) : ((small3 || (small4 && d.s == 1)) && d.Cin % 64 == 0 && (nsw == 4 || nsw == 6)))) return false;
+    const bool deep4 = kh_ == 4 && kw_ == 16 && nsw == 8 && d.s == 1 && d.map_bands == 1;  // one pixel tile per expand wave
+    const bool big = !d.map_tr && d.H == 6 && d.W == 32, small3 = !d.map_tr && d.H == 3 && d.W == 16, small4 = !d.map_tr && d.H == 4 && d.W == 16 && !deep4;
+    if (!zpage || d.cin_pad % 16 || d.Cin % 4 || d.cin_pad < d.Cin || (d.Cin + 31) / 32 != nsw || (d.map_tr && !banded && !deep4)) return false;
+    if (!(deep4 || big ? (deep4 || (nsw >= 2 && nsw <= 4)) : banded ? (nsw >= 3 && nsw <= 5) : ((small3 || (small4 && d.s == 1)) && d.Cin % 64 == 0 && (nsw == 4 || nsw == 6)))) return false;
     const uint32_t inv_ch = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(d.cin_pad / 4)) + 1u;
     MbDesc ld = d;  // LDS sizes follow the block's image: a band's six rows
     ld.Cin = d.cin_pad;
     if (banded) { ld.H = 6; ld.W = 32; }
+    if (deep4) { ld.H = 4; ld.W = 16; }
     const size_t lds = mbmap_ws_lds_bytes(ld, nsw);
     dim3 grid((unsigned)((d.C + nch * 32 - 1) / (nch * 32)), (unsigned)batch, banded ? 2u : 1u);
 #define WS_GO(K, S, NSW, H, W) hipLaunchKernelGGL((mbmap_ws_kernel<K, S, NSW, H, W>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage)
@@ -359,7 +367,10 @@ bool launch_mbmap_ws(hipStream_t s, const MbDesc &d, float *out, const float *in
         else if (d.k == 3) WS_GO(3, 2, NSW, H, W);           \
         else WS_GO(5, 2, NSW, H, W);                         \
     } while (0)
-    if (banded) {
+    if (deep4) {
+        if (d.k == 3) hipLaunchKernelGGL((mbmap_ws_kernel<3, 1, 8, 4, 16, 1, 4, 2, false>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage);
+        else hipLaunchKernelGGL((mbmap_ws_kernel<5, 1, 8, 4, 16, 1, 4, 2, false>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage);
+    } else if (banded) {
 #define WS_GOB(K, S, NSW) hipLaunchKernelGGL((mbmap_ws_kernel<K, S, NSW, 6, 32, 2, 8>), grid, dim3(512), lds, s, d, out, in, w1, b1, w2, b2, gap, nch, inv_ch, zpage)
 #define WS_GOB_KS(NSW)                               \
     do {                                             \

@@ -341,10 +341,13 @@ inline MbmapShape mbmap_shape(const MbDesc &d) {
     const int nst_ws = (d.Cin + 31) / 32;
     const bool ws_on = env_int("BN_MBMAP_WS", 1) != 0 && env_int("BN_MBMAP_WS_BANDS", 1) != 0 && env_int("BN_MBMAP_B3", 1) != 0 && env_int("BN_GEMM3", 2) != 0;
     const bool ws_tr = !r4 && ws_on && d.W == 8 && d.H == 32 && d.Cin % 8 == 0 && nst_ws >= 3 && nst_ws <= 5 && env_int("BN_MBMAP_WS_TR", 1) != 0;
-    if ((r4 && d.W < 16 && (d.H == 32 || d.H == 16)) || ws_tr) { R = d.W; Wc = d.H; sh.tr = 1; }
+    // ... and a 16 x 4 map with K in eight steps of 32 (Perch: K = 232) by its one-pixel-tile-per-wave form
+    const bool ws_deep = !r4 && ws_on && d.W == 4 && d.H == 16 && d.Cin % 8 == 0 && d.Cin % 64 != 0 && nst_ws == 8 && d.s == 1 &&
+                         env_int("BN_MBMAP_WS_DEEP", 1) != 0;
+    if ((r4 && d.W < 16 && (d.H == 32 || d.H == 16)) || ws_tr || (ws_deep && d.W == 4)) { R = d.W; Wc = d.H; sh.tr = 1; }
     if (Wc % 4) return none;
     sh.cin_pad = (d.Cin + 15) & ~15;
-    if (!r4 && !ws_tr && sh.cin_pad != d.Cin) return none;
+    if (!r4 && !ws_tr && !ws_deep && sh.cin_pad != d.Cin) return none;
     MbDesc p = d;
     p.Cin = sh.cin_pad;  // LDS sizes follow the padded rows
     p.H = R; p.W = Wc;
@@ -362,6 +365,8 @@ inline MbmapShape mbmap_shape(const MbDesc &d) {
         if (mbmap_lds_bytes(p, 3, 1, 1, 4, 2) <= cap) sh.cfg = 3;
     } else if (R == 4 && Wc == 16 && cls == 0 && d.s == 1) {  // BirdNET v3.0's last stage (5 s segments: one more row than v2.4's 3 x 16)
         if (mbmap_lds_bytes(p, 2, 1, 2, 2, 2) <= cap) sh.cfg = 4;  // 32-channel chunks (Cin = 192: two filter chunks of 64 would not fit), eight waves
+    } else if (ws_deep && R == 4 && Wc == 16) {
+        sh.cfg = 6;  // (mbmap_ws.hip; no exact-f32 counterpart by default)
     } else if (r4 && R == 4 && Wc == 16 && c1648 && d.s == 1) {
         if (mbmap_lds_bytes(p, 2, 1, 2, 2, 1) <= cap) sh.cfg = 6;
     } else if (ws_bands && R == 8 && Wc == 32) {
@@ -414,6 +419,8 @@ inline std::vector<float> pack_mbmap_w3f(const float *w, int64_t C, int64_t K) {
 inline int mbmap_ws_steps(const MbDesc &d, const MbmapShape &sh) {
     if (env_int("BN_MBMAP_WS", 1) == 0 || env_int("BN_MBMAP_B3", 1) == 0 || env_int("BN_GEMM3", 2) == 0) return 0;
     const int nst = (d.Cin + 31) / 32;
+    if (sh.cfg == 6)  // 4 x 16 (Perch: transposed 16 x 4) with eight steps: one pixel tile per expand wave
+        return (sh.bands == 1 && sh.cin_pad % 16 == 0 && nst == 8 && d.s == 1 && d.Cin % 64 != 0 && env_int("BN_MBMAP_WS_DEEP", 1) != 0) ? nst : 0;
     if (sh.cfg == 5)  // 8 x 32 in two bands of six rows: the 6 x 32 kernel per band
         return (sh.bands == 2 && (sh.tr || sh.cin_pad == d.Cin) && sh.cin_pad % 16 == 0 && nst >= 3 && nst <= (sh.tr ? 5 : 4) && env_int("BN_MBMAP_WS_BANDS", 1) != 0 &&
                 (!sh.tr || env_int("BN_MBMAP_WS_TR", 1) != 0)) ? nst : 0;

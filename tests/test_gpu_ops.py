@@ -968,7 +968,7 @@ def test_pipelined_mbconv_is_bit_identical_to_the_plain_kernel(bn):
     (80, 8, 32, 480, 3, 1, "cfg5,bands,ws "), (112, 8, 32, 672, 5, 1, "cfg5,bands,ws "), (112, 8, 32, 672, 5, 2, "cfg5,bands,ws "), (80, 8, 32, 252, 3, 2, "cfg5,bands,ws "),
     (48, 8, 32, 288, 3, 1, None),   # (1.5 steps: neither the banded ws kernel nor, by default, the exact-f32 banded form)
     # ... Perch's tall maps walked transposed, its Cin = 232 padded to 240 in LDS, the 64-pixel map with four waves ...
-    (232, 16, 4, 1392, 5, 1, "cfg6,transposed kpad=240"), (232, 16, 4, 700, 3, 1, "cfg6,transposed kpad=240"), (48, 4, 16, 288, 5, 1, "cfg6 "),
+    (232, 16, 4, 1392, 5, 1, "cfg6,transposed,ws kpad=240"), (232, 16, 4, 700, 3, 1, "cfg6,transposed,ws kpad=240"), (48, 4, 16, 288, 5, 1, "cfg6 "),
     (96, 32, 8, 576, 3, 1, "cfg5,bands,transposed,ws kpad=96"), (96, 32, 8, 576, 5, 2, "cfg5,bands,transposed,ws kpad=96"),
     (96, 32, 8, 560, 5, 1, "cfg5,bands,transposed,ws kpad=96"),
     # ... Perch's K = 136 (rows padded to 144 in LDS, five steps of 32: 252 registers per expand wave)
@@ -1033,17 +1033,18 @@ def test_fused_expand_depthwise_small_maps(bn, cin, h, w, cmid, k, stride, expec
         assert ("MBCONV" in desc) == (expect is not None) and (expect is None or "map=" + expect in desc + " "), desc
         got2, _ = run_both(bn, data, batch=3)
         assert_close(got2, ref, f"default plan {cin}->{cmid} k{k} s{stride}")
-        if expect and "bands" in expect and ",ws" in expect:
+        if expect and ("bands" in expect or "cfg6" in expect) and ",ws" in expect:
             # the banded wave-specialised form: same bytes whatever the batch (bands / chunks per block follow it), the switch of its own
             # gives the unfused plan, whose result it matches to a few roundings (another summation order in the expand, band-wise squeeze sums)
             one = run_both(bn, data, batch=1)[0][:1]
             many, _ = run_both(bn, data, batch=9)
             assert np.array_equal(one.view(np.uint32), many[:1].view(np.uint32)) and np.array_equal(got2.view(np.uint32), many[:3].view(np.uint32))
-            os.environ["BN_MBMAP_WS_BANDS"] = "0"
+            sw = "BN_MBMAP_WS_DEEP" if "cfg6" in expect else "BN_MBMAP_WS_BANDS"
+            os.environ[sw] = "0"
             try:
                 assert "MBCONV" not in bn.plan_describe(write_model(data))
             finally:
-                del os.environ["BN_MBMAP_WS_BANDS"]
+                del os.environ[sw]
             assert np.abs(got2 - got3).max() <= 2e-5 * np.abs(got3).max()
         elif expect and (",b3" in expect or ",ws" in expect):
             # the exact-f32 expand of the same configuration (BN_MBMAP_B3=0), and the bits of the bf16x3 form do not depend on the batch a

@@ -566,7 +566,7 @@ def test_size_of_an_activation_is_refused_and_of_a_constant_folds(bn, tmp_path):
 def test_round5_small_map_forms_in_the_three_plans(bn, tmp_path, monkeypatch):
     """Planner facts of round 5, on the CPU: v2.4's ten small-map MBConv blocks, v3.0's ten (six of them 8 x 32 maps in two bands: no
     depthwise launch is left in its plan) and Perch's ten transposed 32 x 8 blocks take the wave-specialised kernel; Perch plans 90 launches
-    with 8 depthwise launches (its 16 x 4 stage); every form has its switch."""
+    (six more on the 16 x 4 maps' one-tile-per-wave form): 84 launches, 2 depthwise launches; every form has its switch."""
     def plan(blob, name):
         p = tmp_path / name
         p.write_bytes(blob)
@@ -574,11 +574,14 @@ def test_round5_small_map_forms_in_the_three_plans(bn, tmp_path, monkeypatch):
     d24, d30, dpe = plan(synth.birdnet_v24(), "a.onnx"), plan(synth.birdnet_v30(), "b.onnx"), plan(synth.perch_v2(), "c.onnx")
     assert d24.count(",ws ") == 10 and d24.count("map=cfg") == 10
     assert d30.count(",ws ") == 10 and d30.count("cfg5,bands,ws ") == 6 and " DWCONV " not in d30
-    assert dpe.count("cfg5,bands,transposed,ws ") == 10 and dpe.count(" DWCONV ") == 8 and "TOTAL launches=90 " in dpe
+    assert dpe.count("cfg5,bands,transposed,ws ") == 10 and dpe.count("cfg6,transposed,ws ") == 6 and dpe.count(" DWCONV ") == 2 and "TOTAL launches=84 " in dpe
     assert "kpad=144" in dpe and "kpad=96" in dpe
     monkeypatch.setenv("BN_MBMAP_WS_TR", "0")
+    assert plan(synth.perch_v2(), "c.onnx").count("map=cfg") == 6
+    monkeypatch.setenv("BN_MBMAP_WS_DEEP", "0")
     assert "map=cfg" not in plan(synth.perch_v2(), "c.onnx")
     monkeypatch.delenv("BN_MBMAP_WS_TR")
+    monkeypatch.delenv("BN_MBMAP_WS_DEEP")
     monkeypatch.setenv("BN_MBMAP_WS_BANDS", "0")
     d30b = plan(synth.birdnet_v30(), "b.onnx")
     assert d30b.count(" DWCONV ") == 6 and d30b.count(",ws ") == 4
