@@ -60,6 +60,7 @@ def main():
         else:
             dist.init_process_group(backend=a.backend)
     bn = importlib.import_module("rust-birdnet-onnx_amd")
+    bn.set_sharing_mode(bn.SHARING_SHARED)  # several contexts per rank keep batches in flight: the launches' forms for a shared device
     synth = importlib.import_module("rust-birdnet-onnx_amd.synth")
     dmod = importlib.import_module("rust-birdnet-onnx_amd.distributed")
     with tempfile.NamedTemporaryFile(suffix=".onnx", delete=False) as f:
