@@ -347,3 +347,22 @@ fn group_last_error() -> String {
     unsafe { bn_group_last_error(buf.as_mut_ptr() as *mut _, buf.len()) };
     String::from_utf8_lossy(&buf).trim_end_matches('\0').to_string()
 }
+
+/// How launches size their grids where one launch's latency trades against the work per block (`bn_set_sharing_mode`): `Alone` (default)
+/// for the lowest latency of one batch, `Shared` for a caller that keeps several `BatchInferenceContext`s busy (identical results, bit
+/// for bit; BirdNET v2.4 with four contexts: +7 % segments/s), `Auto` = `Shared` while more than one context lives on the device.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum SharingMode {
+    Auto,
+    Alone,
+    Shared,
+}
+
+pub fn set_sharing_mode(mode: SharingMode) {
+    let m = match mode {
+        SharingMode::Auto => BN_SHARING_AUTO,
+        SharingMode::Alone => BN_SHARING_ALONE,
+        SharingMode::Shared => BN_SHARING_SHARED,
+    };
+    unsafe { bn_set_sharing_mode(m) }
+}
