@@ -632,7 +632,7 @@ def main():
                                 "kernel_is_bf16x3": dom_sym[0] in ("gemm_b3_kernel", "gemm_dma3_kernel", "frame_fold2q_kernel"),
                                 "bf16_pipe_TFLOPs_of_kernel": round(6 * 2.0 * dom_sym[1]["macs"] / (dom_sym[1]["us"] * 1e-6) / 1e12, 1) if dom_sym[0] in ("gemm_b3_kernel", "gemm_dma3_kernel", "frame_fold2q_kernel") else None,
                                 "bf16_pipe_peak_TFLOPs": 2500.0,
-                                "what": "f32 operands split exactly into three bf16 terms, six of nine partial products kept (each exact in f32, the dropped ones < 2^-24 of the product): "
+                                "what": "f32 operands split exactly into three bf16 terms, six of nine partial products kept (each exact in f32; the dropped ones sum to < 2^-21 of the product in the worst case, 2^-24 rms): "
                                         "error against a double-precision product equal to the exact-f32 kernel's (tools/gemm3_bench); dtype stays f32"},
                      "kernel_alone": {"launches_per_step": dom_sym[1]["launches"], "us_per_step": round(dom_sym[1]["us"], 1), "avg_launch_us": round(dom_sym[1]["us"] / dom_sym[1]["launches"], 2),
                                       "TFLOPs": round(2.0 * dom_sym[1]["macs"] / (dom_sym[1]["us"] * 1e-6) / 1e12, 2),
